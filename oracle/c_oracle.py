@@ -1,0 +1,93 @@
+"""ORACLE (test infrastructure, NOT product code): ctypes wrapper around oracle/dsp_oracle.c.
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from . import forward_np as onp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "_build", "libdsp_oracle.so")
+_MODULE_CODE = {"both_bilstm": 0, "seq_bilstm": 1, "signal_bilstm": 2}
+
+
+class _Cfg(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_int32) for k in (
+        "seq_len", "signal_len", "num_layers1", "num_layers2", "num_classes", "hidden_size", "vocab_size",
+        "embedding_size", "is_base", "is_signallen", "module")]
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(HERE, "dsp_oracle.c")
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", HERE])
+    return LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(LIB)
+        _lib.orc_forward.restype = ctypes.c_int
+        _lib.orc_num_threads.restype = ctypes.c_int
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def forward(cfg: onp.OracleConfig, w, kmer, means, stds, lens, signals, states=None, init_mode="explicit",
+            seed=0, site_offset=0, nthreads=0):
+    """fp32 C oracle forward. init_mode: 'zeros' | 'explicit' (states dict) | 'philox' (seed, site_offset)."""
+    L = lib()
+    c = _Cfg(cfg.seq_len, cfg.signal_len, cfg.num_layers1, cfg.num_layers2, cfg.num_classes, cfg.hidden_size,
+             cfg.vocab_size, cfg.embedding_size, int(cfg.is_base), int(cfg.is_signallen), _MODULE_CODE[cfg.module])
+    spec = onp.state_dict_spec(cfg)
+    arrs = [np.ascontiguousarray(w[k], np.float32) for k, _ in spec]
+    for a, (k, shp) in zip(arrs, spec):
+        assert tuple(a.shape) == tuple(shp), (k, a.shape, shp)
+    wptr = (ctypes.POINTER(ctypes.c_float) * len(arrs))(*[_fp(a) for a in arrs])
+    n = int(kmer.shape[0])
+    ins = [np.ascontiguousarray(a, np.float32) for a in (kmer, means, stds, lens, signals)]
+    mode = {"zeros": 0, "explicit": 1, "philox": 2}[init_mode]
+    sptr = None
+    keep = []
+    if mode == 1:
+        ptrs = []
+        for k in ("h_seq", "c_seq", "h_sig", "c_sig", "h_comb", "c_comb"):
+            if states is not None and k in states:
+                a = np.ascontiguousarray(states[k], np.float32)
+                keep.append(a)
+                ptrs.append(_fp(a))
+            else:
+                ptrs.append(ctypes.POINTER(ctypes.c_float)())
+        sptr = (ctypes.POINTER(ctypes.c_float) * 6)(*ptrs)
+    logits = np.empty((n, cfg.num_classes), np.float32)
+    probs = np.empty((n, cfg.num_classes), np.float32)
+    rc = L.orc_forward(ctypes.byref(c), wptr, len(arrs), ctypes.c_int64(n), *[_fp(a) for a in ins], mode, sptr,
+                       ctypes.c_uint64(seed), ctypes.c_uint64(site_offset), _fp(logits), _fp(probs), int(nthreads))
+    if rc != 0:
+        raise RuntimeError("orc_forward failed: %d" % rc)
+    return logits, probs
+
+
+def philox_normal(seed, site, stream, ngroups):
+    out = np.empty(4 * ngroups, np.float32)
+    lib().orc_philox_normal(ctypes.c_uint64(seed), ctypes.c_uint64(site), ctypes.c_uint32(stream),
+                            ctypes.c_uint32(ngroups), _fp(out))
+    return out
+
+
+def num_threads():
+    return lib().orc_num_threads()

@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Generate the F1 forward golden fixtures by IMPORTING THE REFERENCE (build container only).
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+Needs /root/reference (read-only).  Never runs on the GPU box; only its outputs (tests/golden/*.npz,
+data: inputs' seeds + expected outputs) are committed.  No reference source is copied.
+
+What it does:
+  * builds deepsignal_plant.models.ModelBiLSTM with the positional argument order of
+    deepsignal_plant/call_modifications.py:214-217, loads build-defined deterministic weights
+    (oracle.forward_np.make_weights(seed)) through load_state_dict (strict),
+  * pins the LSTM initial states by replacing ``init_hidden`` on the instance with a function that
+    returns the fixture's (h0, c0) in draw order (models.py:169-176) -- the arithmetic under test is
+    untouched,
+  * records logits/probs (and a few intermediate activations through forward hooks) as float32.
+One extra fixture captures TRUE torch.randn draws under torch.manual_seed to document draw order.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True
+
+import torch  # noqa: E402
+
+from deepsignal_plant.models import ModelBiLSTM  # noqa: E402  (the reference)
+from oracle import forward_np as onp  # noqa: E402
+
+FIXTURES = [
+    # name, cfg kwargs, n, wseed, wscale, iseed, sseed
+    ("both_default", dict(), 24, 11, 1.0, 101, 201),
+    ("both_sharp", dict(), 16, 12, 3.0, 102, 202),
+    ("seq_cfg3", dict(module="seq_bilstm", num_layers1=2, num_layers2=1, hidden_size=256), 16, 13, 1.0, 103, 203),
+    ("signal_only", dict(module="signal_bilstm", num_layers1=1, hidden_size=256), 16, 14, 1.0, 104, 204),
+    ("tiny_h64_l2", dict(hidden_size=64, num_layers1=2, num_layers2=2), 40, 15, 2.0, 105, 205),
+    ("nobase_h128", dict(hidden_size=128, num_layers1=1, is_base=False), 16, 16, 1.0, 106, 206),
+    ("nosiglen_h128", dict(hidden_size=128, num_layers1=1, is_signallen=False), 16, 17, 1.0, 107, 207),
+    ("both_h96_wide", dict(hidden_size=192, num_layers1=2), 33, 18, 1.5, 108, 208),
+]
+
+
+def build_ref(cfg, weights):
+    m = ModelBiLSTM(cfg.seq_len, cfg.signal_len, cfg.num_layers1, cfg.num_layers2, cfg.num_classes,
+                    0, cfg.hidden_size, cfg.vocab_size, cfg.embedding_size, cfg.is_base,
+                    cfg.is_signallen, module=cfg.module, device=0)
+    sd = m.state_dict()
+    assert [k for k in sd] == [k for k, _ in onp.state_dict_spec(cfg)], "state_dict order drifted"
+    for k, shp in onp.state_dict_spec(cfg):
+        assert tuple(sd[k].shape) == tuple(shp), (k, sd[k].shape, shp)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in weights.items()})
+    m.eval()
+    return m
+
+
+def pin_states(model, cfg, states):
+    order = [k for k, _ in onp.init_state_shapes(cfg, 1)]
+    pairs = [(order[i], order[i + 1]) for i in range(0, len(order), 2)]
+    it = iter(pairs)
+
+    def pinned(batch_size, num_layers, hidden_size):
+        hk, ck = next(it)
+        h, c = states[hk], states[ck]
+        assert h.shape == (2 * num_layers, batch_size, hidden_size), (hk, h.shape)
+        return torch.from_numpy(h.copy()), torch.from_numpy(c.copy())
+    model.init_hidden = pinned
+
+
+def run_ref(model, inputs, hooks=True):
+    inter = {}
+    hs = []
+    if hooks:
+        for name in ("relu_seq", "relu_signal", "lstm_comb"):
+            mod = getattr(model, name, None)
+            if mod is None:
+                continue
+
+            def mk(nm):
+                def hook(_m, _i, o):
+                    inter[nm] = (o[0] if isinstance(o, tuple) else o).detach().numpy().copy()
+                return hook
+            hs.append(mod.register_forward_hook(mk(name)))
+    with torch.no_grad():
+        logits, probs = model(*[torch.from_numpy(a.copy()) for a in inputs])
+    for h in hs:
+        h.remove()
+    return logits.numpy().copy(), probs.numpy().copy(), inter
+
+
+def checksum(weights):
+    return float(sum(float(np.abs(v.astype(np.float64)).sum()) for v in weights.values()))
+
+
+def main():
+    for name, kw, n, wseed, wscale, iseed, sseed in FIXTURES:
+        cfg = onp.OracleConfig(**kw)
+        w = onp.make_weights(cfg, wseed, wscale)
+        inputs = onp.make_inputs(cfg, n, iseed, wide_alphabet=(name == "both_h96_wide"))
+        states = onp.make_init_states(cfg, n, sseed)
+        model = build_ref(cfg, w)
+        pin_states(model, cfg, states)
+        logits, probs, inter = run_ref(model, inputs)
+        keep = 8
+        out = dict(cfg=np.array(repr(cfg.as_dict())), n=n, wseed=wseed, wscale=wscale, iseed=iseed, sseed=sseed,
+                   wsum=checksum(w), isum=float(sum(np.abs(a.astype(np.float64)).sum() for a in inputs)),
+                   ssum=float(sum(np.abs(a.astype(np.float64)).sum() for a in states.values())),
+                   logits=logits.astype(np.float32), probs=probs.astype(np.float32))
+        for k, v in inter.items():
+            out["inter_" + k] = v[:keep].astype(np.float32)
+        np.savez_compressed(os.path.join(HERE, "f1_%s.npz" % name), **out)
+        # self-check against the float64 restatement
+        lo, po = onp.forward(cfg, w, *inputs, states, dtype=np.float64)
+        print("%-16s n=%3d  max|dlogit|=%.2e max|dprob|=%.2e  p1 range [%.4f, %.4f]" % (
+            name, n, np.abs(lo - logits).max(), np.abs(po - probs).max(), probs[:, 1].min(), probs[:, 1].max()))
+
+    # true torch.randn capture (draw order / shape documentation, models.py:169-176)
+    cfg = onp.OracleConfig()
+    n, wseed, iseed, tseed = 4, 19, 109, 4242
+    w = onp.make_weights(cfg, wseed, 1.0)
+    inputs = onp.make_inputs(cfg, n, iseed)
+    model = build_ref(cfg, w)
+    torch.manual_seed(tseed)
+    logits, probs, _ = run_ref(model, inputs, hooks=False)
+    torch.manual_seed(tseed)
+    states = {k: torch.randn(*s).numpy().copy() for k, s in onp.init_state_shapes(cfg, n)}
+    lo, po = onp.forward(cfg, w, *inputs, states, dtype=np.float64)
+    print("randn_capture    n=%3d  max|dlogit|=%.2e max|dprob|=%.2e" % (n, np.abs(lo - logits).max(), np.abs(po - probs).max()))
+    np.savez_compressed(os.path.join(HERE, "f1_randn_capture.npz"), cfg=np.array(repr(cfg.as_dict())), n=n,
+                        wseed=wseed, wscale=1.0, iseed=iseed, torch_seed=tseed, wsum=checksum(w),
+                        logits=logits.astype(np.float32), probs=probs.astype(np.float32),
+                        **{"state_" + k: v for k, v in states.items()})
+
+
+if __name__ == "__main__":
+    main()

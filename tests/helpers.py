@@ -1,0 +1,39 @@
+"""Shared helpers for the test-suite: load F1 fixtures and rebuild their seeded inputs."""
+import ast
+import glob
+import os
+
+import numpy as np
+
+from oracle import forward_np as onp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def f1_names():
+    return sorted(os.path.basename(p)[3:-4] for p in glob.glob(os.path.join(GOLDEN, "f1_*.npz")))
+
+
+def load_f1(name):
+    """-> dict(cfg, w, inputs, states, logits, probs, inter, n). Regenerates seeded tensors and verifies
+    the checksums stored with the fixture (guards against generator drift)."""
+    d = np.load(os.path.join(GOLDEN, "f1_%s.npz" % name))
+    cfg = onp.OracleConfig(**ast.literal_eval(str(d["cfg"])))
+    n = int(d["n"])
+    w = onp.make_weights(cfg, int(d["wseed"]), float(d["wscale"]))
+    wsum = float(sum(float(np.abs(v.astype(np.float64)).sum()) for v in w.values()))
+    assert abs(wsum - float(d["wsum"])) <= 1e-9 * abs(wsum), "weight generator drifted"
+    inputs = onp.make_inputs(cfg, n, int(d["iseed"]), wide_alphabet=("wide" in name))
+    if "isum" in d.files:
+        isum = float(sum(np.abs(a.astype(np.float64)).sum() for a in inputs))
+        assert abs(isum - float(d["isum"])) <= 1e-9 * abs(isum), "input generator drifted"
+    if "sseed" in d.files:
+        states = onp.make_init_states(cfg, n, int(d["sseed"]))
+        ssum = float(sum(np.abs(a.astype(np.float64)).sum() for a in states.values()))
+        assert abs(ssum - float(d["ssum"])) <= 1e-9 * abs(ssum), "state generator drifted"
+    else:
+        states = {k[6:]: d[k] for k in d.files if k.startswith("state_")}
+    inter = {k[6:]: d[k] for k in d.files if k.startswith("inter_")}
+    return dict(cfg=cfg, w=w, inputs=inputs, states=states, logits=d["logits"], probs=d["probs"], inter=inter,
+                n=n, raw=d)

@@ -1,0 +1,84 @@
+"""CPU: pin the oracle (numpy float64 + C fp32) against the fixtures captured from the reference
+(tests/golden/make_golden.py).  Tolerance: 1e-6 on probs / 5e-6 on logits."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle as oc
+from oracle import forward_np as onp
+from tests.helpers import f1_names, load_f1
+
+
+@pytest.mark.parametrize("name", f1_names())
+def test_numpy_oracle_matches_reference_fixture(name):
+    f = load_f1(name)
+    lo, po, inter = onp.forward(f["cfg"], f["w"], *f["inputs"], f["states"], dtype=np.float64,
+                                want_intermediates=True)
+    assert np.abs(po - f["probs"]).max() <= 1e-6
+    assert np.abs(lo - f["logits"]).max() <= 5e-6
+    # intermediates recorded through forward hooks in the reference (first 8 sites)
+    m = {"relu_seq": "out_seq", "relu_signal": "out_signal", "lstm_comb": "lstm_comb"}
+    for k, v in f["inter"].items():
+        assert np.abs(inter[m[k]][: v.shape[0]] - v).max() <= 5e-6, k
+
+
+@pytest.mark.parametrize("name", f1_names())
+def test_c_oracle_matches_reference_fixture(name):
+    f = load_f1(name)
+    lo, po = oc.forward(f["cfg"], f["w"], *f["inputs"], states=f["states"], init_mode="explicit")
+    assert np.abs(po - f["probs"]).max() <= 1e-6
+    assert np.abs(lo - f["logits"]).max() <= 5e-6
+
+
+def test_randn_capture_documents_draw_order():
+    """models.py:169-176 -- sequential torch.randn on the CPU generator in the order h_seq, c_seq, h_sig,
+    c_sig, h_comb, c_comb with shapes (2*layers, B, H)."""
+    torch = pytest.importorskip("torch")
+    f = load_f1("randn_capture")
+    torch.manual_seed(int(f["raw"]["torch_seed"]))
+    for k, shp in onp.init_state_shapes(f["cfg"], f["n"]):
+        draw = torch.randn(*shp).numpy()
+        assert np.array_equal(draw, f["states"][k]), k
+
+
+def test_c_oracle_modes_and_threads():
+    cfg = onp.OracleConfig(hidden_size=64, num_layers1=1)
+    w = onp.make_weights(cfg, 3)
+    ins = onp.make_inputs(cfg, 37, 4)
+    z = onp.zero_init_states(cfg, 37)
+    a = oc.forward(cfg, w, *ins, init_mode="zeros")
+    b = oc.forward(cfg, w, *ins, states=z, init_mode="explicit", nthreads=1)
+    assert np.array_equal(a[1], b[1])
+    ref = onp.forward(cfg, w, *ins, z)
+    assert np.abs(a[1] - ref[1]).max() <= 1e-6
+    # philox mode: deterministic, depends on seed and on the global site index only
+    p1 = oc.forward(cfg, w, *ins, init_mode="philox", seed=7)
+    p2 = oc.forward(cfg, w, *ins, init_mode="philox", seed=7, nthreads=2)
+    p3 = oc.forward(cfg, w, *ins, init_mode="philox", seed=8)
+    assert np.array_equal(p1[1], p2[1]) and not np.array_equal(p1[1], p3[1])
+    tail = [x[20:] for x in ins]
+    p4 = oc.forward(cfg, w, *tail, init_mode="philox", seed=7, site_offset=20)
+    assert np.array_equal(p1[1][20:], p4[1])
+
+
+def test_philox_known_answer_and_moments():
+    # Philox4x32-10 known-answer vectors from the Random123 distribution (kat_vectors):
+    # ctr=0,key=0 -> 6627e8d5 e169c58d bc57ac4c 9b00dbd8 ; ctr=ff..,key=ff.. -> 408f276d 41c83b0e a20bc7c6 6d5451fd
+    import ctypes
+    lib = oc.lib()
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        out = (ctypes.c_uint32 * 4)()
+        lib.orc_philox_raw((ctypes.c_uint32 * 4)(*ctr), (ctypes.c_uint32 * 2)(*key), out)
+        assert tuple(out) == want
+    x = oc.philox_normal(0, 0, 0, 4096)
+    assert abs(float(x.mean())) < 0.03 and abs(float(x.std()) - 1.0) < 0.03
+    assert np.isfinite(x).all()
+
+
+def test_flop_count_matches_survey():
+    assert onp.flops_per_site(onp.OracleConfig()) == 118447104
+    assert onp.flops_per_site(onp.OracleConfig(module="seq_bilstm", num_layers1=2)) == 85832704
+    assert sum(int(np.prod(s)) for _, s in onp.state_dict_spec(onp.OracleConfig())) == 4694082
