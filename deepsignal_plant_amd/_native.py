@@ -1,0 +1,89 @@
+"""ctypes binding of libdsp_amd.so (include/dsp_amd.h).  Fails loudly when the library is absent."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdsp_amd.so")
+
+DSP_OK, DSP_EINVAL, DSP_ESHAPE, DSP_EHIP, DSP_ENOMEM, DSP_EPARSE = 0, -1, -2, -3, -4, -5
+MODULE_CODE = {"both_bilstm": 0, "seq_bilstm": 1, "signal_bilstm": 2}
+DT_F32, DT_U8, DT_U16, DT_I32 = 0, 1, 2, 3
+INIT_ZEROS, INIT_EXPLICIT, INIT_PHILOX = 0, 1, 2
+
+
+class ModelCfg(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_int32) for k in (
+        "seq_len", "signal_len", "num_layers1", "num_layers2", "num_classes", "hidden_size", "vocab_size",
+        "embedding_size", "is_base", "is_signallen", "module")]
+
+
+class InitState(ctypes.Structure):
+    _fields_ = [("mode", ctypes.c_int32), ("seed", ctypes.c_uint64), ("site_offset", ctypes.c_uint64),
+                ("h_seq", ctypes.c_void_p), ("c_seq", ctypes.c_void_p), ("h_sig", ctypes.c_void_p),
+                ("c_sig", ctypes.c_void_p), ("h_comb", ctypes.c_void_p), ("c_comb", ctypes.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libdsp_amd.so or raise: the product path never falls back to a CPU implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libdsp_amd.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    L.dsp_last_error.restype = ctypes.c_char_p
+    L.dsp_abi_version.restype = ctypes.c_int32
+    L.dsp_weight_count.restype = ctypes.c_int32
+    L.dsp_weight_count.argtypes = [ctypes.POINTER(ModelCfg)]
+    L.dsp_weight_spec.restype = ctypes.c_int32
+    L.dsp_weight_spec.argtypes = [ctypes.POINTER(ModelCfg), ctypes.c_int32, ctypes.c_char_p, ctypes.c_size_t,
+                                  ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32)]
+    L.dsp_flops_per_site.restype = ctypes.c_int64
+    L.dsp_flops_per_site.argtypes = [ctypes.POINTER(ModelCfg)]
+    L.dsp_model_create.restype = ctypes.c_int32
+    L.dsp_model_create.argtypes = [ctypes.POINTER(ModelCfg), ctypes.POINTER(ctypes.c_void_p),
+                                   ctypes.POINTER(ctypes.c_int64), ctypes.c_int32, ctypes.c_int32,
+                                   ctypes.POINTER(ctypes.c_void_p)]
+    L.dsp_model_reserve.restype = ctypes.c_int32
+    L.dsp_model_reserve.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+    L.dsp_workspace_bytes.restype = ctypes.c_size_t
+    L.dsp_workspace_bytes.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+    L.dsp_forward.restype = ctypes.c_int32
+    L.dsp_forward.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32,
+                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+                              ctypes.POINTER(InitState), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.dsp_debug_read_activation.restype = ctypes.c_int32
+    L.dsp_debug_read_activation.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
+                                            ctypes.c_void_p]
+    L.dsp_profile_enable.restype = ctypes.c_int32
+    L.dsp_profile_enable.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    L.dsp_profile_read.restype = ctypes.c_int32
+    L.dsp_profile_read.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t,
+                                   ctypes.POINTER(ctypes.c_float), ctypes.c_int32]
+    L.dsp_model_destroy.restype = None
+    L.dsp_model_destroy.argtypes = [ctypes.c_void_p]
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return (lib().dsp_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(rc: int):
+    """Map C status codes onto the exceptions the reference raises for the same conditions."""
+    if rc >= 0:
+        return rc
+    msg = last_error()
+    if rc == DSP_EINVAL:
+        raise ValueError(msg)
+    if rc == DSP_EPARSE:
+        raise ValueError(msg)
+    raise RuntimeError(msg)

@@ -1,0 +1,606 @@
+// dsp_capi.cpp -- host side of the C ABI declared in include/dsp_amd.h.
+//
+// Replaces (reference, pure Python): model construction + checkpoint load + .cuda() + .eval()
+// (deepsignal_plant/call_modifications.py:214-228) and the forward call (:159-163 -> models.py:178-240).
+// One-time work here: validate the state_dict, repack every weight matrix into MFMA A-fragment order
+// (transposed formulation, see dsp_kernels.hip), pre-sum b_ih + b_hh, upload once.  Per call: nine
+// kernel launches on the caller's stream, no allocation, no host synchronisation.
+#include "dsp_amd.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "dsp_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(DSP_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+
+struct Dims {
+    int T, S, H, C, V, E, l1, l2;
+    int hseq, hsig, Iseq;
+    bool is_base, is_siglen;
+};
+
+int derive(const dsp_model_cfg* c, Dims* d) {
+    if (!c) return fail(DSP_EINVAL, "cfg is NULL");
+    if (c->module < 0 || c->module > 2) return fail(DSP_EINVAL, "--model_type is not right!");  // models.py:127-128
+    if (c->seq_len < 1 || c->signal_len < 1 || c->num_layers1 < 1 || c->num_layers2 < 1 || c->num_classes < 1 ||
+        c->hidden_size < 2 || c->vocab_size < 1 || c->embedding_size < 1)
+        return fail(DSP_EINVAL, "non-positive model dimension");
+    if (c->hidden_size > 256)
+        return fail(DSP_EINVAL, "hidden_size %d > 256 is not supported by this build", c->hidden_size);
+    if (c->num_classes > 64) return fail(DSP_EINVAL, "num_classes %d > 64 is not supported", c->num_classes);
+    if (c->num_layers1 > 15 || c->num_layers2 > 15) return fail(DSP_EINVAL, "too many LSTM layers");
+    d->T = c->seq_len; d->S = c->signal_len; d->H = c->hidden_size; d->C = c->num_classes;
+    d->V = c->vocab_size; d->E = c->embedding_size; d->l1 = c->num_layers1; d->l2 = c->num_layers2;
+    d->is_base = c->is_base != 0; d->is_siglen = c->is_signallen != 0;
+    d->hseq = d->hsig = 0;
+    if (c->module == DSP_MODULE_BOTH) { d->hseq = d->H / 2; d->hsig = d->H - d->hseq; }
+    else if (c->module == DSP_MODULE_SEQ) d->hseq = d->H;
+    else d->hsig = d->H;
+    d->Iseq = (d->is_base ? d->E : 0) + (d->is_siglen ? 3 : 2);  // models.py:135-141
+    return 0;
+}
+
+struct Spec { std::string name; int64_t shape[2]; int ndim; };
+
+void lstm_spec(std::vector<Spec>& v, const char* prefix, int in, int hid, int layers) {
+    for (int k = 0; k < layers; ++k) {
+        const int isz = k == 0 ? in : 2 * hid;
+        for (int d = 0; d < 2; ++d) {
+            const char* suf = d ? "_reverse" : "";
+            char nm[96];
+            snprintf(nm, sizeof(nm), "%s.weight_ih_l%d%s", prefix, k, suf); v.push_back({nm, {4 * hid, isz}, 2});
+            snprintf(nm, sizeof(nm), "%s.weight_hh_l%d%s", prefix, k, suf); v.push_back({nm, {4 * hid, hid}, 2});
+            snprintf(nm, sizeof(nm), "%s.bias_ih_l%d%s", prefix, k, suf); v.push_back({nm, {4 * hid, 0}, 1});
+            snprintf(nm, sizeof(nm), "%s.bias_hh_l%d%s", prefix, k, suf); v.push_back({nm, {4 * hid, 0}, 1});
+        }
+    }
+}
+
+// state_dict order of ModelBiLSTM (models.py:130-161)
+std::vector<Spec> weight_spec(const Dims& d) {
+    std::vector<Spec> v;
+    if (d.hseq) {
+        v.push_back({"embed.weight", {d.V, d.E}, 2});
+        lstm_spec(v, "lstm_seq", d.Iseq, d.hseq, d.l2);
+        v.push_back({"fc_seq.weight", {d.hseq, 2 * d.hseq}, 2});
+        v.push_back({"fc_seq.bias", {d.hseq, 0}, 1});
+    }
+    if (d.hsig) {
+        lstm_spec(v, "lstm_signal", d.S, d.hsig, d.l2);
+        v.push_back({"fc_signal.weight", {d.hsig, 2 * d.hsig}, 2});
+        v.push_back({"fc_signal.bias", {d.hsig, 0}, 1});
+    }
+    lstm_spec(v, "lstm_comb", d.H, d.H, d.l1);
+    v.push_back({"fc1.weight", {d.H, 2 * d.H}, 2});
+    v.push_back({"fc1.bias", {d.H, 0}, 1});
+    v.push_back({"fc2.weight", {d.C, d.H}, 2});
+    v.push_back({"fc2.bias", {d.C, 0}, 1});
+    return v;
+}
+
+int64_t spec_numel(const Spec& s) { return s.ndim == 2 ? s.shape[0] * s.shape[1] : s.shape[0]; }
+
+// ---- feature maps: padded K4 feature index -> column of the reference weight matrix (or -1 = zero pad)
+std::vector<int> map_pad(int n, int padded) {
+    std::vector<int> m(padded, -1);
+    for (int i = 0; i < n; ++i) m[i] = i;
+    return m;
+}
+std::vector<int> map_bidir(int H, int Hp) {  // [fwd Hp | bwd Hp] -> [fwd H | bwd H]
+    std::vector<int> m(2 * Hp, -1);
+    for (int i = 0; i < H; ++i) { m[i] = i; m[Hp + i] = H + i; }
+    return m;
+}
+
+struct DevLstmLayer { int Ipad, H, Hp; float* wpk[2]; float* bias[2]; };
+struct DevLinear { int Fin, ORT; float* wpk; float* bias; };
+
+// A fragments for gates^T = W * act^T :  [UT][NQ][4 gates][64 lanes][4]
+//   value = Wcat[g*H + u*32 + (lane&31)][8q + 4*(lane>>5) + i],  Wcat = [W_ih(in_map) | W_hh]
+void pack_lstm_dir(const float* wih, const float* whh, const float* bih, const float* bhh, int I, int H, int Hp,
+                   const std::vector<int>& in_map, std::vector<float>& wpk, std::vector<float>& bias) {
+    const int Ipad = (int)in_map.size();
+    const int UT = Hp / 32, NQ = (Ipad + Hp) / 8;
+    wpk.assign((size_t)UT * NQ * 4 * 64 * 4, 0.f);
+    bias.assign((size_t)4 * Hp, 0.f);
+    for (int u = 0; u < UT; ++u)
+        for (int q = 0; q < NQ; ++q)
+            for (int g = 0; g < 4; ++g)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int unit = u * 32 + (lane & 31);
+                    if (unit >= H) continue;
+                    const size_t row = (size_t)g * H + unit;
+                    float* dst = &wpk[((((size_t)u * NQ + q) * 4 + g) * 64 + lane) * 4];
+                    for (int i = 0; i < 4; ++i) {
+                        const int kk = 8 * q + 4 * (lane >> 5) + i;
+                        if (kk < Ipad) {
+                            const int col = in_map[kk];
+                            if (col >= 0) dst[i] = wih[row * I + col];
+                        } else {
+                            const int hk = kk - Ipad;
+                            if (hk < H) dst[i] = whh[row * H + hk];
+                        }
+                    }
+                }
+    for (int g = 0; g < 4; ++g)
+        for (int unit = 0; unit < H; ++unit) bias[(size_t)g * Hp + unit] = bih[g * H + unit] + bhh[g * H + unit];
+}
+
+// A fragments for out^T = W * act^T : [ORT][Fin/8][64][4]
+void pack_linear(const float* w, const float* b, int O, int K, const std::vector<int>& in_map, std::vector<float>& wpk,
+                 std::vector<float>& bias) {
+    const int Fin = (int)in_map.size();
+    const int ORT = rup(O, 32) / 32, NQ = Fin / 8;
+    wpk.assign((size_t)ORT * NQ * 64 * 4, 0.f);
+    bias.assign((size_t)ORT * 32, 0.f);
+    for (int rt = 0; rt < ORT; ++rt)
+        for (int q = 0; q < NQ; ++q)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int row = rt * 32 + (lane & 31);
+                if (row >= O) continue;
+                float* dst = &wpk[(((size_t)rt * NQ + q) * 64 + lane) * 4];
+                for (int i = 0; i < 4; ++i) {
+                    const int col = in_map[8 * q + 4 * (lane >> 5) + i];
+                    if (col >= 0) dst[i] = w[(size_t)row * K + col];
+                }
+            }
+    for (int o = 0; o < O; ++o) bias[o] = b[o];
+}
+
+struct ProfEntry { const char* name; hipEvent_t a, b; };
+
+}  // namespace
+
+struct dsp_model {
+    dsp_model_cfg cfg;
+    Dims d;
+    int device = 0;
+    std::vector<void*> dev_allocs;
+    float* embed = nullptr;
+    std::vector<DevLstmLayer> seq, sig, comb;
+    DevLinear fc_seq{}, fc_sig{}, fc1{};
+    float* w2 = nullptr; float* b2 = nullptr;
+    int hseq_p = 0, hsig_p = 0, Hp = 0, Fseq = 0, Fsig = 0, Fcomb = 0, Fwide = 0;
+    std::vector<int> comb_in_map;  // padded comb-input feature -> reference feature
+    // scratch
+    void* ws = nullptr;
+    int64_t ws_sites = 0;
+    long long NTp = 0;
+    float *xseq = nullptr, *xsig = nullptr, *bufA = nullptr, *bufB = nullptr, *comb_in = nullptr;
+    float* last_out = nullptr;
+    // profiling
+    bool prof = false;
+    std::vector<ProfEntry> prof_entries;
+    std::vector<hipEvent_t> event_pool;
+    size_t event_used = 0;
+};
+
+namespace {
+
+int upload(dsp_model* m, const std::vector<float>& h, float** out) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, h.size() * sizeof(float));
+    if (e != hipSuccess) return fail(DSP_ENOMEM, "hipMalloc(%zu) failed: %s", h.size() * sizeof(float), hipGetErrorString(e));
+    m->dev_allocs.push_back(p);
+    HIP_TRY(hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    *out = (float*)p;
+    return 0;
+}
+
+int build_stack(dsp_model* m, const float* const* w, int in, int hid, int layers, std::vector<int> in_map0,
+                std::vector<DevLstmLayer>& out) {
+    const int Hp = rup(hid, 32);
+    for (int k = 0; k < layers; ++k) {
+        const int I = k == 0 ? in : 2 * hid;
+        const std::vector<int> in_map = k == 0 ? in_map0 : map_bidir(hid, Hp);
+        DevLstmLayer L{};
+        L.Ipad = (int)in_map.size(); L.H = hid; L.Hp = Hp;
+        for (int d = 0; d < 2; ++d) {
+            const float* const* p = w + (k * 2 + d) * 4;
+            std::vector<float> wpk, bias;
+            pack_lstm_dir(p[0], p[1], p[2], p[3], I, hid, Hp, in_map, wpk, bias);
+            int rc = upload(m, wpk, &L.wpk[d]);
+            if (rc) return rc;
+            rc = upload(m, bias, &L.bias[d]);
+            if (rc) return rc;
+        }
+        out.push_back(L);
+    }
+    return 0;
+}
+
+size_t ws_layout(const dsp_model* m, int64_t sites, long long* NTp_out, size_t off[5]) {
+    long long nt = (sites + 31) / 32;
+    long long NTp = (nt + 15) / 16 * 16;
+    if (NTp == 0) NTp = 16;
+    const size_t col = (size_t)NTp * m->d.T * 32 * sizeof(float);
+    size_t o = 0;
+    auto take = [&](size_t feats) { size_t r = o; o += (col * feats + 255) / 256 * 256; return r; };
+    off[0] = take(m->Fseq);
+    off[1] = take(m->Fsig);
+    off[2] = take(m->Fwide);
+    off[3] = take(m->Fwide);
+    off[4] = take(m->Fcomb);
+    if (NTp_out) *NTp_out = NTp;
+    return o;
+}
+
+int ensure_ws(dsp_model* m, int64_t sites, hipStream_t stream) {
+    if (sites <= m->ws_sites && m->ws) return 0;
+    if (m->ws) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(m->ws));
+        m->ws = nullptr; m->ws_sites = 0;
+    }
+    size_t off[5];
+    long long NTp;
+    const size_t bytes = ws_layout(m, sites, &NTp, off);
+    hipError_t e = hipMalloc(&m->ws, bytes);
+    if (e != hipSuccess) { m->ws = nullptr; return fail(DSP_ENOMEM, "workspace hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+    char* b = (char*)m->ws;
+    m->xseq = (float*)(b + off[0]); m->xsig = (float*)(b + off[1]);
+    m->bufA = (float*)(b + off[2]); m->bufB = (float*)(b + off[3]); m->comb_in = (float*)(b + off[4]);
+    m->ws_sites = (int64_t)NTp * 32;
+    m->NTp = NTp;
+    return 0;
+}
+
+struct Launcher {
+    dsp_model* m;
+    hipStream_t s;
+    int rc = 0;
+    template <class F> void run(const char* name, F&& f) {
+        if (rc) return;
+        hipEvent_t ea = nullptr, eb = nullptr;
+        if (m->prof) {
+            while (m->event_pool.size() < m->event_used + 2) {
+                hipEvent_t e;
+                if (hipEventCreate(&e) != hipSuccess) { rc = fail(DSP_EHIP, "hipEventCreate failed"); return; }
+                m->event_pool.push_back(e);
+            }
+            ea = m->event_pool[m->event_used++]; eb = m->event_pool[m->event_used++];
+            hipEventRecord(ea, s);
+        }
+        const int e = f();
+        if (e != 0) { rc = fail(DSP_EHIP, "launch %s failed: %s", name, hipGetErrorString((hipError_t)e)); return; }
+        if (m->prof) { hipEventRecord(eb, s); m->prof_entries.push_back({name, ea, eb}); }
+    }
+};
+
+// run one BiLSTM stack; returns the buffer holding the last layer's output
+float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>& layers, int lstm_id, const float* x,
+                 int64_t n, const dsp_init_state* init, const float* h0, const float* c0) {
+    dsp_model* m = L.m;
+    const float* cur = x;
+    float* dst = nullptr;
+    for (size_t k = 0; k < layers.size(); ++k) {
+        const DevLstmLayer& ly = layers[k];
+        dst = ((layers.size() - 1 - k) % 2 == 0) ? m->bufA : m->bufB;
+        LstmArgs a{};
+        a.x = cur; a.out = dst;
+        a.wpk0 = ly.wpk[0]; a.wpk1 = ly.wpk[1]; a.bias0 = ly.bias[0]; a.bias1 = ly.bias[1];
+        a.n = n; a.NTp = m->NTp;
+        a.Ipad = ly.Ipad; a.H = ly.H; a.Hp = ly.Hp; a.T = m->d.T; a.Fout = 2 * ly.Hp;
+        a.UT = ly.Hp / 32; a.SG = 8 / a.UT; if (a.SG < 1) a.SG = 1;
+        a.init_mode = init ? init->mode : DSP_INIT_ZEROS;
+        a.seed = init ? init->seed : 0; a.site_offset = init ? init->site_offset : 0;
+        a.stream_base = lstm_id * 64 + (int)k * 4;
+        if (a.init_mode == DSP_INIT_EXPLICIT) {
+            a.h0 = h0 + (size_t)(2 * k) * (size_t)n * ly.H;
+            a.c0 = c0 + (size_t)(2 * k) * (size_t)n * ly.H;
+        }
+        L.run(name, [&] { return dsp_k_lstm(&a, L.s); });
+        cur = dst;
+    }
+    return dst;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dsp_last_error(void) { return g_err.c_str(); }
+int32_t dsp_abi_version(void) { return DSP_AMD_ABI_VERSION; }
+
+int32_t dsp_weight_count(const dsp_model_cfg* cfg) {
+    Dims d;
+    int rc = derive(cfg, &d);
+    if (rc) return rc;
+    return (int32_t)weight_spec(d).size();
+}
+
+int32_t dsp_weight_spec(const dsp_model_cfg* cfg, int32_t idx, char* name, size_t name_cap, int64_t shape[2],
+                        int32_t* ndim) {
+    Dims d;
+    int rc = derive(cfg, &d);
+    if (rc) return rc;
+    const std::vector<Spec> v = weight_spec(d);
+    if (idx < 0 || (size_t)idx >= v.size()) return fail(DSP_EINVAL, "weight index %d out of range", idx);
+    if (name && name_cap) { strncpy(name, v[idx].name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (shape) { shape[0] = v[idx].shape[0]; shape[1] = v[idx].shape[1]; }
+    if (ndim) *ndim = v[idx].ndim;
+    return 0;
+}
+
+int64_t dsp_flops_per_site(const dsp_model_cfg* cfg) {
+    Dims d;
+    if (derive(cfg, &d)) return -1;
+    auto lstm = [&](int64_t i, int64_t h, int layers) {
+        int64_t mac = 0;
+        for (int k = 0; k < layers; ++k) mac += 2 * (int64_t)d.T * 4 * h * ((k == 0 ? i : 2 * h) + h);
+        return mac;
+    };
+    int64_t mac = 0;
+    if (d.hseq) mac += lstm(d.Iseq, d.hseq, d.l2) + (int64_t)d.T * d.hseq * 2 * d.hseq;
+    if (d.hsig) mac += lstm(d.S, d.hsig, d.l2) + (int64_t)d.T * d.hsig * 2 * d.hsig;
+    mac += lstm(d.H, d.H, d.l1) + (int64_t)d.H * 2 * d.H + (int64_t)d.C * d.H;
+    return 2 * mac;
+}
+
+int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weights, const int64_t* numels,
+                         int32_t n_weights, int32_t device, dsp_model** out) {
+    if (!out) return fail(DSP_EINVAL, "out is NULL");
+    *out = nullptr;
+    Dims d;
+    int rc = derive(cfg, &d);
+    if (rc) return rc;
+    const std::vector<Spec> spec = weight_spec(d);
+    if (!host_weights || !numels) return fail(DSP_EINVAL, "weights are NULL");
+    if ((size_t)n_weights != spec.size())
+        return fail(DSP_ESHAPE, "state_dict has %d tensors, model expects %zu", n_weights, spec.size());
+    for (size_t i = 0; i < spec.size(); ++i) {
+        if (!host_weights[i]) return fail(DSP_ESHAPE, "Missing key(s) in state_dict: \"%s\"", spec[i].name.c_str());
+        if (numels[i] != spec_numel(spec[i]))
+            return fail(DSP_ESHAPE, "size mismatch for %s: got %lld elements, model expects %lld", spec[i].name.c_str(),
+                        (long long)numels[i], (long long)spec_numel(spec[i]));
+    }
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(DSP_EINVAL, "device %d out of range (%d visible)", device, ndev);
+    int prev = 0;
+    HIP_TRY(hipGetDevice(&prev));
+    HIP_TRY(hipSetDevice(device));
+    {
+        const int e = dsp_k_init();
+        if (e) { hipSetDevice(prev); return fail(DSP_EHIP, "kernel attribute setup failed: %s", hipGetErrorString((hipError_t)e)); }
+    }
+
+    dsp_model* m = new (std::nothrow) dsp_model();
+    if (!m) { hipSetDevice(prev); return fail(DSP_ENOMEM, "out of host memory"); }
+    m->cfg = *cfg; m->d = d; m->device = device;
+    m->hseq_p = d.hseq ? rup(d.hseq, 32) : 0;
+    m->hsig_p = d.hsig ? rup(d.hsig, 32) : 0;
+    m->Hp = rup(d.H, 32);
+    m->Fseq = d.hseq ? rup(d.Iseq, 8) : 0;
+    m->Fsig = d.hsig ? rup(d.S, 8) : 0;
+    m->Fcomb = m->hseq_p + m->hsig_p;
+    m->Fwide = 2 * m->Hp;
+    if (2 * m->hseq_p > m->Fwide) m->Fwide = 2 * m->hseq_p;
+    if (2 * m->hsig_p > m->Fwide) m->Fwide = 2 * m->hsig_p;
+    m->comb_in_map.assign(m->Fcomb, -1);
+    for (int i = 0; i < d.hseq; ++i) m->comb_in_map[i] = i;
+    for (int i = 0; i < d.hsig; ++i) m->comb_in_map[m->hseq_p + i] = d.hseq + i;
+
+    const float* const* w = host_weights;
+    int wi = 0;
+    auto done = [&](int code) { hipSetDevice(prev); if (code) { dsp_model_destroy(m); } else { *out = m; } return code; };
+    if (d.hseq) {
+        std::vector<float> emb(w[wi], w[wi] + (size_t)d.V * d.E);
+        rc = upload(m, emb, &m->embed); if (rc) return done(rc);
+        ++wi;
+        rc = build_stack(m, w + wi, d.Iseq, d.hseq, d.l2, map_pad(d.Iseq, m->Fseq), m->seq); if (rc) return done(rc);
+        wi += 8 * d.l2;
+        std::vector<float> wpk, bias;
+        pack_linear(w[wi], w[wi + 1], d.hseq, 2 * d.hseq, map_bidir(d.hseq, m->hseq_p), wpk, bias);
+        m->fc_seq.Fin = 2 * m->hseq_p; m->fc_seq.ORT = m->hseq_p / 32;
+        rc = upload(m, wpk, &m->fc_seq.wpk); if (rc) return done(rc);
+        rc = upload(m, bias, &m->fc_seq.bias); if (rc) return done(rc);
+        wi += 2;
+    }
+    if (d.hsig) {
+        rc = build_stack(m, w + wi, d.S, d.hsig, d.l2, map_pad(d.S, m->Fsig), m->sig); if (rc) return done(rc);
+        wi += 8 * d.l2;
+        std::vector<float> wpk, bias;
+        pack_linear(w[wi], w[wi + 1], d.hsig, 2 * d.hsig, map_bidir(d.hsig, m->hsig_p), wpk, bias);
+        m->fc_sig.Fin = 2 * m->hsig_p; m->fc_sig.ORT = m->hsig_p / 32;
+        rc = upload(m, wpk, &m->fc_sig.wpk); if (rc) return done(rc);
+        rc = upload(m, bias, &m->fc_sig.bias); if (rc) return done(rc);
+        wi += 2;
+    }
+    rc = build_stack(m, w + wi, d.H, d.H, d.l1, m->comb_in_map, m->comb); if (rc) return done(rc);
+    wi += 8 * d.l1;
+    {
+        std::vector<float> wpk, bias;
+        pack_linear(w[wi], w[wi + 1], d.H, 2 * d.H, map_bidir(d.H, m->Hp), wpk, bias);
+        m->fc1.Fin = 2 * m->Hp; m->fc1.ORT = m->Hp / 32;
+        rc = upload(m, wpk, &m->fc1.wpk); if (rc) return done(rc);
+        rc = upload(m, bias, &m->fc1.bias); if (rc) return done(rc);
+        wi += 2;
+        std::vector<float> w2((size_t)d.C * m->Hp, 0.f), b2(w[wi + 1], w[wi + 1] + d.C);
+        for (int c = 0; c < d.C; ++c)
+            for (int k = 0; k < d.H; ++k) w2[(size_t)c * m->Hp + k] = w[wi][(size_t)c * d.H + k];
+        rc = upload(m, w2, &m->w2); if (rc) return done(rc);
+        rc = upload(m, b2, &m->b2); if (rc) return done(rc);
+        wi += 2;
+    }
+    return done(0);
+}
+
+size_t dsp_workspace_bytes(const dsp_model* m, int64_t max_sites) {
+    if (!m) return 0;
+    size_t off[5];
+    return ws_layout(m, max_sites, nullptr, off);
+}
+
+int32_t dsp_model_reserve(dsp_model* m, int64_t max_sites) {
+    if (!m) return fail(DSP_EINVAL, "model is NULL");
+    if (max_sites < 1) return fail(DSP_EINVAL, "max_sites must be >= 1");
+    int prev = 0;
+    HIP_TRY(hipGetDevice(&prev));
+    HIP_TRY(hipSetDevice(m->device));
+    const int rc = ensure_ws(m, max_sites, nullptr);
+    hipSetDevice(prev);
+    return rc;
+}
+
+int32_t dsp_forward(dsp_model* m, void* stream, int64_t n, const void* kmer, int32_t kmer_dtype, const float* means,
+                    const float* stds, const void* lens, int32_t lens_dtype, const float* signals,
+                    const dsp_init_state* init, float* logits, float* probs, uint8_t* labels) {
+    if (!m) return fail(DSP_EINVAL, "model is NULL");
+    if (n < 0) return fail(DSP_EINVAL, "n_sites < 0");
+    if (n == 0) return 0;
+    const Dims& d = m->d;
+    if (kmer_dtype < 0 || kmer_dtype > 3 || lens_dtype < 0 || lens_dtype > 3) return fail(DSP_EINVAL, "bad dtype code");
+    if (d.hseq && (!means || !stds || (d.is_base && !kmer) || (d.is_siglen && !lens)))
+        return fail(DSP_EINVAL, "seq-branch input pointer is NULL");
+    if (d.hsig && !signals) return fail(DSP_EINVAL, "signals pointer is NULL");
+    const int mode = init ? init->mode : DSP_INIT_ZEROS;
+    if (mode < 0 || mode > 2) return fail(DSP_EINVAL, "bad init-state mode %d", mode);
+    if (mode == DSP_INIT_EXPLICIT) {
+        if ((d.hseq && (!init->h_seq || !init->c_seq)) || (d.hsig && (!init->h_sig || !init->c_sig)) || !init->h_comb ||
+            !init->c_comb)
+            return fail(DSP_EINVAL, "explicit init-state pointer is NULL");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    int prev = 0;
+    HIP_TRY(hipGetDevice(&prev));
+    if (prev != m->device) HIP_TRY(hipSetDevice(m->device));
+    int rc = ensure_ws(m, n, s);
+    if (rc) { if (prev != m->device) hipSetDevice(prev); return rc; }
+    // use the tile count of THIS call (padded to 16 tiles), not the capacity
+    const long long NTp = (((n + 31) / 32) + 15) / 16 * 16;
+    const long long cap_NTp = m->NTp;
+    m->NTp = NTp;
+
+    m->prof_entries.clear();
+    m->event_used = 0;
+    Launcher L{m, s};
+
+    PackArgs p{};
+    p.kmer = kmer; p.means = means; p.stds = stds; p.lens = lens; p.signals = signals; p.embed = m->embed;
+    p.xseq = d.hseq ? m->xseq : nullptr; p.xsig = d.hsig ? m->xsig : nullptr;
+    p.n = n; p.NTp = NTp; p.kdt = kmer_dtype; p.ldt = lens_dtype;
+    p.T = d.T; p.S = d.S; p.E = d.E; p.V = d.V; p.is_base = d.is_base; p.is_siglen = d.is_siglen;
+    p.Fseq = m->Fseq; p.Fsig = m->Fsig;
+    L.run("pack", [&] { return dsp_k_pack(&p, s); });
+
+    auto linear = [&](const char* name, const DevLinear& fc, const float* x, int out_off) {
+        LinArgs a{};
+        a.x = x; a.out = m->comb_in; a.wpk = fc.wpk; a.bias = fc.bias;
+        a.ncols = NTp * d.T; a.Fin = fc.Fin; a.Fout = m->Fcomb; a.out_off = out_off; a.ORT = fc.ORT; a.relu = 1;
+        L.run(name, [&] { return dsp_k_linear(&a, s); });
+    };
+    if (d.hseq) {
+        float* o = run_stack(L, "lstm_seq", m->seq, 0, m->xseq, n, init, init ? init->h_seq : nullptr,
+                             init ? init->c_seq : nullptr);
+        linear("fc_seq", m->fc_seq, o, 0);
+    }
+    if (d.hsig) {
+        float* o = run_stack(L, "lstm_signal", m->sig, 1, m->xsig, n, init, init ? init->h_sig : nullptr,
+                             init ? init->c_sig : nullptr);
+        linear("fc_signal", m->fc_sig, o, m->hseq_p);
+    }
+    float* o = run_stack(L, "lstm_comb", m->comb, 2, m->comb_in, n, init, init ? init->h_comb : nullptr,
+                         init ? init->c_comb : nullptr);
+    m->last_out = o;
+    HeadArgs h{};
+    h.x = o; h.w1pk = m->fc1.wpk; h.b1 = m->fc1.bias; h.w2 = m->w2; h.b2 = m->b2;
+    h.logits = logits; h.probs = probs; h.labels = labels; h.n = n; h.Hp = m->Hp; h.T = d.T; h.C = d.C;
+    L.run("head", [&] { return dsp_k_head(&h, s); });
+
+    m->NTp = cap_NTp;
+    if (prev != m->device) hipSetDevice(prev);
+    return L.rc;
+}
+
+int32_t dsp_debug_read_activation(dsp_model* m, void* stream, int32_t which, int64_t n, float* host_out) {
+    if (!m || !host_out) return fail(DSP_EINVAL, "NULL argument");
+    if (!m->ws || !m->last_out) return fail(DSP_EINVAL, "no forward has run yet");
+    if (n < 1 || n > m->ws_sites) return fail(DSP_EINVAL, "n_sites out of range");
+    const Dims& d = m->d;
+    const float* src; int F; std::vector<int> map; int Fref;
+    if (which == 0) { src = m->comb_in; F = m->Fcomb; map = m->comb_in_map; Fref = d.H; }
+    else if (which == 1) { src = m->last_out; F = 2 * m->Hp; map = map_bidir(d.H, m->Hp); Fref = 2 * d.H; }
+    else return fail(DSP_EINVAL, "which must be 0 or 1");
+    const long long nt = (n + 31) / 32;
+    std::vector<float> tmp((size_t)nt * d.T * F * 32);
+    int prev = 0;
+    HIP_TRY(hipGetDevice(&prev));
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(hipMemcpy(tmp.data(), src, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+    hipSetDevice(prev);
+    for (long long site = 0; site < n; ++site)
+        for (int t = 0; t < d.T; ++t)
+            for (int f = 0; f < F; ++f) {
+                if (map[f] < 0) continue;
+                const size_t k4 = ((((size_t)(site / 32) * d.T + t) * (F / 4) + f / 4) * 32 + site % 32) * 4 + f % 4;
+                host_out[((size_t)site * d.T + t) * Fref + map[f]] = tmp[k4];
+            }
+    return 0;
+}
+
+int32_t dsp_profile_enable(dsp_model* m, int32_t on) {
+    if (!m) return fail(DSP_EINVAL, "model is NULL");
+    m->prof = on != 0;
+    return 0;
+}
+
+int32_t dsp_profile_read(dsp_model* m, char* names, size_t names_cap, float* ms, int32_t cap) {
+    if (!m) return fail(DSP_EINVAL, "model is NULL");
+    size_t pos = 0;
+    int32_t k = 0;
+    for (const ProfEntry& e : m->prof_entries) {
+        if (k >= cap) break;
+        float t = 0.f;
+        hipError_t err = hipEventElapsedTime(&t, e.a, e.b);
+        if (err != hipSuccess) return fail(DSP_EHIP, "hipEventElapsedTime: %s (synchronise the stream first)", hipGetErrorString(err));
+        ms[k] = t;
+        const size_t len = strlen(e.name) + 1;
+        if (names && pos + len <= names_cap) { memcpy(names + pos, e.name, len); pos += len; }
+        ++k;
+    }
+    return k;
+}
+
+void dsp_model_destroy(dsp_model* m) {
+    if (!m) return;
+    int prev = 0;
+    hipGetDevice(&prev);
+    hipSetDevice(m->device);
+    for (void* p : m->dev_allocs) hipFree(p);
+    if (m->ws) hipFree(m->ws);
+    for (hipEvent_t e : m->event_pool) hipEventDestroy(e);
+    hipSetDevice(prev);
+    delete m;
+}
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+// dsp_kernels.h -- argument blocks shared by the gfx950 kernels (dsp_kernels.hip) and the host side of the
+// C ABI (dsp_capi.cpp).  All activation pointers use the K4 layout  act[tile][t][F/4][32][4]  (fp32).
+#ifndef DSP_KERNELS_H
+#define DSP_KERNELS_H
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+struct PackArgs {
+    const void* kmer;      // [n, T] codes (kdt: DSP_DT_*)
+    const float* means;    // [n, T]
+    const float* stds;     // [n, T]
+    const void* lens;      // [n, T] (ldt)
+    const float* signals;  // [n, T, S]
+    const float* embed;    // [V, E] device copy of embed.weight
+    float* xseq;           // K4, Fseq features (NULL when the module has no seq branch)
+    float* xsig;           // K4, Fsig features (NULL when the module has no signal branch)
+    long long n;           // live sites
+    long long NTp;         // padded tile count (all of it is written; dead sites get zeros)
+    int kdt, ldt;
+    int T, S, E, V;
+    int is_base, is_siglen;
+    int Fseq, Fsig;
+};
+
+struct LstmArgs {
+    const float* x;        // K4 input, Ipad features
+    float* out;            // K4 output, Fout features; this layer writes [dir*Hp, dir*Hp + Hp)
+    const float* wpk0;     // forward  direction A fragments [UT][(Ipad+Hp)/8][4 gates][64 lanes][4]
+    const float* wpk1;     // backward direction
+    const float* bias0;    // forward  b_ih + b_hh, [4][Hp]
+    const float* bias1;
+    const float* h0;       // EXPLICIT: reference layout, already offset to this layer: [2 dirs][n][H]
+    const float* c0;
+    long long n;
+    long long NTp;
+    unsigned long long seed, site_offset;
+    int Ipad, H, Hp, T, Fout;
+    int UT, SG;            // unit tiles (Hp/32), site groups per workgroup; block = 64*UT*SG threads
+    int init_mode;         // DSP_INIT_*
+    int stream_base;       // philox stream of (lstm, layer, dir=0, h): lstm*64 + layer*4
+};
+
+struct LinArgs {
+    const float* x;        // K4 input, Fin features
+    float* out;            // K4 output, Fout features, rows written at feature offset out_off
+    const float* wpk;      // [ORT][Fin/8][64][4]
+    const float* bias;     // [ORT*32]
+    long long ncols;       // NTp * T column blocks of 32 sites
+    int Fin, Fout, out_off, ORT, relu;
+};
+
+struct HeadArgs {
+    const float* x;        // K4 output of the last combined layer, 2*Hp features
+    const float* w1pk;     // fc1 A fragments [Hp/32][2Hp/8][64][4]
+    const float* b1;       // [Hp]
+    const float* w2;       // [C][Hp] (padded columns zero)
+    const float* b2;       // [C]
+    float* logits;         // [n, C] or NULL
+    float* probs;          // [n, C] or NULL
+    uint8_t* labels;       // [n] or NULL
+    long long n;
+    int Hp, T, C;
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+int dsp_k_init(void);
+int dsp_k_pack(const PackArgs* a, hipStream_t s);
+int dsp_k_lstm(const LstmArgs* a, hipStream_t s);
+int dsp_k_linear(const LinArgs* a, hipStream_t s);
+int dsp_k_head(const HeadArgs* a, hipStream_t s);
+#ifdef __cplusplus
+}
+#endif
+
+#endif

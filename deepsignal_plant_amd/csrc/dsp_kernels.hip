@@ -1,0 +1,453 @@
+// dsp_kernels.hip -- hand-written gfx950 (CDNA4) kernels for the deepsignal-plant call_mods forward.
+//
+// Reference arithmetic being implemented: ModelBiLSTM.forward, deepsignal_plant/models.py:178-240
+// (torch.nn.LSTM cell semantics: gates i,f,g,o; both biases; c' = s(f)c + s(i)tanh(g); h' = s(o)tanh(c')).
+//
+// Formulation (see DESIGN.md "Data layout" / "Kernels"):
+//   * Everything is computed TRANSPOSED:  gates^T[4H, sites] = W[4H, K] * act^T[K, sites], so the weight
+//     matrix is the MFMA A operand (pre-packed on the host in fragment order, streamed from L2 with
+//     coalesced 16-B loads) and a 32-site tile is the MFMA N dimension.
+//   * Activations live in the "K4" layout  act[tile][t][F/4][32 sites][4 feats]  (fp32): one float4 per
+//     lane is exactly 4 consecutive k-steps of the B operand of v_mfma_f32_32x32x2_f32, AND exactly what
+//     one lane holds in 4 consecutive accumulator registers of the 32x32 C/D layout
+//     (row = 8*(r/4) + 4*(lane/32) + r%4, col = lane%32).  So a layer's output registers are stored with
+//     plain float4 stores and re-loaded by the next layer / next time step as B fragments with no
+//     transposition, shuffle or bank conflict.
+//   * fp32 MFMA (v_mfma_f32_32x32x2_f32): bf16/fp16 operands break the 1e-4 parity contract on sharp
+//     models, so the binding roofline is the fp32 matrix peak (157.3 TFLOP/s).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dsp_kernels.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// math helpers: v_exp_f32 / v_rcp_f32 based (about 1 ulp each); abs error of sigmoid/tanh ~1e-7
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+    // tanh(x) = 2*sigmoid(2x) - 1 ; exp overflow -> rcp(inf)=0 -> -1 ; underflow -> 2*1-1 = 1
+    return __builtin_fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)), -1.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11) + Box-Muller: the in-kernel stand-in for torch.randn in
+// init_hidden (models.py:169-176).  Key = seed; counter = (site_lo, site_hi, stream, unit/4).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 philox_normal4(uint64_t seed, uint64_t site, uint32_t stream, uint32_t group) {
+    uint32_t c0 = (uint32_t)site, c1 = (uint32_t)(site >> 32), c2 = stream, c3 = group;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    f32x4 o;
+    {
+        const float u1 = ((float)(c0 >> 9) + 0.5f) * (1.0f / 8388608.0f);
+        const float u2 = ((float)(c1 >> 9) + 0.5f) * (1.0f / 8388608.0f);
+        const float r = sqrtf(-2.0f * logf(u1));
+        float s, c;
+        sincosf(6.283185307179586f * u2, &s, &c);
+        o[0] = r * c; o[1] = r * s;
+    }
+    {
+        const float u1 = ((float)(c2 >> 9) + 0.5f) * (1.0f / 8388608.0f);
+        const float u2 = ((float)(c3 >> 9) + 0.5f) * (1.0f / 8388608.0f);
+        const float r = sqrtf(-2.0f * logf(u1));
+        float s, c;
+        sincosf(6.283185307179586f * u2, &s, &c);
+        o[2] = r * c; o[3] = r * s;
+    }
+    return o;
+}
+
+__device__ __forceinline__ float load_code(const void* p, int dt, size_t i) {
+    switch (dt) {
+        case 1: return (float)((const uint8_t*)p)[i];
+        case 2: return (float)((const uint16_t*)p)[i];
+        case 3: return (float)((const int32_t*)p)[i];
+        default: return ((const float*)p)[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pack_kernel: reference-layout feature rows -> K4 activations for the two front-end LSTMs.
+//   seq features (models.py:182-195): [embed(kmer) (E) | mean | std | (len)] zero-padded to Fseq
+//   signal features (models.py:206): signals[.., S] zero-padded to Fsig
+// One thread per (tile, t, site).  HBM-bound, ~1 KB in / ~1.2 KB out per site: negligible.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dsp_pack_kernel(PackArgs a) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int sl = (int)(idx & 31);
+    const long long rem = idx >> 5;
+    const int t = (int)(rem % a.T);
+    const long long tile = rem / a.T;
+    if (tile >= a.NTp) return;
+    const long long site = tile * 32 + sl;
+    const bool live = site < a.n;
+    const size_t r = (size_t)site * a.T + t;
+    if (a.xseq) {
+        float mean = 0.f, sd = 0.f, len = 0.f;
+        long code = 0;
+        if (live) {
+            mean = a.means[r]; sd = a.stds[r];
+            if (a.is_siglen) len = load_code(a.lens, a.ldt, r);
+            if (a.is_base) code = (long)load_code(a.kmer, a.kdt, r);  // kmer.long(): truncation
+        }
+        f32x4* dst = (f32x4*)a.xseq + ((size_t)(tile * a.T + t) * (a.Fseq >> 2)) * 32 + sl;
+        const int E = a.is_base ? a.E : 0;
+        for (int g = 0; g < (a.Fseq >> 2); ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int f = 4 * g + i;
+                float x = 0.f;
+                if (live) {
+                    if (f < E) x = a.embed[(size_t)code * a.E + f];
+                    else if (f == E) x = mean;
+                    else if (f == E + 1) x = sd;
+                    else if (f == E + 2 && a.is_siglen) x = len;
+                }
+                v[i] = x;
+            }
+            dst[(size_t)g * 32] = v;
+        }
+    }
+    if (a.xsig) {
+        f32x4* dst = (f32x4*)a.xsig + ((size_t)(tile * a.T + t) * (a.Fsig >> 2)) * 32 + sl;
+        const float* src = a.signals + r * a.S;
+        for (int g = 0; g < (a.Fsig >> 2); ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int f = 4 * g + i;
+                v[i] = (live && f < a.S) ? src[f] : 0.f;
+            }
+            dst[(size_t)g * 32] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// lstm_dir_kernel: one direction of one LSTM layer, all T steps, for M = 64*SG sites per workgroup.
+//
+//   wave (u, sg): unit tile u (32 hidden units x 4 gates) for site tiles {2sg, 2sg+1} of the workgroup
+//   per step:  acc[g][m] (32 units x 32 sites, 16 regs each) = bias
+//              += W_ih[u,g] * x_t        (B fragments: coalesced float4 loads of the K4 input, via L1/L2)
+//              += W_hh[u,g] * h_{t-1}    (B fragments: ds_read_b128 from the LDS h buffer, conflict-free)
+//              cell update entirely in registers (c never leaves registers for all T steps)
+//              h_t -> LDS (other buffer, ds_write_b128) and -> global K4 output (float4 stores)
+//              one s_barrier per step (double-buffered h)
+//   Weights (A fragments) are streamed from L2 every step with 1-KiB-per-wave coalesced loads; each
+//   weight is used by exactly one wave of the workgroup, so there is no LDS staging for them.
+//   blockIdx.x & 1 = direction: with the observed block -> XCD (b % 8) placement even XCDs run the
+//   forward and odd XCDs the backward direction, so each XCD's 4 MiB L2 holds one direction's weights.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 init_state4(const float* src, int mode, long long n, long long site, int dir, int H,
+                                             int k4, uint64_t seed, uint64_t site_offset, uint32_t stream) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (site >= n || 4 * k4 >= H) return v;
+    if (mode == 1) {
+        const float* p = src + ((size_t)dir * (size_t)n + (size_t)site) * H + 4 * k4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (4 * k4 + i < H) v[i] = p[i];
+    } else if (mode == 2) {
+        v = philox_normal4(seed, site_offset + (uint64_t)site, stream, (uint32_t)k4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (4 * k4 + i >= H) v[i] = 0.f;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(512) void dsp_lstm_dir_kernel(LstmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* hl = (f32x4*)smem;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int u = w % a.UT, sg = w / a.UT;
+    const int dir = blockIdx.x & 1;
+    const int grp = blockIdx.x >> 1;
+    const int half = lane >> 5, ls = lane & 31;
+    const int M = a.SG * 64;
+    const int HQ = a.Hp >> 2;
+    const int nqx = a.Ipad >> 3, nqh = a.Hp >> 3, nq = nqx + nqh;
+    const int T = a.T;
+
+    const f32x4* wq = (const f32x4*)(dir ? a.wpk1 : a.wpk0) + (size_t)u * nq * 256 + lane;  // + q*256 + g*64
+    const f32x4* bias4 = (const f32x4*)(dir ? a.bias1 : a.bias0);
+    const f32x4* x4 = (const f32x4*)a.x;
+    f32x4* out4 = (f32x4*)a.out;
+
+    int lt[2];
+    long long gt[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        lt[m] = sg * 2 + m;
+        gt[m] = (long long)grp * (a.SG * 2) + lt[m];
+    }
+
+    // ---- initial state: h0 -> LDS buffer 0, c0 -> registers (same (unit, site) mapping as the accumulators)
+    f32x16 c[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const long long site = gt[m] * 32 + ls;
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa) {
+            const int k4 = u * 8 + 2 * aa + half;
+            f32x4 hv = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
+            if (a.init_mode != 0) {
+                hv = init_state4(a.h0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, a.site_offset,
+                                 (uint32_t)(a.stream_base + dir * 2 + 0));
+                cv = init_state4(a.c0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, a.site_offset,
+                                 (uint32_t)(a.stream_base + dir * 2 + 1));
+            }
+            hl[(size_t)k4 * M + lt[m] * 32 + ls] = hv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c[m][4 * aa + i] = cv[i];
+        }
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? (T - 1 - step) : step;
+
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa) {
+                const f32x4 b = bias4[g * HQ + u * 8 + 2 * aa + half];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[g][0][4 * aa + i] = b[i];
+                    acc[g][1][4 * aa + i] = b[i];
+                }
+            }
+        }
+
+        const f32x4* xb0 = x4 + ((size_t)(gt[0] * T + t) * (a.Ipad >> 2) + half) * 32 + ls;  // + q*64
+        const f32x4* xb1 = x4 + ((size_t)(gt[1] * T + t) * (a.Ipad >> 2) + half) * 32 + ls;
+        const f32x4* hb0 = hl + (size_t)(cur * HQ + half) * M + lt[0] * 32 + ls;  // + q*2*M
+        const f32x4* hb1 = hl + (size_t)(cur * HQ + half) * M + lt[1] * 32 + ls;
+
+        // software pipeline: fragments for k-group q+1 are loaded while the 32 MFMAs of q issue
+        f32x4 An[4], Bn[2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) An[g] = wq[g * 64];
+        if (nqx > 0) { Bn[0] = xb0[0]; Bn[1] = xb1[0]; }
+        else { Bn[0] = hb0[0]; Bn[1] = hb1[0]; }
+
+        for (int q = 0; q < nq; ++q) {
+            f32x4 A[4], B[2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) A[g] = An[g];
+            B[0] = Bn[0]; B[1] = Bn[1];
+            const int qn = q + 1;
+            if (qn < nq) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) An[g] = wq[(size_t)qn * 256 + g * 64];
+                if (qn < nqx) { Bn[0] = xb0[(size_t)qn * 64]; Bn[1] = xb1[(size_t)qn * 64]; }
+                else { Bn[0] = hb0[(size_t)(qn - nqx) * 2 * M]; Bn[1] = hb1[(size_t)(qn - nqx) * 2 * M]; }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    acc[g][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g][i], B[0][i], acc[g][0], 0, 0, 0);
+                    acc[g][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g][i], B[1][i], acc[g][1], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- LSTM cell (registers only) + h_t -> LDS[next] and global K4 output
+        const int nxt = cur ^ 1;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa) {
+                f32x4 hv;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 4 * aa + i;
+                    const float ig = fast_sigmoid(acc[0][m][r]);
+                    const float fg = fast_sigmoid(acc[1][m][r]);
+                    const float gg = fast_tanh(acc[2][m][r]);
+                    const float og = fast_sigmoid(acc[3][m][r]);
+                    const float cn = __builtin_fmaf(fg, c[m][r], ig * gg);
+                    c[m][r] = cn;
+                    hv[i] = og * fast_tanh(cn);
+                }
+                const int k4 = u * 8 + 2 * aa + half;
+                hl[(size_t)(nxt * HQ + k4) * M + lt[m] * 32 + ls] = hv;
+                out4[((size_t)(gt[m] * T + t) * (a.Fout >> 2) + (size_t)(dir * HQ + k4)) * 32 + ls] = hv;
+            }
+        }
+        __syncthreads();
+        cur = nxt;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// linear_kernel: out[., out_off + o] = act( W[o,:] . x[., :] + b[o] ) on K4 activations, per (tile, t)
+// column block of 32 sites.  Used for fc_seq / fc_signal (+ReLU; models.py:199-201, :215-217).
+// One wave = one 32-row output tile; 4 waves of a block share the same B fragments through L1.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dsp_linear_kernel(LinArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rt = blockIdx.y * 4 + w;
+    if (rt >= a.ORT) return;
+    const int half = lane >> 5, ls = lane & 31;
+    const size_t col = blockIdx.x;
+    const int nq = a.Fin >> 3;
+    const f32x4* wq = (const f32x4*)a.wpk + (size_t)rt * nq * 64 + lane;
+    const f32x4* xb = (const f32x4*)a.x + (col * (a.Fin >> 2) + half) * 32 + ls;
+    const f32x4* bias4 = (const f32x4*)a.bias;
+    f32x16 acc;
+#pragma unroll
+    for (int aa = 0; aa < 4; ++aa) {
+        const f32x4 b = bias4[rt * 8 + 2 * aa + half];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[4 * aa + i] = b[i];
+    }
+    for (int q = 0; q < nq; ++q) {
+        const f32x4 A = wq[(size_t)q * 64];
+        const f32x4 B = xb[(size_t)q * 64];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[i], B[i], acc, 0, 0, 0);
+    }
+    f32x4* out4 = (f32x4*)a.out + (col * (a.Fout >> 2) + (a.out_off >> 2) + rt * 8 + half) * 32 + ls;
+#pragma unroll
+    for (int aa = 0; aa < 4; ++aa) {
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float y = acc[4 * aa + i];
+            v[i] = a.relu ? fmaxf(y, 0.f) : y;
+        }
+        out4[(size_t)aa * 2 * 32] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// head_kernel: [h_fwd(t=T-1) | h_bwd(t=0)] -> fc1 + ReLU -> fc2 -> softmax (+argmax)
+// (models.py:229-240; dropouts are identity in eval).  One workgroup per 32-site tile.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dsp_head_kernel(HeadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* hid = smem;                 // [Hp][32]
+    float* lg = smem + a.Hp * 32;      // [C][32]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, ls = lane & 31;
+    const size_t tile = blockIdx.x;
+    const int F4 = (2 * a.Hp) >> 2;
+    const int nq = (2 * a.Hp) >> 3;
+    const int nqf = a.Hp >> 3;  // k-groups that come from the forward half (t = T-1)
+    const f32x4* x4 = (const f32x4*)a.x;
+    const f32x4* xf = x4 + ((tile * a.T + (a.T - 1)) * F4 + half) * 32 + ls;
+    const f32x4* xr = x4 + ((tile * a.T + 0) * F4 + half) * 32 + ls;
+    const f32x4* bias4 = (const f32x4*)a.b1;
+    for (int rt = w; rt < (a.Hp >> 5); rt += 4) {
+        const f32x4* wq = (const f32x4*)a.w1pk + (size_t)rt * nq * 64 + lane;
+        f32x16 acc;
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa) {
+            const f32x4 b = bias4[rt * 8 + 2 * aa + half];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[4 * aa + i] = b[i];
+        }
+        for (int q = 0; q < nq; ++q) {
+            const f32x4 A = wq[(size_t)q * 64];
+            const f32x4 B = (q < nqf) ? xf[(size_t)q * 64] : xr[(size_t)q * 64];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[i], B[i], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+            hid[row * 32 + ls] = fmaxf(acc[r], 0.f);
+        }
+    }
+    __syncthreads();
+    for (int cc = tid >> 5; cc < a.C; cc += 8) {
+        const float* w2 = a.w2 + (size_t)cc * a.Hp;
+        float s = 0.f;
+        for (int k = 0; k < a.Hp; ++k) s = __builtin_fmaf(hid[k * 32 + ls], w2[k], s);
+        lg[cc * 32 + ls] = s + a.b2[cc];
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const long long site = (long long)tile * 32 + tid;
+        if (site < a.n) {
+            float mx = -INFINITY;
+            for (int cc = 0; cc < a.C; ++cc) mx = fmaxf(mx, lg[cc * 32 + tid]);
+            float sum = 0.f;
+            for (int cc = 0; cc < a.C; ++cc) sum += expf(lg[cc * 32 + tid] - mx);
+            const float inv = 1.0f / sum;
+            int best = 0;
+            float bp = -1.f;
+            for (int cc = 0; cc < a.C; ++cc) {
+                const float l = lg[cc * 32 + tid];
+                const float p = expf(l - mx) * inv;
+                if (a.logits) a.logits[(size_t)site * a.C + cc] = l;
+                if (a.probs) a.probs[(size_t)site * a.C + cc] = p;
+                if (p > bp) { bp = p; best = cc; }  // first maximum, as torch.max(dim) (call_modifications.py:163)
+            }
+            if (a.labels) a.labels[site] = (uint8_t)best;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers (called from dsp_capi.cpp; keep all <<<>>> syntax in this translation unit)
+// ------------------------------------------------------------------------------------------------
+extern "C" int dsp_k_init(void) {
+    hipError_t e = hipFuncSetAttribute((const void*)dsp_lstm_dir_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)dsp_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    return (int)e;
+}
+
+extern "C" int dsp_k_pack(const PackArgs* a, hipStream_t s) {
+    const long long threads = (long long)a->NTp * a->T * 32;
+    const unsigned blocks = (unsigned)((threads + 255) / 256);
+    hipLaunchKernelGGL(dsp_pack_kernel, dim3(blocks), dim3(256), 0, s, *a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
+    const int waves = a->UT * a->SG;
+    const int M = a->SG * 64;
+    const size_t lds = (size_t)2 * a->Hp * M * sizeof(float);
+    const unsigned groups = (unsigned)(a->NTp / (a->SG * 2));
+    hipLaunchKernelGGL(dsp_lstm_dir_kernel, dim3(groups * 2), dim3(waves * 64), lds, s, *a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dsp_k_linear(const LinArgs* a, hipStream_t s) {
+    hipLaunchKernelGGL(dsp_linear_kernel, dim3((unsigned)a->ncols, (unsigned)((a->ORT + 3) / 4)), dim3(256), 0, s, *a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dsp_k_head(const HeadArgs* a, hipStream_t s) {
+    const size_t lds = (size_t)(a->Hp * 32 + a->C * 32) * sizeof(float);
+    const unsigned tiles = (unsigned)((a->n + 31) / 32);
+    hipLaunchKernelGGL(dsp_head_kernel, dim3(tiles), dim3(256), lds, s, *a);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,136 @@
+/*
+ * dsp_amd.h -- C ABI of libdsp_amd.so: the MI355X (gfx950) implementation of the
+ * `deepsignal_plant call_mods` hot path (feature rows -> ModelBiLSTM forward -> per-site calls).
+ *
+ * The reference (PengNi/deepsignal-plant, pure Python) exposes no FFI; the seam this library sits
+ * behind is the Python call at deepsignal_plant/call_modifications.py:159-163 plus the checkpoint
+ * contract at :214-228.  Each entry point cites the reference interface it
+ * replaces.  Plain pointers and sizes only; no torch types.  All device pointers are caller-owned
+ * (e.g. torch.Tensor.data_ptr() on PyTorch-ROCm); the handle owns only repacked weights + scratch.
+ *
+ * Return convention: 0 on success, negative dsp_status on error; dsp_last_error() returns a
+ * thread-local message.  The Python mirror maps DSP_EINVAL -> ValueError, the rest -> RuntimeError,
+ * matching the exceptions the reference raises (models.py:127-128, call_modifications.py:219-223).
+ */
+#ifndef DSP_AMD_H
+#define DSP_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSP_AMD_ABI_VERSION 1
+
+typedef enum dsp_status {
+    DSP_OK = 0,
+    DSP_EINVAL = -1,      /* bad argument / unsupported configuration (reference: ValueError) */
+    DSP_ESHAPE = -2,      /* weight count/shape mismatch (reference: strict load_state_dict RuntimeError) */
+    DSP_EHIP = -3,        /* HIP runtime error (message carries hipGetErrorString) */
+    DSP_ENOMEM = -4,      /* host or device allocation failure */
+    DSP_EPARSE = -5       /* malformed feature row (reference: KeyError/ValueError in the row parser) */
+} dsp_status;
+
+/* module codes: ModelBiLSTM(module=...) at deepsignal_plant/models.py:120-128 */
+enum { DSP_MODULE_BOTH = 0, DSP_MODULE_SEQ = 1, DSP_MODULE_SIGNAL = 2 };
+
+/* element types accepted for the kmer-code and signal-length inputs.  The reference feeds both as
+ * float32 and casts inside forward (models.py:182-186); compact types are the fast path. */
+enum { DSP_DT_F32 = 0, DSP_DT_U8 = 1, DSP_DT_U16 = 2, DSP_DT_I32 = 3 };
+
+/* LSTM initial-state policy.  The reference draws h0,c0 ~ N(0,1) with torch.randn on every forward
+ * (models.py:169-176).  EXPLICIT pins them (parity runs); PHILOX is the in-kernel counter-based
+ * stand-in (Philox4x32-10 + Box-Muller keyed by seed, global site index, stream, unit/4). */
+enum { DSP_INIT_ZEROS = 0, DSP_INIT_EXPLICIT = 1, DSP_INIT_PHILOX = 2 };
+
+/* Constructor arguments of ModelBiLSTM, deepsignal_plant/models.py:103-106 (dropout_rate and device
+ * excluded: dropout is identity at inference, call_modifications.py:228/:677; device is an argument
+ * of dsp_model_create). */
+typedef struct dsp_model_cfg {
+    int32_t seq_len;        /* --seq_len, default 13 */
+    int32_t signal_len;     /* --signal_len, default 16 */
+    int32_t num_layers1;    /* --layernum1: combined BiLSTM layers, default 3 */
+    int32_t num_layers2;    /* --layernum2: seq / signal BiLSTM layers, default 1 */
+    int32_t num_classes;    /* --class_num, default 2 */
+    int32_t hidden_size;    /* --hid_rnn, default 256 (this build: <= 256) */
+    int32_t vocab_size;     /* --n_vocab, default 16 */
+    int32_t embedding_size; /* --n_embed, default 4 */
+    int32_t is_base;        /* --is_base */
+    int32_t is_signallen;   /* --is_signallen */
+    int32_t module;         /* DSP_MODULE_* */
+} dsp_model_cfg;
+
+typedef struct dsp_init_state {
+    int32_t mode;           /* DSP_INIT_* */
+    uint64_t seed;          /* PHILOX key */
+    uint64_t site_offset;   /* PHILOX: global index of site 0 of this call (range-sharding keeps results
+                               independent of how sites are split over GPUs / batches) */
+    /* EXPLICIT: device pointers in the reference layout (2*num_layers, n_sites, H) fp32, i.e. what
+     * init_hidden returns at models.py:196-198 (seq), :212-214 (signal), :226-228 (comb).  Unused
+     * branches may be NULL. */
+    const float* h_seq;  const float* c_seq;
+    const float* h_sig;  const float* c_sig;
+    const float* h_comb; const float* c_comb;
+} dsp_init_state;
+
+typedef struct dsp_model dsp_model; /* opaque handle: repacked weights + scratch, bound to one device */
+
+/* Number of weight tensors / name and shape of tensor `idx` in the reference's state_dict order
+ * (49 tensors for the default both_bilstm: SURVEY.md 8(b)).  Lets a binding validate a checkpoint
+ * the way strict load_state_dict does (call_modifications.py:219-223). */
+int32_t dsp_weight_count(const dsp_model_cfg* cfg);
+int32_t dsp_weight_spec(const dsp_model_cfg* cfg, int32_t idx, char* name, size_t name_cap, int64_t shape[2],
+                        int32_t* ndim);
+
+/* Algorithmic FLOPs per site (2 x MAC; SURVEY.md 8(d): 118,447,104 for the default model). */
+int64_t dsp_flops_per_site(const dsp_model_cfg* cfg);
+
+/* Replaces: ModelBiLSTM(...) + load_state_dict + .cuda(device) + .eval()
+ * (call_modifications.py:214-228).  host_weights[i] / numels[i]: fp32 tensors in state_dict order,
+ * contiguous, HOST memory.  Repacks once (transpose into MFMA fragment order, pre-summed biases)
+ * and uploads once. */
+int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weights, const int64_t* numels,
+                         int32_t n_weights, int32_t device, dsp_model** out);
+
+/* Pre-size the scratch for batches up to max_sites (no allocation happens inside dsp_forward unless a
+ * larger batch arrives, in which case the scratch grows once, synchronously). */
+int32_t dsp_model_reserve(dsp_model* m, int64_t max_sites);
+size_t dsp_workspace_bytes(const dsp_model* m, int64_t max_sites);
+
+/* Replaces: logits, probs = model(kmer, base_means, base_stds, base_signal_lens, signals)
+ * (call_modifications.py:159-162 -> models.py:178-240) and the argmax at :163.
+ *   kmer    [n, seq_len]              codes 0..vocab-1, dtype kmer_dtype (DSP_DT_*)
+ *   means, stds [n, seq_len]          fp32
+ *   lens    [n, seq_len]              dtype lens_dtype
+ *   signals [n, seq_len, signal_len]  fp32
+ *   logits, probs [n, num_classes]    fp32 (either may be NULL);  labels [n] uint8 argmax (may be NULL)
+ * All pointers are DEVICE pointers on the handle's device.  Asynchronous on `stream` (hipStream_t);
+ * unused inputs of a branch that the module does not have may be NULL. */
+int32_t dsp_forward(dsp_model* m, void* stream, int64_t n_sites, const void* kmer, int32_t kmer_dtype,
+                    const float* means, const float* stds, const void* lens, int32_t lens_dtype,
+                    const float* signals, const dsp_init_state* init, float* logits, float* probs,
+                    uint8_t* labels);
+
+/* Bring-up / test hook: copy an intermediate activation of the LAST dsp_forward into HOST memory in the
+ * reference layout [n_sites, seq_len, features].  which: 0 = combined-LSTM input (relu(fc_seq) |
+ * relu(fc_signal), models.py:225 input), 1 = last combined-LSTM layer output [.., 2*hidden]
+ * (models.py:226-228 output).  Synchronises the stream. */
+int32_t dsp_debug_read_activation(dsp_model* m, void* stream, int32_t which, int64_t n_sites, float* host_out);
+
+/* Per-kernel timing of the LAST dsp_forward measured with HIP events on the launch stream (used by
+ * bench.py for the roofline line).  Enable before the forward; read after stream sync.
+ * names: NUL-separated list written into `names`; ms[i] per launch. Returns the launch count. */
+int32_t dsp_profile_enable(dsp_model* m, int32_t on);
+int32_t dsp_profile_read(dsp_model* m, char* names, size_t names_cap, float* ms, int32_t cap);
+
+void dsp_model_destroy(dsp_model* m);
+
+const char* dsp_last_error(void);
+int32_t dsp_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSP_AMD_H */

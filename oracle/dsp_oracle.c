@@ -54,8 +54,9 @@ static void philox_normal4(uint64_t seed, uint64_t site, uint32_t stream, uint32
     uint32_t c[4] = {(uint32_t)site, (uint32_t)(site >> 32), stream, group};
     philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
     for (int p = 0; p < 2; ++p) {
-        double u1 = ((double)(c[2 * p] >> 8) + 0.5) * (1.0 / 16777216.0);
-        double u2 = ((double)(c[2 * p + 1] >> 8) + 0.5) * (1.0 / 16777216.0);
+        /* 23 random bits + 0.5: exactly representable in fp32 too, so a float implementation sees the same u */
+        double u1 = ((double)(c[2 * p] >> 9) + 0.5) * (1.0 / 8388608.0);
+        double u2 = ((double)(c[2 * p + 1] >> 9) + 0.5) * (1.0 / 8388608.0);
         double r = sqrt(-2.0 * log(u1));
         double th = 6.283185307179586476925 * u2;
         out[2 * p] = (float)(r * cos(th));

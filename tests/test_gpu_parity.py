@@ -1,0 +1,136 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden fixtures captured from the reference
+and against the CPU oracle on seeded inputs.  Contract (BASELINE.json north_star): per-site probabilities
+within 1e-4 (fp32) of the reference forward on identical feature rows with pinned initial states."""
+import numpy as np
+import pytest
+
+from tests.helpers import f1_names, load_f1
+
+pytestmark = pytest.mark.gpu
+
+TOL_PROB = 1e-4   # the contract
+TOL_TIGHT = 2e-5  # what fp32 MFMA + v_exp/v_rcp actually achieves; a regression guard
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def build_model(cfg, w, **kw):
+    torch = _torch()
+    from deepsignal_plant_amd.models import ModelBiLSTM
+    m = ModelBiLSTM(cfg.seq_len, cfg.signal_len, cfg.num_layers1, cfg.num_layers2, cfg.num_classes, 0,
+                    cfg.hidden_size, cfg.vocab_size, cfg.embedding_size, cfg.is_base, cfg.is_signallen,
+                    module=cfg.module, device=0, **kw)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    return m.cuda(0).eval()
+
+
+def to_dev(arrs):
+    torch = _torch()
+    return [torch.from_numpy(np.ascontiguousarray(a)).cuda(0) for a in arrs]
+
+
+@pytest.mark.parametrize("name", f1_names())
+def test_hip_matches_reference_fixture(name):
+    torch = _torch()
+    f = load_f1(name)
+    m = build_model(f["cfg"], f["w"])
+    st = {k: torch.from_numpy(v).cuda(0) for k, v in f["states"].items()}
+    logits, probs, labels = m.forward(*to_dev(f["inputs"]), init_states=st, want_labels=True)
+    torch.cuda.synchronize()
+    dp = np.abs(probs.cpu().numpy() - f["probs"]).max()
+    dl = np.abs(logits.cpu().numpy() - f["logits"]).max()
+    print(name, "max|dprob| %.2e max|dlogit| %.2e" % (dp, dl))
+    assert dp <= TOL_PROB
+    assert dp <= TOL_TIGHT
+    # labels identical except where |p1 - 0.5| < 1e-4
+    ref_lab = f["probs"].argmax(1)
+    sure = np.abs(f["probs"][:, 1] - 0.5) >= 1e-4 if f["probs"].shape[1] == 2 else np.ones(len(ref_lab), bool)
+    assert np.array_equal(labels.cpu().numpy()[sure], ref_lab[sure])
+    # intermediates recorded from the reference through forward hooks (first 8 sites)
+    if "lstm_comb" in f["inter"]:
+        got = m.debug_activation(1, f["n"])[: f["inter"]["lstm_comb"].shape[0]]
+        assert np.abs(got - f["inter"]["lstm_comb"]).max() <= 5e-5
+    if f["cfg"].module == "both_bilstm" and "relu_seq" in f["inter"]:
+        got = m.debug_activation(0, f["n"])[: f["inter"]["relu_seq"].shape[0]]
+        ref = np.concatenate((f["inter"]["relu_seq"], f["inter"]["relu_signal"]), axis=2)
+        assert np.abs(got - ref).max() <= 5e-5
+
+
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 64, 513, 2000])
+def test_hip_matches_oracle_ragged_sizes_philox(n):
+    """ragged batch sizes (tile tails), in-kernel Philox initial states vs the oracle's same generator"""
+    torch = _torch()
+    from oracle import c_oracle as oc
+    from oracle import forward_np as onp
+    cfg = onp.OracleConfig()
+    w = onp.make_weights(cfg, 21, 2.0)
+    ins = onp.make_inputs(cfg, n, 22)
+    m = build_model(cfg, w, init_state="randn", seed=99)
+    m.site_offset = 1000
+    logits, probs = m(*to_dev(ins))
+    torch.cuda.synchronize()
+    lo, po = oc.forward(cfg, w, *ins, init_mode="philox", seed=99, site_offset=1000)
+    assert np.abs(probs.cpu().numpy() - po).max() <= TOL_TIGHT
+
+
+def test_compact_dtypes_and_zero_states_match_float_path():
+    torch = _torch()
+    from oracle import c_oracle as oc
+    from oracle import forward_np as onp
+    cfg = onp.OracleConfig()
+    w = onp.make_weights(cfg, 31, 1.0)
+    n = 300
+    kmer, means, stds, lens, signals = onp.make_inputs(cfg, n, 32, wide_alphabet=True)
+    m = build_model(cfg, w, init_state="zeros")
+    a = m(*to_dev([kmer, means, stds, lens, signals]))[1]
+    b = m(*to_dev([kmer.astype(np.uint8), means, stds, lens.astype(np.uint16), signals]))[1]
+    c = m(*to_dev([kmer.astype(np.int32), means, stds, lens.astype(np.int32), signals]))[1]
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(a, c)
+    lo, po = oc.forward(cfg, w, kmer, means, stds, lens, signals, init_mode="zeros")
+    assert np.abs(a.cpu().numpy() - po).max() <= TOL_TIGHT
+
+
+def test_determinism_and_batch_split_invariance():
+    """same input twice -> bit-identical (catches LDS races); splitting a batch -> identical per-site
+    results when the Philox site offset follows the split (what range-sharding relies on)"""
+    torch = _torch()
+    from oracle import forward_np as onp
+    cfg = onp.OracleConfig()
+    w = onp.make_weights(cfg, 41, 3.0)
+    n = 1000
+    ins = to_dev(onp.make_inputs(cfg, n, 42))
+    m = build_model(cfg, w, init_state="randn", seed=5)
+    p1 = m(*ins)[1].clone()
+    p2 = m(*ins)[1].clone()
+    assert torch.equal(p1, p2)
+    cut = 389
+    m.site_offset = 0
+    pa = m(*[t[:cut] for t in ins])[1].clone()
+    m.site_offset = cut
+    pb = m(*[t[cut:] for t in ins])[1].clone()
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat((pa, pb)), p1)
+
+
+def test_errors_are_loud():
+    torch = _torch()
+    from deepsignal_plant_amd.models import ModelBiLSTM
+    from oracle import forward_np as onp
+    with pytest.raises(ValueError):
+        ModelBiLSTM(module="bogus")
+    with pytest.raises(ValueError):
+        ModelBiLSTM(hidden_size=512).cuda(0)
+    cfg = onp.OracleConfig()
+    m = build_model(cfg, onp.make_weights(cfg, 1))
+    cpu_ins = [torch.from_numpy(a) for a in onp.make_inputs(cfg, 4, 2)]
+    with pytest.raises(RuntimeError):
+        m(*cpu_ins)
+    sd = m.state_dict()
+    sd["fc1.weight"] = sd["fc1.weight"][:, :10]
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(sd)
