@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py -- methylation sites/s of the call_mods forward (both_bilstm bn13_sn16) on N x MI355X.
+
+A "step" is one pass of the hot path over one batch of 65,536 synthetic sites whose feature tensors are
+already resident in HBM (BASELINE.json configs[1]: 10M synthetic sites, fp32, batch 65536; 153 steps =
+10,027,008 sites).  Sites are independent, so N GPUs range-shard the site index space with no data-path
+collective ("weak" scaling: every rank runs K steps of its own range).  One JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH = 65536
+FP32_MATRIX_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+CPU_BASELINE_TARGET_S = 15.0
+
+
+def cpu_baseline(model_cfg_kwargs, sd_numpy, seed):
+    """The oracle's C port (oracle/dsp_oracle.c, OpenMP over site blocks) timed on this box's host cores on
+    a bounded sample of the same workload (same weights, same synthetic row statistics, batch semantics are
+    irrelevant on the CPU: sites are independent)."""
+    import numpy as np
+    from oracle import c_oracle as oc
+    from oracle import forward_np as onp
+    cfg = onp.OracleConfig(**model_cfg_kwargs)
+    threads = oc.num_threads()
+    probe = 32 * max(1, threads)
+    ins = onp.make_inputs(cfg, probe, 7)
+    t0 = time.time()
+    oc.forward(cfg, sd_numpy, *ins, init_mode="philox", seed=seed)
+    rate = probe / max(time.time() - t0, 1e-6)
+    n = int(max(probe, min(rate * CPU_BASELINE_TARGET_S, 1 << 20)))
+    n = (n + 15) // 16 * 16
+    ins = onp.make_inputs(cfg, n, 8)
+    t0 = time.time()
+    oc.forward(cfg, sd_numpy, *ins, init_mode="philox", seed=seed)
+    dt = time.time() - t0
+    return {"value": round(n / dt, 1), "unit": "sites/s", "cores": threads, "kind": "port",
+            "sample": "%d synthetic sites (same model/weights/row statistics), oracle/dsp_oracle.c fp32 + OpenMP, %.1f s"
+                      % (n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=153)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--model_type", default="both_bilstm")
+    ap.add_argument("--layernum1", type=int, default=3)
+    ap.add_argument("--hid_rnn", type=int, default=256)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--gather", action="store_true", help="optional final RCCL all_gather of per-site probs")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from deepsignal_plant_amd import synth
+    from deepsignal_plant_amd.models import ModelBiLSTM
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    K, W, B = args.steps, args.warmup, args.batch
+    model = ModelBiLSTM(13, 16, args.layernum1, 1, 2, 0, args.hid_rnn, 16, 4, True, True, module=args.model_type,
+                        device=local_rank, init_state="randn", seed=2024)
+    sd = synth.random_state_dict(model, seed=1234)
+    model.load_state_dict(sd)
+    model.cuda(local_rank).eval()
+    model.reserve(B)
+    flops_site = model.flops_per_site()
+
+    # resident synthetic input: distinct batches (up to 160 = 10.9 GB); more steps cycle over them
+    nb = min(K, 160) if K > 0 else 1
+    batches = [synth.feature_batch(B, device=str(dev), seed=1000 * rank + i) for i in range(nb)]
+    site0 = rank * K * B  # this rank's range of the global site index space
+    outs = None
+
+    def step(i):
+        model.site_offset = site0 + i * B
+        return model(*batches[i % nb])
+
+    for i in range(W):
+        step(i)
+    torch.cuda.synchronize()
+    model.profile(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K):
+        outs = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = model.profile_read()
+    model.profile(False)
+
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        if args.gather:
+            gathered = [torch.empty_like(outs[1]) for _ in range(world)]
+            dist.all_gather(gathered, outs[1])
+    assert outs is not None and bool(torch.isfinite(outs[1]).all())
+
+    if rank == 0:
+        total_sites = world * K * B
+        value = total_sites / dt
+        # roofline of the dominant kernel, dsp_lstm_dir_kernel (all LSTM launches of the timed region)
+        lstm_ms = [ms for name, ms in prof if name.startswith("lstm")]
+        all_ms = sum(ms for _, ms in prof)
+        lstm_flops_site = flops_site - _non_lstm_flops(model)
+        n_lstm = max(len(lstm_ms), 1)
+        avg_ms = sum(lstm_ms) / n_lstm
+        flops_per_launch = lstm_flops_site * B * K / n_lstm
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        line = {
+            "metric": "methylation sites/sec, both_bilstm bn13_sn16", "value": round(value, 1), "unit": "sites/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / max(K, 1) * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%d synthetic sites, %s bn13_sn16 fp32, batch %d on %dxMI355X (BASELINE.json configs[1])"
+                                   % (total_sites, args.model_type, B, world),
+                       "batch": B, "sites": total_sites, "layernum1": args.layernum1, "hid_rnn": args.hid_rnn,
+                       "init_state": "in-kernel Philox N(0,1) (stand-in for torch.randn, models.py:169-176)",
+                       "weights": "seeded random state_dict, PyTorch default-init scale", "parallelism": "range-shard x%d" % world,
+                       "flops_per_site": flops_site},
+            "roofline": {"bound": "mfma", "kernel": "dsp_lstm_dir_kernel", "achieved": round(achieved, 2),
+                         "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4),
+                         "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": len(lstm_ms),
+                         "flops_per_launch": flops_per_launch,
+                         "whole_forward_tflops": round(value / world * flops_site / 1e12, 2),
+                         "hbm_gbps_algorithmic": round(value / world * 1048 / 1e9, 3),
+                         "kernel_time_frac_of_wall": round(all_ms * 1e-3 / dt, 4)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                kw = dict(num_layers1=args.layernum1, hidden_size=args.hid_rnn, module=args.model_type)
+                line["cpu_baseline"] = cpu_baseline(kw, {k: v.numpy() for k, v in sd.items()}, 2024)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                line["cpu_baseline"] = {"value": None, "unit": "sites/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _non_lstm_flops(model):
+    h, L, c = model.hidden_size, model.seq_len, model.num_classes
+    mac = h * 2 * h + c * h
+    if model.module == "both_bilstm":
+        hs = h // 2
+        hg = h - hs
+        mac += L * hs * 2 * hs + L * hg * 2 * hg
+    else:
+        mac += L * h * 2 * h
+    return 2 * mac
+
+
+if __name__ == "__main__":
+    main()

@@ -37,6 +37,10 @@ def lib():
         raise RuntimeError(
             "libdsp_amd.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    # PyTorch-ROCm bundles its own libamdhip64.so (SONAME libamdhip64.so.7).  Import torch FIRST so that
+    # libdsp_amd.so's NEEDED libamdhip64.so.7 resolves to the already-loaded runtime; loading ours first
+    # would leave two HIP runtimes in one process (the second one reports "no ROCm-capable device").
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     L.dsp_last_error.restype = ctypes.c_char_p
     L.dsp_abi_version.restype = ctypes.c_int32

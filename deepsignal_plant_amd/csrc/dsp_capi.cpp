@@ -500,8 +500,8 @@ int32_t dsp_forward(dsp_model* m, void* stream, int64_t n, const void* kmer, int
     const long long cap_NTp = m->NTp;
     m->NTp = NTp;
 
-    m->prof_entries.clear();
-    m->event_used = 0;
+    // profiling entries accumulate across forwards until dsp_profile_read() drains them
+    if (!m->prof) { m->prof_entries.clear(); m->event_used = 0; }
     Launcher L{m, s};
 
     PackArgs p{};
@@ -588,6 +588,8 @@ int32_t dsp_profile_read(dsp_model* m, char* names, size_t names_cap, float* ms,
         if (names && pos + len <= names_cap) { memcpy(names + pos, e.name, len); pos += len; }
         ++k;
     }
+    m->prof_entries.clear();
+    m->event_used = 0;
     return k;
 }
 

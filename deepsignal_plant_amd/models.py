@@ -227,9 +227,11 @@ class ModelBiLSTM(object):
         nat.check(nat.lib().dsp_profile_enable(self._handle, int(bool(on))))
 
     def profile_read(self):
-        """[(kernel name, ms)] of the last forward (HIP events on the launch stream; sync first)."""
-        names = ctypes.create_string_buffer(4096)
-        ms = (ctypes.c_float * 64)()
-        k = nat.check(nat.lib().dsp_profile_read(self._handle, names, 4096, ms, 64))
+        """[(launch name, ms)] of every launch since profiling was enabled / last read (HIP events on the
+        launch stream; synchronise first)."""
+        cap = 1 << 16
+        names = ctypes.create_string_buffer(cap * 12)
+        ms = (ctypes.c_float * cap)()
+        k = nat.check(nat.lib().dsp_profile_read(self._handle, names, cap * 12, ms, cap))
         raw = names.raw.split(b"\0")
         return [(raw[i].decode(), float(ms[i])) for i in range(k)]

@@ -119,8 +119,9 @@ int32_t dsp_forward(dsp_model* m, void* stream, int64_t n_sites, const void* kme
  * (models.py:226-228 output).  Synchronises the stream. */
 int32_t dsp_debug_read_activation(dsp_model* m, void* stream, int32_t which, int64_t n_sites, float* host_out);
 
-/* Per-kernel timing of the LAST dsp_forward measured with HIP events on the launch stream (used by
- * bench.py for the roofline line).  Enable before the forward; read after stream sync.
+/* Per-kernel timing measured with HIP events on the launch stream (used by bench.py for the roofline
+ * line).  While enabled, every launch of every dsp_forward is bracketed by two events; entries
+ * accumulate until dsp_profile_read() drains them (call it after synchronising the stream).
  * names: NUL-separated list written into `names`; ms[i] per launch. Returns the launch count. */
 int32_t dsp_profile_enable(dsp_model* m, int32_t on);
 int32_t dsp_profile_read(dsp_model* m, char* names, size_t names_cap, float* ms, int32_t cap);
