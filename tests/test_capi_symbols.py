@@ -1,0 +1,70 @@
+"""CPU: the C-ABI library loads and exports every symbol include/dsp_amd.h declares (no compute calls),
+and its metadata entry points agree with the oracle's spec."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "dsp_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dsp_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from deepsignal_plant_amd import _native
+    lib = _native.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 10
+    for s in syms:
+        assert hasattr(lib, s), "libdsp_amd.so does not export %s" % s
+    assert lib.dsp_abi_version() == 1
+
+
+def test_weight_spec_and_flops_match_oracle_spec():
+    from deepsignal_plant_amd.models import ModelBiLSTM
+    from oracle import forward_np as onp
+    for kw in (dict(), dict(module="seq_bilstm", num_layers1=2), dict(module="signal_bilstm", hidden_size=100),
+               dict(hidden_size=64, num_layers2=2, is_base=False), dict(is_signallen=False, num_classes=3)):
+        cfg = onp.OracleConfig(**kw)
+        m = ModelBiLSTM(cfg.seq_len, cfg.signal_len, cfg.num_layers1, cfg.num_layers2, cfg.num_classes, 0,
+                        cfg.hidden_size, cfg.vocab_size, cfg.embedding_size, cfg.is_base, cfg.is_signallen,
+                        module=cfg.module)
+        assert [(k, tuple(s)) for k, s in m._spec] == [(k, tuple(s)) for k, s in onp.state_dict_spec(cfg)]
+        assert m.flops_per_site() == onp.flops_per_site(cfg)
+
+
+def test_no_cpu_fallback_and_reference_error_behaviour():
+    import torch
+    from deepsignal_plant_amd.models import ModelBiLSTM
+    with pytest.raises(ValueError, match="--model_type is not right!"):
+        ModelBiLSTM(module="cnn")
+    m = ModelBiLSTM()
+    sd = m.state_dict()
+    assert len(sd) == 49
+    del sd["fc2.bias"]
+    with pytest.raises(RuntimeError, match="Missing key"):
+        m.load_state_dict(sd)
+    sd = m.state_dict()
+    sd["extra.weight"] = torch.zeros(1)
+    with pytest.raises(RuntimeError, match="Unexpected key"):
+        m.load_state_dict(sd)
+    if not torch.cuda.is_available():
+        # without a GPU the product path must fail loudly, never compute on the CPU
+        with pytest.raises(RuntimeError):
+            m.cuda(0)
+        with pytest.raises(RuntimeError):
+            m(torch.zeros(2, 13), torch.zeros(2, 13), torch.zeros(2, 13), torch.zeros(2, 13), torch.zeros(2, 13, 16))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "deepsignal_plant_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "oracle" not in txt.replace("# oracle-free", ""), "%s mentions the oracle" % f
