@@ -73,6 +73,15 @@ def lib():
                                    ctypes.POINTER(ctypes.c_float), ctypes.c_int32]
     L.dsp_model_destroy.restype = None
     L.dsp_model_destroy.argtypes = [ctypes.c_void_p]
+    L.dsp_count_rows.restype = ctypes.c_int64
+    L.dsp_count_rows.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    L.dsp_parse_feature_rows.restype = ctypes.c_int64
+    L.dsp_parse_feature_rows.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_int32,
+                                         ctypes.c_int64] + [ctypes.c_void_p] * 10 + [ctypes.c_int32]
+    L.dsp_format_calls.restype = ctypes.c_int64
+    L.dsp_format_calls.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
+                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p,
+                                   ctypes.c_size_t, ctypes.c_int32]
     _lib = L
     return L
 

@@ -328,6 +328,7 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
 extern "C" {
 
 const char* dsp_last_error(void) { return g_err.c_str(); }
+void dsp_set_error_(const char* msg) { g_err = msg ? msg : ""; }  // used by dsp_text.cpp
 int32_t dsp_abi_version(void) { return DSP_AMD_ABI_VERSION; }
 
 int32_t dsp_weight_count(const dsp_model_cfg* cfg) {

@@ -1,3 +1,381 @@
-// dsp_text.cpp -- host-side text I/O of the call_mods path (feature-TSV parser, per-read-call formatter).
-// Filled in below; kept as a separate translation unit because it is plain C++ (no HIP).
+// dsp_text.cpp -- host-side text I/O of the call_mods path, plain C++ (no HIP), multi-threaded.
+//
+//   dsp_parse_feature_rows : the row grammar of _read_features_file / parse_a_line2
+//                            (deepsignal_plant/call_modifications.py:76-86, :111-117; dataloader.py:14-31)
+//   dsp_format_calls       : the per-row output of _call_mods (call_modifications.py:175-188) written the way
+//                            _write_predstr_to_file does (:262-282): numpy-float32 round(x, 6) + str()
+//
+// Numeric fidelity: Python float(x) is a correctly rounded double which torch.tensor(dtype=float) then rounds
+// to float32, so tokens are parsed to a correctly rounded double first (Clinger fast path, strtod fallback)
+// and only then narrowed.  The formatter performs the reference's float32 operations literally (this file is
+// compiled with -ffp-contract=off).
 #include "dsp_amd.h"
+
+#include <algorithm>
+#include <charconv>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <thread>
+#include <vector>
+
+extern "C" void dsp_set_error_(const char* msg);  // dsp_capi.cpp: the C ABI has ONE dsp_last_error()
+
+namespace {
+
+int text_fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    dsp_set_error_(buf);
+    return code;
+}
+
+struct CodeTable {
+    int8_t t[256];
+    CodeTable() {
+        for (int i = 0; i < 256; ++i) t[i] = -1;
+        const char* s = "ACGTNWSMKRYBVDHZ";  // base2code_dna, utils/process_utils.py:25-29
+        for (int i = 0; s[i]; ++i) t[(unsigned char)s[i]] = (int8_t)i;
+    }
+};
+const CodeTable g_codes;
+
+const double kPow10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                           1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+
+inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\f' || c == '\v'; }
+
+// parse one float token [p, e) the way Python float() would; returns false on a malformed token
+bool parse_float_token(const char* p, const char* e, double* out) {
+    while (p < e && is_space(*p)) ++p;
+    while (e > p && is_space(e[-1])) --e;
+    if (p >= e) return false;
+    const char* s = p;
+    bool neg = false;
+    if (*p == '+' || *p == '-') { neg = *p == '-'; ++p; }
+    uint64_t mant = 0;
+    int nd = 0, dropped = 0, frac = 0;
+    bool any = false, exact = true;
+    while (p < e && *p >= '0' && *p <= '9') {
+        any = true;
+        if (nd < 19) { mant = mant * 10 + (uint64_t)(*p - '0'); if (mant) ++nd; }
+        else { ++dropped; if (*p != '0') exact = false; }
+        ++p;
+    }
+    if (p < e && *p == '.') {
+        ++p;
+        while (p < e && *p >= '0' && *p <= '9') {
+            any = true;
+            if (nd < 19) { mant = mant * 10 + (uint64_t)(*p - '0'); if (mant) ++nd; ++frac; }
+            else if (*p != '0') exact = false;
+            ++p;
+        }
+    }
+    if (any) {
+        int ex = 0;
+        bool ok = true;
+        if (p < e && (*p == 'e' || *p == 'E')) {
+            const char* q = p + 1;
+            bool eneg = false;
+            if (q < e && (*q == '+' || *q == '-')) { eneg = *q == '-'; ++q; }
+            if (q >= e || *q < '0' || *q > '9') ok = false;
+            int v = 0;
+            while (q < e && *q >= '0' && *q <= '9') { if (v < 100000) v = v * 10 + (*q - '0'); ++q; }
+            ex = eneg ? -v : v;
+            p = q;
+        }
+        if (ok && p == e) {
+            const int e10 = ex - frac + dropped;
+            if (exact && mant < (1ull << 53) && e10 >= -22 && e10 <= 22) {  // Clinger: exactly one rounding
+                double d = (double)mant;
+                d = e10 < 0 ? d / kPow10[-e10] : d * kPow10[e10];
+                *out = neg ? -d : d;
+                return true;
+            }
+            if (mant == 0 && exact) { *out = neg ? -0.0 : 0.0; return true; }
+        }
+    }
+    // slow path: strtod on a bounded copy (handles long mantissas, huge exponents, inf/nan)
+    char tmp[128];
+    const size_t n = (size_t)(e - s);
+    if (n == 0 || n >= sizeof(tmp)) return false;
+    memcpy(tmp, s, n);
+    tmp[n] = 0;
+    for (size_t i = 0; i < n; ++i)
+        if (tmp[i] == 'x' || tmp[i] == 'X' || tmp[i] == 'p' || tmp[i] == 'P') return false;  // no hex floats in Python
+    char* endp = nullptr;
+    const double d = strtod(tmp, &endp);
+    if (endp != tmp + n) return false;
+    *out = d;
+    return true;
+}
+
+bool parse_int_token(const char* p, const char* e, long long* out) {
+    while (p < e && is_space(*p)) ++p;
+    while (e > p && is_space(e[-1])) --e;
+    if (p >= e) return false;
+    bool neg = false;
+    if (*p == '+' || *p == '-') { neg = *p == '-'; ++p; }
+    if (p >= e) return false;
+    long long v = 0;
+    for (; p < e; ++p) {
+        if (*p < '0' || *p > '9') return false;
+        if (v > (1ll << 56)) return false;
+        v = v * 10 + (*p - '0');
+    }
+    *out = neg ? -v : v;
+    return true;
+}
+
+inline const char* find_ch(const char* p, const char* e, char c) {
+    const void* r = memchr(p, c, (size_t)(e - p));
+    return r ? (const char*)r : e;
+}
+
+// n comma-separated floats in [p, e)
+bool parse_float_list(const char* p, const char* e, int n, float* dst) {
+    for (int i = 0; i < n; ++i) {
+        const char* c = find_ch(p, e, ',');
+        if ((i == n - 1) != (c == e)) return false;
+        double d;
+        if (!parse_float_token(p, c, &d)) return false;
+        dst[i] = (float)d;
+        p = c + 1;
+    }
+    return true;
+}
+
+struct RowOut {
+    uint8_t* kmer; float* means; float* stds; int32_t* lens; float* signals; int32_t* labels;
+    uint64_t* row_off; uint32_t* info_len; uint32_t* read_off; uint32_t* read_len;
+};
+
+// returns 0 or an error code (1 fields, 2 kmer, 3 means, 4 stds, 5 lens, 6 signals, 7 label)
+int parse_row(const char* text, const char* ls, const char* le, int L, int S, int64_t r, const RowOut& o) {
+    // line.strip()
+    while (ls < le && is_space(*ls)) ++ls;
+    while (le > ls && is_space(le[-1])) --le;
+    const char* fs[12];
+    const char* fend[12];
+    int nf = 0;
+    for (const char* p = ls; nf < 12;) {
+        const char* t = find_ch(p, le, '\t');
+        fs[nf] = p; fend[nf] = t;
+        ++nf;
+        if (t == le) break;
+        p = t + 1;
+    }
+    if (nf < 12) return 1;
+    const char* const* f = fs;
+    auto fe = [&](int i) { return fend[i]; };
+    o.row_off[r] = (uint64_t)(ls - text);
+    o.info_len[r] = (uint32_t)(fe(5) - ls);
+    o.read_off[r] = (uint32_t)(f[4] - ls);
+    o.read_len[r] = (uint32_t)(fe(4) - f[4]);
+    if (fe(6) - f[6] != L) return 2;
+    for (int i = 0; i < L; ++i) {
+        const int8_t c = g_codes.t[(unsigned char)f[6][i]];
+        if (c < 0) return 2;
+        o.kmer[r * L + i] = (uint8_t)c;
+    }
+    if (!parse_float_list(f[7], fe(7), L, o.means + r * L)) return 3;
+    if (!parse_float_list(f[8], fe(8), L, o.stds + r * L)) return 4;
+    {
+        const char* p = f[9];
+        const char* e = fe(9);
+        for (int i = 0; i < L; ++i) {
+            const char* c = find_ch(p, e, ',');
+            if ((i == L - 1) != (c == e)) return 5;
+            long long v;
+            if (!parse_int_token(p, c, &v) || v < INT32_MIN || v > INT32_MAX) return 5;
+            o.lens[r * L + i] = (int32_t)v;
+            p = c + 1;
+        }
+    }
+    {
+        const char* p = f[10];
+        const char* e = fe(10);
+        for (int i = 0; i < L; ++i) {
+            const char* c = find_ch(p, e, ';');
+            if ((i == L - 1) != (c == e)) return 6;
+            if (!parse_float_list(p, c, S, o.signals + ((size_t)r * L + i) * S)) return 6;
+            p = c + 1;
+        }
+    }
+    {
+        // the 12th field ends at the next tab (extra columns are ignored, as words[11] would) or the line end
+        long long v;
+        if (!parse_int_token(f[11], fe(11), &v)) return 7;
+        o.labels[r] = (int32_t)v;
+    }
+    return 0;
+}
+
+const char* kFieldName[] = {"", "field count (need 12 tab-separated columns)", "k_mer (length/alphabet)", "signal_means",
+                            "signal_stds", "signal_lens", "k_signals", "label"};
+
+// ---- formatter -----------------------------------------------------------------------------------------
+// numpy str(float32): Dragon4 shortest unique digits; positional for 1e-4 <= |x| < 1e16 (and 0) with at least
+// one fractional digit, otherwise scientific d[.ddd]e+XX with the ".0" trimmed.
+int format_f32_numpy(float x, char* out) {
+    if (std::isnan(x)) { memcpy(out, "nan", 3); return 3; }
+    if (std::isinf(x)) { if (x < 0) { memcpy(out, "-inf", 4); return 4; } memcpy(out, "inf", 3); return 3; }
+    char* o = out;
+    if (std::signbit(x)) { *o++ = '-'; x = -x; }
+    if (x == 0.0f) { memcpy(o, "0.0", 3); return (int)(o + 3 - out); }
+    char sci[48];
+    auto res = std::to_chars(sci, sci + sizeof(sci), x, std::chars_format::scientific);  // shortest round-trip
+    *res.ptr = 0;
+    // sci = d[.ddd]e[+-]XX
+    char digits[24];
+    int nd = 0;
+    const char* p = sci;
+    for (; *p && *p != 'e'; ++p)
+        if (*p != '.') digits[nd++] = *p;
+    const int ex = atoi(p + 1);
+    if ((double)x >= 1e-4 && (double)x < 1e16) {  // numpy compares the value promoted to double
+        if (ex >= 0) {
+            for (int i = 0; i <= ex; ++i) *o++ = i < nd ? digits[i] : '0';
+            *o++ = '.';
+            if (nd > ex + 1) for (int i = ex + 1; i < nd; ++i) *o++ = digits[i];
+            else *o++ = '0';
+        } else {
+            *o++ = '0'; *o++ = '.';
+            for (int i = 0; i < -ex - 1; ++i) *o++ = '0';
+            for (int i = 0; i < nd; ++i) *o++ = digits[i];
+        }
+    } else {
+        *o++ = digits[0];
+        if (nd > 1) { *o++ = '.'; for (int i = 1; i < nd; ++i) *o++ = digits[i]; }
+        *o++ = 'e';
+        *o++ = ex < 0 ? '-' : '+';
+        const int a = ex < 0 ? -ex : ex;
+        if (a < 10) *o++ = '0';
+        o += snprintf(o, 8, "%d", a);
+    }
+    return (int)(o - out);
+}
+
+// round(np.float32, 6): numpy multiplies by 1e6, rints (half-even), divides by 1e6 -- all in float32
+inline float np_round6_f32(float x) {
+    volatile float y = x * 1e6f;
+    volatile float r = nearbyintf(y);
+    volatile float z = r / 1e6f;
+    return z;
+}
+
+void run_threads(int nthreads, int64_t n, const std::function<void(int, int64_t, int64_t)>& fn) {
+    if (nthreads < 1) nthreads = 1;
+    if ((int64_t)nthreads > n) nthreads = (int)(n > 0 ? n : 1);
+    if (nthreads == 1) { fn(0, 0, n); return; }
+    std::vector<std::thread> th;
+    const int64_t per = (n + nthreads - 1) / nthreads;
+    for (int t = 0; t < nthreads; ++t) {
+        const int64_t a = t * per, b = std::min<int64_t>(n, a + per);
+        if (a >= b) break;
+        th.emplace_back(fn, t, a, b);
+    }
+    for (auto& x : th) x.join();
+}
+}  // namespace
+
+extern "C" {
+
+int64_t dsp_count_rows(const char* text, size_t len) {
+    int64_t n = 0;
+    const char* p = text;
+    const char* e = text + len;
+    while (p < e) {
+        const char* nl = find_ch(p, e, '\n');
+        ++n;
+        p = nl + 1;
+    }
+    return n;
+}
+
+int64_t dsp_parse_feature_rows(const char* text, size_t len, int32_t seq_len, int32_t signal_len, int64_t max_rows,
+                               uint8_t* kmer, float* means, float* stds, int32_t* lens, float* signals,
+                               int32_t* labels, uint64_t* row_off, uint32_t* info_len, uint32_t* read_off,
+                               uint32_t* read_len, int32_t nthreads) {
+    if (!text || seq_len < 1 || signal_len < 1 || max_rows < 0) return text_fail(DSP_EINVAL, "bad argument");
+    std::vector<const char*> starts;
+    starts.reserve(len / 1024 + 16);
+    const char* p = text;
+    const char* e = text + len;
+    while (p < e) {
+        const char* nl = find_ch(p, e, '\n');
+        starts.push_back(p);
+        p = nl + 1;
+    }
+    const int64_t n = (int64_t)starts.size();
+    if (n > max_rows) return text_fail(DSP_EINVAL, "buffer holds %lld rows but capacity is %lld", (long long)n, (long long)max_rows);
+    starts.push_back(e + 1);
+    RowOut o{kmer, means, stds, lens, signals, labels, row_off, info_len, read_off, read_len};
+    std::vector<int64_t> bad_row((size_t)std::max(1, nthreads), -1);
+    std::vector<int> bad_code((size_t)std::max(1, nthreads), 0);
+    run_threads(nthreads, n, [&](int t, int64_t a, int64_t b) {
+        for (int64_t r = a; r < b; ++r) {
+            const char* ls = starts[r];
+            const char* le = starts[r + 1] - 1;  // the '\n' (or end)
+            if (le > e) le = e;
+            const int rc = parse_row(text, ls, le, seq_len, signal_len, r, o);
+            if (rc) { bad_row[t] = r; bad_code[t] = rc; return; }
+        }
+    });
+    for (size_t t = 0; t < bad_row.size(); ++t)
+        if (bad_row[t] >= 0)
+            return text_fail(DSP_EPARSE, "malformed feature row %lld: bad %s", (long long)bad_row[t], kFieldName[bad_code[t]]);
+    return n;
+}
+
+int64_t dsp_format_calls(const char* text, const uint64_t* row_off, const uint32_t* info_len, const float* probs,
+                         int32_t num_classes, const uint8_t* labels, const uint8_t* kmer, int32_t seq_len, int64_t n,
+                         char* out, size_t out_cap, int32_t nthreads) {
+    if (!text || !row_off || !info_len || !probs || !labels || !kmer || !out || num_classes < 2 || seq_len < 1)
+        return text_fail(DSP_EINVAL, "bad argument");
+    static const char* code2base = "ACGTNWSMKRYBVDHZ";
+    // centre 5-mer: call_modifications.py:181-184
+    const int center = seq_len / 2;
+    const int k0 = center - 2 >= 0 ? center - 2 : 0;
+    const int k1 = center + 3 <= seq_len ? center + 3 : seq_len;
+    if (nthreads < 1) nthreads = 1;
+    std::vector<std::string> parts((size_t)nthreads);
+    run_threads(nthreads, n, [&](int t, int64_t a, int64_t b) {
+        std::string& s = parts[t];
+        s.reserve((size_t)(b - a) * 96);
+        char num[64];
+        for (int64_t r = a; r < b; ++r) {
+            s.append(text + row_off[r], info_len[r]);
+            const float p0 = probs[r * num_classes], p1 = probs[r * num_classes + 1];
+            volatile float sum = p0 + p1;
+            volatile float q = p0 / sum;
+            const float z0 = np_round6_f32(q);          // round(prob_0 / (prob_0 + prob_1), 6)   (:177)
+            volatile float om = 1.0f - z0;
+            const float z1 = np_round6_f32(om);         // round(1 - prob_0_norm, 6)               (:179)
+            s.push_back('\t');
+            s.append(num, (size_t)format_f32_numpy(z0, num));
+            s.push_back('\t');
+            s.append(num, (size_t)format_f32_numpy(z1, num));
+            s.push_back('\t');
+            s.append(num, (size_t)snprintf(num, sizeof(num), "%u", (unsigned)labels[r]));
+            s.push_back('\t');
+            for (int i = k0; i < k1; ++i) s.push_back(code2base[kmer[r * seq_len + i] & 15]);
+            s.push_back('\n');
+        }
+    });
+    size_t total = 0;
+    for (auto& s : parts) total += s.size();
+    if (total > out_cap) return text_fail(DSP_ENOMEM, "output needs %zu bytes, capacity %zu", total, out_cap);
+    size_t pos = 0;
+    for (auto& s : parts) { memcpy(out + pos, s.data(), s.size()); pos += s.size(); }
+    return (int64_t)total;
+}
+
+}  // extern "C"

@@ -128,6 +128,32 @@ int32_t dsp_profile_read(dsp_model* m, char* names, size_t names_cap, float* ms,
 
 void dsp_model_destroy(dsp_model* m);
 
+/* ---- host-side text I/O of the path (plain C++, multi-threaded; no GPU involved) ------------------------
+ *
+ * dsp_parse_feature_rows replaces the row grammar of _read_features_file
+ * (call_modifications.py:76-86, :111-117; same grammar as dataloader.py:14-31): `text` holds complete
+ * lines of 12 tab-separated fields; outputs are SoA host buffers (ideally pinned) with room for max_rows
+ * rows: kmer codes u8 [r][L] (base2code_dna), means/stds f32 [r][L], lens i32 [r][L], signals f32
+ * [r][L][S], labels i32 [r]; row_off/info_len = byte range of the first six fields (the `sampleinfo`
+ * string kept verbatim, :80) inside `text`; read_off/read_len = the readname field (:77) relative to
+ * row_off, for read-boundary batching (:94-109).  Tokens go decimal -> correctly rounded double -> float32,
+ * as Python float() + torch.tensor(dtype=float) do.  Returns the row count, or DSP_EPARSE (unknown base
+ * letter = the reference's KeyError, malformed number = ValueError) / DSP_EINVAL. */
+int64_t dsp_count_rows(const char* text, size_t len);
+int64_t dsp_parse_feature_rows(const char* text, size_t len, int32_t seq_len, int32_t signal_len, int64_t max_rows,
+                               uint8_t* kmer, float* means, float* stds, int32_t* lens, float* signals,
+                               int32_t* labels, uint64_t* row_off, uint32_t* info_len, uint32_t* read_off,
+                               uint32_t* read_len, int32_t nthreads);
+
+/* dsp_format_calls replaces the per-row string building of _call_mods (call_modifications.py:175-188) and
+ * the line writing of _write_predstr_to_file (:262-282): for each row
+ *   sampleinfo \t round(p0/(p0+p1),6) \t round(1-that,6) \t label \t centre-5-mer \n
+ * with the reference's numpy-float32 arithmetic and str() formatting reproduced byte for byte.
+ * Returns bytes written to `out`, or a negative dsp_status (DSP_ENOMEM if out_cap is too small). */
+int64_t dsp_format_calls(const char* text, const uint64_t* row_off, const uint32_t* info_len, const float* probs,
+                         int32_t num_classes, const uint8_t* labels, const uint8_t* kmer, int32_t seq_len, int64_t n,
+                         char* out, size_t out_cap, int32_t nthreads);
+
 const char* dsp_last_error(void);
 int32_t dsp_abi_version(void);
 

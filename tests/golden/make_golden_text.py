@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Generate the F2 (parser), F3 (formatter) and F4 (end-to-end call_mods) fixtures by IMPORTING THE
+REFERENCE (build container only; /root/reference is read-only and never travels).
+
+  F2  f2_rows.tsv(.gz) (rows made by the build's own generator in the extractor's format) +
+      f2_parsed.npz: exactly what deepsignal_plant.call_modifications._read_features_file puts on its
+      queue (arrays + batch boundaries for f5_batch_size=7).
+  F3  f3_format.npz: (sampleinfo, float32 probs incl. crafted edge cases, kmers) -> the exact pred_str lines
+      produced by deepsignal_plant.call_modifications._call_mods (lines :175-188) with a stub model that
+      returns the crafted probabilities.
+  F4  f4_expected.tsv: the reference's whole TSV branch (reader -> _call_mods -> writer semantics) on
+      f2_rows.tsv with a both_bilstm model whose initial states are pinned to zeros, as a keyed set.
+h5py / statsmodels are not installed and are unused on the TSV branch: empty stub modules are registered
+before the import.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True
+for name in ("h5py", "statsmodels"):
+    if name not in sys.modules:
+        sys.modules[name] = types.ModuleType(name)
+sys.modules["statsmodels"].robust = types.SimpleNamespace(mad=None)
+
+import torch  # noqa: E402
+
+from deepsignal_plant import call_modifications as ref  # noqa: E402  (the reference)
+from deepsignal_plant.models import ModelBiLSTM  # noqa: E402
+from deepsignal_plant_amd import tsv  # noqa: E402
+from oracle import forward_np as onp  # noqa: E402
+
+
+class ListQueue(object):
+    def __init__(self):
+        self.items = []
+
+    def put(self, x):
+        self.items.append(x)
+
+    def qsize(self):
+        return 0
+
+
+def main():
+    # ---------------- F2
+    n = 200
+    rows = list(tsv.synth_rows(n, seed=5, sites_per_read=9, wide_alphabet=True))
+    # a few hand-made numeric spellings the Python float()/int() grammar accepts
+    w = rows[3].split("\t")
+    w[7] = ",".join(["1e-05", "-2.5E-3", "3", "+4.25", "-0.0", ".5", "7.", "1234567.125", "0.1", "-1e2", "9.999999", "0.000001", "5e-324"])
+    rows[3] = "\t".join(w)
+    p_plain = os.path.join(HERE, "f2_rows.tsv")
+    with open(p_plain, "w") as f:
+        f.write("\n".join(rows) + "\n")
+    import gzip
+    with gzip.open(p_plain + ".gz", "wt") as f:
+        f.write("\n".join(rows) + "\n")
+    q = ListQueue()
+    ref._read_features_file(p_plain, q, 7)
+    assert q.items[-1] == "kill"
+    batches = q.items[:-1]
+    sizes = [len(b[0]) for b in batches]
+    cat = lambda i: [x for b in batches for x in b[i]]  # noqa: E731
+    np.savez_compressed(os.path.join(HERE, "f2_parsed.npz"),
+                        sampleinfo=np.array(cat(0)), kmers=np.array(cat(1), np.int64),
+                        means=np.array(cat(2), np.float64), stds=np.array(cat(3), np.float64),
+                        lens=np.array(cat(4), np.int64), signals=np.array(cat(5), np.float64),
+                        labels=np.array(cat(6), np.int64), batch_sizes=np.array(sizes), f5_batch_size=7)
+    print("F2: %d rows in %d batches %s" % (n, len(sizes), sizes[:6]))
+
+    # ---------------- F3
+    rng = np.random.default_rng(11)
+    p1 = rng.random(4000).astype(np.float32)
+    crafted = np.array([0.0, 1.0, 1e-5, 1.5e-5, 9.9e-5, 1e-4, 0.5, 0.4999995, 0.5000005, 0.1234565, 0.1234575,
+                        0.999999, 0.9999995, 1e-6, 4e-7, 5e-7, 6e-7, 0.25, 0.3333333, 0.6666667, 1e-7, 0.99999994,
+                        3.1e-5, 0.000123, 0.00001234, 0.7, 0.07, 0.007, 0.0007, 0.00007, 0.000007], np.float32)
+    p1 = np.concatenate((crafted, p1, rng.random(2000).astype(np.float32) * 2e-4,
+                         1 - rng.random(2000).astype(np.float32) * 2e-4)).astype(np.float32)
+    p0 = (np.float32(1.0) - p1).astype(np.float32)
+    # perturb so p0 + p1 != 1 exactly sometimes (softmax outputs rarely sum to exactly 1)
+    p0 = (p0 * (1 + (rng.random(p0.size).astype(np.float32) - 0.5) * np.float32(2e-7))).astype(np.float32)
+    probs = np.stack((p0, p1), axis=1).astype(np.float32)
+    m = probs.shape[0]
+    kmers = rng.integers(0, 16, size=(m, 13)).tolist()
+    sampleinfo = ["chr%d\t%d\t+\t%d\tread%d\tt" % (i % 5, i, i + 1, i // 3) for i in range(m)]
+
+    class Stub(object):
+        def __init__(self, pr):
+            self.pr, self.i = pr, 0
+
+        def __call__(self, kmer, *rest):
+            b = kmer.shape[0]
+            out = torch.from_numpy(self.pr[self.i:self.i + b].copy())
+            self.i += b
+            return out, out
+    z13 = [[0.0] * 13] * m
+    feats = (sampleinfo, kmers, z13, z13, [[1] * 13] * m, [[[0.0] * 16] * 13] * m, [0] * m)
+    pred_str, _, _ = ref._call_mods(feats, Stub(probs), 512, 0)
+    np.savez_compressed(os.path.join(HERE, "f3_format.npz"), probs=probs, kmers=np.array(kmers, np.uint8),
+                        sampleinfo=np.array(sampleinfo), lines=np.array(pred_str))
+    print("F3: %d lines, e.g. %r" % (m, pred_str[:3]))
+
+    # ---------------- F4: the TSV branch end to end with zero initial states
+    cfg = onp.OracleConfig()
+    w8 = onp.make_weights(cfg, 23, 2.0)
+    model = ModelBiLSTM(cfg.seq_len, cfg.signal_len, cfg.num_layers1, cfg.num_layers2, cfg.num_classes, 0,
+                        cfg.hidden_size, cfg.vocab_size, cfg.embedding_size, True, True, module="both_bilstm", device=0)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in w8.items()})
+    model.eval()
+    model.init_hidden = lambda b, nl, h: (torch.zeros(nl * 2, b, h), torch.zeros(nl * 2, b, h))
+    out_lines = []
+    with torch.no_grad():
+        for b in batches:
+            s, _, _ = ref._call_mods(b, model, 512, 0)
+            out_lines += s
+    with open(os.path.join(HERE, "f4_expected.tsv"), "w") as f:
+        f.write("\n".join(out_lines) + "\n")
+    np.savez_compressed(os.path.join(HERE, "f4_meta.npz"), wseed=23, wscale=2.0, init="zeros")
+    print("F4: %d lines, e.g. %r" % (len(out_lines), out_lines[0]))
+
+
+if __name__ == "__main__":
+    main()

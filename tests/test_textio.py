@@ -1,0 +1,116 @@
+"""CPU: native parser / formatter vs fixtures captured from the reference's own
+_read_features_file and _call_mods (tests/golden/make_golden_text.py).  Bit-exact."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from deepsignal_plant_amd import textio
+from tests.helpers import GOLDEN
+
+
+@pytest.fixture(scope="module")
+def f2():
+    return np.load(os.path.join(GOLDEN, "f2_parsed.npz"))
+
+
+@pytest.mark.parametrize("nthreads", [1, 3])
+@pytest.mark.parametrize("gz", [False, True])
+def test_parser_matches_reference_reader(f2, nthreads, gz):
+    path = os.path.join(GOLDEN, "f2_rows.tsv" + (".gz" if gz else ""))
+    data = (gzip.open(path, "rb") if gz else open(path, "rb")).read()
+    r = textio.parse_rows(data, 13, 16, nthreads=nthreads)
+    assert r.n == len(f2["labels"]) == 200
+    assert np.array_equal(r.kmer, f2["kmers"])
+    # the reference holds Python doubles and narrows to float32 when it builds tensors (FloatTensor)
+    assert np.array_equal(r.means, f2["means"].astype(np.float32))
+    assert np.array_equal(r.stds, f2["stds"].astype(np.float32))
+    assert np.array_equal(r.lens, f2["lens"])
+    assert np.array_equal(r.signals, f2["signals"].astype(np.float32))
+    assert np.array_equal(r.labels, f2["labels"])
+    assert [r.sampleinfo(i) for i in range(r.n)] == list(f2["sampleinfo"])
+    assert r.readname(0) == f2["sampleinfo"][0].split("\t")[4]
+
+
+def test_parser_edge_cases():
+    row = open(os.path.join(GOLDEN, "f2_rows.tsv")).readline().rstrip("\n")
+    w = row.split("\t")
+    ok = textio.parse_rows((row + "\r\n" + row).encode(), 13, 16)  # CRLF, no trailing newline
+    assert ok.n == 2 and np.array_equal(ok.means[0], ok.means[1])
+    extra = textio.parse_rows(("  " + row + "\textra\tcols\n").encode(), 13, 16)  # strip(); words[11] ignores extras
+    assert extra.n == 1 and extra.labels[0] == int(w[11])
+    for bad in ("\t".join(w[:11]),                                   # 11 columns
+                "\t".join(w[:6] + ["ACGTXACGTACGT"] + w[7:]),         # unknown base -> KeyError in the reference
+                "\t".join(w[:6] + ["ACGT"] + w[7:]),                  # k-mer of the wrong length
+                "\t".join(w[:7] + [w[7] + ",1.0"] + w[8:]),           # 14 means
+                "\t".join(w[:7] + [w[7].replace(",", ",x", 1)] + w[8:]),
+                "\t".join(w[:9] + [w[9].replace(",", ".5,", 1)] + w[10:]),  # int("3.5") fails in the reference
+                "\t".join(w[:10] + [w[10].replace(";", ",", 1)] + w[11:]),
+                "\t".join(w[:11] + ["one"])):
+        with pytest.raises(ValueError):
+            textio.parse_rows((bad + "\n").encode(), 13, 16)
+    assert textio.parse_rows(b"", 13, 16).n == 0
+    with pytest.raises(ValueError):
+        textio.parse_rows((row + "\n\n" + row + "\n").encode(), 13, 16)  # blank line: IndexError in the reference
+
+
+def test_parser_float_grammar_against_python():
+    rng = np.random.default_rng(3)
+    toks = ["%.*g" % (int(rng.integers(1, 18)), x) for x in rng.standard_normal(3000) * 10.0 ** rng.integers(-8, 8, 3000)]
+    toks += ["1e-45", "1e-46", "3.4028235e38", "3.5e38", "1e39", "-1e39", "0.1", "16777217", "9007199254740993",
+             "0.30000001192092896", "1.00000005960464477539", "123456789012345678901234567890", "1e22", "1e23",
+             "4.35", "0.000001", "2.4703282292062328e-324", "nan", "inf", "-inf", "Infinity", "1.", ".5", "+.5e1"]
+    row = open(os.path.join(GOLDEN, "f2_rows.tsv")).readline().rstrip("\n").split("\t")
+    with np.errstate(over="ignore"):
+        for i in range(0, len(toks) - 12, 13):
+            chunk = toks[i:i + 13]
+            row[7] = ",".join(chunk)
+            got = textio.parse_rows(("\t".join(row) + "\n").encode(), 13, 16).means[0]
+            want = np.array([float(t) for t in chunk], np.float64).astype(np.float32)
+            assert np.array_equal(got, want, equal_nan=True), chunk
+
+
+@pytest.mark.parametrize("nthreads", [1, 4])
+def test_formatter_matches_reference_strings(nthreads):
+    f3 = np.load(os.path.join(GOLDEN, "f3_format.npz"))
+    probs, kmers, info, lines = f3["probs"], f3["kmers"], list(f3["sampleinfo"]), list(f3["lines"])
+    n = len(lines)
+    # build a ParsedRows by hand: text = the sampleinfo strings back to back
+    text = "\n".join(info).encode()
+    offs = np.zeros(n, np.uint64)
+    lens = np.zeros(n, np.uint32)
+    pos = 0
+    for i, s in enumerate(info):
+        offs[i], lens[i] = pos, len(s.encode())
+        pos += lens[i] + 1
+    r = textio.ParsedRows()
+    r.text, r.n, r.kmer, r.row_off, r.info_len = np.frombuffer(text, np.uint8), n, kmers, offs, lens
+    r.seq_len, r.signal_len = 13, 16
+    labels = probs.argmax(1).astype(np.uint8)  # torch.max(.., 1) at call_modifications.py:163
+    got = textio.format_calls(r, probs, labels, nthreads=nthreads).decode().split("\n")
+    assert got[-1] == "" and len(got) == n + 1
+    bad = [(a, b) for a, b in zip(got, lines) if a != b]
+    assert not bad, bad[:5]
+
+
+def test_formatter_exhaustive_rounding_grid_vs_numpy():
+    """every k/1e6 neighbourhood that the 6-decimal rounding can produce, against numpy's own float32
+    round()/str() (what the reference executes at call_modifications.py:177-179, :186-187)"""
+    rng = np.random.default_rng(9)
+    k = np.concatenate((np.arange(0, 2000), rng.integers(0, 1000001, 60000), np.arange(998000, 1000001)))
+    p1 = (k / 1e6).astype(np.float32)
+    p1 = np.concatenate((p1, np.nextafter(p1, np.float32(2)), np.nextafter(p1, np.float32(-1)).clip(0, 1))).astype(np.float32)
+    p0 = (np.float32(1) - p1).astype(np.float32)
+    probs = np.stack((p0, p1), 1)
+    n = probs.shape[0]
+    r = textio.ParsedRows()
+    r.text, r.n = np.frombuffer(b"x", np.uint8), n
+    r.kmer = np.zeros((n, 13), np.uint8)
+    r.row_off, r.info_len, r.seq_len, r.signal_len = np.zeros(n, np.uint64), np.ones(n, np.uint32), 13, 16
+    got = textio.format_calls(r, probs, np.zeros(n, np.uint8)).decode().split("\n")[:-1]
+    for i in rng.integers(0, n, 4000).tolist() + list(range(0, 300)):
+        a, b = probs[i]
+        z0 = round(a / (a + b), 6)
+        z1 = round(1 - z0, 6)
+        assert got[i] == "x\t%s\t%s\t0\tAAAAA" % (str(z0), str(z1)), (i, got[i], z0, z1)
