@@ -1,0 +1,284 @@
+"""call modifications from extracted features (feature TSV in -> per-read-call TSV out) on MI355X.
+
+Host-side mirror of deepsignal_plant/call_modifications.py for the TSV branch of ``call_mods``
+(:584-636): same entry point ``call_mods(args)``, same flags, same input row grammar (:76-86) and the same
+output grammar (chromosome, pos, strand, pos_in_strand, read_name, read_strand, prob_0, prob_1,
+called_label, 5-mer; :175-188, :262-282).  What changed underneath:
+
+  reference                                         this build
+  ------------------------------------------------  ---------------------------------------------------------
+  reader process, per-row Python, pickled lists     FeatureReader thread + native multi-threaded parser into
+  over mp.Queue (:55-127)                            pinned SoA buffers (feed.py, csrc/dsp_text.cpp)
+  N model processes x (5 sync H2D copies +          one process per GPU: async H2D on the compute stream's
+  nn.LSTM forward + 1 sync D2H) per 512 rows         predecessor, one fused-kernel forward per block through
+  (:130-170, :195-259)                               the C ABI, async D2H of probs/labels (models.py)
+  per-row Python string building (:175-188)         native formatter, byte-identical strings
+  writer process (:262-282)                          writer thread, rows in INPUT order
+
+Multi-GPU: contiguous byte-range split of the file over ranks (dist.py); per-rank part files concatenated by
+rank 0.  Results do not depend on the number of GPUs or on batching: the in-kernel initial states are keyed
+by the global row index.  The fast5-directory branch (:559-583) is out of scope.
+"""
+from __future__ import annotations
+
+import argparse
+import gzip
+import os
+import queue
+import shutil
+import sys
+import threading
+import time
+
+import numpy as np
+
+from . import dist as dsp_dist
+from . import feed, textio
+from .models import ModelBiLSTM
+from .utils.process_utils import display_args, str2bool
+
+
+def _get_gpus():
+    """Visible GPUs (HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES honoured by the runtime); the reference's
+    round-robin list at call_modifications.py:523-529."""
+    import torch
+    n = torch.cuda.device_count()
+    return list(range(n))
+
+
+def load_model(args, device):
+    """Replaces the head of _call_mods_q (call_modifications.py:214-228)."""
+    import torch
+    model = ModelBiLSTM(args.seq_len, args.signal_len, args.layernum1, args.layernum2, args.class_num,
+                        args.dropout_rate, args.hid_rnn, args.n_vocab, args.n_embed, str2bool(args.is_base),
+                        str2bool(args.is_signallen), module=args.model_type, device=device,
+                        init_state=getattr(args, "init_state", "randn"), seed=getattr(args, "seed", 0))
+    para_dict = torch.load(args.model_path, map_location=torch.device('cpu'))
+    model_dict = model.state_dict()
+    model_dict.update(para_dict)
+    model.load_state_dict(model_dict)
+    model.cuda(device)
+    model.eval()
+    return model
+
+
+class _Writer(threading.Thread):
+    """Replaces _write_predstr_to_file (:262-282): formats finished blocks natively and appends them in order."""
+
+    def __init__(self, path, is_gzip, nthreads, reader):
+        super().__init__(daemon=True)
+        self.q = queue.Queue(maxsize=4)
+        self.path, self.is_gzip, self.nthreads, self.reader = path, is_gzip, nthreads, reader
+        self.error = None
+        self.rows = 0
+
+    def run(self):
+        try:
+            wf = gzip.open(self.path, "wb", compresslevel=4) if self.is_gzip else open(self.path, "wb")
+            with wf:
+                while True:
+                    item = self.q.get()
+                    if item is None:
+                        break
+                    block, probs_t, labels_t, event = item
+                    event.synchronize()
+                    probs = probs_t.numpy()[:block.rows.n]
+                    labels = labels_t.numpy()[:block.rows.n]
+                    wf.write(textio.format_calls(block.rows, probs, labels, nthreads=self.nthreads))
+                    self.rows += block.rows.n
+                    self.reader.release(block)
+        except BaseException as e:
+            self.error = e
+            while self.q.get() is not None:  # drain so the producer never blocks on a dead writer
+                pass
+
+
+def _call_mods_file(args, rank, local_rank, world):
+    """One rank = one GPU: reader -> H2D -> forward -> D2H -> formatter -> part file."""
+    import torch
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    model = load_model(args, local_rank)
+    input_path = os.path.abspath(args.input_path)
+    nthreads = max(1, (args.nproc if args.nproc > 0 else 1))
+    nthreads = min(nthreads, os.cpu_count() or 1)
+
+    # my byte range and the global index of my first row (plain text only; .gz ranks inflate everything)
+    first_row, byte_range = 0, None
+    if not input_path.endswith(".gz") and world > 1:
+        import mmap
+        size = os.path.getsize(input_path)
+        if size:
+            with open(input_path, "rb") as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as mm:
+                byte_range = dsp_dist.byte_range_for_rank(mm, size, world, rank)
+            mine = feed.count_rows_in_range(input_path, *byte_range)
+            counts = dsp_dist.all_gather_ints(mine, world, dev)
+            first_row = dsp_dist.exclusive_prefix(counts, rank)
+
+    out_path = args.result_file
+    if args.gzip and not out_path.endswith(".gz"):
+        out_path += ".gz"  # call_modifications.py:264-267
+    part_path = out_path if world == 1 else "%s.part%05d" % (out_path, rank)
+
+    reader = feed.FeatureReader(input_path, args.seq_len, args.signal_len, rank=rank, world=world, nthreads=nthreads,
+                                nbuf=4, first_row=first_row, byte_range=byte_range)
+    writer = _Writer(part_path, args.gzip, nthreads, reader)
+    cap = reader.cap
+    model.reserve(cap)
+    reader.start()
+    writer.start()
+    stream = torch.cuda.current_stream(dev)
+    nout = 4
+    out_probs = [torch.empty((cap, args.class_num), dtype=torch.float32, pin_memory=True) for _ in range(nout)]
+    out_labels = [torch.empty((cap,), dtype=torch.uint8, pin_memory=True) for _ in range(nout)]
+    out_events = [torch.cuda.Event() for _ in range(nout)]
+    k = 0
+    n_rows = 0
+    for block in reader:
+        if writer.error is not None:
+            break
+        rows = block.rows
+        n = rows.n
+        if n == 0:
+            reader.release(block)
+            continue
+        if n > out_probs[0].shape[0]:  # a block grew past the pinned output capacity
+            out_probs = [torch.empty((n, args.class_num), dtype=torch.float32, pin_memory=True) for _ in range(nout)]
+            out_labels = [torch.empty((n,), dtype=torch.uint8, pin_memory=True) for _ in range(nout)]
+        tt = block.slot.get("_torch")
+
+        def dev_t(name):
+            src = tt[name][:n] if tt is not None else torch.from_numpy(getattr(rows, name))
+            return src.to(dev, non_blocking=True)
+        kmer, means, stds = dev_t("kmer"), dev_t("means"), dev_t("stds")
+        lens, signals = dev_t("lens"), dev_t("signals")
+        model.site_offset = block.first_row
+        _logits, probs, labels = model.forward(kmer, means, stds, lens, signals, want_labels=True)
+        slot = k % nout
+        out_events[slot].synchronize()  # the writer is done with this slot's previous contents
+        out_probs[slot][:n].copy_(probs, non_blocking=True)
+        out_labels[slot][:n].copy_(labels, non_blocking=True)
+        out_events[slot].record(stream)
+        writer.q.put((block, out_probs[slot], out_labels[slot], out_events[slot]))
+        k += 1
+        n_rows += n
+    writer.q.put(None)
+    writer.join()
+    torch.cuda.synchronize(dev)
+    if writer.error is not None:
+        raise writer.error
+    return n_rows, part_path, out_path
+
+
+def _merge_parts(out_path, world):
+    with open(out_path, "wb") as wf:
+        for r in range(world):
+            part = "%s.part%05d" % (out_path, r)
+            with open(part, "rb") as rf:
+                shutil.copyfileobj(rf, wf, 16 << 20)  # gzip members concatenate into a valid .gz
+            os.remove(part)
+
+
+def call_mods(args):
+    """Main function of calling modifications (mirror of call_modifications.py:532-640, TSV branch)."""
+    print("[main] call_mods starts..")
+    start = time.time()
+    import torch
+    from . import _native
+    _native.lib()  # fail loudly before any work if the HIP library is missing
+    print("cuda availability: {}".format(torch.cuda.is_available()))
+
+    model_path = os.path.abspath(args.model_path)
+    if not os.path.exists(model_path):
+        raise ValueError("--model_path is not set right!")  # :550-551
+    input_path = os.path.abspath(args.input_path)
+    if not os.path.exists(input_path):
+        raise ValueError("--input_path does not exist!")  # :553-554
+    if os.path.isdir(input_path):
+        raise ValueError("--input_path is a directory: calling from fast5 files is outside this build's scope; "
+                         "run `extract` first and pass the feature file")
+    if not torch.cuda.is_available():
+        raise RuntimeError("no MI355X visible: this build has no CPU path")
+
+    rank, local_rank, world = dsp_dist.env_world()
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_rows, part_path, out_path = _call_mods_file(args, rank, local_rank, world)
+    if world > 1:
+        import torch.distributed as dist
+        total = sum(dsp_dist.all_gather_ints(n_rows, world, torch.device("cuda", local_rank)))
+        dist.barrier()
+        if rank == 0:
+            _merge_parts(out_path, world)
+        dist.barrier()
+    else:
+        total = n_rows
+    if rank == 0:
+        dt = time.time() - start
+        print("[main] call_mods costs %.2f seconds.." % dt)
+        print("[main] %d sites on %d GPU(s): %.0f sites/s" % (total, world, total / max(dt, 1e-9)))
+    return total
+
+
+def add_call_mods_args(p):
+    """The reference's call_mods flag surface (deepsignal_plant.py:204-316 == call_modifications.py:643-765)
+    plus the build-only flags --init_state / --seed."""
+    g = p.add_argument_group("INPUT")
+    g.add_argument("--input_path", "-i", type=str, required=True,
+                   help="feature file written by `extract` (plain or .gz)")
+    g.add_argument("--f5_batch_size", type=int, default=30,
+                   help="reads per reader batch in the reference (default 30); accepted for compatibility, results do not depend on it")
+    g = p.add_argument_group("CALL")
+    g.add_argument("--model_path", "-m", type=str, required=True, help="trained model checkpoint (.ckpt, a state_dict)")
+    g.add_argument("--model_type", type=str, default="both_bilstm", choices=["both_bilstm", "seq_bilstm", "signal_bilstm"])
+    g.add_argument("--seq_len", type=int, default=13, help="k-mer length, default 13")
+    g.add_argument("--signal_len", type=int, default=16, help="signals per base, default 16")
+    g.add_argument("--layernum1", type=int, default=3, help="BiLSTM layers on the combined feature, default 3")
+    g.add_argument("--layernum2", type=int, default=1, help="BiLSTM layers on seq / signal features, default 1")
+    g.add_argument("--class_num", type=int, default=2)
+    g.add_argument("--dropout_rate", type=float, default=0)
+    g.add_argument("--n_vocab", type=int, default=16, help="base vocabulary size (IUPAC)")
+    g.add_argument("--n_embed", type=int, default=4, help="base embedding size")
+    g.add_argument("--is_base", type=str, default="yes", help="use base features in the seq model, default yes")
+    g.add_argument("--is_signallen", type=str, default="yes", help="use per-base signal length in the seq model, default yes")
+    g.add_argument("--batch_size", "-b", type=int, default=512,
+                   help="batch size of the reference (default 512); this build batches whole parsed blocks, results do not depend on it")
+    g.add_argument("--hid_rnn", type=int, default=256, help="BiLSTM hidden size for the combined feature")
+    g = p.add_argument_group("OUTPUT")
+    g.add_argument("--result_file", "-o", type=str, required=True, help="per-read call file to write")
+    g.add_argument("--gzip", action="store_true", default=False, help="gzip the output")
+    g = p.add_argument_group("FAST5_EXTRACTION (accepted for compatibility; the fast5 branch is not part of this build)")
+    g.add_argument("--recursively", "-r", type=str, default="yes")
+    g.add_argument("--corrected_group", type=str, default="RawGenomeCorrected_000")
+    g.add_argument("--basecall_subgroup", type=str, default="BaseCalled_template")
+    g.add_argument("--is_dna", type=str, default="yes")
+    g.add_argument("--normalize_method", type=str, choices=["mad", "zscore"], default="mad")
+    g.add_argument("--motifs", type=str, default="CG")
+    g.add_argument("--mod_loc", type=int, default=0)
+    g.add_argument("--region", type=str, default=None)
+    g.add_argument("--positions", type=str, default=None)
+    g.add_argument("--reference_path", type=str, default=None)
+    p.add_argument("--nproc", "-p", type=int, default=10, help="host threads for parsing/formatting, default 10")
+    p.add_argument("--nproc_gpu", type=int, default=2,
+                   help="model processes per run in the reference; this build runs one process per GPU (torch.distributed.run)")
+    g = p.add_argument_group("MI355X build")
+    g.add_argument("--init_state", type=str, default="randn", choices=["randn", "zeros"],
+                   help="LSTM initial states: 'randn' = N(0,1) like the reference's init_hidden (in-kernel Philox), 'zeros'")
+    g.add_argument("--seed", type=int, default=0, help="seed of the in-kernel initial-state generator")
+    return p
+
+
+def main():
+    parser = add_call_mods_args(argparse.ArgumentParser("call modifications"))
+    args = parser.parse_args()
+    display_args(args)
+    call_mods(args)
+
+
+if __name__ == '__main__':
+    sys.exit(main())

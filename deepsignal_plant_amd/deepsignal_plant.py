@@ -1,0 +1,53 @@
+#!/usr/bin/env python
+"""`deepsignal_plant` command line (mirror of deepsignal_plant/deepsignal_plant.py:85-481).
+
+Only the sub-command on the hot path is implemented natively: ``call_mods`` (feature file in, per-read calls
+out).  The other sub-commands of the reference (extract, call_freq, train, denoise) are registered so that
+scripts see the same command set, and exit with a clear message (out of scope for this build)."""
+from __future__ import absolute_import
+
+import argparse
+import sys
+
+from ._version import VERSION
+from .utils.process_utils import display_args
+
+
+def main_call_mods(args):
+    from .call_modifications import call_mods  # lazy, like deepsignal_plant.py:50-54
+    display_args(args)
+    call_mods(args)
+
+
+def _not_in_this_build(name):
+    def run(_args):
+        sys.stderr.write("deepsignal_plant %s: not part of the MI355X call_mods build (use the reference "
+                         "implementation for this step)\n" % name)
+        sys.exit(2)
+    return run
+
+
+def main():
+    parser = argparse.ArgumentParser(prog="deepsignal_plant",
+                                     description="detecting base modifications from Nanopore sequencing reads of plants, "
+                                                 "MI355X-native call_mods path",
+                                     formatter_class=argparse.RawTextHelpFormatter)
+    parser.add_argument("-v", "--version", action="version", version="deepsignal-plant_amd version: {}".format(VERSION))
+    sub = parser.add_subparsers(title="modules", help="deepsignal_plant modules, use -h/--help for help")
+    from .call_modifications import add_call_mods_args
+    sub_call_mods = sub.add_parser("call_mods", description="call modifications")
+    add_call_mods_args(sub_call_mods)
+    sub_call_mods.set_defaults(func=main_call_mods)
+    for name in ("extract", "call_freq", "train", "denoise"):
+        sp = sub.add_parser(name, description="%s (not part of this build)" % name, add_help=True)
+        sp.add_argument("rest", nargs=argparse.REMAINDER)
+        sp.set_defaults(func=_not_in_this_build(name))
+    args = parser.parse_args()
+    if hasattr(args, "func"):
+        args.func(args)
+    else:
+        parser.print_help()
+
+
+if __name__ == '__main__':
+    sys.exit(main())

@@ -1,0 +1,153 @@
+"""Block reader + pinned, multi-buffered feed of the call_mods path.
+
+Replaces the reference's reader process and pickled-list queue (_read_features_file,
+call_modifications.py:55-127, Queue at :40-44): a reader thread cuts the input into blocks of complete rows
+(plain files: this rank's byte range via mmap; .gz: sequential inflate), the native parser
+(csrc/dsp_text.cpp, multi-threaded, GIL released) writes straight into PINNED SoA buffers, and the consumer
+issues async H2D copies on a HIP stream.  NBUF buffer sets rotate, so parse(k+1), H2D/compute(k) and
+format/write(k-1) overlap."""
+from __future__ import annotations
+
+import gzip
+import mmap
+import os
+import queue
+import threading
+
+import numpy as np
+
+from . import dist as dsp_dist
+from . import textio
+
+BLOCK_BYTES = int(os.environ.get("DSP_BLOCK_BYTES", 0) or (48 << 20))  # ~23k rows of ~2.08 kB per block
+
+
+class Block(object):
+    __slots__ = ("rows", "first_row", "slot")
+
+
+def count_rows_in_range(path, a, b):
+    """Rows in bytes [a, b) of a plain file whose ends are row boundaries (native memchr scan over mmap'd
+    chunks, GIL released): newlines + 1 if the range does not end with one."""
+    if b <= a:
+        return 0
+    newlines = 0
+    with open(path, "rb") as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as mm:
+        pos = a
+        while pos < b:
+            end = min(b, pos + (256 << 20))
+            view = np.frombuffer(mm, dtype=np.uint8, count=end - pos, offset=pos)
+            k = textio.count_rows(view)  # = newlines, +1 when the chunk has an unterminated tail
+            if view[-1] != 10:
+                k -= 1
+            del view
+            newlines += k
+            pos = end
+        tail_open = mm[b - 1:b] != b"\n"
+    return newlines + (1 if tail_open else 0)
+
+
+class FeatureReader(threading.Thread):
+    """Producer thread: yields parsed blocks of this rank's rows, in file order, through a bounded queue."""
+
+    def __init__(self, path, seq_len, signal_len, rank=0, world=1, nthreads=4, nbuf=3, block_bytes=BLOCK_BYTES,
+                 first_row=0, byte_range=None, pinned=True, max_rows_per_block=None):
+        super().__init__(daemon=True)
+        self.path, self.L, self.S = path, seq_len, signal_len
+        self.rank, self.world, self.nthreads = rank, world, max(1, nthreads)
+        self.block_bytes = block_bytes
+        self.first_row = first_row
+        self.byte_range = byte_range
+        self.q = queue.Queue(maxsize=max(1, nbuf - 1))
+        self.free = queue.Queue()
+        cap = max_rows_per_block or max(1024, block_bytes // 600)
+        self.cap = cap
+        for s in range(nbuf):
+            self.free.put(textio.alloc_rows(cap, seq_len, signal_len, pinned=pinned))
+        self.error = None
+
+    # -- consumer side
+    def __iter__(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                if self.error is not None:
+                    raise self.error
+                return
+            yield item
+
+    def release(self, block):
+        self.free.put(block.slot)
+
+    # -- producer side
+    def _emit(self, data, row0):
+        slot = self.free.get()
+        n = textio.count_rows(data)
+        if n > self.cap:  # rows much shorter than expected: grow this slot once (not pinned)
+            slot = textio.alloc_rows(n, self.L, self.S, pinned=False)
+        rows = textio.parse_rows(data, self.L, self.S, nthreads=self.nthreads, out=slot)
+        b = Block()
+        b.rows, b.first_row, b.slot = rows, row0, slot
+        self.q.put(b)
+        return rows.n
+
+    def run(self):
+        try:
+            row = self.first_row
+            if self.path.endswith(".gz"):
+                row = self._run_gz(row)
+            else:
+                row = self._run_plain(row)
+        except BaseException as e:  # surfaced in the consumer
+            self.error = e
+        finally:
+            self.q.put(None)
+
+    def _run_plain(self, row):
+        size = os.path.getsize(self.path)
+        if size == 0:
+            return row
+        with open(self.path, "rb") as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as mm:
+            a, b = self.byte_range if self.byte_range is not None else dsp_dist.byte_range_for_rank(mm, size, self.world, self.rank)
+            pos = a
+            while pos < b:
+                end = min(b, pos + self.block_bytes)
+                if end < b:
+                    nl = mm.rfind(b"\n", pos, end)
+                    if nl < 0:
+                        nl = mm.find(b"\n", end)
+                        nl = b - 1 if nl < 0 else nl
+                    end = min(b, nl + 1)
+                data = mm[pos:end]  # one copy out of the page cache; parsed in place, kept for sampleinfo
+                row += self._emit(data, row)
+                pos = end
+        return row
+
+    def _run_gz(self, row):
+        # .gz cannot be range-split: every rank inflates the stream and keeps the blocks it owns
+        # (block i -> rank i % world), counting the rows of foreign blocks to keep global row indices.
+        carry = b""
+        i = 0
+        with gzip.open(self.path, "rb") as f:
+            while True:
+                chunk = f.read(self.block_bytes)
+                if not chunk:
+                    break
+                data = carry + chunk
+                nl = data.rfind(b"\n")
+                if nl < 0:
+                    carry = data
+                    continue
+                carry = data[nl + 1:]
+                data = data[:nl + 1]
+                if i % self.world == self.rank:
+                    row += self._emit(data, row)
+                else:
+                    row += textio.count_rows(data)
+                i += 1
+        if carry.strip():
+            if i % self.world == self.rank:
+                row += self._emit(carry, row)
+            else:
+                row += 1
+        return row

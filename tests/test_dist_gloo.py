@@ -1,0 +1,122 @@
+"""CPU, world_size 2 over gloo: the N>1 path of the file sharding (byte-range split at row starts, global
+first-row index through an all_gather of per-rank row counts, ragged gather of per-site probabilities).
+The forward itself needs a GPU; everything around it is exercised here."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, path, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import mmap
+
+    import torch
+    import torch.distributed as dist
+
+    from deepsignal_plant_amd import dist as dd
+    from deepsignal_plant_amd import feed
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    size = os.path.getsize(path)
+    with open(path, "rb") as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as mm:
+        a, b = dd.byte_range_for_rank(mm, size, world, rank)
+    mine = feed.count_rows_in_range(path, a, b)
+    counts = dd.all_gather_ints(mine, world)
+    first = dd.exclusive_prefix(counts, rank)
+    reader = feed.FeatureReader(path, 13, 16, rank=rank, world=world, nthreads=2, nbuf=2, block_bytes=100_000,
+                                first_row=first, byte_range=(a, b), pinned=False)
+    reader.start()
+    rows, firsts = [], []
+    for blk in reader:
+        firsts.append(blk.first_row)
+        rows += [blk.rows.sampleinfo(i) for i in range(blk.rows.n)]
+        means = blk.rows.means.copy()
+        reader.release(blk)
+    # fake per-site probabilities keyed by the global row index, then the optional final gather
+    idx = torch.arange(first, first + len(rows), dtype=torch.float32)
+    probs = torch.stack((idx, -idx), 1)
+    gathered = dd.gather_probs(probs, world)
+    if rank == 0:
+        allp = torch.cat(gathered)
+        assert torch.equal(allp[:, 0], torch.arange(allp.shape[0], dtype=torch.float32))
+    np.savez(os.path.join(outdir, "r%d.npz" % rank), rows=np.array(rows), first=first, firsts=np.array(firsts),
+             a=a, b=b, counts=np.array(counts))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_range_shard_covers_every_row_once(tmp_path, world):
+    import torch.multiprocessing as mp
+    path = os.path.join(ROOT, "tests", "golden", "f2_rows.tsv")
+    port = _free_port()
+    mp.start_processes(_worker, args=(world, port, path, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    want = [l.split("\t") for l in open(path).read().splitlines()]
+    want = ["\t".join(w[:6]) for w in want]
+    got, pos = [], 0
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), "r%d.npz" % r))
+        assert int(d["first"]) == len(got)               # global index of my first row
+        assert int(d["a"]) == pos                        # ranges tile the file
+        pos = int(d["b"])
+        if len(d["firsts"]):
+            assert int(d["firsts"][0]) == len(got)
+        got += list(d["rows"])
+        assert int(d["counts"].sum()) == len(want)
+    assert pos == os.path.getsize(path)
+    assert got == want
+
+
+def test_split_helpers():
+    from deepsignal_plant_amd import dist as dd
+    for n in (0, 1, 7, 8, 9, 100):
+        for w in (1, 2, 3, 8):
+            cover = []
+            for r in range(w):
+                a, b = dd.split_range(n, w, r)
+                assert 0 <= a <= b <= n
+                cover += list(range(a, b))
+            assert cover == list(range(n))
+    buf = b"aa\nbbbb\nc\n"
+    assert [dd.align_to_line_start(buf, p, len(buf)) for p in range(len(buf) + 1)] == [0, 3, 3, 3, 8, 8, 8, 8, 8, 10, 10]
+
+
+def test_reader_gz_block_cyclic_matches_plain(tmp_path):
+    from deepsignal_plant_amd import feed
+    gz = os.path.join(ROOT, "tests", "golden", "f2_rows.tsv.gz")
+    plain = os.path.join(ROOT, "tests", "golden", "f2_rows.tsv")
+    want = ["\t".join(l.split("\t")[:6]) for l in open(plain).read().splitlines()]
+    for world in (1, 2):
+        seen = {}
+        for rank in range(world):
+            rd = feed.FeatureReader(gz, 13, 16, rank=rank, world=world, nthreads=1, nbuf=2, block_bytes=90_000, pinned=False)
+            rd.start()
+            for blk in rd:
+                for i in range(blk.rows.n):
+                    seen[blk.first_row + i] = blk.rows.sampleinfo(i)
+                rd.release(blk)
+        assert [seen[i] for i in range(len(want))] == want
+
+
+def test_reader_surfaces_parse_errors(tmp_path):
+    from deepsignal_plant_amd import feed
+    p = tmp_path / "bad.tsv"
+    p.write_text("chr1\t1\t+\n")
+    rd = feed.FeatureReader(str(p), 13, 16, nthreads=1, nbuf=2, pinned=False)
+    rd.start()
+    with pytest.raises(ValueError):
+        for _ in rd:
+            pass
