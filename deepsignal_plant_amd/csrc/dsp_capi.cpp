@@ -9,8 +9,10 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -39,6 +41,9 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+// hidden sizes are zero-padded to whole unit tiles: 32 units, or pairs of them (64) above 32 so that every
+// wave of the lstm2 kernel owns two unit tiles
+inline int pad_hidden(int h) { return h <= 32 ? 32 : rup(h, 64); }
 
 struct Dims {
     int T, S, H, C, V, E, l1, l2;
@@ -127,11 +132,11 @@ struct DevLinear { int Fin, ORT; float* wpk; float* bias; };
 void pack_lstm_dir(const float* wih, const float* whh, const float* bih, const float* bhh, int I, int H, int Hp,
                    const std::vector<int>& in_map, std::vector<float>& wpk, std::vector<float>& bias) {
     const int Ipad = (int)in_map.size();
-    const int UT = Hp / 32, NQ = (Ipad + Hp) / 8;
+    const int UT = Hp / 32, NQ = rup((Ipad + Hp) / 8, 4);  // padded k-groups keep zero weights
     wpk.assign((size_t)UT * NQ * 4 * 64 * 4, 0.f);
     bias.assign((size_t)4 * Hp, 0.f);
     for (int u = 0; u < UT; ++u)
-        for (int q = 0; q < NQ; ++q)
+        for (int q = 0; q < (Ipad + Hp) / 8; ++q)
             for (int g = 0; g < 4; ++g)
                 for (int lane = 0; lane < 64; ++lane) {
                     const int unit = u * 32 + (lane & 31);
@@ -189,11 +194,12 @@ struct dsp_model {
     float* w2 = nullptr; float* b2 = nullptr;
     int hseq_p = 0, hsig_p = 0, Hp = 0, Fseq = 0, Fsig = 0, Fcomb = 0, Fwide = 0;
     std::vector<int> comb_in_map;  // padded comb-input feature -> reference feature
+    int lstm_variant = 3;          // 1 = first kernel (8 waves, LDS h, 1-deep prefetch), 3 = lstm3 (4 waves, ring)
     // scratch
     void* ws = nullptr;
     int64_t ws_sites = 0;
     long long NTp = 0;
-    float *xseq = nullptr, *xsig = nullptr, *bufA = nullptr, *bufB = nullptr, *comb_in = nullptr;
+    float *xseq = nullptr, *xsig = nullptr, *bufA = nullptr, *bufB = nullptr, *comb_in = nullptr, *h0buf = nullptr;
     float* last_out = nullptr;
     // profiling
     bool prof = false;
@@ -216,7 +222,7 @@ int upload(dsp_model* m, const std::vector<float>& h, float** out) {
 
 int build_stack(dsp_model* m, const float* const* w, int in, int hid, int layers, std::vector<int> in_map0,
                 std::vector<DevLstmLayer>& out) {
-    const int Hp = rup(hid, 32);
+    const int Hp = pad_hidden(hid);
     for (int k = 0; k < layers; ++k) {
         const int I = k == 0 ? in : 2 * hid;
         const std::vector<int> in_map = k == 0 ? in_map0 : map_bidir(hid, Hp);
@@ -236,7 +242,7 @@ int build_stack(dsp_model* m, const float* const* w, int in, int hid, int layers
     return 0;
 }
 
-size_t ws_layout(const dsp_model* m, int64_t sites, long long* NTp_out, size_t off[5]) {
+size_t ws_layout(const dsp_model* m, int64_t sites, long long* NTp_out, size_t off[6]) {
     long long nt = (sites + 31) / 32;
     long long NTp = (nt + 15) / 16 * 16;
     if (NTp == 0) NTp = 16;
@@ -248,6 +254,7 @@ size_t ws_layout(const dsp_model* m, int64_t sites, long long* NTp_out, size_t o
     off[2] = take(m->Fwide);
     off[3] = take(m->Fwide);
     off[4] = take(m->Fcomb);
+    off[5] = o; o += ((size_t)NTp * m->Fwide * 32 * sizeof(float) + 255) / 256 * 256;  // h0 scratch (no T)
     if (NTp_out) *NTp_out = NTp;
     return o;
 }
@@ -260,7 +267,7 @@ int ensure_ws(dsp_model* m, int64_t sites, hipStream_t stream) {
         HIP_TRY(hipFree(m->ws));
         m->ws = nullptr; m->ws_sites = 0;
     }
-    size_t off[5];
+    size_t off[6];
     long long NTp;
     const size_t bytes = ws_layout(m, sites, &NTp, off);
     hipError_t e = hipMalloc(&m->ws, bytes);
@@ -268,6 +275,7 @@ int ensure_ws(dsp_model* m, int64_t sites, hipStream_t stream) {
     char* b = (char*)m->ws;
     m->xseq = (float*)(b + off[0]); m->xsig = (float*)(b + off[1]);
     m->bufA = (float*)(b + off[2]); m->bufB = (float*)(b + off[3]); m->comb_in = (float*)(b + off[4]);
+    m->h0buf = (float*)(b + off[5]);
     m->ws_sites = (int64_t)NTp * 32;
     m->NTp = NTp;
     return 0;
@@ -309,7 +317,13 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
         a.wpk0 = ly.wpk[0]; a.wpk1 = ly.wpk[1]; a.bias0 = ly.bias[0]; a.bias1 = ly.bias[1];
         a.n = n; a.NTp = m->NTp;
         a.Ipad = ly.Ipad; a.H = ly.H; a.Hp = ly.Hp; a.T = m->d.T; a.Fout = 2 * ly.Hp;
-        a.UT = ly.Hp / 32; a.SG = 8 / a.UT; if (a.SG < 1) a.SG = 1;
+        a.NQ = rup((ly.Ipad + ly.Hp) / 8, 4);
+        a.h0buf = m->h0buf;
+        a.UT = ly.Hp / 32;
+        const int variant = m->lstm_variant;
+        int upw = 1;
+        if (variant == 1) { a.SG = 8 / a.UT; if (a.SG < 1) a.SG = 1; }
+        else { upw = a.UT == 1 ? 1 : 2; a.SG = 4 / (a.UT / upw); if (a.SG < 1) a.SG = 1; }
         a.init_mode = init ? init->mode : DSP_INIT_ZEROS;
         a.seed = init ? init->seed : 0; a.site_offset = init ? init->site_offset : 0;
         a.stream_base = lstm_id * 64 + (int)k * 4;
@@ -317,7 +331,7 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
             a.h0 = h0 + (size_t)(2 * k) * (size_t)n * ly.H;
             a.c0 = c0 + (size_t)(2 * k) * (size_t)n * ly.H;
         }
-        L.run(name, [&] { return dsp_k_lstm(&a, L.s); });
+        L.run(name, [&] { return variant == 1 ? dsp_k_lstm(&a, L.s) : dsp_k_lstm3(&a, upw, L.s); });
         cur = dst;
     }
     return dst;
@@ -397,11 +411,14 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
     dsp_model* m = new (std::nothrow) dsp_model();
     if (!m) { hipSetDevice(prev); return fail(DSP_ENOMEM, "out of host memory"); }
     m->cfg = *cfg; m->d = d; m->device = device;
-    m->hseq_p = d.hseq ? rup(d.hseq, 32) : 0;
-    m->hsig_p = d.hsig ? rup(d.hsig, 32) : 0;
-    m->Hp = rup(d.H, 32);
-    m->Fseq = d.hseq ? rup(d.Iseq, 8) : 0;
-    m->Fsig = d.hsig ? rup(d.S, 8) : 0;
+    if (const char* v = getenv("DSP_LSTM_VARIANT")) m->lstm_variant = atoi(v) == 1 ? 1 : 3;
+    m->hseq_p = d.hseq ? pad_hidden(d.hseq) : 0;
+    m->hsig_p = d.hsig ? pad_hidden(d.hsig) : 0;
+    m->Hp = pad_hidden(d.H);
+    // front-end inputs are padded to >= 32 features so that the first four k-groups of every step are
+    // x-part groups (lstm3 requests them before h_t exists)
+    m->Fseq = d.hseq ? std::max(32, rup(d.Iseq, 8)) : 0;
+    m->Fsig = d.hsig ? std::max(32, rup(d.S, 8)) : 0;
     m->Fcomb = m->hseq_p + m->hsig_p;
     m->Fwide = 2 * m->Hp;
     if (2 * m->hseq_p > m->Fwide) m->Fwide = 2 * m->hseq_p;
@@ -457,7 +474,7 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
 
 size_t dsp_workspace_bytes(const dsp_model* m, int64_t max_sites) {
     if (!m) return 0;
-    size_t off[5];
+    size_t off[6];
     return ws_layout(m, max_sites, nullptr, off);
 }
 

@@ -26,16 +26,18 @@ struct PackArgs {
 struct LstmArgs {
     const float* x;        // K4 input, Ipad features
     float* out;            // K4 output, Fout features; this layer writes [dir*Hp, dir*Hp + Hp)
-    const float* wpk0;     // forward  direction A fragments [UT][(Ipad+Hp)/8][4 gates][64 lanes][4]
+    const float* wpk0;     // forward  direction A fragments [UT][NQ][4 gates][64 lanes][4]
     const float* wpk1;     // backward direction
     const float* bias0;    // forward  b_ih + b_hh, [4][Hp]
     const float* bias1;
     const float* h0;       // EXPLICIT: reference layout, already offset to this layer: [2 dirs][n][H]
     const float* c0;
+    float* h0buf;          // lstm3: K4 scratch [NTp][Fout/4][32][4] holding h0 (read by step 0 as "h_{-1}")
     long long n;
     long long NTp;
     unsigned long long seed, site_offset;
     int Ipad, H, Hp, T, Fout;
+    int NQ;                // k-groups per unit tile in wpk: (Ipad+Hp)/8 padded to a multiple of 4 (zero weights)
     int UT, SG;            // unit tiles (Hp/32), site groups per workgroup; block = 64*UT*SG threads
     int init_mode;         // DSP_INIT_*
     int stream_base;       // philox stream of (lstm, layer, dir=0, h): lstm*64 + layer*4
@@ -69,6 +71,7 @@ extern "C" {
 int dsp_k_init(void);
 int dsp_k_pack(const PackArgs* a, hipStream_t s);
 int dsp_k_lstm(const LstmArgs* a, hipStream_t s);
+int dsp_k_lstm3(const LstmArgs* a, int upw, hipStream_t s);
 int dsp_k_linear(const LinArgs* a, hipStream_t s);
 int dsp_k_head(const HeadArgs* a, hipStream_t s);
 #ifdef __cplusplus

@@ -22,6 +22,10 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// explicit address spaces keep hipcc from merging a global and an LDS load of the same variable into one
+// flat_load (which counts on both vmcnt and lgkmcnt and forces s_waitcnt 0 on everything in flight)
+typedef __attribute__((address_space(1))) const f32x4 gf32x4;  // global
+typedef __attribute__((address_space(3))) const f32x4 lf32x4;  // LDS
 
 // ------------------------------------------------------------------------------------------------
 // math helpers: v_exp_f32 / v_rcp_f32 based (about 1 ulp each); abs error of sigmoid/tanh ~1e-7
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(512) void dsp_lstm_dir_kernel(LstmArgs a) {
     const int nqx = a.Ipad >> 3, nqh = a.Hp >> 3, nq = nqx + nqh;
     const int T = a.T;
 
-    const f32x4* wq = (const f32x4*)(dir ? a.wpk1 : a.wpk0) + (size_t)u * nq * 256 + lane;  // + q*256 + g*64
+    const f32x4* wq = (const f32x4*)(dir ? a.wpk1 : a.wpk0) + (size_t)u * a.NQ * 256 + lane;  // + q*256 + g*64
     const f32x4* bias4 = (const f32x4*)(dir ? a.bias1 : a.bias0);
     const f32x4* x4 = (const f32x4*)a.x;
     f32x4* out4 = (f32x4*)a.out;
@@ -257,10 +261,19 @@ __global__ __launch_bounds__(512) void dsp_lstm_dir_kernel(LstmArgs a) {
             B[0] = Bn[0]; B[1] = Bn[1];
             const int qn = q + 1;
             if (qn < nq) {
+#ifndef ABL_NOWLOAD
 #pragma unroll
                 for (int g = 0; g < 4; ++g) An[g] = wq[(size_t)qn * 256 + g * 64];
+#endif
+#ifndef ABL_NOXLOAD
                 if (qn < nqx) { Bn[0] = xb0[(size_t)qn * 64]; Bn[1] = xb1[(size_t)qn * 64]; }
-                else { Bn[0] = hb0[(size_t)(qn - nqx) * 2 * M]; Bn[1] = hb1[(size_t)(qn - nqx) * 2 * M]; }
+                else
+#endif
+#ifndef ABL_NOHLOAD
+                if (qn >= nqx) { Bn[0] = hb0[(size_t)(qn - nqx) * 2 * M]; Bn[1] = hb1[(size_t)(qn - nqx) * 2 * M]; }
+#else
+                {}
+#endif
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -282,6 +295,10 @@ __global__ __launch_bounds__(512) void dsp_lstm_dir_kernel(LstmArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int r = 4 * aa + i;
+#ifdef ABL_NOCELL
+                    hv[i] = acc[0][m][r] + acc[1][m][r] + acc[2][m][r] + acc[3][m][r] + c[m][r];
+                    continue;
+#endif
                     const float ig = fast_sigmoid(acc[0][m][r]);
                     const float fg = fast_sigmoid(acc[1][m][r]);
                     const float gg = fast_tanh(acc[2][m][r]);
@@ -292,11 +309,228 @@ __global__ __launch_bounds__(512) void dsp_lstm_dir_kernel(LstmArgs a) {
                 }
                 const int k4 = u * 8 + 2 * aa + half;
                 hl[(size_t)(nxt * HQ + k4) * M + lt[m] * 32 + ls] = hv;
+#ifndef ABL_NOSTORE
                 out4[((size_t)(gt[m] * T + t) * (a.Fout >> 2) + (size_t)(dir * HQ + k4)) * 32 + ls] = hv;
+#else
+                if (hv[0] == 123.456f) out4[ls] = hv;
+#endif
             }
         }
+#ifndef ABL_NOBARRIER
         __syncthreads();
+#endif
         cur = nxt;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// lstm3 (round-1 ablation result: operand-load latency, not MFMA issue, cost ~25 % in dsp_lstm_dir_kernel):
+// same math and K4 layout, restructured for latency tolerance.
+//   * ONE wave per SIMD (<= 4 waves, up to 512 registers each); a wave owns UPW unit tiles x 2 site tiles
+//     (UPW*8 accumulator tiles in AGPRs), 64 MFMAs per k-group.
+//   * EVERY operand is a coalesced global load: weights (A), x_t (B) and also h_{t-1} (B), which is read
+//     back from the K4 output the workgroup itself stored one step earlier (same CU, visible after the
+//     per-step workgroup barrier; L2-resident).  No LDS at all, so no flat/LDS/global mixing and the
+//     compiler can count vmcnt exactly.
+//   * Register rings: an A fragment (weights of one unit tile x gate) is reloaded for k-group q+2 right after
+//     its 8 MFMAs of group q; B fragments sit in a 4-deep ring (group q+4 requested after group q).  Every
+//     operand therefore has ~2-3 k-groups (8-12k cycles) to arrive -- longer than an L2 miss to HBM.  The
+//     k-group count is padded to a multiple of 4 with zero weights (host side), so the loop body is
+//     branch-free; the last groups of step t request the first groups of step t+1 (weights and x_{t+1},
+//     which do not depend on h_t) before the cell phase.
+// ------------------------------------------------------------------------------------------------
+// Every global access of lstm3 is "wave-uniform byte base (SGPRs) + lane*16": one VGPR of addressing in
+// total, so the 512-register budget goes to accumulators (256), cell state (64) and the fragment rings (96).
+__device__ __forceinline__ f32x4 ldg16(const char* ubase, uint32_t voff) {
+    return *(gf32x4*)(ubase + voff);
+}
+__device__ __forceinline__ void stg16(char* ubase, uint32_t voff, f32x4 v) {
+    *(__attribute__((address_space(1))) f32x4*)(ubase + voff) = v;
+}
+
+template <int UPW>
+__global__ __launch_bounds__(256, 1) void dsp_lstm3_kernel(LstmArgs a) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const uint32_t voff = (uint32_t)lane * 16u;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int UTP = a.UT / UPW;
+    const int ug = w % UTP, sg = w / UTP;
+    const int dir = blockIdx.x & 1;
+    const int grp = blockIdx.x >> 1;
+    const int half = lane >> 5, ls = lane & 31;
+    const int HQ = a.Hp >> 2;
+    const int nqx = a.Ipad >> 3, nq = nqx + (a.Hp >> 3), NQ = a.NQ;
+    const int T = a.T;
+    const int F4 = a.Fout >> 2;
+    const size_t xrow = (size_t)(a.Ipad >> 2) * 512;  // bytes of one (tile, t) block of the input
+    const size_t orow = (size_t)F4 * 512;             // bytes of one (tile, t) block of the output
+
+    // uniform byte bases
+    const char* wbase[UPW];
+#pragma unroll
+    for (int uu = 0; uu < UPW; ++uu)
+        wbase[uu] = (const char*)(dir ? a.wpk1 : a.wpk0) + (size_t)(ug * UPW + uu) * NQ * 4096;  // + q*4096 + g*1024
+    const f32x4* bias4 = (const f32x4*)(dir ? a.bias1 : a.bias0);
+    char* outb = (char*)a.out + (size_t)dir * HQ * 512;   // + (tile*T + t)*orow + k4*512
+    char* h0b = (char*)a.h0buf + (size_t)dir * HQ * 512;  // + tile*orow + k4*512
+    const char* xbb = (const char*)a.x;
+
+    long long gt[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) gt[m] = (long long)grp * (a.SG * 2) + sg * 2 + m;
+
+    // ---- initial state: c0 -> registers, h0 -> the K4 scratch that step 0 reads as "h_{-1}"
+    f32x16 c[UPW][2];
+#pragma unroll
+    for (int uu = 0; uu < UPW; ++uu) {
+        const int u = ug * UPW + uu;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const long long site = gt[m] * 32 + ls;
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa) {
+                const int k4 = u * 8 + 2 * aa + half;
+                f32x4 hv = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
+                if (a.init_mode != 0) {
+                    hv = init_state4(a.h0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, a.site_offset,
+                                     (uint32_t)(a.stream_base + dir * 2 + 0));
+                    cv = init_state4(a.c0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, a.site_offset,
+                                     (uint32_t)(a.stream_base + dir * 2 + 1));
+                }
+                stg16(h0b + (size_t)gt[m] * orow + (size_t)(u * 8 + 2 * aa) * 512, voff, hv);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c[uu][m][4 * aa + i] = cv[i];
+            }
+        }
+    }
+    __syncthreads();  // h0 stored (vmcnt drained) before any wave reads it back
+
+    // B-operand bases of a step (uniform): x_t, and h_{t-1} (= the K4 output of the previous step, or the h0
+    // scratch), the latter biased by -nqx k-groups so that both parts are "base + q*1024"
+    const char* xb[2];
+    const char* hb[2];
+    auto set_bases = [&](int step) {
+        const int t = dir ? (T - 1 - step) : step;
+        const int tp = dir ? (t + 1) : (t - 1);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            xb[m] = xbb + (size_t)(gt[m] * T + t) * xrow;
+            const char* hp = step == 0 ? h0b + (size_t)gt[m] * orow : outb + (size_t)(gt[m] * T + tp) * orow;
+            hb[m] = hp - (size_t)nqx * 1024;
+        }
+    };
+
+    // register rings: A two stages deep (an A fragment is reloaded right after its 8 MFMAs, for group q+2),
+    // B four stages deep (reloaded after the whole group, for group q+4)
+    f32x4 A0[UPW][4], A1[UPW][4], B0[2], B1[2], B2[2], B3[2];
+    f32x16 acc[UPW][4][2];
+    auto loadB = [&](f32x4 (&B)[2], int q) {
+        const int qc = q < nq ? q : nq - 1;  // padded k-groups have zero weights: any finite B will do
+        const bool isx = qc < nqx;
+#ifdef ABL3_NOB
+        if (q > 3) return;
+#endif
+#pragma unroll
+        for (int m = 0; m < 2; ++m) B[m] = ldg16((isx ? xb[m] : hb[m]) + (size_t)qc * 1024, voff);
+    };
+    auto loadA = [&](f32x4 (&A)[UPW][4], int q) {
+#pragma unroll
+        for (int uu = 0; uu < UPW; ++uu)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) A[uu][g] = ldg16(wbase[uu] + (size_t)q * 4096 + g * 1024, voff);
+    };
+    // one k-group: 8 MFMAs per (unit tile, gate), then that A fragment is refilled for group qa
+    auto stage = [&](f32x4 (&A)[UPW][4], const f32x4 (&B)[2], int qa) {
+#pragma unroll
+        for (int uu = 0; uu < UPW; ++uu)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[uu][g][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[uu][g][i], B[0][i], acc[uu][g][0], 0, 0, 0);
+                    acc[uu][g][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[uu][g][i], B[1][i], acc[uu][g][1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // keep "8 MFMAs, then the refill of that fragment" in order
+#ifndef ABL3_NOA
+                A[uu][g] = ldg16(wbase[uu] + (size_t)qa * 4096 + g * 1024, voff);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+
+    set_bases(0);
+    loadA(A0, 0); loadB(B0, 0);
+    loadA(A1, 1); loadB(B1, 1);
+    loadB(B2, 2); loadB(B3, 3);
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? (T - 1 - step) : step;
+#pragma unroll
+        for (int uu = 0; uu < UPW; ++uu)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int aa = 0; aa < 4; ++aa) {
+                    const f32x4 b = bias4[g * HQ + (ug * UPW + uu) * 8 + 2 * aa + half];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc[uu][g][0][4 * aa + i] = b[i];
+                        acc[uu][g][1][4 * aa + i] = b[i];
+                    }
+                }
+
+        for (int q = 0; q < NQ - 4; q += 4) {
+            stage(A0, B0, q + 2); loadB(B0, q + 4); __builtin_amdgcn_sched_barrier(0);
+            stage(A1, B1, q + 3); loadB(B1, q + 5); __builtin_amdgcn_sched_barrier(0);
+            stage(A0, B2, q + 4); loadB(B2, q + 6); __builtin_amdgcn_sched_barrier(0);
+            stage(A1, B3, q + 5); loadB(B3, q + 7); __builtin_amdgcn_sched_barrier(0);
+        }
+        // last four k-groups of the step; refills wrap to the first groups of step+1 (weights and x_{t+1} do
+        // not depend on h_t, so they are requested before the cell phase).  On the last step the wrapped
+        // requests re-read the same step (valid addresses, results unused): no branches in the stream.
+        stage(A0, B0, NQ - 2);
+        stage(A1, B1, NQ - 1);
+        set_bases(step + 1 < T ? step + 1 : step);
+        loadB(B0, 0);
+        loadB(B1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        stage(A0, B2, 0);
+        loadB(B2, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        stage(A1, B3, 1);
+        loadB(B3, 3);
+        __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll
+        for (int uu = 0; uu < UPW; ++uu) {
+            const int u = ug * UPW + uu;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                char* ob = outb + (size_t)(gt[m] * T + t) * orow + (size_t)(u * 8) * 512;
+#pragma unroll
+                for (int aa = 0; aa < 4; ++aa) {
+                    f32x4 hv;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 4 * aa + i;
+#ifdef ABL3_NOCELL
+                        hv[i] = acc[uu][0][m][r] + acc[uu][1][m][r] + acc[uu][2][m][r] + acc[uu][3][m][r] + c[uu][m][r];
+                        continue;
+#endif
+                        const float ig = fast_sigmoid(acc[uu][0][m][r]);
+                        const float fg = fast_sigmoid(acc[uu][1][m][r]);
+                        const float gg = fast_tanh(acc[uu][2][m][r]);
+                        const float og = fast_sigmoid(acc[uu][3][m][r]);
+                        const float cn = __builtin_fmaf(fg, c[uu][m][r], ig * gg);
+                        c[uu][m][r] = cn;
+                        hv[i] = og * fast_tanh(cn);
+                    }
+                    stg16(ob + (size_t)(2 * aa) * 512, voff, hv);
+                }
+            }
+        }
+        __syncthreads();  // h_t stored by every wave (vmcnt(0) + barrier) before the next step reads it
     }
 }
 
@@ -428,6 +662,14 @@ extern "C" int dsp_k_pack(const PackArgs* a, hipStream_t s) {
     const long long threads = (long long)a->NTp * a->T * 32;
     const unsigned blocks = (unsigned)((threads + 255) / 256);
     hipLaunchKernelGGL(dsp_pack_kernel, dim3(blocks), dim3(256), 0, s, *a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dsp_k_lstm3(const LstmArgs* a, int upw, hipStream_t s) {
+    const int waves = (a->UT / upw) * a->SG;
+    const unsigned groups = (unsigned)(a->NTp / (a->SG * 2));
+    if (upw == 2) hipLaunchKernelGGL(dsp_lstm3_kernel<2>, dim3(groups * 2), dim3(waves * 64), 0, s, *a);
+    else hipLaunchKernelGGL(dsp_lstm3_kernel<1>, dim3(groups * 2), dim3(waves * 64), 0, s, *a);
     return (int)hipGetLastError();
 }
 
