@@ -124,7 +124,7 @@ std::vector<int> map_bidir(int H, int Hp) {  // [fwd Hp | bwd Hp] -> [fwd H | bw
     return m;
 }
 
-struct DevLstmLayer { int Ipad, H, Hp; float* wpk[2]; float* bias[2]; };
+struct DevLstmLayer { int Ipad, H, Hp; float* wpk[2]; float* bias[2]; float* sbias[2]; };
 struct DevLinear { int Fin, ORT; float* wpk; float* bias; };
 
 // A fragments for gates^T = W * act^T :  [UT][NQ][4 gates][64 lanes][4]
@@ -236,6 +236,13 @@ int build_stack(dsp_model* m, const float* const* w, int in, int hid, int layers
             if (rc) return rc;
             rc = upload(m, bias, &L.bias[d]);
             if (rc) return rc;
+            std::vector<float> sb(bias.size());
+            for (size_t i = 0; i < bias.size(); ++i) {  // gate-major [4][Hp]: gate 2 (g) feeds tanh
+                const bool is_g = i / (size_t)Hp == 2;
+                sb[i] = (float)((is_g ? -2.8853900817779268 : -1.4426950408889634) * (double)bias[i]);
+            }
+            rc = upload(m, sb, &L.sbias[d]);
+            if (rc) return rc;
         }
         out.push_back(L);
     }
@@ -315,6 +322,7 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
         LstmArgs a{};
         a.x = cur; a.out = dst;
         a.wpk0 = ly.wpk[0]; a.wpk1 = ly.wpk[1]; a.bias0 = ly.bias[0]; a.bias1 = ly.bias[1];
+        a.sbias0 = ly.sbias[0]; a.sbias1 = ly.sbias[1];
         a.n = n; a.NTp = m->NTp;
         a.Ipad = ly.Ipad; a.H = ly.H; a.Hp = ly.Hp; a.T = m->d.T; a.Fout = 2 * ly.Hp;
         a.NQ = rup((ly.Ipad + ly.Hp) / 8, 4);
@@ -331,7 +339,22 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
             a.h0 = h0 + (size_t)(2 * k) * (size_t)n * ly.H;
             a.c0 = c0 + (size_t)(2 * k) * (size_t)n * ly.H;
         }
+        unsigned long long* dbg = nullptr;
+        if (getenv("DSP_TIMING_DUMP") && k + 1 == layers.size() && lstm_id == 2) {  // last combined layer
+            if (hipMalloc((void**)&dbg, 16 * 8 * sizeof(unsigned long long)) == hipSuccess) hipMemset(dbg, 0, 16 * 8 * 8);
+            a.dbg = dbg;
+        }
         L.run(name, [&] { return variant == 1 ? dsp_k_lstm(&a, L.s) : dsp_k_lstm3(&a, upw, L.s); });
+        if (dbg) {
+            unsigned long long h[16 * 8];
+            hipStreamSynchronize(L.s);
+            hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+            hipFree(dbg);
+            for (int st = 0; st < m->d.T && st < 16; ++st)
+                fprintf(stderr, "[timing] step %2d: bias %6llu  main %8llu  tail %7llu  cell %6llu  barrier %6llu  (total %8llu)\n", st,
+                        h[st * 8 + 1] - h[st * 8], h[st * 8 + 2] - h[st * 8 + 1], h[st * 8 + 3] - h[st * 8 + 2],
+                        h[st * 8 + 4] - h[st * 8 + 3], h[st * 8 + 5] - h[st * 8 + 4], h[st * 8 + 5] - h[st * 8]);
+        }
         cur = dst;
     }
     return dst;

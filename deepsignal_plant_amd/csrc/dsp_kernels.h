@@ -30,8 +30,11 @@ struct LstmArgs {
     const float* wpk1;     // backward direction
     const float* bias0;    // forward  b_ih + b_hh, [4][Hp]
     const float* bias1;
+    const float* sbias0;   // pre-scaled biases for lstm3: -log2e*b (gates i,f,o), -2*log2e*b (gate g), [4][Hp]
+    const float* sbias1;
     const float* h0;       // EXPLICIT: reference layout, already offset to this layer: [2 dirs][n][H]
     const float* c0;
+    unsigned long long* dbg;  // optional per-step phase timestamps of (block 0, wave 0) [T][8] (DSP_TIMING builds)
     float* h0buf;          // lstm3: K4 scratch [NTp][Fout/4][32][4] holding h0 (read by step 0 as "h_{-1}")
     long long n;
     long long NTp;

@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "dsp_kernels.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -71,6 +73,14 @@ __device__ __forceinline__ f32x4 philox_normal4(uint64_t seed, uint64_t site, ui
         o[2] = r * c; o[3] = r * s;
     }
     return o;
+}
+
+// activations with the bias folded into the exp2 argument: bp = -log2e*b (sigmoid) / -2*log2e*b (tanh)
+__device__ __forceinline__ float sigmoid_pre(float x, float bp) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(x, -1.4426950408889634f, bp)));
+}
+__device__ __forceinline__ float tanh_pre(float x, float bp) {
+    return __builtin_fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(x, -2.8853900817779268f, bp))), -1.0f);
 }
 
 __device__ __forceinline__ float load_code(const void* p, int dt, size_t i) {
@@ -345,11 +355,27 @@ __device__ __forceinline__ f32x4 ldg16(const char* ubase, uint32_t voff) {
     return *(gf32x4*)(ubase + voff);
 }
 __device__ __forceinline__ void stg16(char* ubase, uint32_t voff, f32x4 v) {
+#ifdef ABL3_NTST
+    __builtin_nontemporal_store(v, (__attribute__((address_space(1))) f32x4*)(ubase + voff));
+#else
     *(__attribute__((address_space(1))) f32x4*)(ubase + voff) = v;
+#endif
+}
+__device__ __forceinline__ f32x4 ldg16_stream(const char* ubase, uint32_t voff) {
+#ifdef ABL3_NTX
+    return __builtin_nontemporal_load((gf32x4*)(ubase + voff));
+#else
+    return *(gf32x4*)(ubase + voff);
+#endif
 }
 
 template <int UPW>
 __global__ __launch_bounds__(256, 1) void dsp_lstm3_kernel(LstmArgs a) {
+    // LDS: the cell state c (own-lane scratch, [UPW*2*4 groups][256 threads] float4, conflict-free) and the
+    // pre-scaled biases [4][Hp].  Keeping c out of the VGPRs leaves them to the fragment rings (no spills).
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* c_lds = (f32x4*)smem;
+    f32x4* b_lds = c_lds + UPW * 8 * 256;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const uint32_t voff = (uint32_t)lane * 16u;
@@ -371,7 +397,7 @@ __global__ __launch_bounds__(256, 1) void dsp_lstm3_kernel(LstmArgs a) {
 #pragma unroll
     for (int uu = 0; uu < UPW; ++uu)
         wbase[uu] = (const char*)(dir ? a.wpk1 : a.wpk0) + (size_t)(ug * UPW + uu) * NQ * 4096;  // + q*4096 + g*1024
-    const f32x4* bias4 = (const f32x4*)(dir ? a.bias1 : a.bias0);
+    const f32x4* bias4 = (const f32x4*)(dir ? a.sbias1 : a.sbias0);
     char* outb = (char*)a.out + (size_t)dir * HQ * 512;   // + (tile*T + t)*orow + k4*512
     char* h0b = (char*)a.h0buf + (size_t)dir * HQ * 512;  // + tile*orow + k4*512
     const char* xbb = (const char*)a.x;
@@ -380,8 +406,8 @@ __global__ __launch_bounds__(256, 1) void dsp_lstm3_kernel(LstmArgs a) {
 #pragma unroll
     for (int m = 0; m < 2; ++m) gt[m] = (long long)grp * (a.SG * 2) + sg * 2 + m;
 
-    // ---- initial state: c0 -> registers, h0 -> the K4 scratch that step 0 reads as "h_{-1}"
-    f32x16 c[UPW][2];
+    // ---- initial state: c0 -> LDS, h0 -> the K4 scratch that step 0 reads as "h_{-1}"; biases -> LDS
+    for (int i = tid; i < a.Hp; i += blockDim.x) b_lds[i] = bias4[i];
 #pragma unroll
     for (int uu = 0; uu < UPW; ++uu) {
         const int u = ug * UPW + uu;
@@ -399,8 +425,7 @@ __global__ __launch_bounds__(256, 1) void dsp_lstm3_kernel(LstmArgs a) {
                                      (uint32_t)(a.stream_base + dir * 2 + 1));
                 }
                 stg16(h0b + (size_t)gt[m] * orow + (size_t)(u * 8 + 2 * aa) * 512, voff, hv);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) c[uu][m][4 * aa + i] = cv[i];
+                c_lds[((uu * 2 + m) * 4 + aa) * 256 + tid] = cv;
             }
         }
     }
@@ -432,7 +457,14 @@ __global__ __launch_bounds__(256, 1) void dsp_lstm3_kernel(LstmArgs a) {
         if (q > 3) return;
 #endif
 #pragma unroll
-        for (int m = 0; m < 2; ++m) B[m] = ldg16((isx ? xb[m] : hb[m]) + (size_t)qc * 1024, voff);
+        for (int m = 0; m < 2; ++m) {
+#ifdef ABL3_NTX
+            if (isx) B[m] = ldg16_stream(xb[m] + (size_t)qc * 1024, voff);
+            else B[m] = ldg16(hb[m] + (size_t)qc * 1024, voff);
+#else
+            B[m] = ldg16((isx ? xb[m] : hb[m]) + (size_t)qc * 1024, voff);
+#endif
+        }
     };
     auto loadA = [&](f32x4 (&A)[UPW][4], int q) {
 #pragma unroll
@@ -440,20 +472,33 @@ __global__ __launch_bounds__(256, 1) void dsp_lstm3_kernel(LstmArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) A[uu][g] = ldg16(wbase[uu] + (size_t)q * 4096 + g * 1024, voff);
     };
-    // one k-group: 8 MFMAs per (unit tile, gate), then that A fragment is refilled for group qa
-    auto stage = [&](f32x4 (&A)[UPW][4], const f32x4 (&B)[2], int qa) {
+    // one k-group: 8 MFMAs per (unit tile, gate).  After the MFMAs of fragment j the fragment j-1 is refilled
+    // (for k-group qa); fragment UPW*4-1 of the PREVIOUS stage's ring slot Ap is refilled after j = 0 (for
+    // k-group qp).  Refilling one fragment late keeps the load from writing registers that the MFMA issued
+    // just before it is still reading (a WAR interlock that otherwise stalls the in-order issue).
+    // first = true: the very first k-step of a time step accumulates onto literal zero (no accumulator init;
+    // the biases are folded into the activation arguments of the cell phase instead)
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto stage = [&](f32x4 (&A)[UPW][4], const f32x4 (&B)[2], int qa, f32x4 (&Ap)[UPW][4], int qp, auto first) {
 #pragma unroll
         for (int uu = 0; uu < UPW; ++uu)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    acc[uu][g][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[uu][g][i], B[0][i], acc[uu][g][0], 0, 0, 0);
-                    acc[uu][g][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[uu][g][i], B[1][i], acc[uu][g][1], 0, 0, 0);
+                    if (decltype(first)::value && i == 0) {
+                        acc[uu][g][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[uu][g][i], B[0][i], zero16, 0, 0, 0);
+                        acc[uu][g][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[uu][g][i], B[1][i], zero16, 0, 0, 0);
+                    } else {
+                        acc[uu][g][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[uu][g][i], B[0][i], acc[uu][g][0], 0, 0, 0);
+                        acc[uu][g][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[uu][g][i], B[1][i], acc[uu][g][1], 0, 0, 0);
+                    }
                 }
-                __builtin_amdgcn_sched_barrier(0);  // keep "8 MFMAs, then the refill of that fragment" in order
+                __builtin_amdgcn_sched_barrier(0);  // keep "8 MFMAs, then one refill" in program order
 #ifndef ABL3_NOA
-                A[uu][g] = ldg16(wbase[uu] + (size_t)qa * 4096 + g * 1024, voff);
+                const int j = uu * 4 + g;
+                if (j == 0) Ap[UPW - 1][3] = ldg16(wbase[UPW - 1] + (size_t)qp * 4096 + 3 * 1024, voff);
+                else A[(j - 1) >> 2][(j - 1) & 3] = ldg16(wbase[(j - 1) >> 2] + (size_t)qa * 4096 + ((j - 1) & 3) * 1024, voff);
 #endif
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -464,73 +509,76 @@ __global__ __launch_bounds__(256, 1) void dsp_lstm3_kernel(LstmArgs a) {
     loadA(A1, 1); loadB(B1, 1);
     loadB(B2, 2); loadB(B3, 3);
 
+#ifdef DSP_TIMING
+#define TSTAMP(k) do { if (a.dbg && blockIdx.x == 0 && tid == 0) a.dbg[step * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TSTAMP(k) do { } while (0)
+#endif
     for (int step = 0; step < T; ++step) {
         const int t = dir ? (T - 1 - step) : step;
-#pragma unroll
-        for (int uu = 0; uu < UPW; ++uu)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int aa = 0; aa < 4; ++aa) {
-                    const f32x4 b = bias4[g * HQ + (ug * UPW + uu) * 8 + 2 * aa + half];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        acc[uu][g][0][4 * aa + i] = b[i];
-                        acc[uu][g][1][4 * aa + i] = b[i];
-                    }
-                }
-
-        for (int q = 0; q < NQ - 4; q += 4) {
-            stage(A0, B0, q + 2); loadB(B0, q + 4); __builtin_amdgcn_sched_barrier(0);
-            stage(A1, B1, q + 3); loadB(B1, q + 5); __builtin_amdgcn_sched_barrier(0);
-            stage(A0, B2, q + 4); loadB(B2, q + 6); __builtin_amdgcn_sched_barrier(0);
-            stage(A1, B3, q + 5); loadB(B3, q + 7); __builtin_amdgcn_sched_barrier(0);
+        TSTAMP(0);
+        TSTAMP(1);
+        // (the previous step's last stage used A1 for k-group NQ-1 and left its last fragment to us: qp = 1)
+        stage(A0, B0, 2, A1, 1, std::true_type{}); loadB(B0, 4); __builtin_amdgcn_sched_barrier(0);
+        stage(A1, B1, 3, A0, 2, std::false_type{}); loadB(B1, 5); __builtin_amdgcn_sched_barrier(0);
+        stage(A0, B2, 4, A1, 3, std::false_type{}); loadB(B2, 6); __builtin_amdgcn_sched_barrier(0);
+        stage(A1, B3, 5, A0, 4, std::false_type{}); loadB(B3, 7); __builtin_amdgcn_sched_barrier(0);
+        for (int q = 4; q < NQ - 4; q += 4) {
+            stage(A0, B0, q + 2, A1, q + 1, std::false_type{}); loadB(B0, q + 4); __builtin_amdgcn_sched_barrier(0);
+            stage(A1, B1, q + 3, A0, q + 2, std::false_type{}); loadB(B1, q + 5); __builtin_amdgcn_sched_barrier(0);
+            stage(A0, B2, q + 4, A1, q + 3, std::false_type{}); loadB(B2, q + 6); __builtin_amdgcn_sched_barrier(0);
+            stage(A1, B3, q + 5, A0, q + 4, std::false_type{}); loadB(B3, q + 7); __builtin_amdgcn_sched_barrier(0);
         }
+        TSTAMP(2);
         // last four k-groups of the step; refills wrap to the first groups of step+1 (weights and x_{t+1} do
         // not depend on h_t, so they are requested before the cell phase).  On the last step the wrapped
         // requests re-read the same step (valid addresses, results unused): no branches in the stream.
-        stage(A0, B0, NQ - 2);
-        stage(A1, B1, NQ - 1);
+        stage(A0, B0, NQ - 2, A1, NQ - 3, std::false_type{});
+        stage(A1, B1, NQ - 1, A0, NQ - 2, std::false_type{});
         set_bases(step + 1 < T ? step + 1 : step);
         loadB(B0, 0);
         loadB(B1, 1);
         __builtin_amdgcn_sched_barrier(0);
-        stage(A0, B2, 0);
+        stage(A0, B2, 0, A1, NQ - 1, std::false_type{});
         loadB(B2, 2);
         __builtin_amdgcn_sched_barrier(0);
-        stage(A1, B3, 1);
+        stage(A1, B3, 1, A0, 0, std::false_type{});
         loadB(B3, 3);
         __builtin_amdgcn_sched_barrier(0);
+        TSTAMP(3);
 
+        // LSTM cell.  b_lds holds the PRE-SCALED biases (-log2e*b for i,f,o; -2*log2e*b for g), so
+        // sigmoid(x+b) = rcp(1 + exp2(fma(x, -log2e, b'))) costs no extra instruction for the bias.
 #pragma unroll
         for (int uu = 0; uu < UPW; ++uu) {
             const int u = ug * UPW + uu;
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                char* ob = outb + (size_t)(gt[m] * T + t) * orow + (size_t)(u * 8) * 512;
+            for (int aa = 0; aa < 4; ++aa) {
+                const int k4 = u * 8 + 2 * aa + half;
+                const f32x4 bi = b_lds[0 * HQ + k4], bf = b_lds[1 * HQ + k4], bg = b_lds[2 * HQ + k4], bo = b_lds[3 * HQ + k4];
 #pragma unroll
-                for (int aa = 0; aa < 4; ++aa) {
+                for (int m = 0; m < 2; ++m) {
+                    f32x4 cv = c_lds[((uu * 2 + m) * 4 + aa) * 256 + tid];
                     f32x4 hv;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int r = 4 * aa + i;
-#ifdef ABL3_NOCELL
-                        hv[i] = acc[uu][0][m][r] + acc[uu][1][m][r] + acc[uu][2][m][r] + acc[uu][3][m][r] + c[uu][m][r];
-                        continue;
-#endif
-                        const float ig = fast_sigmoid(acc[uu][0][m][r]);
-                        const float fg = fast_sigmoid(acc[uu][1][m][r]);
-                        const float gg = fast_tanh(acc[uu][2][m][r]);
-                        const float og = fast_sigmoid(acc[uu][3][m][r]);
-                        const float cn = __builtin_fmaf(fg, c[uu][m][r], ig * gg);
-                        c[uu][m][r] = cn;
+                        const float ig = sigmoid_pre(acc[uu][0][m][r], bi[i]);
+                        const float fg = sigmoid_pre(acc[uu][1][m][r], bf[i]);
+                        const float gg = tanh_pre(acc[uu][2][m][r], bg[i]);
+                        const float og = sigmoid_pre(acc[uu][3][m][r], bo[i]);
+                        const float cn = __builtin_fmaf(fg, cv[i], ig * gg);
+                        cv[i] = cn;
                         hv[i] = og * fast_tanh(cn);
                     }
-                    stg16(ob + (size_t)(2 * aa) * 512, voff, hv);
+                    c_lds[((uu * 2 + m) * 4 + aa) * 256 + tid] = cv;
+                    stg16(outb + (size_t)(gt[m] * T + t) * orow + (size_t)(u * 8 + 2 * aa) * 512, voff, hv);
                 }
             }
         }
+        TSTAMP(4);
         __syncthreads();  // h_t stored by every wave (vmcnt(0) + barrier) before the next step reads it
+        TSTAMP(5);
     }
 }
 
@@ -654,6 +702,10 @@ extern "C" int dsp_k_init(void) {
     hipError_t e = hipFuncSetAttribute((const void*)dsp_lstm_dir_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024);
     if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)dsp_lstm3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)dsp_lstm3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)dsp_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     return (int)e;
 }
@@ -668,8 +720,9 @@ extern "C" int dsp_k_pack(const PackArgs* a, hipStream_t s) {
 extern "C" int dsp_k_lstm3(const LstmArgs* a, int upw, hipStream_t s) {
     const int waves = (a->UT / upw) * a->SG;
     const unsigned groups = (unsigned)(a->NTp / (a->SG * 2));
-    if (upw == 2) hipLaunchKernelGGL(dsp_lstm3_kernel<2>, dim3(groups * 2), dim3(waves * 64), 0, s, *a);
-    else hipLaunchKernelGGL(dsp_lstm3_kernel<1>, dim3(groups * 2), dim3(waves * 64), 0, s, *a);
+    const size_t lds = (size_t)upw * 8 * 256 * 16 + (size_t)a->Hp * 16;
+    if (upw == 2) hipLaunchKernelGGL(dsp_lstm3_kernel<2>, dim3(groups * 2), dim3(waves * 64), lds, s, *a);
+    else hipLaunchKernelGGL(dsp_lstm3_kernel<1>, dim3(groups * 2), dim3(waves * 64), lds, s, *a);
     return (int)hipGetLastError();
 }
 

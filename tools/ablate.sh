@@ -8,7 +8,7 @@ VARIANTS=${VARIANTS:-"BASE 3_NOA 3_NOB 3_NOBX 3_NOBH 3_NOCELL 3_NOA_NOB"}
 if [ "$1" = build ]; then
   mkdir -p $REPO/gpurun_abl
   for V in $VARIANTS; do
-    D=""; [ $V != BASE ] && D=$(echo "$V" | sed 's/_NO/ -DABL3_NO/g; s/^3//')
+    D=""; [ $V != BASE ] && D=$(echo "$V" | sed 's/^3//; s/_\([A-Z0-9]*\)/ -DABL3_\1/g')
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $D -I$REPO/include -I$C -c $C/dsp_kernels.hip -o /tmp/abl_$V.o &&
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $REPO/gpurun_abl/libdsp_$V.so /tmp/abl_$V.o $C/_obj/dsp_capi.o $C/_obj/dsp_text.o -pthread &
   done
