@@ -349,24 +349,19 @@ __global__ __launch_bounds__(512) void dsp_lstm_dir_kernel(LstmArgs a) {
 //     branch-free; the last groups of step t request the first groups of step t+1 (weights and x_{t+1},
 //     which do not depend on h_t) before the cell phase.
 // ------------------------------------------------------------------------------------------------
-// Every global access of lstm3 is "wave-uniform byte base (SGPRs) + lane*16": one VGPR of addressing in
-// total, so the 512-register budget goes to accumulators (256), cell state (64) and the fragment rings (96).
-__device__ __forceinline__ f32x4 ldg16(const char* ubase, uint32_t voff) {
-    return *(gf32x4*)(ubase + voff);
+// Every global access of lstm3 is a BUFFER access: a wave-uniform 128-bit descriptor (SGPRs) + a
+// wave-uniform byte offset (SGPR soffset) + lane*16 (the only address VGPR of the kernel).  Compared with
+// flat/global addressing this removes all 64-bit VALU address arithmetic from the MFMA stream (measured: the
+// refills cost ~5 % of the MFMA issue rate with global_load + v_lshl_add_u64/v_addc chains).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7ffffff0, 0x00020000);
 }
-__device__ __forceinline__ void stg16(char* ubase, uint32_t voff, f32x4 v) {
-#ifdef ABL3_NTST
-    __builtin_nontemporal_store(v, (__attribute__((address_space(1))) f32x4*)(ubase + voff));
-#else
-    *(__attribute__((address_space(1))) f32x4*)(ubase + voff) = v;
-#endif
+__device__ __forceinline__ f32x4 bld16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
-__device__ __forceinline__ f32x4 ldg16_stream(const char* ubase, uint32_t voff) {
-#ifdef ABL3_NTX
-    return __builtin_nontemporal_load((gf32x4*)(ubase + voff));
-#else
-    return *(gf32x4*)(ubase + voff);
-#endif
+__device__ __forceinline__ void bst16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, (int)soff, 0);
 }
 
 template <int UPW>
@@ -389,22 +384,17 @@ __global__ __launch_bounds__(256, 1) void dsp_lstm3_kernel(LstmArgs a) {
     const int nqx = a.Ipad >> 3, nq = nqx + (a.Hp >> 3), NQ = a.NQ;
     const int T = a.T;
     const int F4 = a.Fout >> 2;
-    const size_t xrow = (size_t)(a.Ipad >> 2) * 512;  // bytes of one (tile, t) block of the input
-    const size_t orow = (size_t)F4 * 512;             // bytes of one (tile, t) block of the output
+    const uint32_t xrow = (uint32_t)(a.Ipad >> 2) * 512u;  // bytes of one (tile, t) block of the input
+    const uint32_t orow = (uint32_t)F4 * 512u;             // bytes of one (tile, t) block of the output
 
-    // uniform byte bases
-    const char* wbase[UPW];
-#pragma unroll
-    for (int uu = 0; uu < UPW; ++uu)
-        wbase[uu] = (const char*)(dir ? a.wpk1 : a.wpk0) + (size_t)(ug * UPW + uu) * NQ * 4096;  // + q*4096 + g*1024
+    // first site tile of this wave; its two tiles are adjacent, so one descriptor per buffer serves both
+    const long long gt0 = (long long)grp * (a.SG * 2) + sg * 2;
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc((const char*)(dir ? a.wpk1 : a.wpk0) + (size_t)(ug * UPW) * NQ * 4096);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)a.x + (size_t)gt0 * T * xrow);
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)a.out + (size_t)gt0 * T * orow + (size_t)dir * HQ * 512);
+    const __amdgpu_buffer_rsrc_t rh0 = make_rsrc((const char*)a.h0buf + (size_t)gt0 * orow + (size_t)dir * HQ * 512);
+    const uint32_t wstride = (uint32_t)NQ * 4096u;  // bytes between the unit tiles of this wave
     const f32x4* bias4 = (const f32x4*)(dir ? a.sbias1 : a.sbias0);
-    char* outb = (char*)a.out + (size_t)dir * HQ * 512;   // + (tile*T + t)*orow + k4*512
-    char* h0b = (char*)a.h0buf + (size_t)dir * HQ * 512;  // + tile*orow + k4*512
-    const char* xbb = (const char*)a.x;
-
-    long long gt[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) gt[m] = (long long)grp * (a.SG * 2) + sg * 2 + m;
 
     // ---- initial state: c0 -> LDS, h0 -> the K4 scratch that step 0 reads as "h_{-1}"; biases -> LDS
     for (int i = tid; i < a.Hp; i += blockDim.x) b_lds[i] = bias4[i];
@@ -413,7 +403,7 @@ __global__ __launch_bounds__(256, 1) void dsp_lstm3_kernel(LstmArgs a) {
         const int u = ug * UPW + uu;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            const long long site = gt[m] * 32 + ls;
+            const long long site = (gt0 + m) * 32 + ls;
 #pragma unroll
             for (int aa = 0; aa < 4; ++aa) {
                 const int k4 = u * 8 + 2 * aa + half;
@@ -424,30 +414,29 @@ __global__ __launch_bounds__(256, 1) void dsp_lstm3_kernel(LstmArgs a) {
                     cv = init_state4(a.c0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, a.site_offset,
                                      (uint32_t)(a.stream_base + dir * 2 + 1));
                 }
-                stg16(h0b + (size_t)gt[m] * orow + (size_t)(u * 8 + 2 * aa) * 512, voff, hv);
+                bst16(rh0, voff, (uint32_t)m * orow + (uint32_t)(u * 8 + 2 * aa) * 512u, hv);
                 c_lds[((uu * 2 + m) * 4 + aa) * 256 + tid] = cv;
             }
         }
     }
     __syncthreads();  // h0 stored (vmcnt drained) before any wave reads it back
 
-    // B-operand bases of a step (uniform): x_t, and h_{t-1} (= the K4 output of the previous step, or the h0
-    // scratch), the latter biased by -nqx k-groups so that both parts are "base + q*1024"
-    const char* xb[2];
-    const char* hb[2];
+    // B-operand source of a step (all uniform): x_t from rx, h_{t-1} from the K4 output of the previous step
+    // (ro) or, at step 0, from the h0 scratch (rh0).  Offsets are biased so that both parts are "base + q*1024".
+    __amdgpu_buffer_rsrc_t rhp = rh0;
+    uint32_t xo[2], ho[2];
     auto set_bases = [&](int step) {
         const int t = dir ? (T - 1 - step) : step;
         const int tp = dir ? (t + 1) : (t - 1);
+        rhp = step == 0 ? rh0 : ro;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            xb[m] = xbb + (size_t)(gt[m] * T + t) * xrow;
-            const char* hp = step == 0 ? h0b + (size_t)gt[m] * orow : outb + (size_t)(gt[m] * T + tp) * orow;
-            hb[m] = hp - (size_t)nqx * 1024;
+            xo[m] = (uint32_t)(m * T + t) * xrow;
+            ho[m] = (step == 0 ? (uint32_t)m * orow : (uint32_t)(m * T + tp) * orow) - (uint32_t)nqx * 1024u;
         }
     };
 
-    // register rings: A two stages deep (an A fragment is reloaded right after its 8 MFMAs, for group q+2),
-    // B four stages deep (reloaded after the whole group, for group q+4)
+    // register rings: A two stages deep, B four stages deep
     f32x4 A0[UPW][4], A1[UPW][4], B0[2], B1[2], B2[2], B3[2];
     f32x16 acc[UPW][4][2];
     auto loadB = [&](f32x4 (&B)[2], int q) {
@@ -456,21 +445,15 @@ __global__ __launch_bounds__(256, 1) void dsp_lstm3_kernel(LstmArgs a) {
 #ifdef ABL3_NOB
         if (q > 3) return;
 #endif
+        const __amdgpu_buffer_rsrc_t r = isx ? rx : rhp;
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-#ifdef ABL3_NTX
-            if (isx) B[m] = ldg16_stream(xb[m] + (size_t)qc * 1024, voff);
-            else B[m] = ldg16(hb[m] + (size_t)qc * 1024, voff);
-#else
-            B[m] = ldg16((isx ? xb[m] : hb[m]) + (size_t)qc * 1024, voff);
-#endif
-        }
+        for (int m = 0; m < 2; ++m) B[m] = bld16(r, voff, (isx ? xo[m] : ho[m]) + (uint32_t)qc * 1024u);
     };
     auto loadA = [&](f32x4 (&A)[UPW][4], int q) {
 #pragma unroll
         for (int uu = 0; uu < UPW; ++uu)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) A[uu][g] = ldg16(wbase[uu] + (size_t)q * 4096 + g * 1024, voff);
+            for (int g = 0; g < 4; ++g) A[uu][g] = bld16(rw, voff, (uint32_t)uu * wstride + (uint32_t)q * 4096u + g * 1024u);
     };
     // one k-group: 8 MFMAs per (unit tile, gate).  After the MFMAs of fragment j the fragment j-1 is refilled
     // (for k-group qa); fragment UPW*4-1 of the PREVIOUS stage's ring slot Ap is refilled after j = 0 (for
@@ -497,8 +480,8 @@ __global__ __launch_bounds__(256, 1) void dsp_lstm3_kernel(LstmArgs a) {
                 __builtin_amdgcn_sched_barrier(0);  // keep "8 MFMAs, then one refill" in program order
 #ifndef ABL3_NOA
                 const int j = uu * 4 + g;
-                if (j == 0) Ap[UPW - 1][3] = ldg16(wbase[UPW - 1] + (size_t)qp * 4096 + 3 * 1024, voff);
-                else A[(j - 1) >> 2][(j - 1) & 3] = ldg16(wbase[(j - 1) >> 2] + (size_t)qa * 4096 + ((j - 1) & 3) * 1024, voff);
+                if (j == 0) Ap[UPW - 1][3] = bld16(rw, voff, (uint32_t)(UPW - 1) * wstride + (uint32_t)qp * 4096u + 3 * 1024u);
+                else A[(j - 1) >> 2][(j - 1) & 3] = bld16(rw, voff, (uint32_t)((j - 1) >> 2) * wstride + (uint32_t)qa * 4096u + ((j - 1) & 3) * 1024u);
 #endif
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -517,7 +500,6 @@ __global__ __launch_bounds__(256, 1) void dsp_lstm3_kernel(LstmArgs a) {
     for (int step = 0; step < T; ++step) {
         const int t = dir ? (T - 1 - step) : step;
         TSTAMP(0);
-        TSTAMP(1);
         // (the previous step's last stage used A1 for k-group NQ-1 and left its last fragment to us: qp = 1)
         stage(A0, B0, 2, A1, 1, std::true_type{}); loadB(B0, 4); __builtin_amdgcn_sched_barrier(0);
         stage(A1, B1, 3, A0, 2, std::false_type{}); loadB(B1, 5); __builtin_amdgcn_sched_barrier(0);
@@ -572,7 +554,7 @@ __global__ __launch_bounds__(256, 1) void dsp_lstm3_kernel(LstmArgs a) {
                         hv[i] = og * fast_tanh(cn);
                     }
                     c_lds[((uu * 2 + m) * 4 + aa) * 256 + tid] = cv;
-                    stg16(outb + (size_t)(gt[m] * T + t) * orow + (size_t)(u * 8 + 2 * aa) * 512, voff, hv);
+                    bst16(ro, voff, (uint32_t)(m * T + t) * orow + (uint32_t)(u * 8 + 2 * aa) * 512u, hv);
                 }
             }
         }
