@@ -124,7 +124,7 @@ std::vector<int> map_bidir(int H, int Hp) {  // [fwd Hp | bwd Hp] -> [fwd H | bw
     return m;
 }
 
-struct DevLstmLayer { int Ipad, H, Hp; float* wpk[2]; float* bias[2]; float* sbias[2]; };
+struct DevLstmLayer { int Ipad, H, Hp; float* wpk[2]; float* sbias[2]; };
 struct DevLinear { int Fin, ORT; float* wpk; float* bias; };
 
 // A fragments for gates^T = W * act^T :  [UT][NQ][4 gates][64 lanes][4]
@@ -194,7 +194,6 @@ struct dsp_model {
     float* w2 = nullptr; float* b2 = nullptr;
     int hseq_p = 0, hsig_p = 0, Hp = 0, Fseq = 0, Fsig = 0, Fcomb = 0, Fwide = 0;
     std::vector<int> comb_in_map;  // padded comb-input feature -> reference feature
-    int lstm_variant = 3;          // 1 = first kernel (8 waves, LDS h, 1-deep prefetch), 3 = lstm3 (4 waves, ring)
     // scratch
     void* ws = nullptr;
     int64_t ws_sites = 0;
@@ -234,8 +233,7 @@ int build_stack(dsp_model* m, const float* const* w, int in, int hid, int layers
             pack_lstm_dir(p[0], p[1], p[2], p[3], I, hid, Hp, in_map, wpk, bias);
             int rc = upload(m, wpk, &L.wpk[d]);
             if (rc) return rc;
-            rc = upload(m, bias, &L.bias[d]);
-            if (rc) return rc;
+            // the kernel folds the bias into the exp2 argument of the activations: upload it pre-scaled
             std::vector<float> sb(bias.size());
             for (size_t i = 0; i < bias.size(); ++i) {  // gate-major [4][Hp]: gate 2 (g) feeds tanh
                 const bool is_g = i / (size_t)Hp == 2;
@@ -321,17 +319,15 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
         dst = ((layers.size() - 1 - k) % 2 == 0) ? m->bufA : m->bufB;
         LstmArgs a{};
         a.x = cur; a.out = dst;
-        a.wpk0 = ly.wpk[0]; a.wpk1 = ly.wpk[1]; a.bias0 = ly.bias[0]; a.bias1 = ly.bias[1];
-        a.sbias0 = ly.sbias[0]; a.sbias1 = ly.sbias[1];
+        a.wpk0 = ly.wpk[0]; a.wpk1 = ly.wpk[1]; a.sbias0 = ly.sbias[0]; a.sbias1 = ly.sbias[1];
         a.n = n; a.NTp = m->NTp;
         a.Ipad = ly.Ipad; a.H = ly.H; a.Hp = ly.Hp; a.T = m->d.T; a.Fout = 2 * ly.Hp;
         a.NQ = rup((ly.Ipad + ly.Hp) / 8, 4);
         a.h0buf = m->h0buf;
         a.UT = ly.Hp / 32;
-        const int variant = m->lstm_variant;
-        int upw = 1;
-        if (variant == 1) { a.SG = 8 / a.UT; if (a.SG < 1) a.SG = 1; }
-        else { upw = a.UT == 1 ? 1 : 2; a.SG = 4 / (a.UT / upw); if (a.SG < 1) a.SG = 1; }
+        const int upw = a.UT == 1 ? 1 : 2;  // unit tiles per wave; one wave per SIMD -> <= 4 waves per workgroup
+        a.SG = 4 / (a.UT / upw);
+        if (a.SG < 1) a.SG = 1;
         a.init_mode = init ? init->mode : DSP_INIT_ZEROS;
         a.seed = init ? init->seed : 0; a.site_offset = init ? init->site_offset : 0;
         a.stream_base = lstm_id * 64 + (int)k * 4;
@@ -344,7 +340,7 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
             if (hipMalloc((void**)&dbg, 16 * 8 * sizeof(unsigned long long)) == hipSuccess) hipMemset(dbg, 0, 16 * 8 * 8);
             a.dbg = dbg;
         }
-        L.run(name, [&] { return variant == 1 ? dsp_k_lstm(&a, L.s) : dsp_k_lstm3(&a, upw, L.s); });
+        L.run(name, [&] { return dsp_k_lstm3(&a, upw, L.s); });
         if (dbg) {
             unsigned long long h[16 * 8];
             hipStreamSynchronize(L.s);
@@ -434,7 +430,6 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
     dsp_model* m = new (std::nothrow) dsp_model();
     if (!m) { hipSetDevice(prev); return fail(DSP_ENOMEM, "out of host memory"); }
     m->cfg = *cfg; m->d = d; m->device = device;
-    if (const char* v = getenv("DSP_LSTM_VARIANT")) m->lstm_variant = atoi(v) == 1 ? 1 : 3;
     m->hseq_p = d.hseq ? pad_hidden(d.hseq) : 0;
     m->hsig_p = d.hsig ? pad_hidden(d.hsig) : 0;
     m->Hp = pad_hidden(d.H);

@@ -28,10 +28,8 @@ struct LstmArgs {
     float* out;            // K4 output, Fout features; this layer writes [dir*Hp, dir*Hp + Hp)
     const float* wpk0;     // forward  direction A fragments [UT][NQ][4 gates][64 lanes][4]
     const float* wpk1;     // backward direction
-    const float* bias0;    // forward  b_ih + b_hh, [4][Hp]
-    const float* bias1;
-    const float* sbias0;   // pre-scaled biases for lstm3: -log2e*b (gates i,f,o), -2*log2e*b (gate g), [4][Hp]
-    const float* sbias1;
+    const float* sbias0;   // forward  pre-scaled biases: -log2e*(b_ih+b_hh) (gates i,f,o), -2*log2e*(..) (gate g), [4][Hp]
+    const float* sbias1;   // backward
     const float* h0;       // EXPLICIT: reference layout, already offset to this layer: [2 dirs][n][H]
     const float* c0;
     unsigned long long* dbg;  // optional per-step phase timestamps of (block 0, wave 0) [T][8] (DSP_TIMING builds)
@@ -41,7 +39,7 @@ struct LstmArgs {
     unsigned long long seed, site_offset;
     int Ipad, H, Hp, T, Fout;
     int NQ;                // k-groups per unit tile in wpk: (Ipad+Hp)/8 padded to a multiple of 4 (zero weights)
-    int UT, SG;            // unit tiles (Hp/32), site groups per workgroup; block = 64*UT*SG threads
+    int UT, SG;            // unit tiles (Hp/32), site groups per workgroup; block = 64*(UT/UPW)*SG threads
     int init_mode;         // DSP_INIT_*
     int stream_base;       // philox stream of (lstm, layer, dir=0, h): lstm*64 + layer*4
 };
@@ -73,7 +71,6 @@ extern "C" {
 #endif
 int dsp_k_init(void);
 int dsp_k_pack(const PackArgs* a, hipStream_t s);
-int dsp_k_lstm(const LstmArgs* a, hipStream_t s);
 int dsp_k_lstm3(const LstmArgs* a, int upw, hipStream_t s);
 int dsp_k_linear(const LinArgs* a, hipStream_t s);
 int dsp_k_head(const HeadArgs* a, hipStream_t s);

@@ -151,19 +151,8 @@ __global__ __launch_bounds__(256) void dsp_pack_kernel(PackArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// lstm_dir_kernel: one direction of one LSTM layer, all T steps, for M = 64*SG sites per workgroup.
-//
-//   wave (u, sg): unit tile u (32 hidden units x 4 gates) for site tiles {2sg, 2sg+1} of the workgroup
-//   per step:  acc[g][m] (32 units x 32 sites, 16 regs each) = bias
-//              += W_ih[u,g] * x_t        (B fragments: coalesced float4 loads of the K4 input, via L1/L2)
-//              += W_hh[u,g] * h_{t-1}    (B fragments: ds_read_b128 from the LDS h buffer, conflict-free)
-//              cell update entirely in registers (c never leaves registers for all T steps)
-//              h_t -> LDS (other buffer, ds_write_b128) and -> global K4 output (float4 stores)
-//              one s_barrier per step (double-buffered h)
-//   Weights (A fragments) are streamed from L2 every step with 1-KiB-per-wave coalesced loads; each
-//   weight is used by exactly one wave of the workgroup, so there is no LDS staging for them.
-//   blockIdx.x & 1 = direction: with the observed block -> XCD (b % 8) placement even XCDs run the
-//   forward and odd XCDs the backward direction, so each XCD's 4 MiB L2 holds one direction's weights.
+// initial LSTM state of 4 consecutive hidden units of one site (init_hidden, models.py:169-176):
+// zeros, explicit buffers in the reference layout (2*layers, n, H), or in-kernel Philox N(0,1)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ f32x4 init_state4(const float* src, int mode, long long n, long long site, int dir, int H,
                                              int k4, uint64_t seed, uint64_t site_offset, uint32_t stream) {
@@ -183,171 +172,26 @@ __device__ __forceinline__ f32x4 init_state4(const float* src, int mode, long lo
     return v;
 }
 
-__global__ __launch_bounds__(512) void dsp_lstm_dir_kernel(LstmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    f32x4* hl = (f32x4*)smem;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int u = w % a.UT, sg = w / a.UT;
-    const int dir = blockIdx.x & 1;
-    const int grp = blockIdx.x >> 1;
-    const int half = lane >> 5, ls = lane & 31;
-    const int M = a.SG * 64;
-    const int HQ = a.Hp >> 2;
-    const int nqx = a.Ipad >> 3, nqh = a.Hp >> 3, nq = nqx + nqh;
-    const int T = a.T;
-
-    const f32x4* wq = (const f32x4*)(dir ? a.wpk1 : a.wpk0) + (size_t)u * a.NQ * 256 + lane;  // + q*256 + g*64
-    const f32x4* bias4 = (const f32x4*)(dir ? a.bias1 : a.bias0);
-    const f32x4* x4 = (const f32x4*)a.x;
-    f32x4* out4 = (f32x4*)a.out;
-
-    int lt[2];
-    long long gt[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        lt[m] = sg * 2 + m;
-        gt[m] = (long long)grp * (a.SG * 2) + lt[m];
-    }
-
-    // ---- initial state: h0 -> LDS buffer 0, c0 -> registers (same (unit, site) mapping as the accumulators)
-    f32x16 c[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const long long site = gt[m] * 32 + ls;
-#pragma unroll
-        for (int aa = 0; aa < 4; ++aa) {
-            const int k4 = u * 8 + 2 * aa + half;
-            f32x4 hv = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
-            if (a.init_mode != 0) {
-                hv = init_state4(a.h0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, a.site_offset,
-                                 (uint32_t)(a.stream_base + dir * 2 + 0));
-                cv = init_state4(a.c0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, a.site_offset,
-                                 (uint32_t)(a.stream_base + dir * 2 + 1));
-            }
-            hl[(size_t)k4 * M + lt[m] * 32 + ls] = hv;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) c[m][4 * aa + i] = cv[i];
-        }
-    }
-    __syncthreads();
-
-    int cur = 0;
-    for (int step = 0; step < T; ++step) {
-        const int t = dir ? (T - 1 - step) : step;
-
-        f32x16 acc[4][2];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-#pragma unroll
-            for (int aa = 0; aa < 4; ++aa) {
-                const f32x4 b = bias4[g * HQ + u * 8 + 2 * aa + half];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    acc[g][0][4 * aa + i] = b[i];
-                    acc[g][1][4 * aa + i] = b[i];
-                }
-            }
-        }
-
-        const f32x4* xb0 = x4 + ((size_t)(gt[0] * T + t) * (a.Ipad >> 2) + half) * 32 + ls;  // + q*64
-        const f32x4* xb1 = x4 + ((size_t)(gt[1] * T + t) * (a.Ipad >> 2) + half) * 32 + ls;
-        const f32x4* hb0 = hl + (size_t)(cur * HQ + half) * M + lt[0] * 32 + ls;  // + q*2*M
-        const f32x4* hb1 = hl + (size_t)(cur * HQ + half) * M + lt[1] * 32 + ls;
-
-        // software pipeline: fragments for k-group q+1 are loaded while the 32 MFMAs of q issue
-        f32x4 An[4], Bn[2];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) An[g] = wq[g * 64];
-        if (nqx > 0) { Bn[0] = xb0[0]; Bn[1] = xb1[0]; }
-        else { Bn[0] = hb0[0]; Bn[1] = hb1[0]; }
-
-        for (int q = 0; q < nq; ++q) {
-            f32x4 A[4], B[2];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) A[g] = An[g];
-            B[0] = Bn[0]; B[1] = Bn[1];
-            const int qn = q + 1;
-            if (qn < nq) {
-#ifndef ABL_NOWLOAD
-#pragma unroll
-                for (int g = 0; g < 4; ++g) An[g] = wq[(size_t)qn * 256 + g * 64];
-#endif
-#ifndef ABL_NOXLOAD
-                if (qn < nqx) { Bn[0] = xb0[(size_t)qn * 64]; Bn[1] = xb1[(size_t)qn * 64]; }
-                else
-#endif
-#ifndef ABL_NOHLOAD
-                if (qn >= nqx) { Bn[0] = hb0[(size_t)(qn - nqx) * 2 * M]; Bn[1] = hb1[(size_t)(qn - nqx) * 2 * M]; }
-#else
-                {}
-#endif
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    acc[g][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g][i], B[0][i], acc[g][0], 0, 0, 0);
-                    acc[g][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g][i], B[1][i], acc[g][1], 0, 0, 0);
-                }
-            }
-        }
-
-        // ---- LSTM cell (registers only) + h_t -> LDS[next] and global K4 output
-        const int nxt = cur ^ 1;
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-#pragma unroll
-            for (int aa = 0; aa < 4; ++aa) {
-                f32x4 hv;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = 4 * aa + i;
-#ifdef ABL_NOCELL
-                    hv[i] = acc[0][m][r] + acc[1][m][r] + acc[2][m][r] + acc[3][m][r] + c[m][r];
-                    continue;
-#endif
-                    const float ig = fast_sigmoid(acc[0][m][r]);
-                    const float fg = fast_sigmoid(acc[1][m][r]);
-                    const float gg = fast_tanh(acc[2][m][r]);
-                    const float og = fast_sigmoid(acc[3][m][r]);
-                    const float cn = __builtin_fmaf(fg, c[m][r], ig * gg);
-                    c[m][r] = cn;
-                    hv[i] = og * fast_tanh(cn);
-                }
-                const int k4 = u * 8 + 2 * aa + half;
-                hl[(size_t)(nxt * HQ + k4) * M + lt[m] * 32 + ls] = hv;
-#ifndef ABL_NOSTORE
-                out4[((size_t)(gt[m] * T + t) * (a.Fout >> 2) + (size_t)(dir * HQ + k4)) * 32 + ls] = hv;
-#else
-                if (hv[0] == 123.456f) out4[ls] = hv;
-#endif
-            }
-        }
-#ifndef ABL_NOBARRIER
-        __syncthreads();
-#endif
-        cur = nxt;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// lstm3 (round-1 ablation result: operand-load latency, not MFMA issue, cost ~25 % in dsp_lstm_dir_kernel):
-// same math and K4 layout, restructured for latency tolerance.
-//   * ONE wave per SIMD (<= 4 waves, up to 512 registers each); a wave owns UPW unit tiles x 2 site tiles
-//     (UPW*8 accumulator tiles in AGPRs), 64 MFMAs per k-group.
+// dsp_lstm3_kernel: one direction of one LSTM layer, all T steps, for 64*SG sites per workgroup.
+// blockIdx.x & 1 = direction: with the observed block -> XCD (b % 8) placement even XCDs run the forward and
+// odd XCDs the backward direction, so each XCD's 4 MiB L2 holds one direction's weights.
+// (History: the first kernel of this round -- 8 waves, h in LDS, one-deep prefetch -- reached 76 % of the
+// fp32 MFMA peak; ablation showed operand loads, not MFMA issue, cost ~25 %.  This is the restructured form.)
+//   * ONE wave per SIMD (<= 4 waves, up to 512 registers each); a wave owns UPW unit tiles (32 hidden units x
+//     4 gates each) x 2 site tiles = UPW*8 accumulator tiles (256 AGPRs), 64 MFMAs per k-group (8 k).
 //   * EVERY operand is a coalesced global load: weights (A), x_t (B) and also h_{t-1} (B), which is read
 //     back from the K4 output the workgroup itself stored one step earlier (same CU, visible after the
 //     per-step workgroup barrier; L2-resident).  No LDS at all, so no flat/LDS/global mixing and the
 //     compiler can count vmcnt exactly.
-//   * Register rings: an A fragment (weights of one unit tile x gate) is reloaded for k-group q+2 right after
-//     its 8 MFMAs of group q; B fragments sit in a 4-deep ring (group q+4 requested after group q).  Every
-//     operand therefore has ~2-3 k-groups (8-12k cycles) to arrive -- longer than an L2 miss to HBM.  The
-//     k-group count is padded to a multiple of 4 with zero weights (host side), so the loop body is
-//     branch-free; the last groups of step t request the first groups of step t+1 (weights and x_{t+1},
+//   * Register rings, four k-groups deep: an A fragment (weights of one unit tile x gate, 4 VGPRs) is
+//     re-requested for k-group q+4 after its 8 MFMAs of group q; B fragments likewise.  The k-group count is
+//     padded to a multiple of 4 with zero weights (host side), so the loop body is branch-free with exact
+//     vmcnt counts; the last groups of step t request the first groups of step t+1 (weights and x_{t+1},
 //     which do not depend on h_t) before the cell phase.
+//   * The cell state c and the (pre-scaled) biases live in LDS (own-lane float4 slots, conflict-free), the
+//     accumulators start from literal zero (first MFMA of a step takes C = 0) and the biases are folded into
+//     the exp2 arguments of the activations.
 // ------------------------------------------------------------------------------------------------
 // Every global access of lstm3 is a BUFFER access: a wave-uniform 128-bit descriptor (SGPRs) + a
 // wave-uniform byte offset (SGPR soffset) + lane*16 (the only address VGPR of the kernel).  Compared with
@@ -436,15 +280,13 @@ __global__ __launch_bounds__(256, 1) void dsp_lstm3_kernel(LstmArgs a) {
         }
     };
 
-    // register rings: A two stages deep, B four stages deep
-    f32x4 A0[UPW][4], A1[UPW][4], B0[2], B1[2], B2[2], B3[2];
+    // register rings: A and B four k-groups deep
+#define ARING 4
+    f32x4 A0[UPW][4], A1[UPW][4], A2[UPW][4], A3[UPW][4], B0[2], B1[2], B2[2], B3[2];
     f32x16 acc[UPW][4][2];
     auto loadB = [&](f32x4 (&B)[2], int q) {
         const int qc = q < nq ? q : nq - 1;  // padded k-groups have zero weights: any finite B will do
         const bool isx = qc < nqx;
-#ifdef ABL3_NOB
-        if (q > 3) return;
-#endif
         const __amdgpu_buffer_rsrc_t r = isx ? rx : rhp;
 #pragma unroll
         for (int m = 0; m < 2; ++m) B[m] = bld16(r, voff, (isx ? xo[m] : ho[m]) + (uint32_t)qc * 1024u);
@@ -478,11 +320,9 @@ __global__ __launch_bounds__(256, 1) void dsp_lstm3_kernel(LstmArgs a) {
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);  // keep "8 MFMAs, then one refill" in program order
-#ifndef ABL3_NOA
                 const int j = uu * 4 + g;
                 if (j == 0) Ap[UPW - 1][3] = bld16(rw, voff, (uint32_t)(UPW - 1) * wstride + (uint32_t)qp * 4096u + 3 * 1024u);
                 else A[(j - 1) >> 2][(j - 1) & 3] = bld16(rw, voff, (uint32_t)((j - 1) >> 2) * wstride + (uint32_t)qa * 4096u + ((j - 1) & 3) * 1024u);
-#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
     };
@@ -490,6 +330,7 @@ __global__ __launch_bounds__(256, 1) void dsp_lstm3_kernel(LstmArgs a) {
     set_bases(0);
     loadA(A0, 0); loadB(B0, 0);
     loadA(A1, 1); loadB(B1, 1);
+    loadA(A2, 2); loadA(A3, 3);
     loadB(B2, 2); loadB(B3, 3);
 
 #ifdef DSP_TIMING
@@ -500,31 +341,34 @@ __global__ __launch_bounds__(256, 1) void dsp_lstm3_kernel(LstmArgs a) {
     for (int step = 0; step < T; ++step) {
         const int t = dir ? (T - 1 - step) : step;
         TSTAMP(0);
-        // (the previous step's last stage used A1 for k-group NQ-1 and left its last fragment to us: qp = 1)
-        stage(A0, B0, 2, A1, 1, std::true_type{}); loadB(B0, 4); __builtin_amdgcn_sched_barrier(0);
-        stage(A1, B1, 3, A0, 2, std::false_type{}); loadB(B1, 5); __builtin_amdgcn_sched_barrier(0);
-        stage(A0, B2, 4, A1, 3, std::false_type{}); loadB(B2, 6); __builtin_amdgcn_sched_barrier(0);
-        stage(A1, B3, 5, A0, 4, std::false_type{}); loadB(B3, 7); __builtin_amdgcn_sched_barrier(0);
+        // stage(q): slot q%ARING is refilled for k-group q+ARING; the last fragment of the previous stage's
+        // slot is refilled (for k-group q-1+ARING) after this stage's first fragment.  k-groups >= NQ wrap to
+        // the next step.
+#define QW(x) ((x) < NQ ? (x) : (x) - NQ)
+        stage(A0, B0, 0 + ARING, A3, QW(NQ - 1 + ARING), std::true_type{}); loadB(B0, 4); __builtin_amdgcn_sched_barrier(0);
+        stage(A1, B1, 1 + ARING, A0, 0 + ARING, std::false_type{}); loadB(B1, 5); __builtin_amdgcn_sched_barrier(0);
+        stage(A2, B2, 2 + ARING, A1, 1 + ARING, std::false_type{}); loadB(B2, 6); __builtin_amdgcn_sched_barrier(0);
+        stage(A3, B3, 3 + ARING, A2, 2 + ARING, std::false_type{}); loadB(B3, 7); __builtin_amdgcn_sched_barrier(0);
         for (int q = 4; q < NQ - 4; q += 4) {
-            stage(A0, B0, q + 2, A1, q + 1, std::false_type{}); loadB(B0, q + 4); __builtin_amdgcn_sched_barrier(0);
-            stage(A1, B1, q + 3, A0, q + 2, std::false_type{}); loadB(B1, q + 5); __builtin_amdgcn_sched_barrier(0);
-            stage(A0, B2, q + 4, A1, q + 3, std::false_type{}); loadB(B2, q + 6); __builtin_amdgcn_sched_barrier(0);
-            stage(A1, B3, q + 5, A0, q + 4, std::false_type{}); loadB(B3, q + 7); __builtin_amdgcn_sched_barrier(0);
+            stage(A0, B0, q + 0 + ARING, A3, q - 1 + ARING, std::false_type{}); loadB(B0, q + 4); __builtin_amdgcn_sched_barrier(0);
+            stage(A1, B1, q + 1 + ARING, A0, q + 0 + ARING, std::false_type{}); loadB(B1, q + 5); __builtin_amdgcn_sched_barrier(0);
+            stage(A2, B2, q + 2 + ARING, A1, q + 1 + ARING, std::false_type{}); loadB(B2, q + 6); __builtin_amdgcn_sched_barrier(0);
+            stage(A3, B3, q + 3 + ARING, A2, q + 2 + ARING, std::false_type{}); loadB(B3, q + 7); __builtin_amdgcn_sched_barrier(0);
         }
         TSTAMP(2);
         // last four k-groups of the step; refills wrap to the first groups of step+1 (weights and x_{t+1} do
         // not depend on h_t, so they are requested before the cell phase).  On the last step the wrapped
         // requests re-read the same step (valid addresses, results unused): no branches in the stream.
-        stage(A0, B0, NQ - 2, A1, NQ - 3, std::false_type{});
-        stage(A1, B1, NQ - 1, A0, NQ - 2, std::false_type{});
+        stage(A0, B0, QW(NQ - 4 + ARING), A3, QW(NQ - 5 + ARING), std::false_type{});
+        stage(A1, B1, QW(NQ - 3 + ARING), A0, QW(NQ - 4 + ARING), std::false_type{});
         set_bases(step + 1 < T ? step + 1 : step);
         loadB(B0, 0);
         loadB(B1, 1);
         __builtin_amdgcn_sched_barrier(0);
-        stage(A0, B2, 0, A1, NQ - 1, std::false_type{});
+        stage(A2, B2, QW(NQ - 2 + ARING), A1, QW(NQ - 3 + ARING), std::false_type{});
         loadB(B2, 2);
         __builtin_amdgcn_sched_barrier(0);
-        stage(A1, B3, 1, A0, 0, std::false_type{});
+        stage(A3, B3, QW(NQ - 1 + ARING), A2, QW(NQ - 2 + ARING), std::false_type{});
         loadB(B3, 3);
         __builtin_amdgcn_sched_barrier(0);
         TSTAMP(3);
@@ -562,6 +406,8 @@ __global__ __launch_bounds__(256, 1) void dsp_lstm3_kernel(LstmArgs a) {
         __syncthreads();  // h_t stored by every wave (vmcnt(0) + barrier) before the next step reads it
         TSTAMP(5);
     }
+#undef QW
+#undef ARING
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -681,10 +527,7 @@ __global__ __launch_bounds__(256) void dsp_head_kernel(HeadArgs a) {
 // launch wrappers (called from dsp_capi.cpp; keep all <<<>>> syntax in this translation unit)
 // ------------------------------------------------------------------------------------------------
 extern "C" int dsp_k_init(void) {
-    hipError_t e = hipFuncSetAttribute((const void*)dsp_lstm_dir_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)dsp_lstm3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)dsp_lstm3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)dsp_lstm3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
@@ -705,15 +548,6 @@ extern "C" int dsp_k_lstm3(const LstmArgs* a, int upw, hipStream_t s) {
     const size_t lds = (size_t)upw * 8 * 256 * 16 + (size_t)a->Hp * 16;
     if (upw == 2) hipLaunchKernelGGL(dsp_lstm3_kernel<2>, dim3(groups * 2), dim3(waves * 64), lds, s, *a);
     else hipLaunchKernelGGL(dsp_lstm3_kernel<1>, dim3(groups * 2), dim3(waves * 64), lds, s, *a);
-    return (int)hipGetLastError();
-}
-
-extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
-    const int waves = a->UT * a->SG;
-    const int M = a->SG * 64;
-    const size_t lds = (size_t)2 * a->Hp * M * sizeof(float);
-    const unsigned groups = (unsigned)(a->NTp / (a->SG * 2));
-    hipLaunchKernelGGL(dsp_lstm_dir_kernel, dim3(groups * 2), dim3(waves * 64), lds, s, *a);
     return (int)hipGetLastError();
 }
 
