@@ -132,6 +132,13 @@ def main():
         avg_ms = sum(lstm_ms) / n_lstm
         flops_per_launch = lstm_flops_site * B * K / n_lstm
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        traffic = None
+        try:  # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r1", "traffic.json")))
+            if B == BATCH and args.model_type == "both_bilstm" and args.layernum1 == 3 and args.hid_rnn == 256:
+                traffic = tj["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         line = {
             "metric": "methylation sites/sec, both_bilstm bn13_sn16", "value": round(value, 1), "unit": "sites/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / max(K, 1) * 1e3, 3),
@@ -144,7 +151,7 @@ def main():
                        "flops_per_site": flops_site},
             "roofline": {"bound": "mfma", "kernel": "dsp_lstm3_kernel", "achieved": round(achieved, 2),
                          "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4),
-                         "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": len(lstm_ms),
+                         "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches": len(lstm_ms),
                          "flops_per_launch": flops_per_launch,
                          "whole_forward_tflops": round(value / world * flops_site / 1e12, 2),
                          "hbm_gbps_algorithmic": round(value / world * 1048 / 1e9, 3),
