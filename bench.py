@@ -32,13 +32,13 @@ def cpu_baseline(model_cfg_kwargs, sd_numpy, seed):
     probe = 32 * max(1, threads)
     ins = onp.make_inputs(cfg, probe, 7)
     t0 = time.time()
-    oc.forward(cfg, sd_numpy, *ins, init_mode="philox", seed=seed)
+    oc.forward(cfg, sd_numpy, *ins, init_mode="philox", seed=seed, nthreads=threads)
     rate = probe / max(time.time() - t0, 1e-6)
     n = int(max(probe, min(rate * CPU_BASELINE_TARGET_S, 1 << 20)))
     n = (n + 15) // 16 * 16
     ins = onp.make_inputs(cfg, n, 8)
     t0 = time.time()
-    oc.forward(cfg, sd_numpy, *ins, init_mode="philox", seed=seed)
+    oc.forward(cfg, sd_numpy, *ins, init_mode="philox", seed=seed, nthreads=threads)
     dt = time.time() - t0
     return {"value": round(n / dt, 1), "unit": "sites/s", "cores": threads, "kind": "port",
             "sample": "%d synthetic sites (same model/weights/row statistics), oracle/dsp_oracle.c fp32 + OpenMP, %.1f s"

@@ -10,11 +10,12 @@ import numpy as np
 _BASES = "ACGT"
 
 
-def synth_rows(n, seq_len=13, signal_len=16, seed=0, sites_per_read=50, n_chroms=5, wide_alphabet=False):
+def synth_rows(n, seq_len=13, signal_len=16, seed=0, sites_per_read=50, n_chroms=5, wide_alphabet=False,
+               first_index=0):
     """Yield n text rows (no trailing newline), SURVEY.md 8(d) statistics."""
     rng = np.random.default_rng(seed)
     alphabet = "ACGTNWSMKRYBVDHZ" if wide_alphabet else _BASES
-    for i in range(n):
+    for i in range(first_index, first_index + n):
         read = i // sites_per_read
         chrom = "chr%d" % (read % n_chroms + 1)
         pos = 1000 + 7 * i

@@ -90,4 +90,17 @@ def philox_normal(seed, site, stream, ngroups):
 
 
 def num_threads():
-    return lib().orc_num_threads()
+    """Host threads worth using: min(OpenMP default, CPU affinity, cgroup CPU quota) -- a container with a
+    16-CPU quota on a 256-thread host must not spawn 256 OpenMP threads."""
+    n = lib().orc_num_threads()
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)

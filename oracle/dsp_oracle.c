@@ -94,6 +94,9 @@ typedef struct {
  *   h, c [SB][H]     initial state in, final state out
  *   wt  [(I+H)][4H]  transposed, concatenated weights (k-major) ; b [4H] = b_ih + b_hh
  */
+#if defined(__GNUC__) && defined(__x86_64__)
+__attribute__((target_clones("avx512f", "avx2", "default")))  /* resolved at load time */
+#endif
 static void lstm_dir_block(int L, int I, int H, int dir, int nb, const float* x, float* out, float* h,
                            float* c, const float* wt, const float* b, float* gates) {
     const int G = 4 * H;
