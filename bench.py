@@ -66,14 +66,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    assert ndev > 0, "bench.py needs an MI355X"
+    dev_index = local_rank % ndev
+    # one process per GPU over RCCL; if fewer GPUs than ranks are visible (the 1-GPU dev box), the ranks share
+    # GPU 0 and the two control-plane collectives (barrier, max of the wall time) run over gloo instead
+    backend = "nccl" if ndev >= world else "gloo"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
+    local_rank = dev_index
 
     K, W, B = args.steps, args.warmup, args.batch
     model = ModelBiLSTM(13, 16, args.layernum1, 1, 2, 0, args.hid_rnn, 16, 4, True, True, module=args.model_type,
@@ -113,12 +123,13 @@ def main():
     model.profile(False)
 
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        if args.gather:
-            gathered = [torch.empty_like(outs[1]) for _ in range(world)]
-            dist.all_gather(gathered, outs[1])
+        if args.gather:  # optional final gather of the per-site probabilities of the last step (RCCL over xGMI)
+            src = outs[1] if backend == "nccl" else outs[1].cpu()
+            gathered = [torch.empty_like(src) for _ in range(world)]
+            dist.all_gather(gathered, src)
     assert outs is not None and bool(torch.isfinite(outs[1]).all())
 
     if rank == 0:
@@ -140,11 +151,12 @@ def main():
         except Exception:
             pass
         line = {
-            "metric": "methylation sites/sec, both_bilstm bn13_sn16", "value": round(value, 1), "unit": "sites/s",
+            "metric": "methylation sites/sec, %s bn13_sn16" % args.model_type, "value": round(value, 1), "unit": "sites/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / max(K, 1) * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%d synthetic sites, %s bn13_sn16 fp32, batch %d on %dxMI355X (BASELINE.json configs[1])"
-                                   % (total_sites, args.model_type, B, world),
+            "config": {"workload": "%d synthetic sites, %s bn13_sn16 fp32, batch %d on %dxMI355X (BASELINE.json configs[%d])"
+                                   % (total_sites, args.model_type, B, world,
+                                      2 if args.model_type == "seq_bilstm" else (1 if world == 1 else 3)),
                        "batch": B, "sites": total_sites, "layernum1": args.layernum1, "hid_rnn": args.hid_rnn,
                        "init_state": "in-kernel Philox N(0,1) (stand-in for torch.randn, models.py:169-176)",
                        "weights": "seeded random state_dict, PyTorch default-init scale", "parallelism": "range-shard x%d" % world,

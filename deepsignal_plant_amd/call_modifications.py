@@ -96,8 +96,11 @@ class _Writer(threading.Thread):
 def _call_mods_file(args, rank, local_rank, world):
     """One rank = one GPU: reader -> H2D -> forward -> D2H -> formatter -> part file."""
     import torch
+    import torch.distributed as dist
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    # control-plane collectives run on the GPU over RCCL, or on the host when the ranks had to fall back to gloo
+    coll_dev = dev if (world > 1 and dist.get_backend() == "nccl") else None
     model = load_model(args, local_rank)
     input_path = os.path.abspath(args.input_path)
     nthreads = max(1, (args.nproc if args.nproc > 0 else 1))
@@ -112,7 +115,7 @@ def _call_mods_file(args, rank, local_rank, world):
             with open(input_path, "rb") as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as mm:
                 byte_range = dsp_dist.byte_range_for_rank(mm, size, world, rank)
             mine = feed.count_rows_in_range(input_path, *byte_range)
-            counts = dsp_dist.all_gather_ints(mine, world, dev)
+            counts = dsp_dist.all_gather_ints(mine, world, coll_dev)
             first_row = dsp_dist.exclusive_prefix(counts, rank)
 
     out_path = args.result_file
@@ -201,17 +204,23 @@ def call_mods(args):
         raise RuntimeError("no MI355X visible: this build has no CPU path")
 
     rank, local_rank, world = dsp_dist.env_world()
+    ndev = torch.cuda.device_count()
+    local_rank = local_rank % ndev
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         if not dist.is_initialized():
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            if ndev >= world:  # one process per GPU: RCCL
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:              # more ranks than visible GPUs (dev box): ranks share GPUs, control plane over gloo
+                dist.init_process_group("gloo")
     n_rows, part_path, out_path = _call_mods_file(args, rank, local_rank, world)
     if world > 1:
         import torch.distributed as dist
-        total = sum(dsp_dist.all_gather_ints(n_rows, world, torch.device("cuda", local_rank)))
+        cdev = torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else None
+        total = sum(dsp_dist.all_gather_ints(n_rows, world, cdev))
         dist.barrier()
         if rank == 0:
             _merge_parts(out_path, world)

@@ -103,3 +103,23 @@ def test_cli_errors(tmp_path):
     bad.write_text("chr1\t1\t+\t1\tr\tt\tACGTXACGTACGT\t0\t0\t0\t0\t0\n")
     r = _run_cli(["-i", str(bad), "-m", ck, "-o", os.path.join(str(tmp_path), "o.tsv")])
     assert r.returncode != 0 and "malformed feature row" in r.stderr
+
+
+def test_cli_two_ranks_give_the_same_calls_as_one(tmp_path):
+    """range-shard invariance (SURVEY.md 4 'Multi-GPU'): 2 ranks (sharing this box's GPU, control plane over
+    gloo) write byte-identical output to 1 rank, in the default randn (Philox) mode"""
+    import socket
+    ck = _ckpt(tmp_path)
+    inp = os.path.join(GOLDEN, "f2_rows.tsv")
+    one = os.path.join(str(tmp_path), "one.tsv")
+    r = _run_cli(["-i", inp, "-m", ck, "-o", one, "--seed", "5"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    two = os.path.join(str(tmp_path), "two.tsv")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), "-m", "deepsignal_plant_amd.deepsignal_plant", "call_mods",
+           "-i", inp, "-m", ck, "-o", two, "--seed", "5"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert open(one).read() == open(two).read()
+    assert not [f for f in os.listdir(str(tmp_path)) if ".part" in f]
