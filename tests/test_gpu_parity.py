@@ -134,3 +134,77 @@ def test_errors_are_loud():
     sd["fc1.weight"] = sd["fc1.weight"][:, :10]
     with pytest.raises(RuntimeError):
         m.load_state_dict(sd)
+
+
+def _rand_cfg(rng):
+    from oracle import forward_np as onp
+    module = ["both_bilstm", "seq_bilstm", "signal_bilstm"][int(rng.integers(0, 3))]
+    hidden = int(rng.choice([20, 32, 50, 64, 96, 128, 160, 200, 256]))
+    if module == "both_bilstm" and hidden % 2:
+        hidden += 1
+    return onp.OracleConfig(seq_len=int(rng.choice([5, 9, 13, 17, 21])), signal_len=int(rng.choice([8, 12, 16, 24])),
+                            num_layers1=int(rng.integers(1, 4)), num_layers2=int(rng.integers(1, 3)),
+                            num_classes=int(rng.choice([2, 2, 3, 5])), hidden_size=hidden,
+                            vocab_size=int(rng.choice([5, 16])), embedding_size=int(rng.choice([2, 4, 6])),
+                            is_base=bool(rng.integers(0, 2)), is_signallen=bool(rng.integers(0, 2)), module=module)
+
+
+@pytest.mark.parametrize("case", range(14))
+def test_random_model_shapes_match_oracle(case):
+    """the generic kernels (hidden-size padding, unit-tile pairing, k-group padding, feature maps) over random
+    model shapes: every flag of the reference constructor is exercised, explicit N(0,1) initial states"""
+    torch = _torch()
+    from oracle import c_oracle as oc
+    from oracle import forward_np as onp
+    rng = np.random.default_rng(1000 + case)
+    cfg = _rand_cfg(rng)
+    n = int(rng.choice([1, 7, 33, 100, 257]))
+    w = onp.make_weights(cfg, 2000 + case, float(rng.choice([1.0, 2.0, 3.0])))
+    ins = onp.make_inputs(cfg, n, 3000 + case, wide_alphabet=cfg.vocab_size == 16)
+    if cfg.vocab_size < 16:
+        ins = (np.minimum(ins[0], cfg.vocab_size - 1),) + ins[1:]
+    st = onp.make_init_states(cfg, n, 4000 + case)
+    m = build_model(cfg, w)
+    logits, probs = m.forward(*to_dev(ins), init_states={k: torch.from_numpy(v).cuda(0) for k, v in st.items()})
+    torch.cuda.synchronize()
+    lo, po = oc.forward(cfg, w, *ins, states=st, init_mode="explicit")
+    d = np.abs(probs.cpu().numpy() - po).max()
+    assert d <= TOL_TIGHT, (cfg.as_dict(), n, d)
+    assert np.abs(logits.cpu().numpy() - lo).max() <= 1e-4
+
+
+def test_full_batch_properties():
+    """BASELINE size (65,536 + a ragged tail): size-independent properties -- determinism, permutation
+    equivariance under pinned zero states, split invariance, finite normalised probabilities -- plus an oracle
+    spot check on a strided sample of the same batch"""
+    torch = _torch()
+    from deepsignal_plant_amd import synth
+    from oracle import c_oracle as oc
+    from oracle import forward_np as onp
+    cfg = onp.OracleConfig()
+    w = onp.make_weights(cfg, 51, 2.0)
+    n = 65536 + 1234
+    ins = synth.feature_batch(n, device="cuda:0", seed=52)
+    m = build_model(cfg, w, init_state="zeros")
+    p = m(*ins)[1].clone()
+    assert torch.isfinite(p).all() and float((p.sum(1) - 1).abs().max()) <= 1e-6
+    assert torch.equal(p, m(*ins)[1])
+    perm = torch.randperm(n, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(1))
+    pp = m(*[t[perm] for t in ins])[1]
+    assert torch.equal(pp, p[perm])
+    cut = 40000
+    assert torch.equal(torch.cat((m(*[t[:cut] for t in ins])[1], m(*[t[cut:] for t in ins])[1])), p)
+    idx = torch.arange(0, n, 97, device="cuda:0")
+    sample = [t[idx].cpu().numpy() for t in ins]
+    lo, po = oc.forward(cfg, w, *sample, init_mode="zeros")
+    assert np.abs(p[idx].cpu().numpy() - po).max() <= TOL_TIGHT
+
+
+def test_empty_batch():
+    torch = _torch()
+    from oracle import forward_np as onp
+    cfg = onp.OracleConfig()
+    m = build_model(cfg, onp.make_weights(cfg, 1))
+    z = [torch.zeros((0, 13), device="cuda:0")] * 4 + [torch.zeros((0, 13, 16), device="cuda:0")]
+    logits, probs = m(*z)
+    assert logits.shape == (0, 2) and probs.shape == (0, 2)
