@@ -82,6 +82,19 @@ def lib():
     L.dsp_format_calls.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p,
                                    ctypes.c_size_t, ctypes.c_int32]
+    L.dsp_freq_create.restype = ctypes.c_void_p
+    L.dsp_freq_create.argtypes = [ctypes.c_double]
+    L.dsp_freq_destroy.restype = None
+    L.dsp_freq_destroy.argtypes = [ctypes.c_void_p]
+    L.dsp_freq_add_calls_text.restype = ctypes.c_int64
+    L.dsp_freq_add_calls_text.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p]
+    L.dsp_freq_add_block.restype = ctypes.c_int64
+    L.dsp_freq_add_block.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64]
+    L.dsp_freq_counts.restype = None
+    L.dsp_freq_counts.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int64)] * 3
+    L.dsp_freq_format.restype = ctypes.c_int64
+    L.dsp_freq_format.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_size_t]
     _lib = L
     return L
 

@@ -65,10 +65,11 @@ def load_model(args, device):
 class _Writer(threading.Thread):
     """Replaces _write_predstr_to_file (:262-282): formats finished blocks natively and appends them in order."""
 
-    def __init__(self, path, is_gzip, nthreads, reader):
+    def __init__(self, path, is_gzip, nthreads, reader, freq=None):
         super().__init__(daemon=True)
         self.q = queue.Queue(maxsize=4)
         self.path, self.is_gzip, self.nthreads, self.reader = path, is_gzip, nthreads, reader
+        self.freq = freq  # optional SiteFrequency fed straight from the GPU results (fused call_freq)
         self.error = None
         self.rows = 0
 
@@ -85,6 +86,8 @@ class _Writer(threading.Thread):
                     probs = probs_t.numpy()[:block.rows.n]
                     labels = labels_t.numpy()[:block.rows.n]
                     wf.write(textio.format_calls(block.rows, probs, labels, nthreads=self.nthreads))
+                    if self.freq is not None:
+                        self.freq.add_block(block.rows, probs, labels)
                     self.rows += block.rows.n
                     self.reader.release(block)
         except BaseException as e:
@@ -125,7 +128,11 @@ def _call_mods_file(args, rank, local_rank, world):
 
     reader = feed.FeatureReader(input_path, args.seq_len, args.signal_len, rank=rank, world=world, nthreads=nthreads,
                                 nbuf=4, first_row=first_row, byte_range=byte_range)
-    writer = _Writer(part_path, args.gzip, nthreads, reader)
+    freq = None
+    if getattr(args, "freq_file", None) and world == 1:
+        from .call_mods_freq import SiteFrequency
+        freq = SiteFrequency(args.prob_cf)
+    writer = _Writer(part_path, args.gzip, nthreads, reader, freq)
     cap = reader.cap
     model.reserve(cap)
     reader.start()
@@ -170,6 +177,8 @@ def _call_mods_file(args, rank, local_rank, world):
     torch.cuda.synchronize(dev)
     if writer.error is not None:
         raise writer.error
+    if freq is not None:
+        freq.write(args.freq_file, args.freq_sort, args.freq_bed, args.gzip)
     return n_rows, part_path, out_path
 
 
@@ -224,6 +233,13 @@ def call_mods(args):
         dist.barrier()
         if rank == 0:
             _merge_parts(out_path, world)
+            if getattr(args, "freq_file", None):
+                # sites span ranks: aggregate the merged per-read calls in file order so that the double sums
+                # are associated exactly like the reference's (single pass, native text path)
+                from .call_mods_freq import SiteFrequency
+                agg = SiteFrequency(args.prob_cf)
+                agg.add_calls_file(out_path)
+                agg.write(args.freq_file, args.freq_sort, args.freq_bed, args.gzip)
         dist.barrier()
     else:
         total = n_rows
@@ -279,6 +295,12 @@ def add_call_mods_args(p):
     g.add_argument("--init_state", type=str, default="randn", choices=["randn", "zeros"],
                    help="LSTM initial states: 'randn' = N(0,1) like the reference's init_hidden (in-kernel Philox), 'zeros'")
     g.add_argument("--seed", type=int, default=0, help="seed of the in-kernel initial-state generator")
+    g.add_argument("--freq_file", type=str, default=None,
+                   help="also write the per-site modification frequency (what `call_freq` computes from the result file) "
+                        "without re-reading the per-read calls")
+    g.add_argument("--prob_cf", type=float, default=0.5, help="call_freq threshold on abs(prob1-prob0), default 0.5")
+    g.add_argument("--freq_bed", action="store_true", default=False, help="--freq_file in bedMethyl format")
+    g.add_argument("--freq_sort", action="store_true", default=False, help="sort --freq_file by chromosome and position")
     return p
 
 

@@ -288,6 +288,10 @@ void run_threads(int nthreads, int64_t n, const std::function<void(int, int64_t,
 
 extern "C" {
 
+// shared with dsp_freq.cpp (the fused call_mods -> call_freq path re-derives the printed probabilities)
+int dsp_format_prob_f32_(float x, char* out) { return format_f32_numpy(x, out); }
+float dsp_np_round6_f32_(float x) { return np_round6_f32(x); }
+
 int64_t dsp_count_rows(const char* text, size_t len) {
     int64_t n = 0;
     const char* p = text;

@@ -1,9 +1,10 @@
 #!/usr/bin/env python
 """`deepsignal_plant` command line (mirror of deepsignal_plant/deepsignal_plant.py:85-481).
 
-Only the sub-command on the hot path is implemented natively: ``call_mods`` (feature file in, per-read calls
-out).  The other sub-commands of the reference (extract, call_freq, train, denoise) are registered so that
-scripts see the same command set, and exit with a clear message (out of scope for this build)."""
+Implemented natively: ``call_mods`` (feature file in, per-read calls out -- the hot path) and ``call_freq``
+(per-read calls in, per-site frequency out -- SURVEY.md 8(f) next-1).  The other sub-commands of the
+reference (extract, train, denoise) are registered so that scripts see the same command set, and exit with a
+clear message (out of scope for this build)."""
 from __future__ import absolute_import
 
 import argparse
@@ -17,6 +18,12 @@ def main_call_mods(args):
     from .call_modifications import call_mods  # lazy, like deepsignal_plant.py:50-54
     display_args(args)
     call_mods(args)
+
+
+def main_call_freq(args):
+    from .call_mods_freq import call_mods_frequency_to_file
+    display_args(args)
+    call_mods_frequency_to_file(args)
 
 
 def _not_in_this_build(name):
@@ -38,7 +45,11 @@ def main():
     sub_call_mods = sub.add_parser("call_mods", description="call modifications")
     add_call_mods_args(sub_call_mods)
     sub_call_mods.set_defaults(func=main_call_mods)
-    for name in ("extract", "call_freq", "train", "denoise"):
+    from .call_mods_freq import add_call_freq_args
+    sub_call_freq = sub.add_parser("call_freq", description="call frequency from the per-read call file(s) of call_mods")
+    add_call_freq_args(sub_call_freq)
+    sub_call_freq.set_defaults(func=main_call_freq)
+    for name in ("extract", "train", "denoise"):
         sp = sub.add_parser(name, description="%s (not part of this build)" % name, add_help=True)
         sp.add_argument("rest", nargs=argparse.REMAINDER)
         sp.set_defaults(func=_not_in_this_build(name))

@@ -154,6 +154,26 @@ int64_t dsp_format_calls(const char* text, const uint64_t* row_off, const uint32
                          int32_t num_classes, const uint8_t* labels, const uint8_t* kmer, int32_t seq_len, int64_t n,
                          char* out, size_t out_cap, int32_t nthreads);
 
+/* ---- per-site modification frequency (the reference's `call_freq`) ----------------
+ *
+ * dsp_freq replaces calculate_mods_frequency + SiteStats/ModRecord (call_mods_freq.py:29-74,
+ * utils/txt_formater.py:8-46): sites keyed by (chromosome, pos); a record is used when
+ * |prob_0 - prob_1| >= prob_cf; prob sums, met/unmet/coverage per site; first used record fixes
+ * strand / pos_in_strand / k-mer.  dsp_freq_add_calls_text consumes per-read call lines (the file call_mods
+ * writes; `contig` non-NULL keeps only that chromosome, :53-54); dsp_freq_add_block consumes parsed call_mods
+ * blocks + GPU results directly (no text round-trip, bit-identical sums).  dsp_freq_format replaces
+ * write_sitekey2stats (:77-122): tsv or bedMethyl lines, insertion order or sorted by (chrom, pos); returns
+ * the byte count (call with out=NULL to size the buffer). */
+typedef struct dsp_freq dsp_freq;
+dsp_freq* dsp_freq_create(double prob_cf);
+void dsp_freq_destroy(dsp_freq* f);
+int64_t dsp_freq_add_calls_text(dsp_freq* f, const char* text, size_t len, const char* contig);
+int64_t dsp_freq_add_block(dsp_freq* f, const char* text, const uint64_t* row_off, const uint32_t* info_len,
+                           const float* probs, int32_t num_classes, const uint8_t* labels, const uint8_t* kmer,
+                           int32_t seq_len, int64_t n);
+void dsp_freq_counts(const dsp_freq* f, int64_t* count, int64_t* used, int64_t* sites);
+int64_t dsp_freq_format(const dsp_freq* f, int32_t is_sort, int32_t is_bed, char* out, size_t cap);
+
 const char* dsp_last_error(void);
 int32_t dsp_abi_version(void);
 

@@ -126,5 +126,48 @@ def main():
     print("F4: %d lines, e.g. %r" % (len(out_lines), out_lines[0]))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and os.environ.get("DSP_GOLDEN_ONLY") != "f5":
     main()
+    os.environ["DSP_GOLDEN_ONLY"] = "f5"
+
+
+def make_f5():
+    """F5 (call_freq): a per-read call file with many reads per site -> the reference's
+    call_mods_frequency_to_file outputs (tsv and bedMethyl, sorted and unsorted, two prob_cf values)."""
+    import argparse
+    from deepsignal_plant import call_mods_freq as cf
+    rng = np.random.default_rng(21)
+    lines = []
+    chroms = ["chr2", "chr1", "chrM", "scaffold_10"]
+    for i in range(6000):
+        ch = chroms[int(rng.integers(0, 4))]
+        pos = int(rng.integers(100, 160)) * 7
+        strand = "+" if pos % 2 == 0 else "-"
+        p1 = np.float32(rng.random() ** (0.35 if rng.random() < 0.5 else 3.0))
+        p0 = np.float32(1) - p1
+        z0 = round(p0 / (p0 + p1), 6)
+        z1 = round(1 - z0, 6)
+        lab = 1 if p1 > p0 else 0
+        lines.append("\t".join([ch, str(pos), strand, str(pos + 5), "read%d" % (i // 7), "t", str(z0), str(z1), str(lab),
+                                "ACGTC"[i % 5:] + "CGTA"[: i % 5]]))
+    # ties of the %.3f rounding and exactly-at-threshold differences
+    for k in range(40):
+        lines.append("\t".join(["chrT", "77", "+", "80", "tie%d" % k, "t", "0.7505" if k % 2 else "0.7495",
+                                "0.2495" if k % 2 else "0.2505", "0", "AACGT"]))
+    lines.append("\t".join(["chrT", "78", "-", "90", "edge", "t", "0.75", "0.25", "0", "TTCGA"]))   # |d| == 0.5
+    lines.append("\t".join(["chrT", "79", "-", "91", "edge2", "t", "0.749999", "0.250001", "0", "TTCGA"]))
+    lines.append("\t".join(["chrT", "78", "-", "90", "edge3", "t", "1e-06", "0.999999", "1", "TTCGA"]))
+    path = os.path.join(HERE, "f5_calls.tsv")
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    for tag, kw in (("tsv", dict(bed=False, sort=False, prob_cf=0.5)), ("tsv_sorted", dict(bed=False, sort=True, prob_cf=0.5)),
+                    ("bed_sorted", dict(bed=True, sort=True, prob_cf=0.5)), ("tsv_cf0", dict(bed=False, sort=False, prob_cf=0.0)),
+                    ("bed_cf02", dict(bed=True, sort=False, prob_cf=0.2))):
+        out = os.path.join(HERE, "f5_freq_%s.txt" % tag)
+        args = argparse.Namespace(input_path=[path], result_file=out, file_uid=None, contigs=None, nproc=1, gzip=False, **kw)
+        cf.call_mods_frequency_to_file(args)
+        print("F5 %s: %d sites" % (tag, sum(1 for _ in open(out))))
+
+
+if __name__ == "__main__" and os.environ.get("DSP_GOLDEN_ONLY") == "f5":
+    make_f5()

@@ -123,3 +123,31 @@ def test_cli_two_ranks_give_the_same_calls_as_one(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     assert open(one).read() == open(two).read()
     assert not [f for f in os.listdir(str(tmp_path)) if ".part" in f]
+
+
+def test_cli_fused_freq_file_equals_call_freq_on_the_result(tmp_path):
+    """call_mods --freq_file (aggregated straight from GPU results) == call_freq run on the per-read result
+    file, for the tsv and the sorted bedMethyl flavours"""
+    ck = _ckpt(tmp_path)
+    inp = os.path.join(GOLDEN, "f2_rows.tsv")
+    # many reads per site: reuse the 200 rows with positions folded onto a few sites
+    rows = open(inp).read().splitlines()
+    folded = []
+    for i, l in enumerate(rows * 6):
+        w = l.split("\t")
+        w[1] = str(1000 + 7 * (i % 23))
+        w[4] = "r%d" % i
+        folded.append("\t".join(w))
+    inp2 = os.path.join(str(tmp_path), "folded.tsv")
+    open(inp2, "w").write("\n".join(folded) + "\n")
+    out = os.path.join(str(tmp_path), "calls.tsv")
+    for flags, cf_flags in (([], []), (["--freq_bed", "--freq_sort"], ["--bed", "--sort"])):
+        fq = os.path.join(str(tmp_path), "fused.freq")
+        r = _run_cli(["-i", inp2, "-m", ck, "-o", out, "--freq_file", fq, "--prob_cf", "0.02"] + flags)
+        assert r.returncode == 0, r.stderr[-2000:]
+        fq2 = os.path.join(str(tmp_path), "two_step.freq")
+        cmd = [sys.executable, "-m", "deepsignal_plant_amd.deepsignal_plant", "call_freq", "-i", out, "-o", fq2,
+               "--prob_cf", "0.02"] + cf_flags
+        r2 = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
+        assert r2.returncode == 0, r2.stderr[-2000:]
+        assert open(fq, "rb").read() == open(fq2, "rb").read() and os.path.getsize(fq) > 0
