@@ -135,7 +135,7 @@ def main():
     if rank == 0:
         total_sites = world * K * B
         value = total_sites / dt
-        # roofline of the dominant kernel, dsp_lstm3_kernel (all LSTM launches of the timed region)
+        # roofline of the dominant kernel, dsp_lstm4_kernel (all LSTM launches of the timed region)
         lstm_ms = [ms for name, ms in prof if name.startswith("lstm")]
         all_ms = sum(ms for _, ms in prof)
         lstm_flops_site = flops_site - _non_lstm_flops(model)
@@ -161,7 +161,7 @@ def main():
                        "init_state": "in-kernel Philox N(0,1) (stand-in for torch.randn, models.py:169-176)",
                        "weights": "seeded random state_dict, PyTorch default-init scale", "parallelism": "range-shard x%d" % world,
                        "flops_per_site": flops_site},
-            "roofline": {"bound": "mfma", "kernel": "dsp_lstm3_kernel", "achieved": round(achieved, 2),
+            "roofline": {"bound": "mfma", "kernel": "dsp_lstm4_kernel", "achieved": round(achieved, 2),
                          "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4),
                          "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches": len(lstm_ms),
                          "flops_per_launch": flops_per_launch,

@@ -194,6 +194,7 @@ struct dsp_model {
     float* w2 = nullptr; float* b2 = nullptr;
     int hseq_p = 0, hsig_p = 0, Hp = 0, Fseq = 0, Fsig = 0, Fcomb = 0, Fwide = 0;
     std::vector<int> comb_in_map;  // padded comb-input feature -> reference feature
+    int lstm_kernel = 4;           // 4 = dsp_lstm4_kernel (2 waves/SIMD, default); 3 = dsp_lstm3_kernel (1 wave/SIMD)
     // scratch
     void* ws = nullptr;
     int64_t ws_sites = 0;
@@ -325,8 +326,9 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
         a.NQ = rup((ly.Ipad + ly.Hp) / 8, 4);
         a.h0buf = m->h0buf;
         a.UT = ly.Hp / 32;
-        const int upw = a.UT == 1 ? 1 : 2;  // unit tiles per wave; one wave per SIMD -> <= 4 waves per workgroup
-        a.SG = 4 / (a.UT / upw);
+        const bool k4 = m->lstm_kernel == 4 && a.UT <= 8;
+        const int upw = k4 ? 1 : (a.UT == 1 ? 1 : 2);  // lstm4: 1 unit tile per wave, 8 waves (2 per SIMD)
+        a.SG = (k4 ? 8 : 4) / (a.UT / upw);
         if (a.SG < 1) a.SG = 1;
         a.init_mode = init ? init->mode : DSP_INIT_ZEROS;
         a.seed = init ? init->seed : 0; a.site_offset = init ? init->site_offset : 0;
@@ -340,7 +342,7 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
             if (hipMalloc((void**)&dbg, 16 * 8 * sizeof(unsigned long long)) == hipSuccess) hipMemset(dbg, 0, 16 * 8 * 8);
             a.dbg = dbg;
         }
-        L.run(name, [&] { return dsp_k_lstm3(&a, upw, L.s); });
+        L.run(name, [&] { return k4 ? dsp_k_lstm4(&a, L.s) : dsp_k_lstm3(&a, upw, L.s); });
         if (dbg) {
             unsigned long long h[16 * 8];
             hipStreamSynchronize(L.s);
@@ -430,6 +432,7 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
     dsp_model* m = new (std::nothrow) dsp_model();
     if (!m) { hipSetDevice(prev); return fail(DSP_ENOMEM, "out of host memory"); }
     m->cfg = *cfg; m->d = d; m->device = device;
+    if (const char* v = getenv("DSP_LSTM_KERNEL")) m->lstm_kernel = atoi(v) == 3 ? 3 : 4;  // A/B switch
     m->hseq_p = d.hseq ? pad_hidden(d.hseq) : 0;
     m->hsig_p = d.hsig ? pad_hidden(d.hsig) : 0;
     m->Hp = pad_hidden(d.H);

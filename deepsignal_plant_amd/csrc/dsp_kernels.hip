@@ -411,6 +411,171 @@ __global__ __launch_bounds__(256, 1) void dsp_lstm3_kernel(LstmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// dsp_lstm4_kernel (the default): the same math, K4 layout and operand scheme as dsp_lstm3_kernel (buffer loads
+// with SGPR offsets, register rings, h_{t-1} read back from the K4 output, zero-C first MFMA, biases folded into
+// the activations, cell state in LDS), but TWO waves per SIMD:
+//   * 8 waves x 256 registers: a wave owns ONE unit tile (4 gates) x 2 site tiles = 8 accumulator tiles (128
+//     registers); A ring 4 x 16 VGPRs, B ring 4 x 8 VGPRs.  Weight traffic per site is unchanged (a fragment
+//     still feeds 8 MFMAs).
+//   * The per-step cost that does not scale with K (the transcendental-bound cell phase; intercept of launch
+//     time vs k-groups) drops from 8.2 us (lstm3, one wave per SIMD) to 4.5 us: each wave's cell phase covers
+//     half the elements and the two waves of a SIMD interleave their v_exp/v_rcp streams (a single wave reaches
+//     only 64 % of the TRANS issue rate, tools/micro/trans_rate.hip); the MFMA stream stays at 97 % of peak.
+//   * Tried and measured null: placing the per-step rendezvous at different k-groups for the two waves of a SIMD
+//     (so that they run 4..24 k-groups apart and one wave's cell phase meets the other's MFMAs): with half-size
+//     cell phases already sharing the VALU there is nothing left to win (18.15 ms for every skew incl. 0).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void dsp_lstm4_kernel(LstmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* c_lds = (f32x4*)smem;           // [2 site tiles][4 groups][512 threads] float4
+    f32x4* b_lds = c_lds + 8 * 512;        // [unit tile][aa][gate][half] float4
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const uint32_t voff = (uint32_t)lane * 16u;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int u = w % a.UT, sg = w / a.UT;
+    const int dir = blockIdx.x & 1;
+    const int grp = blockIdx.x >> 1;
+    const int half = lane >> 5, ls = lane & 31;
+    const int HQ = a.Hp >> 2;
+    const int nqx = a.Ipad >> 3, nq = nqx + (a.Hp >> 3), NQ = a.NQ;
+    const int T = a.T;
+    const int F4 = a.Fout >> 2;
+    const uint32_t xrow = (uint32_t)(a.Ipad >> 2) * 512u;
+    const uint32_t orow = (uint32_t)F4 * 512u;
+
+    const long long gt0 = (long long)grp * (a.SG * 2) + sg * 2;
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc((const char*)(dir ? a.wpk1 : a.wpk0) + (size_t)u * NQ * 4096);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)a.x + (size_t)gt0 * T * xrow);
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)a.out + (size_t)gt0 * T * orow + (size_t)dir * HQ * 512);
+    const __amdgpu_buffer_rsrc_t rh0 = make_rsrc((const char*)a.h0buf + (size_t)gt0 * orow + (size_t)dir * HQ * 512);
+    const f32x4* bias4 = (const f32x4*)(dir ? a.sbias1 : a.sbias0);
+
+    for (int i = tid; i < a.Hp; i += blockDim.x) {
+        const int h = i & 1, g = (i >> 1) & 3, aa = (i >> 3) & 3, ut = i >> 5;
+        b_lds[i] = bias4[g * HQ + ut * 8 + 2 * aa + h];
+    }
+    const f32x4* b_my = b_lds + (size_t)u * 32 + half;  // + aa*8 + gate*2
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const long long site = (gt0 + m) * 32 + ls;
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa) {
+            const int k4 = u * 8 + 2 * aa + half;
+            f32x4 hv = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
+            if (a.init_mode != 0) {
+                hv = init_state4(a.h0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, a.site_offset,
+                                 (uint32_t)(a.stream_base + dir * 2 + 0));
+                cv = init_state4(a.c0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, a.site_offset,
+                                 (uint32_t)(a.stream_base + dir * 2 + 1));
+            }
+            bst16(rh0, voff + aa * 1024u, (uint32_t)m * orow + (uint32_t)u * 4096u, hv);
+            c_lds[(m * 4 + aa) * 512 + tid] = cv;
+        }
+    }
+    __syncthreads();  // h0 stored (vmcnt drained) before any wave reads it back
+
+    __amdgpu_buffer_rsrc_t rhp = rh0;
+    uint32_t xo[2], ho[2];
+    auto set_bases = [&](int step) __attribute__((always_inline)) {
+        const int t = dir ? (T - 1 - step) : step;
+        const int tp = dir ? (t + 1) : (t - 1);
+        rhp = step == 0 ? rh0 : ro;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            xo[m] = (uint32_t)(m * T + t) * xrow;
+            ho[m] = (step == 0 ? (uint32_t)m * orow : (uint32_t)(m * T + tp) * orow) - (uint32_t)nqx * 1024u;
+        }
+    };
+
+    f32x4 A0[4], A1[4], A2[4], A3[4], B0[2], B1[2], B2[2], B3[2];
+    f32x16 acc[4][2];
+    auto loadB = [&](f32x4 (&B)[2], int q) __attribute__((always_inline)) {
+        const int qc = q < nq ? q : nq - 1;  // padded k-groups have zero weights: any finite B will do
+        const bool isx = qc < nqx;
+        const __amdgpu_buffer_rsrc_t r = isx ? rx : rhp;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) B[m] = bld16(r, voff, (isx ? xo[m] : ho[m]) + (uint32_t)qc * 1024u);
+    };
+    auto loadA = [&](f32x4 (&A)[4], int q) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) A[g] = bld16(rw, voff + g * 1024u, (uint32_t)q * 4096u);
+    };
+#define QW(x) ((x) < NQ ? (x) : (x) - NQ)
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // one k-group: 8 MFMAs per gate fragment; fragment g-1 is re-requested (k-group q+4) after the MFMAs of
+    // fragment g, fragment 3 of the previous stage's slot after fragment 0 (late refill, see lstm3)
+    auto stage = [&](f32x4 (&A)[4], const f32x4 (&B)[2], f32x4 (&Ap)[4], int q, auto first) __attribute__((always_inline)) {
+        const int qa = QW(q + 4), qp = QW(q + 3);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (decltype(first)::value && i == 0) {
+                    acc[g][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g][i], B[0][i], zero16, 0, 0, 0);
+                    acc[g][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g][i], B[1][i], zero16, 0, 0, 0);
+                } else {
+                    acc[g][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g][i], B[0][i], acc[g][0], 0, 0, 0);
+                    acc[g][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g][i], B[1][i], acc[g][1], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (g == 0) Ap[3] = bld16(rw, voff + 3 * 1024u, (uint32_t)qp * 4096u);
+            else A[g - 1] = bld16(rw, voff + (g - 1) * 1024u, (uint32_t)qa * 4096u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto stage4 = [&](int q, auto first) __attribute__((always_inline)) {
+        stage(A0, B0, A3, q + 0, first); loadB(B0, QW(q + 4)); __builtin_amdgcn_sched_barrier(0);
+        stage(A1, B1, A0, q + 1, std::false_type{}); loadB(B1, QW(q + 5)); __builtin_amdgcn_sched_barrier(0);
+        stage(A2, B2, A1, q + 2, std::false_type{}); loadB(B2, QW(q + 6)); __builtin_amdgcn_sched_barrier(0);
+        stage(A3, B3, A2, q + 3, std::false_type{}); loadB(B3, QW(q + 7)); __builtin_amdgcn_sched_barrier(0);
+    };
+
+    set_bases(0);
+    loadA(A0, 0); loadB(B0, 0);
+    loadA(A1, 1); loadB(B1, 1);
+    loadA(A2, 2); loadB(B2, 2);
+    loadA(A3, 3); loadB(B3, 3);
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? (T - 1 - step) : step;
+        if (step > 0) __syncthreads();  // h_{t-1} of every wave stored (vmcnt(0) + barrier) before anyone reads it back
+        stage4(0, std::true_type{});
+        for (int q = 4; q < NQ - 4; q += 4) stage4(q, std::false_type{});
+        set_bases(step + 1 < T ? step + 1 : step);  // B requests from here on belong to the next step
+        stage4(NQ - 4, std::false_type{});
+        // (stage NQ-1 leaves the last fragment of A3, for the next step's k-group 3, to "the next stage")
+        A3[3] = bld16(rw, voff + 3 * 1024u, 3u * 4096u);
+
+        // LSTM cell (see lstm3): pre-scaled biases folded into the exp2 arguments
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa) {
+            const f32x4 bi = b_my[aa * 8 + 0], bf = b_my[aa * 8 + 2], bg = b_my[aa * 8 + 4], bo = b_my[aa * 8 + 6];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                f32x4 cv = c_lds[(m * 4 + aa) * 512 + tid];
+                f32x4 hv;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 4 * aa + i;
+                    const float ig = sigmoid_pre(acc[0][m][r], bi[i]);
+                    const float fg = sigmoid_pre(acc[1][m][r], bf[i]);
+                    const float gg = tanh_pre(acc[2][m][r], bg[i]);
+                    const float og = sigmoid_pre(acc[3][m][r], bo[i]);
+                    const float cn = __builtin_fmaf(fg, cv[i], ig * gg);
+                    cv[i] = cn;
+                    hv[i] = og * fast_tanh(cn);
+                }
+                c_lds[(m * 4 + aa) * 512 + tid] = cv;
+                bst16(ro, voff + aa * 1024u, (uint32_t)(m * T + t) * orow + (uint32_t)u * 4096u, hv);
+            }
+        }
+    }
+#undef QW
+}
+
+// ------------------------------------------------------------------------------------------------
 // linear_kernel: out[., out_off + o] = act( W[o,:] . x[., :] + b[o] ) on K4 activations, per (tile, t)
 // column block of 32 sites.  Used for fc_seq / fc_signal (+ReLU; models.py:199-201, :215-217).
 // One wave = one 32-row output tile; 4 waves of a block share the same B fragments through L1.
@@ -531,6 +696,8 @@ extern "C" int dsp_k_init(void) {
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)dsp_lstm3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)dsp_lstm4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)dsp_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     return (int)e;
 }
@@ -548,6 +715,14 @@ extern "C" int dsp_k_lstm3(const LstmArgs* a, int upw, hipStream_t s) {
     const size_t lds = (size_t)upw * 8 * 256 * 16 + (size_t)a->Hp * 16;
     if (upw == 2) hipLaunchKernelGGL(dsp_lstm3_kernel<2>, dim3(groups * 2), dim3(waves * 64), lds, s, *a);
     else hipLaunchKernelGGL(dsp_lstm3_kernel<1>, dim3(groups * 2), dim3(waves * 64), lds, s, *a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dsp_k_lstm4(const LstmArgs* a, hipStream_t s) {
+    const int waves = a->UT * a->SG;
+    const unsigned groups = (unsigned)(a->NTp / (a->SG * 2));
+    const size_t lds = (size_t)8 * 512 * 16 + (size_t)a->Hp * 16;
+    hipLaunchKernelGGL(dsp_lstm4_kernel, dim3(groups * 2), dim3(waves * 64), lds, s, *a);
     return (int)hipGetLastError();
 }
 
