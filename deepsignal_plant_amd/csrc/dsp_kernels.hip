@@ -578,42 +578,73 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm4_kernel(LstmArgs a) {
 // ------------------------------------------------------------------------------------------------
 // linear_kernel: out[., out_off + o] = act( W[o,:] . x[., :] + b[o] ) on K4 activations, per (tile, t)
 // column block of 32 sites.  Used for fc_seq / fc_signal (+ReLU; models.py:199-201, :215-217).
-// One wave = one 32-row output tile; 4 waves of a block share the same B fragments through L1.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dsp_linear_kernel(LinArgs a) {
+// A wave computes 4 row tiles (128 output rows) x 2 column blocks (2 x 32 sites): 8 accumulator tiles, 32 MFMAs
+// per k-group against 6 fragment loads (the first version -- one tile per wave, 4 MFMAs per 2 loads -- was bound
+// by the L1 fill rate at 32 B/clk/CU and reached 88 TFLOP/s).  Fragments of k-group q+1 are requested before the
+// MFMAs of group q.
+__global__ __launch_bounds__(256, 2) void dsp_linear_kernel(LinArgs a) {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int rt = blockIdx.y * 4 + w;
-    if (rt >= a.ORT) return;
+    const int rt0 = blockIdx.y * 4;
     const int half = lane >> 5, ls = lane & 31;
-    const size_t col = blockIdx.x;
+    const long long col0 = ((long long)blockIdx.x * 4 + w) * 2;
+    if (col0 >= a.ncols) return;
+    const bool two = col0 + 1 < a.ncols;
     const int nq = a.Fin >> 3;
-    const f32x4* wq = (const f32x4*)a.wpk + (size_t)rt * nq * 64 + lane;
-    const f32x4* xb = (const f32x4*)a.x + (col * (a.Fin >> 2) + half) * 32 + ls;
+    const int nrt = a.ORT - rt0 < 4 ? a.ORT - rt0 : 4;
+    const f32x4* wq = (const f32x4*)a.wpk + (size_t)rt0 * nq * 64 + lane;  // + r*nq*64 + q*64
+    const f32x4* xb0 = (const f32x4*)a.x + ((size_t)col0 * (a.Fin >> 2) + half) * 32 + ls;
+    const f32x4* xb1 = two ? xb0 + (size_t)(a.Fin >> 2) * 32 : xb0;
     const f32x4* bias4 = (const f32x4*)a.bias;
-    f32x16 acc;
+    f32x16 acc[4][2];
 #pragma unroll
-    for (int aa = 0; aa < 4; ++aa) {
-        const f32x4 b = bias4[rt * 8 + 2 * aa + half];
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[4 * aa + i] = b[i];
-    }
-    for (int q = 0; q < nq; ++q) {
-        const f32x4 A = wq[(size_t)q * 64];
-        const f32x4 B = xb[(size_t)q * 64];
+        for (int aa = 0; aa < 4; ++aa) {
+            const f32x4 b = r < nrt ? bias4[(rt0 + r) * 8 + 2 * aa + half] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[i], B[i], acc, 0, 0, 0);
-    }
-    f32x4* out4 = (f32x4*)a.out + (col * (a.Fout >> 2) + (a.out_off >> 2) + rt * 8 + half) * 32 + ls;
-#pragma unroll
-    for (int aa = 0; aa < 4; ++aa) {
-        f32x4 v;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float y = acc[4 * aa + i];
-            v[i] = a.relu ? fmaxf(y, 0.f) : y;
+            for (int i = 0; i < 4; ++i) { acc[r][0][4 * aa + i] = b[i]; acc[r][1][4 * aa + i] = b[i]; }
         }
-        out4[(size_t)aa * 2 * 32] = v;
+    f32x4 An[4], Bn[2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) An[r] = wq[(size_t)(r < nrt ? r : 0) * nq * 64];
+    Bn[0] = xb0[0]; Bn[1] = xb1[0];
+    for (int q = 0; q < nq; ++q) {
+        f32x4 A[4], B[2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) A[r] = An[r];
+        B[0] = Bn[0]; B[1] = Bn[1];
+        const int qn = q + 1 < nq ? q + 1 : q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) An[r] = wq[(size_t)(r < nrt ? r : 0) * nq * 64 + (size_t)qn * 64];
+        Bn[0] = xb0[(size_t)qn * 64]; Bn[1] = xb1[(size_t)qn * 64];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[r][i], B[0][i], acc[r][0], 0, 0, 0);
+                acc[r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[r][i], B[1][i], acc[r][1], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        if (c == 1 && !two) break;
+        f32x4* out4 = (f32x4*)a.out + ((size_t)(col0 + c) * (a.Fout >> 2) + (a.out_off >> 2) + half) * 32 + ls;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (r >= nrt) break;
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa) {
+                f32x4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float y = acc[r][c][4 * aa + i];
+                    v[i] = a.relu ? fmaxf(y, 0.f) : y;
+                }
+                out4[(size_t)((rt0 + r) * 8 + aa * 2) * 32] = v;
+            }
+        }
     }
 }
 
@@ -727,7 +758,8 @@ extern "C" int dsp_k_lstm4(const LstmArgs* a, hipStream_t s) {
 }
 
 extern "C" int dsp_k_linear(const LinArgs* a, hipStream_t s) {
-    hipLaunchKernelGGL(dsp_linear_kernel, dim3((unsigned)a->ncols, (unsigned)((a->ORT + 3) / 4)), dim3(256), 0, s, *a);
+    const unsigned bx = (unsigned)((a->ncols + 7) / 8);  // 4 waves x 2 column blocks per workgroup
+    hipLaunchKernelGGL(dsp_linear_kernel, dim3(bx, (unsigned)((a->ORT + 3) / 4)), dim3(256), 0, s, *a);
     return (int)hipGetLastError();
 }
 
