@@ -124,7 +124,7 @@ std::vector<int> map_bidir(int H, int Hp) {  // [fwd Hp | bwd Hp] -> [fwd H | bw
     return m;
 }
 
-struct DevLstmLayer { int Ipad, H, Hp; float* wpk[2]; float* sbias[2]; };
+struct DevLstmLayer { int Ipad, Iused, H, Hp; float* wpk[2]; float* sbias[2]; };
 struct DevLinear { int Fin, ORT; float* wpk; float* bias; };
 
 // A fragments for gates^T = W * act^T :  [UT][NQ][4 gates][64 lanes][4]
@@ -228,6 +228,9 @@ int build_stack(dsp_model* m, const float* const* w, int in, int hid, int layers
         const std::vector<int> in_map = k == 0 ? in_map0 : map_bidir(hid, Hp);
         DevLstmLayer L{};
         L.Ipad = (int)in_map.size(); L.H = hid; L.Hp = Hp;
+        L.Iused = 0;  // features up to the last mapped one carry data; whole k-groups beyond it are padding
+        for (int i = 0; i < L.Ipad; ++i)
+            if (in_map[i] >= 0) L.Iused = i + 1;
         for (int d = 0; d < 2; ++d) {
             const float* const* p = w + (k * 2 + d) * 4;
             std::vector<float> wpk, bias;
@@ -324,6 +327,7 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
         a.n = n; a.NTp = m->NTp;
         a.Ipad = ly.Ipad; a.H = ly.H; a.Hp = ly.Hp; a.T = m->d.T; a.Fout = 2 * ly.Hp;
         a.NQ = rup((ly.Ipad + ly.Hp) / 8, 4);
+        a.nqx_used = (ly.Iused + 7) / 8;
         a.h0buf = m->h0buf;
         a.UT = ly.Hp / 32;
         const bool k4 = m->lstm_kernel == 4 && a.UT <= 8;

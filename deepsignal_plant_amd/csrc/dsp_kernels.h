@@ -38,6 +38,7 @@ struct LstmArgs {
     long long NTp;
     unsigned long long seed, site_offset;
     int Ipad, H, Hp, T, Fout;
+    int nqx_used;          // x-part k-groups that carry real features (the rest of Ipad/8 is zero padding)
     int NQ;                // k-groups per unit tile in wpk: (Ipad+Hp)/8 padded to a multiple of 4 (zero weights)
     int UT, SG;            // unit tiles (Hp/32), site groups per workgroup; block = 64*(UT/UPW)*SG threads
     int init_mode;         // DSP_INIT_*

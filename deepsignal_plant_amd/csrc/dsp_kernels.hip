@@ -425,6 +425,10 @@ __global__ __launch_bounds__(256, 1) void dsp_lstm3_kernel(LstmArgs a) {
 //     (so that they run 4..24 k-groups apart and one wave's cell phase meets the other's MFMAs): with half-size
 //     cell phases already sharing the VALU there is nothing left to win (18.15 ms for every skew incl. 0).
 // ------------------------------------------------------------------------------------------------
+// SPARSE = true (front-end layers): k-groups that are pure zero padding -- the x part padded from 8/16 to 32
+// features so that the first four k-groups never depend on h_t, and the tail padded to a multiple of four -- keep
+// their (branch-free) operand requests but skip their MFMAs behind a wave-uniform test.
+template <bool SPARSE>
 __global__ __launch_bounds__(512, 2) void dsp_lstm4_kernel(LstmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* c_lds = (f32x4*)smem;           // [2 site tiles][4 groups][512 threads] float4
@@ -505,12 +509,15 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm4_kernel(LstmArgs a) {
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // one k-group: 8 MFMAs per gate fragment; fragment g-1 is re-requested (k-group q+4) after the MFMAs of
     // fragment g, fragment 3 of the previous stage's slot after fragment 0 (late refill, see lstm3)
+    const int nqx_used = a.nqx_used;
     auto stage = [&](f32x4 (&A)[4], const f32x4 (&B)[2], f32x4 (&Ap)[4], int q, auto first) __attribute__((always_inline)) {
         const int qa = QW(q + 4), qp = QW(q + 3);
+        const bool live = !SPARSE || q < nqx_used || (q >= nqx && q < nq);  // wave-uniform
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                if (SPARSE && !live) break;
                 if (decltype(first)::value && i == 0) {
                     acc[g][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g][i], B[0][i], zero16, 0, 0, 0);
                     acc[g][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g][i], B[1][i], zero16, 0, 0, 0);
@@ -727,7 +734,9 @@ extern "C" int dsp_k_init(void) {
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)dsp_lstm3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)dsp_lstm4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    e = hipFuncSetAttribute((const void*)dsp_lstm4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)dsp_lstm4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)dsp_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     return (int)e;
@@ -753,7 +762,9 @@ extern "C" int dsp_k_lstm4(const LstmArgs* a, hipStream_t s) {
     const int waves = a->UT * a->SG;
     const unsigned groups = (unsigned)(a->NTp / (a->SG * 2));
     const size_t lds = (size_t)8 * 512 * 16 + (size_t)a->Hp * 16;
-    hipLaunchKernelGGL(dsp_lstm4_kernel, dim3(groups * 2), dim3(waves * 64), lds, s, *a);
+    const bool sparse = a->nqx_used < (a->Ipad >> 3) || a->NQ > ((a->Ipad + a->Hp) >> 3);
+    if (sparse) hipLaunchKernelGGL(dsp_lstm4_kernel<true>, dim3(groups * 2), dim3(waves * 64), lds, s, *a);
+    else hipLaunchKernelGGL(dsp_lstm4_kernel<false>, dim3(groups * 2), dim3(waves * 64), lds, s, *a);
     return (int)hipGetLastError();
 }
 
