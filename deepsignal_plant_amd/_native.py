@@ -95,6 +95,25 @@ def lib():
     L.dsp_freq_counts.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int64)] * 3
     L.dsp_freq_format.restype = ctypes.c_int64
     L.dsp_freq_format.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_size_t]
+    L.dsp_feat_writer_create.restype = ctypes.c_int32
+    L.dsp_feat_writer_create.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
+                                         ctypes.POINTER(ctypes.c_void_p)]
+    L.dsp_feat_writer_add.restype = ctypes.c_int32
+    L.dsp_feat_writer_add.argtypes = [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 11
+    L.dsp_feat_writer_close.restype = ctypes.c_int32
+    L.dsp_feat_writer_close.argtypes = [ctypes.c_void_p]
+    L.dsp_feat_open.restype = ctypes.c_int32
+    L.dsp_feat_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
+    L.dsp_feat_info.restype = ctypes.c_int32
+    L.dsp_feat_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
+                                ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+    L.dsp_feat_block_info.restype = ctypes.c_int32
+    L.dsp_feat_block_info.argtypes = [ctypes.c_void_p, ctypes.c_int64] + [ctypes.POINTER(ctypes.c_int64)] * 3
+    L.dsp_feat_read_block.restype = ctypes.c_int64
+    L.dsp_feat_read_block.argtypes = ([ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64] + [ctypes.c_void_p] * 7 +
+                                      [ctypes.c_size_t] + [ctypes.c_void_p] * 4 + [ctypes.c_int32])
+    L.dsp_feat_close.restype = None
+    L.dsp_feat_close.argtypes = [ctypes.c_void_p]
     _lib = L
     return L
 

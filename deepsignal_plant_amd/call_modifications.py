@@ -33,7 +33,7 @@ import time
 import numpy as np
 
 from . import dist as dsp_dist
-from . import feed, textio
+from . import featfile, feed, textio
 from .models import ModelBiLSTM
 from .utils.process_utils import display_args, str2bool
 
@@ -111,7 +111,7 @@ def _call_mods_file(args, rank, local_rank, world):
 
     # my byte range and the global index of my first row (plain text only; .gz ranks inflate everything)
     first_row, byte_range = 0, None
-    if not input_path.endswith(".gz") and world > 1:
+    if not input_path.endswith(".gz") and world > 1 and not featfile.is_feature_file(input_path):
         import mmap
         size = os.path.getsize(input_path)
         if size:
@@ -255,7 +255,7 @@ def add_call_mods_args(p):
     plus the build-only flags --init_state / --seed."""
     g = p.add_argument_group("INPUT")
     g.add_argument("--input_path", "-i", type=str, required=True,
-                   help="feature file written by `extract` (plain or .gz)")
+                   help="feature file written by `extract` (plain or .gz), or its binary form written by `pack_features` (.dspf)")
     g.add_argument("--f5_batch_size", type=int, default=30,
                    help="reads per reader batch in the reference (default 30); accepted for compatibility, results do not depend on it")
     g = p.add_argument_group("CALL")

@@ -26,6 +26,13 @@ def main_call_freq(args):
     call_mods_frequency_to_file(args)
 
 
+def main_pack_features(args):
+    from .featfile import pack_features
+    display_args(args)
+    n = pack_features(args.input_path, args.result_file, args.seq_len, args.signal_len, args.block_rows, args.nproc)
+    print("[main] pack_features: %d rows -> %s" % (n, args.result_file))
+
+
 def _not_in_this_build(name):
     def run(_args):
         sys.stderr.write("deepsignal_plant %s: not part of the MI355X call_mods build (use the reference "
@@ -49,6 +56,11 @@ def main():
     sub_call_freq = sub.add_parser("call_freq", description="call frequency from the per-read call file(s) of call_mods")
     add_call_freq_args(sub_call_freq)
     sub_call_freq.set_defaults(func=main_call_freq)
+    from .featfile import add_pack_features_args
+    sub_pack = sub.add_parser("pack_features", description="feature TSV -> binary feature container (.dspf) that "
+                                                           "call_mods reads without parsing (build-only helper)")
+    add_pack_features_args(sub_pack)
+    sub_pack.set_defaults(func=main_pack_features)
     for name in ("extract", "train", "denoise"):
         sp = sub.add_parser(name, description="%s (not part of this build)" % name, add_help=True)
         sp.add_argument("rest", nargs=argparse.REMAINDER)

@@ -2,7 +2,8 @@
 
 Replaces the reference's reader process and pickled-list queue (_read_features_file,
 call_modifications.py:55-127, Queue at :40-44): a reader thread cuts the input into blocks of complete rows
-(plain files: this rank's byte range via mmap; .gz: sequential inflate), the native parser
+(plain files: this rank's byte range via mmap; .gz: sequential inflate; .dspf binary containers: this rank's
+block range, read with no parsing at all -- featfile.py), the native parser
 (csrc/dsp_text.cpp, multi-threaded, GIL released) writes straight into PINNED SoA buffers, and the consumer
 issues async H2D copies on a HIP stream.  NBUF buffer sets rotate, so parse(k+1), H2D/compute(k) and
 format/write(k-1) overlap."""
@@ -17,7 +18,7 @@ import threading
 import numpy as np
 
 from . import dist as dsp_dist
-from . import textio
+from . import featfile, textio
 
 BLOCK_BYTES = int(os.environ.get("DSP_BLOCK_BYTES", 0) or (48 << 20))  # ~23k rows of ~2.08 kB per block
 
@@ -54,6 +55,13 @@ class FeatureReader(threading.Thread):
                  first_row=0, byte_range=None, pinned=True, max_rows_per_block=None):
         super().__init__(daemon=True)
         self.path, self.L, self.S = path, seq_len, signal_len
+        self.ff = None
+        if featfile.is_feature_file(path):
+            self.ff = featfile.FeatureFile(path)
+            if (self.ff.seq_len, self.ff.signal_len) != (seq_len, signal_len):
+                raise ValueError("%s holds seq_len=%d signal_len=%d features, the model expects %d / %d" % (
+                    path, self.ff.seq_len, self.ff.signal_len, seq_len, signal_len))
+            max_rows_per_block = max(1, self.ff.max_block_rows())
         self.rank, self.world, self.nthreads = rank, world, max(1, nthreads)
         self.block_bytes = block_bytes
         self.first_row = first_row
@@ -94,7 +102,9 @@ class FeatureReader(threading.Thread):
     def run(self):
         try:
             row = self.first_row
-            if self.path.endswith(".gz"):
+            if self.ff is not None:
+                row = self._run_dspf()
+            elif self.path.endswith(".gz"):
                 row = self._run_gz(row)
             else:
                 row = self._run_plain(row)
@@ -102,6 +112,19 @@ class FeatureReader(threading.Thread):
             self.error = e
         finally:
             self.q.put(None)
+
+    def _run_dspf(self):
+        b0, b1 = self.ff.blocks_for_rank(self.world, self.rank)
+        row = 0
+        for bi in range(b0, b1):
+            slot = self.free.get()
+            rows, _out, info = self.ff.read_block(bi, out=slot, info=slot.get("_info"), nthreads=self.nthreads)
+            slot["_info"] = info
+            b = Block()
+            b.rows, b.first_row, b.slot = rows, int(self.ff.block_first_row[bi]), slot
+            self.q.put(b)
+            row = b.first_row + rows.n
+        return row
 
     def _run_plain(self, row):
         size = os.path.getsize(self.path)

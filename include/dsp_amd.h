@@ -154,6 +154,35 @@ int64_t dsp_format_calls(const char* text, const uint64_t* row_off, const uint32
                          int32_t num_classes, const uint8_t* labels, const uint8_t* kmer, int32_t seq_len, int64_t n,
                          char* out, size_t out_cap, int32_t nthreads);
 
+/* ---- binary feature container (.dspf) ----------------------------------------------
+ *
+ * The parsed form of the feature TSV (rows written by extract_features.py:381-395, read by
+ * call_modifications.py:76-86) as blocks of ready-to-copy SoA arrays + the rows' sampleinfo strings, so that
+ * call_mods reads straight into pinned buffers.  Array meanings and dtypes are those of
+ * dsp_parse_feature_rows; values are bit-identical to what it yields for the same rows (layout:
+ * csrc/dsp_featfile.cpp).  The writer coalesces added rows into blocks of `block_rows` (<=0: 32768);
+ * dsp_feat_writer_close writes the block index and frees the writer.  Readers are thread-safe (pread);
+ * dsp_feat_read_block fills the buffers (NULL = skip that array), `info` receives the concatenated
+ * sampleinfo bytes with row_off/info_len/read_off/read_len addressing it, and returns the block's row count
+ * (DSP_ENOMEM if max_rows / info_cap are too small, DSP_EPARSE for a corrupt or truncated file). */
+typedef struct dsp_feat_writer dsp_feat_writer;
+typedef struct dsp_feat_file dsp_feat_file;
+int32_t dsp_feat_writer_create(const char* path, int32_t seq_len, int32_t signal_len, int64_t block_rows,
+                               dsp_feat_writer** out);
+int32_t dsp_feat_writer_add(dsp_feat_writer* w, int64_t n, const uint8_t* kmer, const float* means, const float* stds,
+                            const int32_t* lens, const float* signals, const int32_t* labels, const char* text,
+                            const uint64_t* row_off, const uint32_t* info_len, const uint32_t* read_off,
+                            const uint32_t* read_len);
+int32_t dsp_feat_writer_close(dsp_feat_writer* w);
+int32_t dsp_feat_open(const char* path, dsp_feat_file** out);
+int32_t dsp_feat_info(const dsp_feat_file* f, int32_t* seq_len, int32_t* signal_len, int64_t* n_rows, int64_t* n_blocks);
+int32_t dsp_feat_block_info(const dsp_feat_file* f, int64_t block, int64_t* n, int64_t* first_row, int64_t* info_bytes);
+int64_t dsp_feat_read_block(const dsp_feat_file* f, int64_t block, int64_t max_rows, uint8_t* kmer, float* means,
+                            float* stds, int32_t* lens, float* signals, int32_t* labels, char* info, size_t info_cap,
+                            uint64_t* row_off, uint32_t* info_len, uint32_t* read_off, uint32_t* read_len,
+                            int32_t nthreads);
+void dsp_feat_close(dsp_feat_file* f);
+
 /* ---- per-site modification frequency (the reference's `call_freq`) ----------------
  *
  * dsp_freq replaces calculate_mods_frequency + SiteStats/ModRecord (call_mods_freq.py:29-74,

@@ -151,3 +151,36 @@ def test_cli_fused_freq_file_equals_call_freq_on_the_result(tmp_path):
         r2 = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
         assert r2.returncode == 0, r2.stderr[-2000:]
         assert open(fq, "rb").read() == open(fq2, "rb").read() and os.path.getsize(fq) > 0
+
+
+def test_cli_binary_feature_container_gives_the_same_calls_as_the_tsv(tmp_path):
+    """call_mods on a .dspf (pack_features of the TSV) writes byte-identical per-read calls,
+    on one rank and on two (block-range sharding, no collective for the row offsets)"""
+    import socket
+    from deepsignal_plant_amd import featfile
+    ck = _ckpt(tmp_path)
+    inp = os.path.join(GOLDEN, "f2_rows.tsv")
+    ref_out = os.path.join(str(tmp_path), "tsv.tsv")
+    ref_fq = os.path.join(str(tmp_path), "tsv.freq")
+    r = _run_cli(["-i", inp, "-m", ck, "-o", ref_out, "--seed", "9", "--freq_file", ref_fq, "--prob_cf", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    packed = os.path.join(str(tmp_path), "f2.dspf")
+    assert featfile.pack_features(inp, packed, block_rows=48) == 200
+    out = os.path.join(str(tmp_path), "bin.tsv")
+    fq = os.path.join(str(tmp_path), "bin.freq")
+    r = _run_cli(["-i", packed, "-m", ck, "-o", out, "--seed", "9", "--freq_file", fq, "--prob_cf", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert open(out, "rb").read() == open(ref_out, "rb").read()
+    assert open(fq, "rb").read() == open(ref_fq, "rb").read() and os.path.getsize(fq) > 0
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    two = os.path.join(str(tmp_path), "bin2.tsv")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), "-m", "deepsignal_plant_amd.deepsignal_plant", "call_mods",
+           "-i", packed, "-m", ck, "-o", two, "--seed", "9"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert open(two, "rb").read() == open(ref_out, "rb").read()
+    bad = os.path.join(str(tmp_path), "bad.dspf")
+    open(bad, "wb").write(open(packed, "rb").read()[:5000])
+    r = _run_cli(["-i", bad, "-m", ck, "-o", out])
+    assert r.returncode != 0 and "dsp_feat_open" in r.stderr and "truncated" in r.stderr

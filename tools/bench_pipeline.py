@@ -40,7 +40,28 @@ def main():
                               "call_mods_s": secs, "process_wall_s": round(wall, 2), "sites_per_s": round(n / secs, 1),
                               "text_mb_per_s": round(os.path.getsize(tsv) / 1e6 / secs, 1), "gen_s": round(gen, 1)}), flush=True)
             os.remove(out)
+        # the same rows as a binary feature container (pack_features): no parsing on the call_mods side
+        packed = os.path.join(work, "feat_%d.dspf" % n)
+        t0 = time.time()
+        subprocess.check_call([sys.executable, "-m", "deepsignal_plant_amd.deepsignal_plant", "pack_features", "-i", tsv,
+                               "-o", packed, "-p", "16"], cwd=ROOT, stdout=subprocess.DEVNULL)
+        pack_s = time.time() - t0
         os.remove(tsv)
+        for rep in range(2):
+            out = os.path.join(work, "calls_%d.tsv" % n)
+            t0 = time.time()
+            r = subprocess.run([sys.executable, "-m", "deepsignal_plant_amd.deepsignal_plant", "call_mods", "-i", packed,
+                                "-m", ck, "-o", out, "-p", "16"], cwd=ROOT, capture_output=True, text=True)
+            wall = time.time() - t0
+            assert r.returncode == 0, r.stderr[-3000:]
+            inner = [l for l in r.stdout.splitlines() if "call_mods costs" in l][0]
+            secs = float(inner.split("costs")[1].split("seconds")[0])
+            assert sum(1 for _ in open(out)) == n
+            print(json.dumps({"rows": n, "input": "dspf", "dspf_mb": round(os.path.getsize(packed) / 1e6, 1),
+                              "pack_s": round(pack_s, 2), "call_mods_s": secs, "process_wall_s": round(wall, 2),
+                              "sites_per_s": round(n / secs, 1)}), flush=True)
+            os.remove(out)
+        os.remove(packed)
 
 
 if __name__ == "__main__":
