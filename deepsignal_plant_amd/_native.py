@@ -11,6 +11,7 @@ DSP_OK, DSP_EINVAL, DSP_ESHAPE, DSP_EHIP, DSP_ENOMEM, DSP_EPARSE = 0, -1, -2, -3
 MODULE_CODE = {"both_bilstm": 0, "seq_bilstm": 1, "signal_bilstm": 2}
 DT_F32, DT_U8, DT_U16, DT_I32 = 0, 1, 2, 3
 INIT_ZEROS, INIT_EXPLICIT, INIT_PHILOX = 0, 1, 2
+NORM_MAD, NORM_ZSCORE = 0, 1
 
 
 class ModelCfg(ctypes.Structure):
@@ -114,6 +115,19 @@ def lib():
                                       [ctypes.c_size_t] + [ctypes.c_void_p] * 4 + [ctypes.c_int32])
     L.dsp_feat_close.restype = None
     L.dsp_feat_close.argtypes = [ctypes.c_void_p]
+    L.dsp_extract_normalize.restype = ctypes.c_int32
+    L.dsp_extract_normalize.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    L.dsp_extract_base_stats.restype = ctypes.c_int32
+    L.dsp_extract_base_stats.argtypes = [ctypes.c_void_p] * 8
+    L.dsp_extract_gather.restype = ctypes.c_int32
+    L.dsp_extract_gather.argtypes = ([ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p] +
+                                     [ctypes.c_int32] * 3 + [ctypes.c_uint64] + [ctypes.c_void_p] * 6)
+    L.dsp_extract_sites.restype = ctypes.c_int64
+    L.dsp_extract_sites.argtypes = ([ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_char_p, ctypes.c_char_p] + [ctypes.c_void_p] * 4 +
+                                    [ctypes.c_char_p] + [ctypes.c_int32] * 4 + [ctypes.c_int64, ctypes.c_void_p,
+                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)] +
+                                    [ctypes.c_void_p] * 4)
     _lib = L
     return L
 

@@ -1,0 +1,200 @@
+"""Feature extraction from resquiggled reads on MI355X.
+
+Host-side mirror of deepsignal_plant/extract_features.py for everything after the HDF5 reads: given read
+records (reads.py: raw DAQ samples, channel scaling, resquiggle events, alignment attributes) it produces the
+features of every motif site -- as device tensors in the layout dsp_forward consumes (the reference's fast5
+route of call_mods, call_modifications.py:285-325), or rounded the way the feature TSV carries them
+(_features_to_str, :381-395) for writing `extract` output.  The arithmetic runs in csrc/dsp_extract.hip
+(float64, numpy's evaluation order); the motif scan / coordinates / sampleinfo strings in csrc/dsp_sites.cpp.
+
+Difference from the reference, by necessity: bases longer than signal_len are subsampled with a counter-based
+sampler keyed by (seed, read uid, base index) instead of the unseeded process-global random.sample
+(:247-249), so results are reproducible and independent of batching."""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _native as nat
+from . import textio
+from .utils.process_utils import get_motif_seqs, parse_region_str
+
+KEY_SEP = "||"  # extract_features.py:40
+
+
+class ReadBatchC(ctypes.Structure):
+    _fields_ = [("n_reads", ctypes.c_int64), ("n_samples", ctypes.c_int64), ("n_events", ctypes.c_int64),
+                ("raw", ctypes.c_void_p), ("raw_off", ctypes.c_void_p), ("scaling", ctypes.c_void_p),
+                ("offset", ctypes.c_void_p), ("ev_start", ctypes.c_void_p), ("ev_len", ctypes.c_void_p),
+                ("ev_base", ctypes.c_void_p), ("ev_off", ctypes.c_void_p)]
+
+
+class ExtractedBatch(object):
+    """rows: textio.ParsedRows whose text/row_off/... address the sites' sampleinfo strings (host; its feature
+    arrays are filled only by to_host()); kmer/means/stds/lens/signals: device tensors [n, L(, S)]."""
+    __slots__ = ("rows", "n", "kmer", "means", "stds", "lens", "signals", "shift", "scale")
+
+    def to_host(self):
+        r = self.rows
+        r.kmer, r.means, r.stds = self.kmer.cpu().numpy(), self.means.cpu().numpy(), self.stds.cpu().numpy()
+        r.lens, r.signals = self.lens.cpu().numpy(), self.signals.cpu().numpy()
+        return r
+
+
+def _read_position_file(position_file):
+    """chrom \\t pos \\t strand per line -> set of "chrom||pos||strand" (extract_features.py:520-529)"""
+    positions = set()
+    with open(position_file, "r") as rf:
+        for line in rf:
+            words = line.strip().split("\t")
+            if len(words) < 3:
+                raise ValueError("--position file in wrong format. If you didn't use Tab as delimiter, Please do.")
+            positions.add(KEY_SEP.join(words[:3]))
+    return positions
+
+
+class FeatureExtractor(object):
+    def __init__(self, motifs="CG", mod_loc=0, seq_len=13, signal_len=16, normalize_method="mad", chrom2len=None,
+                 positions=None, region=None, methy_label=1, is_dna=True, device=0, seed=0, round_stats=False):
+        if seq_len % 2 == 0:
+            raise ValueError("kmer_len must be odd")  # extract_features.py:296-297
+        if normalize_method not in ("mad", "zscore"):
+            raise ValueError("")  # :185
+        import torch
+        self.torch = torch
+        self.dev = torch.device("cuda", device) if not isinstance(device, torch.device) else device
+        self.motif_seqs = get_motif_seqs(motifs, is_dna) if isinstance(motifs, str) else list(motifs)
+        mlens = set(len(m) for m in self.motif_seqs)
+        self.motif_len = len(self.motif_seqs[0])
+        # the reference takes the length of an arbitrary set element (:107): mixed-length motif sets are undefined there
+        if len(mlens) != 1:
+            raise ValueError("--motifs must all have the same length")
+        self.mod_loc, self.L, self.S = int(mod_loc), int(seq_len), int(signal_len)
+        self.method = nat.NORM_MAD if normalize_method == "mad" else nat.NORM_ZSCORE
+        self.chrom2len, self.positions = chrom2len, positions
+        self.regioninfo = parse_region_str(region) if (region is None or isinstance(region, str)) else tuple(region)
+        self.methy_label, self.seed, self.round_stats = int(methy_label), int(seed), bool(round_stats)
+        self._motif_blob = "".join(self.motif_seqs).encode()
+        nat.lib()
+
+    # -- host: which reads / region bounds (extract_features.py:311-314, :337-341)
+    def _select_reads(self, reads):
+        rg_chrom, rg_start, rg_end = self.regioninfo
+        keep, lo, hi = [], [], []
+        for rd in reads:
+            if rg_chrom is not None and rg_chrom != rd.chrom:
+                continue
+            nbases = int(rd.ev_base.shape[0])
+            a = rd.chrom_start if rg_start is None else rg_start
+            b = rd.chrom_start + nbases if rg_end is None else rg_end
+            if a >= rd.chrom_start + nbases or b <= rd.chrom_start:
+                continue
+            keep.append(rd)
+            lo.append(a)
+            hi.append(b)
+        return keep, np.array(lo, np.int64), np.array(hi, np.int64)
+
+    def _sites(self, reads, ev_base, ev_off, rg_lo, rg_hi):
+        L = nat.lib()
+        n = len(reads)
+        strs = lambda xs: (ctypes.c_char_p * n)(*[x.encode() for x in xs])
+        chrom, names = strs([r.chrom for r in reads]), strs([r.readname for r in reads])
+        rstrand = "".join(r.strand[:1] or "t" for r in reads).encode()
+        astrand = "".join(r.alignstrand[:1] or "+" for r in reads).encode()
+        cstart = np.array([r.chrom_start for r in reads], np.int64)
+        clen = np.array([(self.chrom2len.get(r.chrom, -1) if self.chrom2len is not None else -1) for r in reads], np.int64)
+        use_rg = self.regioninfo[0] is not None
+        p = textio._ptr
+        args = [n, p(ev_base), p(ev_off), chrom, names, rstrand, astrand, p(cstart), p(clen),
+                p(rg_lo) if use_rg else None, p(rg_hi) if use_rg else None, self._motif_blob, len(self.motif_seqs),
+                self.motif_len, self.mod_loc, self.L]
+        need = ctypes.c_size_t()
+        cnt = nat.check(int(L.dsp_extract_sites(*args, 0, None, None, None, 0, ctypes.byref(need), None, None, None, None)))
+        site_read, site_loc = np.empty(cnt, np.int32), np.empty(cnt, np.int32)
+        info = np.empty(max(need.value, 1), np.uint8)
+        row_off, info_len = np.empty(cnt, np.uint64), np.empty(cnt, np.uint32)
+        read_off, read_len = np.empty(cnt, np.uint32), np.empty(cnt, np.uint32)
+        got = nat.check(int(L.dsp_extract_sites(*args, cnt, p(site_read), p(site_loc), p(info), info.nbytes, None,
+                                                p(row_off), p(info_len), p(read_off), p(read_len))))
+        assert got == cnt
+        if self.positions is not None and cnt:  # :356-357 (hash-set lookup on the host)
+            keep = np.zeros(cnt, bool)
+            for i in range(cnt):
+                w = bytes(info[int(row_off[i]):int(row_off[i]) + int(info_len[i])]).decode().split("\t")
+                keep[i] = KEY_SEP.join(w[:3]) in self.positions
+            site_read, site_loc, row_off = site_read[keep], site_loc[keep], row_off[keep]
+            info_len, read_off, read_len = info_len[keep], read_off[keep], read_len[keep]
+        return site_read, site_loc, info, row_off, info_len, read_off, read_len
+
+    def extract(self, reads, first_read_uid=0, stream=None):
+        """reads: sequence of reads.ReadRecord -> ExtractedBatch (sites in read order, then position order)."""
+        torch = self.torch
+        uid_of = {id(r): first_read_uid + i for i, r in enumerate(reads)}
+        reads, rg_lo, rg_hi = self._select_reads(reads)
+        R = len(reads)
+        out = ExtractedBatch()
+        rows = textio.ParsedRows()
+        rows.seq_len, rows.signal_len = self.L, self.S
+        out.rows = rows
+        i64 = lambda xs: np.concatenate([[0], np.cumsum(xs)]).astype(np.int64)
+        raw_off = i64([r.raw.shape[0] for r in reads])
+        ev_off = i64([r.ev_base.shape[0] for r in reads])
+        cat = lambda xs, dt: (np.concatenate(xs).astype(dt, copy=False) if xs else np.zeros(0, dt))
+        ev_base = cat([r.ev_base for r in reads], np.uint8)
+        site_read, site_loc, info, row_off, info_len, read_off, read_len = (
+            self._sites(reads, ev_base, ev_off, rg_lo, rg_hi) if R else
+            (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(1, np.uint8), np.zeros(0, np.uint64),
+             np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint32)))
+        n = int(site_read.shape[0])
+        rows.text, rows.n = info, n
+        rows.row_off, rows.info_len, rows.read_off, rows.read_len = row_off, info_len, read_off, read_len
+        rows.labels = np.full(n, self.methy_label, np.int32)
+        out.n = n
+        dev = self.dev
+        st = stream if stream is not None else torch.cuda.current_stream(dev)
+        with torch.cuda.device(dev), torch.cuda.stream(st):
+            up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)
+            d_raw = up(cat([r.raw for r in reads], np.int16))
+            d_raw_off, d_ev_off = up(raw_off), up(ev_off)
+            d_scaling = up(np.array([r.scaling for r in reads], np.float64))
+            d_offset = up(np.array([r.offset for r in reads], np.float64))
+            d_ev_start = up(cat([r.ev_start for r in reads], np.int64))
+            d_ev_len = up(cat([r.ev_len for r in reads], np.int64))
+            d_ev_base = up(ev_base)
+            E = int(ev_off[-1])
+            batch = ReadBatchC(R, int(raw_off[-1]), E, d_raw.data_ptr(), d_raw_off.data_ptr(), d_scaling.data_ptr(),
+                               d_offset.data_ptr(), d_ev_start.data_ptr(), d_ev_len.data_ptr(), d_ev_base.data_ptr(),
+                               d_ev_off.data_ptr())
+            f64 = dict(dtype=torch.float64, device=dev)
+            shift, scale = torch.empty(R, **f64), torch.empty(R, **f64)
+            base_mean, base_std = torch.empty(E, **f64), torch.empty(E, **f64)
+            base_len = torch.empty(E, dtype=torch.int32, device=dev)
+            base_lo = torch.empty(E, dtype=torch.int64, device=dev)
+            out.kmer = torch.empty((n, self.L), dtype=torch.uint8, device=dev)
+            out.means = torch.empty((n, self.L), dtype=torch.float32, device=dev)
+            out.stds = torch.empty((n, self.L), dtype=torch.float32, device=dev)
+            out.lens = torch.empty((n, self.L), dtype=torch.int32, device=dev)
+            out.signals = torch.empty((n, self.L, self.S), dtype=torch.float32, device=dev)
+            out.shift, out.scale = shift, scale
+            if R:
+                L = nat.lib()
+                sp = ctypes.c_void_p(st.cuda_stream)
+                ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+                nat.check(L.dsp_extract_normalize(sp, ctypes.byref(batch), self.method, ptr(shift), ptr(scale)))
+                nat.check(L.dsp_extract_base_stats(sp, ctypes.byref(batch), ptr(shift), ptr(scale), ptr(base_mean),
+                                                   ptr(base_std), ptr(base_len), ptr(base_lo)))
+                if n:
+                    d_site_read, d_site_loc = up(site_read), up(site_loc)
+                    d_uid = up(np.array([uid_of[id(r)] for r in reads], np.uint64).view(np.int64))
+                    nat.check(L.dsp_extract_gather(sp, ctypes.byref(batch), ptr(shift), ptr(scale), ptr(base_mean),
+                                                   ptr(base_std), ptr(base_len), ptr(base_lo), n, ptr(d_site_read),
+                                                   ptr(d_site_loc), self.L, self.S, int(self.round_stats),
+                                                   ctypes.c_uint64(self.seed & ((1 << 64) - 1)), ptr(d_uid),
+                                                   ptr(out.kmer), ptr(out.means), ptr(out.stds), ptr(out.lens),
+                                                   ptr(out.signals)))
+                    # the inputs must outlive the asynchronous kernels
+                    for t in (d_raw, d_raw_off, d_ev_off, d_scaling, d_offset, d_ev_start, d_ev_len, d_ev_base,
+                              base_mean, base_std, base_len, base_lo, d_site_read, d_site_loc, d_uid):
+                        t.record_stream(st)
+        return out

@@ -183,6 +183,68 @@ int64_t dsp_feat_read_block(const dsp_feat_file* f, int64_t block, int64_t max_r
                             int32_t nthreads);
 void dsp_feat_close(dsp_feat_file* f);
 
+/* ---- feature extraction from resquiggled reads -------------------------------------
+ *
+ * Replaces the arithmetic of extract_features.py after the HDF5 reads: _rescale_signals (:273-274),
+ * _normalize_signals (:179-190), event slicing + per-base np.mean / np.std (:331-335, :363-365), the k-mer
+ * window and _get_signals_rect (:360-368, :232-251), producing the tensors dsp_forward consumes directly in
+ * HBM (the reference's fast5 route of call_mods, call_modifications.py:285-325) -- or, with round_stats=1,
+ * exactly the values the feature TSV would carry (_features_to_str, :381-395).  float64 arithmetic in numpy's
+ * evaluation order: results are bit-identical to the reference's for every base that is not subsampled.
+ *
+ * A batch of reads is SoA with CSR offsets; ALL pointers are DEVICE pointers:
+ *   raw [n_samples] int16 DAQ values of the reads back to back, raw_off [n_reads+1];
+ *   scaling, offset [n_reads]   pA = scaling * (raw + offset)  (_get_scaling_of_a_read, :255-270);
+ *   ev_start, ev_len [n_events] event start (relative to the read's raw, read_start_rel_to_raw added, :81) and
+ *   length; ev_base [n_events] ASCII base; ev_off [n_reads+1]   (_get_label_raw, :44-91). */
+typedef struct dsp_read_batch {
+    int64_t n_reads, n_samples, n_events;
+    const int16_t* raw;
+    const int64_t* raw_off;
+    const double* scaling;
+    const double* offset;
+    const int64_t* ev_start;
+    const int64_t* ev_len;
+    const uint8_t* ev_base;
+    const int64_t* ev_off;
+} dsp_read_batch;
+
+enum { DSP_NORM_MAD = 0, DSP_NORM_ZSCORE = 1 }; /* --normalize_method, extract_features.py:179-185 */
+
+/* per-read shift / scale [n_reads] float64: mad -> (np.median, statsmodels robust.mad), zscore -> (np.mean, np.std) */
+int32_t dsp_extract_normalize(void* stream, const dsp_read_batch* b, int32_t method, double* shift, double* scale);
+/* per-base float64 mean / std of the normalised, 6-decimal-rounded samples, clamped length and first sample
+ * index [n_events] */
+int32_t dsp_extract_base_stats(void* stream, const dsp_read_batch* b, const double* shift, const double* scale,
+                               double* base_mean, double* base_std, int32_t* base_len, int64_t* base_lo);
+/* window gather for n_sites sites (site_read = read index in the batch, site_loc = base index of the targeted
+ * base in the read; the caller guarantees seq_len/2 <= loc < n_bases - seq_len/2): kmer u8 [n][L] codes
+ * (base2code_dna), means/stds f32 [n][L] (rounded to 6 decimals first when round_stats), lens i32 [n][L],
+ * signals f32 [n][L][S] (centred zero padding; bases longer than S keep S samples in time order chosen by a
+ * counter-based sampler keyed by (seed, read_uid[read], base index) -- the reference draws them from the
+ * unseeded process-global random.sample, :247-249). */
+int32_t dsp_extract_gather(void* stream, const dsp_read_batch* b, const double* shift, const double* scale,
+                           const double* base_mean, const double* base_std, const int32_t* base_len,
+                           const int64_t* base_lo, int64_t n_sites, const int32_t* site_read, const int32_t* site_loc,
+                           int32_t seq_len, int32_t signal_len, int32_t round_stats, uint64_t seed,
+                           const uint64_t* read_uid, uint8_t* kmer, float* means, float* stds, int32_t* lens,
+                           float* signals);
+/* HOST side of the same stage: motif sites of every read (get_refloc_of_methysite_in_motif,
+ * utils/process_utils.py:97-112), the +/- strand coordinates and window bounds of _extract_features
+ * (:346-358) and the per-read region bounds [rg_lo, rg_hi) (NULL = no region).  All pointers are HOST pointers.
+ * motifs = n_motifs strings of motif_len bases back to back.  Writes site_read / site_loc and the sites'
+ * sampleinfo strings (chrom \t pos \t strand \t pos_in_strand \t readname \t read_strand) into `info` with the
+ * addressing arrays of dsp_parse_feature_rows.  Returns the number of sites; with site_read == NULL only counts
+ * (and stores the info bytes needed in *info_bytes).  DSP_ENOMEM when max_sites / info_cap are too small,
+ * DSP_EPARSE for a base outside the alphabet inside a window (the reference's KeyError). */
+int64_t dsp_extract_sites(int64_t n_reads, const uint8_t* ev_base, const int64_t* ev_off, const char* const* chrom,
+                          const char* const* readname, const char* read_strand, const char* align_strand,
+                          const int64_t* chrom_start, const int64_t* chrom_len, const int64_t* rg_lo,
+                          const int64_t* rg_hi, const char* motifs, int32_t n_motifs, int32_t motif_len,
+                          int32_t methyloc, int32_t seq_len, int64_t max_sites, int32_t* site_read, int32_t* site_loc,
+                          char* info, size_t info_cap, size_t* info_bytes, uint64_t* row_off, uint32_t* info_len,
+                          uint32_t* read_off, uint32_t* read_len);
+
 /* ---- per-site modification frequency (the reference's `call_freq`) ----------------
  *
  * dsp_freq replaces calculate_mods_frequency + SiteStats/ModRecord (call_mods_freq.py:29-74,

@@ -1,0 +1,60 @@
+"""CPU: the host half of the extraction stage (motif sites, strand coordinates, region / positions filters,
+sampleinfo strings: csrc/dsp_sites.cpp + extract_features.FeatureExtractor) against the site lists of fixture F6,
+captured from the reference's _extract_features."""
+import numpy as np
+import pytest
+
+from deepsignal_plant_amd import extract_features as ef
+from deepsignal_plant_amd.utils import process_utils as pu
+from tests.test_extract_oracle import CASES, case_inputs
+
+
+@pytest.mark.parametrize("c", CASES, ids=[c["name"] for c in CASES])
+def test_site_lists_match_reference(c):
+    rs, motif_seqs, chrom2len, region, positions, g = case_inputs(c)
+    fx = ef.FeatureExtractor(motifs=c["motifs"], mod_loc=c["mod_loc"], seq_len=c["k"], signal_len=c["s"],
+                             normalize_method=c["method"], chrom2len=chrom2len, positions=positions, region=region)
+    assert fx.motif_seqs == motif_seqs
+    keep, lo, hi = fx._select_reads(rs)
+    ev_off = np.concatenate([[0], np.cumsum([r.ev_base.shape[0] for r in keep])]).astype(np.int64)
+    ev_base = np.concatenate([r.ev_base for r in keep])
+    site_read, site_loc, info, row_off, info_len, read_off, read_len = fx._sites(keep, ev_base, ev_off, lo, hi)
+    got = [bytes(info[int(o):int(o) + int(n)]).decode() for o, n in zip(row_off, info_len)]
+    assert got == g("info").tolist()
+    nb = (c["k"] - 1) // 2
+    kmers = [keep[r].seq[l - nb:l + nb + 1] for r, l in zip(site_read, site_loc)]
+    assert kmers == g("kmer").tolist()
+    names = [bytes(info[int(o) + int(a):int(o) + int(a) + int(n)]).decode() for o, a, n in zip(row_off, read_off, read_len)]
+    assert names == [s.split("\t")[4] for s in got]
+
+
+def test_motif_expansion_region_parsing_and_contig_lengths(tmp_path):
+    assert pu.get_motif_seqs("CG") == ["CG"]
+    assert pu.get_motif_seqs("chg, CHH") == ["CAG", "CCG", "CTG", "CAA", "CAC", "CAT", "CCA", "CCC", "CCT", "CTA", "CTC", "CTT"]
+    assert pu.get_motif_seqs("N") == list("ACGT")
+    with pytest.raises(KeyError):
+        pu.get_motif_seqs("CX")
+    assert pu.parse_region_str(None) == (None, None, None)
+    assert pu.parse_region_str("chr1") == ("chr1", None, None)
+    assert pu.parse_region_str("chr1:100") == ("chr1", 100, None)
+    assert pu.parse_region_str("chr1:100-250") == ("chr1", 100, 250)
+    with pytest.raises(ValueError):
+        pu.parse_region_str("chr1:a-b")
+    fa = tmp_path / "ref.fa"
+    fa.write_text(">chr1 something\nACGT\nAC\n>chr2\n\nGGGTT\n")
+    assert pu.get_contig2len(str(fa)) == {"chr1": 6, "chr2": 5}
+    with pytest.raises(ValueError):
+        ef.FeatureExtractor(seq_len=12)
+    with pytest.raises(ValueError):
+        ef.FeatureExtractor(motifs="CG,CHG")
+
+
+def test_unknown_base_in_a_window_is_rejected():
+    from deepsignal_plant_amd import reads as R
+    rd = R.synth_reads(1, seed=3, mean_bases=120)[0]
+    fx = ef.FeatureExtractor()
+    loc = rd.seq.index("CG", 20)
+    rd.ev_base[loc + 2] = ord("X")
+    ev_off = np.array([0, rd.ev_base.shape[0]], np.int64)
+    with pytest.raises(ValueError, match="not in the alphabet"):
+        fx._sites([rd], rd.ev_base, ev_off, np.zeros(1, np.int64), np.zeros(1, np.int64))
