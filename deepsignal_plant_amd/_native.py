@@ -127,7 +127,7 @@ def lib():
                                      ctypes.c_char_p, ctypes.c_char_p] + [ctypes.c_void_p] * 4 +
                                     [ctypes.c_char_p] + [ctypes.c_int32] * 4 + [ctypes.c_int64, ctypes.c_void_p,
                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)] +
-                                    [ctypes.c_void_p] * 4)
+                                    [ctypes.c_void_p] * 4 + [ctypes.c_int32])
     _lib = L
     return L
 

@@ -113,6 +113,76 @@ __device__ double np_sum_thread(const F& f, int64_t lo, int64_t n) {
     return total;
 }
 
+// The same sums by a group of 8 adjacent lanes (lane l8 owns accumulator r[l8] of numpy's 8-way unrolled loop);
+// all 8 lanes follow the same control flow and end up with the same value.  IEEE addition is commutative, so
+// the xor-butterfly reproduces ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) on every lane.
+template <class F>
+__device__ double pw_block8(const F& f, int64_t lo, int n, int l8) {  // n <= 128
+    if (n < 8) {
+        double r = 0.0;
+        for (int i = 0; i < n; i++) r += f(lo + i);
+        return r;
+    }
+    double r = f(lo + l8);
+    const int lim = n - (n % 8);
+    for (int i = 8; i < lim; i += 8) r += f(lo + i + l8);
+    r = r + __shfl_xor(r, 1);
+    r = r + __shfl_xor(r, 2);
+    r = r + __shfl_xor(r, 4);
+    for (int i = lim; i < n; i++) r += f(lo + i);
+    return r;
+}
+
+template <class F>
+__device__ double pw_chunk8(const F& f, int64_t lo, int n, int l8) {  // n <= 8192
+    if (n <= 128) return pw_block8(f, lo, n, l8);
+    int s_lo[16], s_n[16], s_phase[16];
+    double s_left[16];
+    int sp = 0;
+    s_lo[0] = 0; s_n[0] = n; s_phase[0] = 0;
+    double ret = 0.0;
+    bool have = false;
+    while (true) {
+        if (!have) {
+            if (s_n[sp] <= 128) {
+                ret = pw_block8(f, lo + s_lo[sp], s_n[sp], l8);
+                have = true;
+                sp--;
+            } else {
+                int n2 = s_n[sp] / 2;
+                n2 -= n2 % 8;
+                s_phase[sp] = 1;
+                s_lo[sp + 1] = s_lo[sp]; s_n[sp + 1] = n2; s_phase[sp + 1] = 0;
+                sp++;
+            }
+        } else {
+            if (sp < 0) return ret;
+            if (s_phase[sp] == 1) {
+                int n2 = s_n[sp] / 2;
+                n2 -= n2 % 8;
+                s_left[sp] = ret;
+                s_phase[sp] = 2;
+                s_lo[sp + 1] = s_lo[sp] + n2; s_n[sp + 1] = s_n[sp] - n2; s_phase[sp + 1] = 0;
+                sp++;
+                have = false;
+            } else {
+                ret = s_left[sp] + ret;
+                sp--;
+            }
+        }
+    }
+}
+
+template <class F>
+__device__ double np_sum8(const F& f, int64_t lo, int64_t n, int l8) {
+    double total = 0.0;
+    for (int64_t c = 0; c < n; c += kChunk) {
+        const int m = (int)((n - c) < kChunk ? (n - c) : kChunk);
+        total = total + pw_chunk8(f, lo + c, m, l8);
+    }
+    return total;
+}
+
 // np.add.reduce of f(0 .. n) by a whole workgroup: one chunk per thread, chunk sums accumulated in order
 template <class F>
 __device__ double np_sum_block(const F& f, int64_t n, double* lds /*[blockDim.x]*/) {
@@ -145,43 +215,48 @@ __device__ __forceinline__ double ord_value(uint64_t k) {
 
 struct SelectLds {
     uint32_t hist[256];
-    uint32_t sel;
-    int64_t k;
+    uint32_t sel[2];
+    int64_t k[2];
 };
 
-// k-th smallest (0-based) of key(0..n) as a double; all threads of the workgroup take part and get the result
+// One radix pass over key(0..n) restricted to the candidates whose bits above `shift + 8` equal `prefix`:
+// fills s->hist with the histogram of the next byte.  All threads of the workgroup take part.
 template <class K>
-__device__ double select_kth(const K& key, int64_t n, int64_t k, SelectLds* s) {
-    uint64_t prefix = 0;
+__device__ void select_pass(const K& key, int64_t n, uint64_t prefix, int shift, int top_shift, SelectLds* s) {
     const int lane = threadIdx.x & 63;
-    for (int pass = 0; pass < 8; pass++) {
-        const int shift = 56 - 8 * pass;
-        const uint64_t mask = pass == 0 ? 0ull : (~0ull << (shift + 8));
-        __syncthreads();
-        for (int i = threadIdx.x; i < 256; i += blockDim.x) s->hist[i] = 0;
-        __syncthreads();
-        const int64_t nround = (n + blockDim.x - 1) / blockDim.x * blockDim.x;  // whole waves stay converged
-        for (int64_t i = threadIdx.x; i < nround; i += blockDim.x) {
-            bool match = false;
-            uint32_t d = 0;
-            if (i < n) {
-                const uint64_t u = ord_bits(key(i));
-                match = (u & mask) == prefix;
-                d = (uint32_t)(u >> shift) & 255u;
-            }
-            // samples of one read share their high bytes: count a unanimous wave with one atomic
-            const uint64_t m = __ballot(match);
-            if (m == 0) continue;
-            const int first = __ffsll((long long)m) - 1;
-            const uint32_t d0 = (uint32_t)__shfl((int)d, first);
-            const uint64_t same = __ballot(match && d == d0);
-            if (same == m) {
-                if (lane == first) atomicAdd(&s->hist[d0], (uint32_t)__popcll(m));
-            } else if (match) {
-                atomicAdd(&s->hist[d], 1u);
-            }
+    const uint64_t mask = shift == top_shift ? 0ull : (~0ull << (shift + 8));
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s->hist[i] = 0;
+    __syncthreads();
+    const int64_t nround = (n + blockDim.x - 1) / blockDim.x * blockDim.x;  // whole waves stay converged
+    for (int64_t i = threadIdx.x; i < nround; i += blockDim.x) {
+        bool match = false;
+        uint32_t d = 0;
+        if (i < n) {
+            const uint64_t u = key(i);
+            match = (u & mask) == prefix;
+            d = (uint32_t)(u >> shift) & 255u;
         }
-        __syncthreads();
+        // samples of one read share their high bytes: count a unanimous wave with one atomic
+        const uint64_t m = __ballot(match);
+        if (m == 0) continue;
+        const int first = __ffsll((long long)m) - 1;
+        const uint32_t d0 = (uint32_t)__shfl((int)d, first);
+        const uint64_t same = __ballot(match && d == d0);
+        if (same == m) {
+            if (lane == first) atomicAdd(&s->hist[d0], (uint32_t)__popcll(m));
+        } else if (match) {
+            atomicAdd(&s->hist[d], 1u);
+        }
+    }
+    __syncthreads();
+}
+
+// k-th smallest key (0-based) among the candidates of `prefix`, continuing at byte `shift`
+template <class K>
+__device__ uint64_t select_from(const K& key, int64_t n, uint64_t prefix, int64_t k, int shift, int top_shift, SelectLds* s) {
+    for (; shift >= 0; shift -= 8) {
+        select_pass(key, n, prefix, shift, top_shift, s);
         if (threadIdx.x == 0) {
             int64_t cum = 0;
             uint32_t sel = 255;
@@ -190,22 +265,58 @@ __device__ double select_kth(const K& key, int64_t n, int64_t k, SelectLds* s) {
                 if (k < cum + h) { sel = b; break; }
                 cum += h;
             }
-            s->sel = sel;
-            s->k = k - cum;
+            s->sel[0] = sel;
+            s->k[0] = k - cum;
         }
         __syncthreads();
-        prefix |= (uint64_t)s->sel << shift;
-        k = s->k;
+        prefix |= (uint64_t)s->sel[0] << shift;
+        k = s->k[0];
     }
-    return ord_value(prefix);
+    return prefix;
 }
 
+// the k-th and (k+1)-th smallest keys: one walk while both fall into the same bucket, two after they part
 template <class K>
-__device__ double np_median(const K& key, int64_t n, SelectLds* s) {
-    if (n & 1) return select_kth(key, n, n / 2, s);
-    const double a = select_kth(key, n, n / 2 - 1, s);
-    const double b = select_kth(key, n, n / 2, s);
-    return ((0.0 + a) + b) / 2.0;  // np.mean of the two middle values
+__device__ void select_pair(const K& key, int64_t n, int64_t k, int top_shift, SelectLds* s, uint64_t* lo, uint64_t* hi) {
+    uint64_t prefix = 0;
+    for (int shift = top_shift; shift >= 0; shift -= 8) {
+        select_pass(key, n, prefix, shift, top_shift, s);
+        if (threadIdx.x == 0) {
+            int64_t cum = 0;
+            int found = 0;
+            for (uint32_t b = 0; b < 256 && found < 2; b++) {
+                const int64_t h = s->hist[b];
+                while (found < 2 && k + found < cum + h) {
+                    s->sel[found] = b;
+                    s->k[found] = k + found - cum;
+                    found++;
+                }
+                cum += h;
+            }
+        }
+        __syncthreads();
+        const uint32_t b0 = s->sel[0], b1 = s->sel[1];
+        const int64_t k0 = s->k[0], k1 = s->k[1];
+        if (b0 != b1) {
+            const uint64_t p0 = prefix | ((uint64_t)b0 << shift), p1 = prefix | ((uint64_t)b1 << shift);
+            *lo = select_from(key, n, p0, k0, shift - 8, top_shift, s);
+            *hi = select_from(key, n, p1, k1, shift - 8, top_shift, s);
+            return;
+        }
+        prefix |= (uint64_t)b0 << shift;
+        k = k0;
+    }
+    *lo = *hi = prefix;  // equal keys
+}
+
+// np.median of value(key) over n >= 1 elements; `bits` = 64 (doubles through ord_bits) or 16 (raw DAQ codes)
+template <class K, class V>
+__device__ double np_median(const K& key, const V& value, int64_t n, int top_shift, SelectLds* s) {
+    if (n & 1) return value(select_from(key, n, 0, n / 2, top_shift, top_shift, s));
+    if (n < 2) return value(select_from(key, n, 0, 0, top_shift, top_shift, s));
+    uint64_t lo, hi;
+    select_pair(key, n, n / 2 - 1, top_shift, s, &lo, &hi);
+    return ((0.0 + value(lo)) + value(hi)) / 2.0;  // np.mean of the two middle values
 }
 
 // ---- kernel 1: per-read shift / scale (extract_features.py:179-185) --------------------------------------------
@@ -220,10 +331,20 @@ __global__ __launch_bounds__(256) void dsp_ext_normalize_kernel(dsp_read_batch b
     if (n <= 0) {
         shift = 0.0; scale = 0.0;
     } else if (method == 0) {  // mad
-        auto kx = [&](int64_t i) { return rd.pa(i); };
-        shift = np_median(kx, n, &sel);
-        auto ke = [&](int64_t i) { return fabs(rd.pa(i) - shift) / kMadC; };
-        scale = np_median(ke, n, &sel);
+        if (rd.scaling > 0.0) {
+            // pA is a non-decreasing function of the DAQ code: take the order statistics on the 16-bit codes
+            auto kraw = [&](int64_t i) { return (uint64_t)(uint16_t)(rd.raw[i] ^ (int16_t)0x8000); };
+            auto vraw = [&](uint64_t u) { return rd.scaling * ((double)(int16_t)((uint16_t)u ^ 0x8000u) + rd.offset); };
+            shift = np_median(kraw, vraw, n, 8, &sel);
+        } else {
+            auto kx = [&](int64_t i) { return ord_bits(rd.pa(i)); };
+            auto vx = [&](uint64_t u) { return ord_value(u); };
+            shift = np_median(kx, vx, n, 56, &sel);
+        }
+        // median(|x - med| / c): x / c is monotone in x, so select on |x - med| and divide the selected values
+        auto ke = [&](int64_t i) { return ord_bits(fabs(rd.pa(i) - shift)); };
+        auto ve = [&](uint64_t u) { return ord_value(u) / kMadC; };
+        scale = np_median(ke, ve, n, 56, &sel);
     } else {  // zscore: np.mean, np.std
         auto fx = [&](int64_t i) { return rd.pa(i); };
         shift = np_sum_block(fx, n, sums) / (double)n;
@@ -249,7 +370,10 @@ __device__ __forceinline__ int64_t read_of_event(const int64_t* ev_off, int64_t 
 __global__ __launch_bounds__(256) void dsp_ext_base_stats_kernel(dsp_read_batch b, const double* shift, const double* scale,
                                                                  double* base_mean, double* base_std, int32_t* base_len,
                                                                  int64_t* base_lo) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // 8 adjacent lanes per base (32 bases per 256-thread workgroup)
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t e = t >> 3;
+    const int l8 = (int)(t & 7);
     if (e >= b.n_events) return;
     const int64_t r = read_of_event(b.ev_off, b.n_reads, e);
     const int64_t n_raw = b.raw_off[r + 1] - b.raw_off[r];
@@ -259,13 +383,15 @@ __global__ __launch_bounds__(256) void dsp_ext_base_stats_kernel(dsp_read_batch 
     hi = hi < lo ? lo : (hi > n_raw ? n_raw : hi);
     const int64_t n = hi - lo;
     NormView nv = {{b.raw + b.raw_off[r], n_raw, b.scaling[r], b.offset[r]}, shift[r], scale[r]};
-    const double mean = np_sum_thread(nv, lo, n) / (double)n;  // n == 0 -> nan, like np.mean([])
+    const double mean = np_sum8(nv, lo, n, l8) / (double)n;  // n == 0 -> nan, like np.mean([])
     auto dev2 = [&](int64_t i) { const double d = nv(i) - mean; return d * d; };
-    const double var = np_sum_thread(dev2, lo, n) / (double)n;
-    base_mean[e] = mean;
-    base_std[e] = sqrt(var);
-    base_len[e] = (int32_t)n;
-    base_lo[e] = lo;
+    const double var = np_sum8(dev2, lo, n, l8) / (double)n;
+    if (l8 == 0) {
+        base_mean[e] = mean;
+        base_std[e] = sqrt(var);
+        base_len[e] = (int32_t)n;
+        base_lo[e] = lo;
+    }
 }
 
 // ---- kernel 3: k-mer window gather (extract_features.py:360-368, :232-251) -------------------------------------
@@ -330,13 +456,20 @@ __global__ __launch_bounds__(256) void dsp_ext_gather_kernel(GatherArgs a) {
         for (int i = 0; i < left; i++) out[i] = 0.f;
         for (int i = 0; i < n; i++) out[left + i] = (float)nv(lo + i);
         for (int i = left + n; i < S; i++) out[i] = 0.f;
-    } else {  // S of n samples in time order: selection sampling over a counter-based stream
+    } else {  // S of n samples in time order: Floyd's subset sampling over a counter-based stream, O(S^2)
         const uint64_t h = mix64((a.seed ^ (a.read_uid[r] * 0x9E3779B97F4A7C15ull)) + (uint64_t)bi * 0xD1B54A32D192ED03ull);
-        int taken = 0;
-        for (int i = 0; i < n && taken < S; i++) {
-            const uint64_t rnd = mix64(h + (uint64_t)i) >> 32;
-            if (((rnd * (uint64_t)(n - i)) >> 32) < (uint64_t)(S - taken)) out[taken++] = (float)nv(lo + i);
+        int* sel = reinterpret_cast<int*>(out);  // the sorted sample indices live in the output slots first
+        for (int q = 0; q < S; q++) {
+            const int jj = n - S + q;
+            const uint64_t rnd = mix64(h + (uint64_t)q) >> 32;
+            int v = (int)((rnd * (uint64_t)(jj + 1)) >> 32);  // uniform on [0, jj]
+            for (int k = 0; k < q; k++)
+                if (sel[k] == v) { v = jj; break; }
+            int k = q;
+            for (; k > 0 && sel[k - 1] > v; k--) sel[k] = sel[k - 1];
+            sel[k] = v;
         }
+        for (int k = 0; k < S; k++) out[k] = (float)nv(lo + sel[k]);
     }
 }
 
@@ -375,7 +508,7 @@ int32_t dsp_extract_base_stats(void* stream, const dsp_read_batch* b, const doub
     if (!b || !shift || !scale || !base_mean || !base_std || !base_len || !base_lo)
         return ext_fail(DSP_EINVAL, "dsp_extract_base_stats: bad arguments");
     if (b->n_events == 0) return DSP_OK;
-    const unsigned grid = (unsigned)((b->n_events + 255) / 256);
+    const unsigned grid = (unsigned)((b->n_events * 8 + 255) / 256);
     hipLaunchKernelGGL(dsp_ext_base_stats_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *b, shift, scale,
                        base_mean, base_std, base_len, base_lo);
     return ext_check_launch("dsp_extract_base_stats");

@@ -56,7 +56,7 @@ def _read_position_file(position_file):
 
 class FeatureExtractor(object):
     def __init__(self, motifs="CG", mod_loc=0, seq_len=13, signal_len=16, normalize_method="mad", chrom2len=None,
-                 positions=None, region=None, methy_label=1, is_dna=True, device=0, seed=0, round_stats=False):
+                 positions=None, region=None, methy_label=1, is_dna=True, device=0, seed=0, round_stats=False, nthreads=8):
         if seq_len % 2 == 0:
             raise ValueError("kmer_len must be odd")  # extract_features.py:296-297
         if normalize_method not in ("mad", "zscore"):
@@ -76,6 +76,8 @@ class FeatureExtractor(object):
         self.regioninfo = parse_region_str(region) if (region is None or isinstance(region, str)) else tuple(region)
         self.methy_label, self.seed, self.round_stats = int(methy_label), int(seed), bool(round_stats)
         self._motif_blob = "".join(self.motif_seqs).encode()
+        self.nthreads = max(1, int(nthreads))
+        self._stage = {}  # pinned staging buffers, grown on demand
         nat.lib()
 
     # -- host: which reads / region bounds (extract_features.py:311-314, :337-341)
@@ -110,13 +112,13 @@ class FeatureExtractor(object):
                 p(rg_lo) if use_rg else None, p(rg_hi) if use_rg else None, self._motif_blob, len(self.motif_seqs),
                 self.motif_len, self.mod_loc, self.L]
         need = ctypes.c_size_t()
-        cnt = nat.check(int(L.dsp_extract_sites(*args, 0, None, None, None, 0, ctypes.byref(need), None, None, None, None)))
+        cnt = nat.check(int(L.dsp_extract_sites(*args, 0, None, None, None, 0, ctypes.byref(need), None, None, None, None, self.nthreads)))
         site_read, site_loc = np.empty(cnt, np.int32), np.empty(cnt, np.int32)
         info = np.empty(max(need.value, 1), np.uint8)
         row_off, info_len = np.empty(cnt, np.uint64), np.empty(cnt, np.uint32)
         read_off, read_len = np.empty(cnt, np.uint32), np.empty(cnt, np.uint32)
         got = nat.check(int(L.dsp_extract_sites(*args, cnt, p(site_read), p(site_loc), p(info), info.nbytes, None,
-                                                p(row_off), p(info_len), p(read_off), p(read_len))))
+                                                p(row_off), p(info_len), p(read_off), p(read_len), self.nthreads)))
         assert got == cnt
         if self.positions is not None and cnt:  # :356-357 (hash-set lookup on the host)
             keep = np.zeros(cnt, bool)
@@ -153,15 +155,29 @@ class FeatureExtractor(object):
         out.n = n
         dev = self.dev
         st = stream if stream is not None else torch.cuda.current_stream(dev)
+        if self._stage.get("_event") is not None:
+            self._stage["_event"].synchronize()  # the previous batch's uploads have left the staging buffers
         with torch.cuda.device(dev), torch.cuda.stream(st):
-            up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)
-            d_raw = up(cat([r.raw for r in reads], np.int16))
-            d_raw_off, d_ev_off = up(raw_off), up(ev_off)
-            d_scaling = up(np.array([r.scaling for r in reads], np.float64))
-            d_offset = up(np.array([r.offset for r in reads], np.float64))
-            d_ev_start = up(cat([r.ev_start for r in reads], np.int64))
-            d_ev_len = up(cat([r.ev_len for r in reads], np.int64))
-            d_ev_base = up(ev_base)
+            def up(name, parts, dt):
+                """concatenate host arrays into a pinned staging buffer and start the H2D copy"""
+                if isinstance(parts, np.ndarray):
+                    parts = [parts]
+                total = int(sum(p.shape[0] for p in parts))
+                buf = self._stage.get(name)
+                if buf is None or buf.shape[0] < total or buf.dtype != dt:
+                    buf = torch.empty(max(total + total // 2, 1024), dtype=dt, pin_memory=True)
+                    self._stage[name] = buf
+                view = buf[:total]
+                if total:
+                    np.concatenate(parts, out=view.numpy(), casting="same_kind")
+                return view.to(dev, non_blocking=True)
+            d_raw = up("raw", [r.raw for r in reads], torch.int16)
+            d_raw_off, d_ev_off = up("raw_off", raw_off, torch.int64), up("ev_off", ev_off, torch.int64)
+            d_scaling = up("scaling", np.array([r.scaling for r in reads], np.float64), torch.float64)
+            d_offset = up("offset", np.array([r.offset for r in reads], np.float64), torch.float64)
+            d_ev_start = up("ev_start", [r.ev_start for r in reads], torch.int64)
+            d_ev_len = up("ev_len", [r.ev_len for r in reads], torch.int64)
+            d_ev_base = up("ev_base", ev_base, torch.uint8)
             E = int(ev_off[-1])
             batch = ReadBatchC(R, int(raw_off[-1]), E, d_raw.data_ptr(), d_raw_off.data_ptr(), d_scaling.data_ptr(),
                                d_offset.data_ptr(), d_ev_start.data_ptr(), d_ev_len.data_ptr(), d_ev_base.data_ptr(),
@@ -185,8 +201,8 @@ class FeatureExtractor(object):
                 nat.check(L.dsp_extract_base_stats(sp, ctypes.byref(batch), ptr(shift), ptr(scale), ptr(base_mean),
                                                    ptr(base_std), ptr(base_len), ptr(base_lo)))
                 if n:
-                    d_site_read, d_site_loc = up(site_read), up(site_loc)
-                    d_uid = up(np.array([uid_of[id(r)] for r in reads], np.uint64).view(np.int64))
+                    d_site_read, d_site_loc = up("site_read", site_read, torch.int32), up("site_loc", site_loc, torch.int32)
+                    d_uid = up("uid", np.array([uid_of[id(r)] for r in reads], np.uint64).view(np.int64), torch.int64)
                     nat.check(L.dsp_extract_gather(sp, ctypes.byref(batch), ptr(shift), ptr(scale), ptr(base_mean),
                                                    ptr(base_std), ptr(base_len), ptr(base_lo), n, ptr(d_site_read),
                                                    ptr(d_site_loc), self.L, self.S, int(self.round_stats),
@@ -197,4 +213,7 @@ class FeatureExtractor(object):
                     for t in (d_raw, d_raw_off, d_ev_off, d_scaling, d_offset, d_ev_start, d_ev_len, d_ev_base,
                               base_mean, base_std, base_len, base_lo, d_site_read, d_site_loc, d_uid):
                         t.record_stream(st)
+            ev = torch.cuda.Event()
+            ev.record(st)
+            self._stage["_event"] = ev
         return out

@@ -235,7 +235,7 @@ int32_t dsp_extract_gather(void* stream, const dsp_read_batch* b, const double* 
  * motifs = n_motifs strings of motif_len bases back to back.  Writes site_read / site_loc and the sites'
  * sampleinfo strings (chrom \t pos \t strand \t pos_in_strand \t readname \t read_strand) into `info` with the
  * addressing arrays of dsp_parse_feature_rows.  Returns the number of sites; with site_read == NULL only counts
- * (and stores the info bytes needed in *info_bytes).  DSP_ENOMEM when max_sites / info_cap are too small,
+ * (and stores the info bytes needed in *info_bytes).  Reads are processed by `nthreads` host threads.  DSP_ENOMEM when max_sites / info_cap are too small,
  * DSP_EPARSE for a base outside the alphabet inside a window (the reference's KeyError). */
 int64_t dsp_extract_sites(int64_t n_reads, const uint8_t* ev_base, const int64_t* ev_off, const char* const* chrom,
                           const char* const* readname, const char* read_strand, const char* align_strand,
@@ -243,7 +243,7 @@ int64_t dsp_extract_sites(int64_t n_reads, const uint8_t* ev_base, const int64_t
                           const int64_t* rg_hi, const char* motifs, int32_t n_motifs, int32_t motif_len,
                           int32_t methyloc, int32_t seq_len, int64_t max_sites, int32_t* site_read, int32_t* site_loc,
                           char* info, size_t info_cap, size_t* info_bytes, uint64_t* row_off, uint32_t* info_len,
-                          uint32_t* read_off, uint32_t* read_len);
+                          uint32_t* read_off, uint32_t* read_len, int32_t nthreads);
 
 /* ---- per-site modification frequency (the reference's `call_freq`) ----------------
  *

@@ -18,7 +18,7 @@ function is restated from its published definition and is unpinned by the refere
 Sampling of long bases: the reference calls the process-global, unseeded `random.sample`, i.e. it is not
 reproducible against itself.  sampler="python" uses the same `random.sample` calls in the same order (pins the
 restatement against a reference run made under random.seed); sampler="hash" is the product's deterministic
-counter-based sampler (selection sampling over a 64-bit mix of (seed, read uid, base index, step))."""
+counter-based sampler (Floyd's subset sampling over a 64-bit mix of (seed, read uid, base index, step))."""
 from __future__ import annotations
 
 import random
@@ -68,17 +68,17 @@ def mix64(x):
 
 
 def hash_sample_sorted(n, k, seed, read_uid, base_index):
-    """k of range(n), ascending: Knuth's selection sampling (Algorithm S) driven by a counter-based 32-bit
-    stream -- element t is taken when floor(r_t * (n - t) / 2^32) < k - taken."""
+    """k of range(n), ascending, uniform over all subsets: Floyd's algorithm driven by a counter-based 32-bit
+    stream -- step q draws v uniformly from [0, n-k+q] as floor(r_q * (n-k+q+1) / 2^32) and takes n-k+q instead
+    when v is already in the sample."""
     h = mix64((seed ^ ((read_uid * 0x9E3779B97F4A7C15) & M64)) + ((base_index * 0xD1B54A32D192ED03) & M64))
     out = []
-    for t in range(n):
-        r = mix64(h + t) >> 32
-        if ((r * (n - t)) >> 32) < k - len(out):
-            out.append(t)
-            if len(out) == k:
-                break
-    return out
+    for q in range(k):
+        jj = n - k + q
+        r = mix64(h + q) >> 32
+        v = (r * (jj + 1)) >> 32
+        out.append(jj if v in out else v)
+    return sorted(out)
 
 
 def get_signals_rect(signals_list, signals_len=16, sampler="python", seed=0, read_uid=0, first_base=0):
