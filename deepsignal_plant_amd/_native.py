@@ -118,7 +118,7 @@ def lib():
     L.dsp_extract_normalize.restype = ctypes.c_int32
     L.dsp_extract_normalize.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
     L.dsp_extract_base_stats.restype = ctypes.c_int32
-    L.dsp_extract_base_stats.argtypes = [ctypes.c_void_p] * 8
+    L.dsp_extract_base_stats.argtypes = [ctypes.c_void_p] * 9
     L.dsp_extract_gather.restype = ctypes.c_int32
     L.dsp_extract_gather.argtypes = ([ctypes.c_void_p] * 8 + [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p] +
                                      [ctypes.c_int32] * 3 + [ctypes.c_uint64] + [ctypes.c_void_p] * 6)

@@ -42,85 +42,15 @@ struct NormView {
 };
 
 // ---- numpy pairwise summation -------------------------------------------------------------------------------
-template <class F>
-__device__ double pw_block(const F& f, int64_t lo, int n) {  // n <= 128
-    if (n < 8) {
-        double r = 0.0;
-        for (int i = 0; i < n; i++) r += f(lo + i);
-        return r;
-    }
-    double r0 = f(lo), r1 = f(lo + 1), r2 = f(lo + 2), r3 = f(lo + 3);
-    double r4 = f(lo + 4), r5 = f(lo + 5), r6 = f(lo + 6), r7 = f(lo + 7);
-    int i = 8;
-    const int lim = n - (n % 8);
-    for (; i < lim; i += 8) {
-        r0 += f(lo + i);     r1 += f(lo + i + 1); r2 += f(lo + i + 2); r3 += f(lo + i + 3);
-        r4 += f(lo + i + 4); r5 += f(lo + i + 5); r6 += f(lo + i + 6); r7 += f(lo + i + 7);
-    }
-    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-    for (; i < n; i++) res += f(lo + i);
-    return res;
-}
-
-template <class F>
-__device__ double pw_chunk(const F& f, int64_t lo, int n) {  // n <= 8192; explicit-stack post-order walk
-    if (n <= 128) return pw_block(f, lo, n);
-    int s_lo[16], s_n[16], s_phase[16];
-    double s_left[16];
-    int sp = 0;
-    s_lo[0] = 0; s_n[0] = n; s_phase[0] = 0;
-    double ret = 0.0;
-    bool have = false;
-    while (true) {
-        if (!have) {
-            if (s_n[sp] <= 128) {
-                ret = pw_block(f, lo + s_lo[sp], s_n[sp]);
-                have = true;
-                sp--;
-            } else {
-                int n2 = s_n[sp] / 2;
-                n2 -= n2 % 8;
-                s_phase[sp] = 1;
-                s_lo[sp + 1] = s_lo[sp]; s_n[sp + 1] = n2; s_phase[sp + 1] = 0;
-                sp++;
-            }
-        } else {
-            if (sp < 0) return ret;
-            if (s_phase[sp] == 1) {
-                int n2 = s_n[sp] / 2;
-                n2 -= n2 % 8;
-                s_left[sp] = ret;
-                s_phase[sp] = 2;
-                s_lo[sp + 1] = s_lo[sp] + n2; s_n[sp + 1] = s_n[sp] - n2; s_phase[sp + 1] = 0;
-                sp++;
-                have = false;
-            } else {
-                ret = s_left[sp] + ret;
-                sp--;
-            }
-        }
-    }
-}
-
-// np.add.reduce of f(lo .. lo+n) by ONE thread
-template <class F>
-__device__ double np_sum_thread(const F& f, int64_t lo, int64_t n) {
-    double total = 0.0;
-    for (int64_t c = 0; c < n; c += kChunk) {
-        const int m = (int)((n - c) < kChunk ? (n - c) : kChunk);
-        total = total + pw_chunk(f, lo + c, m);
-    }
-    return total;
-}
-
 // The same sums by a group of 8 adjacent lanes (lane l8 owns accumulator r[l8] of numpy's 8-way unrolled loop);
 // all 8 lanes follow the same control flow and end up with the same value.  IEEE addition is commutative, so
 // the xor-butterfly reproduces ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) on every lane.
 template <class F>
 __device__ double pw_block8(const F& f, int64_t lo, int n, int l8) {  // n <= 128
-    if (n < 8) {
+    if (n < 8) {  // r = 0; r += a[0]; r += a[1]; ...  -- one evaluation per lane, the adds replayed on every lane
+        const double v = l8 < n ? f(lo + l8) : 0.0;
         double r = 0.0;
-        for (int i = 0; i < n; i++) r += f(lo + i);
+        for (int i = 0; i < n; i++) r += __shfl(v, i, 8);
         return r;
     }
     double r = f(lo + l8);
@@ -129,44 +59,53 @@ __device__ double pw_block8(const F& f, int64_t lo, int n, int l8) {  // n <= 12
     r = r + __shfl_xor(r, 1);
     r = r + __shfl_xor(r, 2);
     r = r + __shfl_xor(r, 4);
-    for (int i = lim; i < n; i++) r += f(lo + i);
+    const int tail = n - lim;
+    const double v = l8 < tail ? f(lo + lim + l8) : 0.0;
+    for (int i = 0; i < tail; i++) r += __shfl(v, i, 8);
     return r;
 }
 
+// walk stack of one 8-lane group (n <= 8192 -> at most 7 levels); lives in LDS to keep the kernels' VGPR count low
+struct PwStack {
+    int lo[8], n[8], phase[8];
+    double left[8];
+};
+
 template <class F>
-__device__ double pw_chunk8(const F& f, int64_t lo, int n, int l8) {  // n <= 8192
+__device__ double pw_chunk8(const F& f, int64_t lo, int n, int l8, PwStack* st) {  // n <= 8192
     if (n <= 128) return pw_block8(f, lo, n, l8);
-    int s_lo[16], s_n[16], s_phase[16];
-    double s_left[16];
+    // post-order walk of numpy's recursion; all 8 lanes execute it identically (same-value LDS writes are benign)
     int sp = 0;
-    s_lo[0] = 0; s_n[0] = n; s_phase[0] = 0;
+    st->lo[0] = 0; st->n[0] = n; st->phase[0] = 0;
     double ret = 0.0;
     bool have = false;
     while (true) {
         if (!have) {
-            if (s_n[sp] <= 128) {
-                ret = pw_block8(f, lo + s_lo[sp], s_n[sp], l8);
+            const int cn = st->n[sp], clo = st->lo[sp];
+            if (cn <= 128) {
+                ret = pw_block8(f, lo + clo, cn, l8);
                 have = true;
                 sp--;
             } else {
-                int n2 = s_n[sp] / 2;
+                int n2 = cn / 2;
                 n2 -= n2 % 8;
-                s_phase[sp] = 1;
-                s_lo[sp + 1] = s_lo[sp]; s_n[sp + 1] = n2; s_phase[sp + 1] = 0;
+                st->phase[sp] = 1;
+                st->lo[sp + 1] = clo; st->n[sp + 1] = n2; st->phase[sp + 1] = 0;
                 sp++;
             }
         } else {
             if (sp < 0) return ret;
-            if (s_phase[sp] == 1) {
-                int n2 = s_n[sp] / 2;
+            const int cn = st->n[sp], clo = st->lo[sp];
+            if (st->phase[sp] == 1) {
+                int n2 = cn / 2;
                 n2 -= n2 % 8;
-                s_left[sp] = ret;
-                s_phase[sp] = 2;
-                s_lo[sp + 1] = s_lo[sp] + n2; s_n[sp + 1] = s_n[sp] - n2; s_phase[sp + 1] = 0;
+                st->left[sp] = ret;
+                st->phase[sp] = 2;
+                st->lo[sp + 1] = clo + n2; st->n[sp + 1] = cn - n2; st->phase[sp + 1] = 0;
                 sp++;
                 have = false;
             } else {
-                ret = s_left[sp] + ret;
+                ret = st->left[sp] + ret;
                 sp--;
             }
         }
@@ -174,29 +113,32 @@ __device__ double pw_chunk8(const F& f, int64_t lo, int n, int l8) {  // n <= 81
 }
 
 template <class F>
-__device__ double np_sum8(const F& f, int64_t lo, int64_t n, int l8) {
+__device__ double np_sum8(const F& f, int64_t lo, int64_t n, int l8, PwStack* st) {
     double total = 0.0;
     for (int64_t c = 0; c < n; c += kChunk) {
         const int m = (int)((n - c) < kChunk ? (n - c) : kChunk);
-        total = total + pw_chunk8(f, lo + c, m, l8);
+        total = total + pw_chunk8(f, lo + c, m, l8, st);
     }
     return total;
 }
 
-// np.add.reduce of f(0 .. n) by a whole workgroup: one chunk per thread, chunk sums accumulated in order
+// np.add.reduce of f(0 .. n) by a whole workgroup: one 8192-element chunk per group of 8 lanes, chunk sums
+// accumulated in order
 template <class F>
-__device__ double np_sum_block(const F& f, int64_t n, double* lds /*[blockDim.x]*/) {
+__device__ double np_sum_block(const F& f, int64_t n, double* lds /*[blockDim.x / 8]*/, PwStack* stacks) {
     double total = 0.0;
+    const int groups = blockDim.x >> 3, grp = threadIdx.x >> 3, l8 = threadIdx.x & 7;
     const int64_t nchunks = (n + kChunk - 1) / kChunk;
-    for (int64_t c0 = 0; c0 < nchunks; c0 += blockDim.x) {
-        const int64_t c = c0 + threadIdx.x;
+    for (int64_t c0 = 0; c0 < nchunks; c0 += groups) {
+        const int64_t c = c0 + grp;
         __syncthreads();
         if (c < nchunks) {
             const int64_t lo = c * kChunk;
-            lds[threadIdx.x] = pw_chunk(f, lo, (int)((n - lo) < kChunk ? (n - lo) : kChunk));
+            const double v = pw_chunk8(f, lo, (int)((n - lo) < kChunk ? (n - lo) : kChunk), l8, &stacks[grp]);
+            if (l8 == 0) lds[grp] = v;
         }
         __syncthreads();
-        const int m = (int)((nchunks - c0) < (int64_t)blockDim.x ? (nchunks - c0) : (int64_t)blockDim.x);
+        const int m = (int)((nchunks - c0) < (int64_t)groups ? (nchunks - c0) : (int64_t)groups);
         for (int i = 0; i < m; i++) total = total + lds[i];  // every thread: identical order, identical result
     }
     __syncthreads();
@@ -215,38 +157,94 @@ __device__ __forceinline__ double ord_value(uint64_t k) {
 
 struct SelectLds {
     uint32_t hist[256];
+    uint32_t wsum[4];
     uint32_t sel[2];
     int64_t k[2];
 };
 
-// One radix pass over key(0..n) restricted to the candidates whose bits above `shift + 8` equal `prefix`:
-// fills s->hist with the histogram of the next byte.  All threads of the workgroup take part.
+// After a pass: the bucket holding the k-th candidate (and the (k+1)-th when nk == 2) and its rank inside the
+// bucket, by a 256-wide prefix scan (waves 0..3).  Leaves the answer in s->sel / s->k for every thread.
+__device__ void select_pick(SelectLds* s, int64_t k, int nk) {
+    const int lane = threadIdx.x & 63;
+    uint32_t h = 0, x = 0;
+    if (threadIdx.x < 256) {
+        h = s->hist[threadIdx.x];
+        x = h;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) s->wsum[threadIdx.x >> 6] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        uint32_t base = 0;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); w++) base += s->wsum[w];
+        const int64_t incl = (int64_t)base + x, excl = incl - h;
+        for (int q = 0; q < nk; q++)
+            if (excl <= k + q && k + q < incl) {
+                s->sel[q] = threadIdx.x;
+                s->k[q] = k + q - excl;
+            }
+    }
+    __syncthreads();
+}
+
+// histogram one candidate: samples of one read share their high bytes, so a unanimous wave costs one atomic
+__device__ __forceinline__ void select_count(bool match, uint32_t d, int lane, uint32_t* hist) {
+    const uint64_t m = __ballot(match);
+    if (m == 0) return;
+    const int first = __ffsll((long long)m) - 1;
+    const uint32_t d0 = (uint32_t)__shfl((int)d, first);
+    const uint64_t same = __ballot(match && d == d0);
+    if (same == m) {
+        if (lane == first) atomicAdd(&hist[d0], (uint32_t)__popcll(m));
+    } else if (match) {
+        atomicAdd(&hist[d], 1u);
+    }
+}
+
+// One radix pass over key(raw[0..n)) restricted to the candidates whose bits above `shift + 8` equal `prefix`:
+// fills s->hist with the histogram of the next byte.  All threads of the workgroup take part; the body of the
+// read is streamed as 16-byte vectors (8 samples per lane and load).
 template <class K>
-__device__ void select_pass(const K& key, int64_t n, uint64_t prefix, int shift, int top_shift, SelectLds* s) {
+__device__ void select_pass(const int16_t* raw, int64_t n, const K& key, uint64_t prefix, int shift, int top_shift,
+                            SelectLds* s) {
     const int lane = threadIdx.x & 63;
     const uint64_t mask = shift == top_shift ? 0ull : (~0ull << (shift + 8));
     __syncthreads();
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s->hist[i] = 0;
     __syncthreads();
-    const int64_t nround = (n + blockDim.x - 1) / blockDim.x * blockDim.x;  // whole waves stay converged
-    for (int64_t i = threadIdx.x; i < nround; i += blockDim.x) {
-        bool match = false;
-        uint32_t d = 0;
-        if (i < n) {
-            const uint64_t u = key(i);
-            match = (u & mask) == prefix;
-            d = (uint32_t)(u >> shift) & 255u;
+    int64_t head = (int64_t)((16 - ((uintptr_t)raw & 15)) & 15) >> 1;  // samples before the first 16 B boundary
+    if (head > n) head = n;
+    const int64_t nvec = (n - head) >> 3;
+    const int64_t tail0 = head + (nvec << 3);
+    {   // head + tail: fewer than 16 samples, one per thread
+        const int64_t t = threadIdx.x;
+        const int64_t i = t < head ? t : tail0 + (t - head);
+        if (threadIdx.x < 64) {  // wave 0, converged
+            bool match = false;
+            uint32_t d = 0;
+            if (t < head + (n - tail0)) {
+                const uint64_t u = key(raw[i]);
+                match = (u & mask) == prefix;
+                d = (uint32_t)(u >> shift) & 255u;
+            }
+            select_count(match, d, lane, s->hist);
         }
-        // samples of one read share their high bytes: count a unanimous wave with one atomic
-        const uint64_t m = __ballot(match);
-        if (m == 0) continue;
-        const int first = __ffsll((long long)m) - 1;
-        const uint32_t d0 = (uint32_t)__shfl((int)d, first);
-        const uint64_t same = __ballot(match && d == d0);
-        if (same == m) {
-            if (lane == first) atomicAdd(&s->hist[d0], (uint32_t)__popcll(m));
-        } else if (match) {
-            atomicAdd(&s->hist[d], 1u);
+    }
+    const int4* vec = reinterpret_cast<const int4*>(raw + head);
+    const int64_t nround = (nvec + blockDim.x - 1) / blockDim.x * blockDim.x;  // whole waves stay converged
+    for (int64_t g = threadIdx.x; g < nround; g += blockDim.x) {
+        const bool live = g < nvec;
+        int4 v = make_int4(0, 0, 0, 0);
+        if (live) v = vec[g];
+        const int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int16_t code = (int16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffff));
+            const uint64_t u = key(code);
+            select_count(live && (u & mask) == prefix, (uint32_t)(u >> shift) & 255u, lane, s->hist);
         }
     }
     __syncthreads();
@@ -254,21 +252,11 @@ __device__ void select_pass(const K& key, int64_t n, uint64_t prefix, int shift,
 
 // k-th smallest key (0-based) among the candidates of `prefix`, continuing at byte `shift`
 template <class K>
-__device__ uint64_t select_from(const K& key, int64_t n, uint64_t prefix, int64_t k, int shift, int top_shift, SelectLds* s) {
+__device__ uint64_t select_from(const int16_t* raw, int64_t n, const K& key, uint64_t prefix, int64_t k, int shift, int top_shift,
+                               SelectLds* s) {
     for (; shift >= 0; shift -= 8) {
-        select_pass(key, n, prefix, shift, top_shift, s);
-        if (threadIdx.x == 0) {
-            int64_t cum = 0;
-            uint32_t sel = 255;
-            for (uint32_t b = 0; b < 256; b++) {
-                const int64_t h = s->hist[b];
-                if (k < cum + h) { sel = b; break; }
-                cum += h;
-            }
-            s->sel[0] = sel;
-            s->k[0] = k - cum;
-        }
-        __syncthreads();
+        select_pass(raw, n, key, prefix, shift, top_shift, s);
+        select_pick(s, k, 1);
         prefix |= (uint64_t)s->sel[0] << shift;
         k = s->k[0];
     }
@@ -277,30 +265,18 @@ __device__ uint64_t select_from(const K& key, int64_t n, uint64_t prefix, int64_
 
 // the k-th and (k+1)-th smallest keys: one walk while both fall into the same bucket, two after they part
 template <class K>
-__device__ void select_pair(const K& key, int64_t n, int64_t k, int top_shift, SelectLds* s, uint64_t* lo, uint64_t* hi) {
+__device__ void select_pair(const int16_t* raw, int64_t n, const K& key, int64_t k, int top_shift, SelectLds* s, uint64_t* lo,
+                            uint64_t* hi) {
     uint64_t prefix = 0;
     for (int shift = top_shift; shift >= 0; shift -= 8) {
-        select_pass(key, n, prefix, shift, top_shift, s);
-        if (threadIdx.x == 0) {
-            int64_t cum = 0;
-            int found = 0;
-            for (uint32_t b = 0; b < 256 && found < 2; b++) {
-                const int64_t h = s->hist[b];
-                while (found < 2 && k + found < cum + h) {
-                    s->sel[found] = b;
-                    s->k[found] = k + found - cum;
-                    found++;
-                }
-                cum += h;
-            }
-        }
-        __syncthreads();
+        select_pass(raw, n, key, prefix, shift, top_shift, s);
+        select_pick(s, k, 2);
         const uint32_t b0 = s->sel[0], b1 = s->sel[1];
         const int64_t k0 = s->k[0], k1 = s->k[1];
         if (b0 != b1) {
             const uint64_t p0 = prefix | ((uint64_t)b0 << shift), p1 = prefix | ((uint64_t)b1 << shift);
-            *lo = select_from(key, n, p0, k0, shift - 8, top_shift, s);
-            *hi = select_from(key, n, p1, k1, shift - 8, top_shift, s);
+            *lo = select_from(raw, n, key, p0, k0, shift - 8, top_shift, s);
+            *hi = select_from(raw, n, key, p1, k1, shift - 8, top_shift, s);
             return;
         }
         prefix |= (uint64_t)b0 << shift;
@@ -309,47 +285,58 @@ __device__ void select_pair(const K& key, int64_t n, int64_t k, int top_shift, S
     *lo = *hi = prefix;  // equal keys
 }
 
-// np.median of value(key) over n >= 1 elements; `bits` = 64 (doubles through ord_bits) or 16 (raw DAQ codes)
+// np.median of value(key(raw[i])) over n >= 1 samples; top_shift = 56 for doubles through ord_bits, 8 for the
+// 16-bit DAQ codes themselves
 template <class K, class V>
-__device__ double np_median(const K& key, const V& value, int64_t n, int top_shift, SelectLds* s) {
-    if (n & 1) return value(select_from(key, n, 0, n / 2, top_shift, top_shift, s));
-    if (n < 2) return value(select_from(key, n, 0, 0, top_shift, top_shift, s));
+__device__ double np_median(const int16_t* raw, int64_t n, const K& key, const V& value, int top_shift, SelectLds* s) {
+    if ((n & 1) || n < 2) return value(select_from(raw, n, key, 0, n / 2, top_shift, top_shift, s));
     uint64_t lo, hi;
-    select_pair(key, n, n / 2 - 1, top_shift, s, &lo, &hi);
+    select_pair(raw, n, key, n / 2 - 1, top_shift, s, &lo, &hi);
     return ((0.0 + value(lo)) + value(hi)) / 2.0;  // np.mean of the two middle values
 }
 
-// ---- kernel 1: per-read shift / scale (extract_features.py:179-185) --------------------------------------------
-__global__ __launch_bounds__(256) void dsp_ext_normalize_kernel(dsp_read_batch b, int method, double* shift_out,
-                                                                double* scale_out) {
+// ---- kernel 1: per-read shift / scale (extract_features.py:179-185); one workgroup per read ----------------------
+__global__ __launch_bounds__(1024) void dsp_ext_mad_kernel(dsp_read_batch b, double* shift_out, double* scale_out) {
     __shared__ SelectLds sel;
-    __shared__ double sums[256];
+    const int64_t r = blockIdx.x;
+    const int16_t* raw = b.raw + b.raw_off[r];
+    const int64_t n = b.raw_off[r + 1] - b.raw_off[r];
+    const double scaling = b.scaling[r], offset = b.offset[r];
+    double shift = 0.0, scale = 0.0;
+    if (n > 0) {
+        if (scaling > 0.0) {
+            // pA is a non-decreasing function of the DAQ code: take the order statistics on the 16-bit codes
+            auto kraw = [](int16_t c) { return (uint64_t)(uint16_t)(c ^ (int16_t)0x8000); };
+            auto vraw = [&](uint64_t u) { return scaling * ((double)(int16_t)((uint16_t)u ^ 0x8000u) + offset); };
+            shift = np_median(raw, n, kraw, vraw, 8, &sel);
+        } else {
+            auto kx = [&](int16_t c) { return ord_bits(scaling * ((double)c + offset)); };
+            auto vx = [](uint64_t u) { return ord_value(u); };
+            shift = np_median(raw, n, kx, vx, 56, &sel);
+        }
+        // median(|x - med| / c): x / c is monotone in x, so select on |x - med| and divide the selected values
+        auto ke = [&](int16_t c) { return ord_bits(fabs(scaling * ((double)c + offset) - shift)); };
+        auto ve = [](uint64_t u) { return ord_value(u) / kMadC; };
+        scale = np_median(raw, n, ke, ve, 56, &sel);
+    }
+    if (threadIdx.x == 0) {
+        shift_out[r] = shift;
+        scale_out[r] = scale;
+    }
+}
+
+__global__ __launch_bounds__(256) void dsp_ext_zscore_kernel(dsp_read_batch b, double* shift_out, double* scale_out) {
+    __shared__ double sums[32];
+    __shared__ PwStack stacks[32];
     const int64_t r = blockIdx.x;
     ReadView rd = {b.raw + b.raw_off[r], b.raw_off[r + 1] - b.raw_off[r], b.scaling[r], b.offset[r]};
     const int64_t n = rd.n;
-    double shift, scale;
-    if (n <= 0) {
-        shift = 0.0; scale = 0.0;
-    } else if (method == 0) {  // mad
-        if (rd.scaling > 0.0) {
-            // pA is a non-decreasing function of the DAQ code: take the order statistics on the 16-bit codes
-            auto kraw = [&](int64_t i) { return (uint64_t)(uint16_t)(rd.raw[i] ^ (int16_t)0x8000); };
-            auto vraw = [&](uint64_t u) { return rd.scaling * ((double)(int16_t)((uint16_t)u ^ 0x8000u) + rd.offset); };
-            shift = np_median(kraw, vraw, n, 8, &sel);
-        } else {
-            auto kx = [&](int64_t i) { return ord_bits(rd.pa(i)); };
-            auto vx = [&](uint64_t u) { return ord_value(u); };
-            shift = np_median(kx, vx, n, 56, &sel);
-        }
-        // median(|x - med| / c): x / c is monotone in x, so select on |x - med| and divide the selected values
-        auto ke = [&](int64_t i) { return ord_bits(fabs(rd.pa(i) - shift)); };
-        auto ve = [&](uint64_t u) { return ord_value(u) / kMadC; };
-        scale = np_median(ke, ve, n, 56, &sel);
-    } else {  // zscore: np.mean, np.std
+    double shift = 0.0, scale = 0.0;
+    if (n > 0) {  // np.mean, np.std
         auto fx = [&](int64_t i) { return rd.pa(i); };
-        shift = np_sum_block(fx, n, sums) / (double)n;
+        shift = np_sum_block(fx, n, sums, stacks) / (double)n;
         auto fd = [&](int64_t i) { const double d = rd.pa(i) - shift; return d * d; };
-        scale = sqrt(np_sum_block(fd, n, sums) / (double)n);
+        scale = sqrt(np_sum_block(fd, n, sums, stacks) / (double)n);
     }
     if (threadIdx.x == 0) {
         shift_out[r] = shift;
@@ -358,39 +345,66 @@ __global__ __launch_bounds__(256) void dsp_ext_normalize_kernel(dsp_read_batch b
 }
 
 // ---- kernel 2: per-base statistics (extract_features.py:331-335, :363-365) -------------------------------------
-__device__ __forceinline__ int64_t read_of_event(const int64_t* ev_off, int64_t n_reads, int64_t e) {
-    int64_t lo = 0, hi = n_reads;  // last r with ev_off[r] <= e
-    while (hi - lo > 1) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (ev_off[mid] <= e) lo = mid; else hi = mid;
+// Workgroups own 256 consecutive bases of ONE read (8 rounds of 32 bases x 8 lanes), so everything per read is
+// wave-uniform (scalar loads) and the read lookup is paid once per 256 bases; blk_off[r] = first workgroup of
+// read r, built by the scan kernel below.
+constexpr int kBasesPerBlock = 256;
+
+__global__ __launch_bounds__(1024) void dsp_ext_blkoff_kernel(const int64_t* ev_off, int64_t n_reads, int64_t* blk_off) {
+    __shared__ int64_t part[1024];
+    const int64_t per = (n_reads + blockDim.x - 1) / blockDim.x;
+    const int64_t r0 = (int64_t)threadIdx.x * per, r1 = (r0 + per < n_reads) ? r0 + per : n_reads;
+    int64_t sum = 0;
+    for (int64_t r = r0; r < r1; r++) sum += (ev_off[r + 1] - ev_off[r] + kBasesPerBlock - 1) / kBasesPerBlock;
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t run = 0;
+        for (int i = 0; i < (int)blockDim.x; i++) { const int64_t v = part[i]; part[i] = run; run += v; }
+        blk_off[n_reads] = run;
     }
-    return lo;
+    __syncthreads();
+    int64_t run = part[threadIdx.x];
+    for (int64_t r = r0; r < r1; r++) {
+        blk_off[r] = run;
+        run += (ev_off[r + 1] - ev_off[r] + kBasesPerBlock - 1) / kBasesPerBlock;
+    }
 }
 
 __global__ __launch_bounds__(256) void dsp_ext_base_stats_kernel(dsp_read_batch b, const double* shift, const double* scale,
-                                                                 double* base_mean, double* base_std, int32_t* base_len,
-                                                                 int64_t* base_lo) {
-    // 8 adjacent lanes per base (32 bases per 256-thread workgroup)
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t e = t >> 3;
-    const int l8 = (int)(t & 7);
-    if (e >= b.n_events) return;
-    const int64_t r = read_of_event(b.ev_off, b.n_reads, e);
+                                                                 const int64_t* blk_off, double* base_mean,
+                                                                 double* base_std, int32_t* base_len, int64_t* base_lo) {
+    __shared__ PwStack stacks[32];
+    const int64_t blk = blockIdx.x;
+    if (blk >= blk_off[b.n_reads]) return;
+    int64_t rlo = 0, rhi = b.n_reads;  // last r with blk_off[r] <= blk (uniform: scalar loads)
+    while (rhi - rlo > 1) {
+        const int64_t mid = (rlo + rhi) >> 1;
+        if (blk_off[mid] <= blk) rlo = mid; else rhi = mid;
+    }
+    const int64_t r = rlo;
+    const int grp = threadIdx.x >> 3, l8 = threadIdx.x & 7;
+    const int64_t e0 = b.ev_off[r], n_ev = b.ev_off[r + 1] - e0;
     const int64_t n_raw = b.raw_off[r + 1] - b.raw_off[r];
-    // norm_signals[start:start+length] with Python's clamping of the slice ends
-    int64_t lo = b.ev_start[e], hi = lo + b.ev_len[e];
-    lo = lo < 0 ? 0 : (lo > n_raw ? n_raw : lo);
-    hi = hi < lo ? lo : (hi > n_raw ? n_raw : hi);
-    const int64_t n = hi - lo;
-    NormView nv = {{b.raw + b.raw_off[r], n_raw, b.scaling[r], b.offset[r]}, shift[r], scale[r]};
-    const double mean = np_sum8(nv, lo, n, l8) / (double)n;  // n == 0 -> nan, like np.mean([])
-    auto dev2 = [&](int64_t i) { const double d = nv(i) - mean; return d * d; };
-    const double var = np_sum8(dev2, lo, n, l8) / (double)n;
-    if (l8 == 0) {
-        base_mean[e] = mean;
-        base_std[e] = sqrt(var);
-        base_len[e] = (int32_t)n;
-        base_lo[e] = lo;
+    const NormView nv = {{b.raw + b.raw_off[r], n_raw, b.scaling[r], b.offset[r]}, shift[r], scale[r]};
+    for (int round = 0; round < kBasesPerBlock / 32; round++) {
+        const int64_t e_local = (blk - blk_off[r]) * kBasesPerBlock + round * 32 + grp;
+        if (e_local >= n_ev) return;  // whole 8-lane groups leave together
+        const int64_t e = e0 + e_local;
+        // norm_signals[start:start+length] with Python's clamping of the slice ends
+        int64_t lo = b.ev_start[e], hi = lo + b.ev_len[e];
+        lo = lo < 0 ? 0 : (lo > n_raw ? n_raw : lo);
+        hi = hi < lo ? lo : (hi > n_raw ? n_raw : hi);
+        const int64_t n = hi - lo;
+        const double mean = np_sum8(nv, lo, n, l8, &stacks[grp]) / (double)n;  // n == 0 -> nan, like np.mean([])
+        auto dev2 = [&](int64_t i) { const double d = nv(i) - mean; return d * d; };
+        const double var = np_sum8(dev2, lo, n, l8, &stacks[grp]) / (double)n;
+        if (l8 == 0) {
+            base_mean[e] = mean;
+            base_std[e] = sqrt(var);
+            base_len[e] = (int32_t)n;
+            base_lo[e] = lo;
+        }
     }
 }
 
@@ -429,48 +443,161 @@ struct GatherArgs {
     float* signals;
 };
 
+// One thread per OUTPUT SAMPLE (element of signals[n][L][S]): stores are contiguous across the wave.  The thread
+// of sample 0 of a (site, base) pair is its leader: it writes the pair's k-mer code / mean / std / length and, for
+// a base longer than S, draws the sorted subset into LDS for the pair's other threads.
 __global__ __launch_bounds__(256) void dsp_ext_gather_kernel(GatherArgs a) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= a.n_sites * a.L) return;
-    const int64_t site = t / a.L;
-    const int j = (int)(t - site * a.L);
-    const int64_t r = a.site_read[site];
-    const int64_t bi = (int64_t)a.site_loc[site] - (a.L - 1) / 2 + j;  // base index within the read
-    const int64_t e = a.b.ev_off[r] + bi;
-    a.kmer[t] = base_code(a.b.ev_base[e]);
-    double m = a.base_mean[e], sd = a.base_std[e];
-    if (a.round_stats) {  // the TSV route rounds them when it prints the row (:389-390)
-        m = rint(m * 1e6) / 1e6;
-        sd = rint(sd * 1e6) / 1e6;
-    }
-    a.means[t] = (float)m;
-    a.stds[t] = (float)sd;
-    const int n = a.base_len[e];
-    a.lens[t] = n;
-    NormView nv = {{a.b.raw + a.b.raw_off[r], 0, a.b.scaling[r], a.b.offset[r]}, a.shift[r], a.scale[r]};
-    const int64_t lo = a.base_lo[e];
-    float* out = a.signals + t * a.S;
+    extern __shared__ int sel_lds[];  // [pairs touched by this workgroup][S]
     const int S = a.S;
+    const int64_t total = a.n_sites * a.L * (int64_t)S;
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x;
+    const int64_t t = t0 + threadIdx.x;
+    const int64_t pair0 = t0 / S;  // first (site, base) pair this workgroup touches
+    const bool live = t < total;
+    const int64_t pair = live ? t / S : 0;
+    const int sidx = (int)(t - pair * S);
+    const int64_t site = pair / a.L;
+    const int j = (int)(pair - site * a.L);
+    int64_t r = 0, bi = 0, e = 0, lo = 0;
+    int n = 0;
+    if (live) {
+        r = a.site_read[site];
+        bi = (int64_t)a.site_loc[site] - (a.L - 1) / 2 + j;  // base index within the read
+        e = a.b.ev_off[r] + bi;
+        n = a.base_len[e];
+        lo = a.base_lo[e];
+    }
+    // leaders: sample 0 of a pair, or the first thread of the workgroup when its pair started in the previous one
+    const bool leader = live && (sidx == 0 || threadIdx.x == 0);
+    int* sel = sel_lds + (pair - pair0) * S;
+    if (leader) {
+        if (sidx == 0) {
+            a.kmer[pair] = base_code(a.b.ev_base[e]);
+            double m = a.base_mean[e], sd = a.base_std[e];
+            if (a.round_stats) {  // the TSV route rounds them when it prints the row (:389-390)
+                m = rint(m * 1e6) / 1e6;
+                sd = rint(sd * 1e6) / 1e6;
+            }
+            a.means[pair] = (float)m;
+            a.stds[pair] = (float)sd;
+            a.lens[pair] = n;
+        }
+        if (n > S) {  // S of n samples in time order: Floyd's subset sampling over a counter-based stream, O(S^2)
+            const uint64_t h = mix64((a.seed ^ (a.read_uid[r] * 0x9E3779B97F4A7C15ull)) + (uint64_t)bi * 0xD1B54A32D192ED03ull);
+            for (int q = 0; q < S; q++) {
+                const int jj = n - S + q;
+                const uint64_t rnd = mix64(h + (uint64_t)q) >> 32;
+                int v = (int)((rnd * (uint64_t)(jj + 1)) >> 32);  // uniform on [0, jj]
+                for (int k = 0; k < q; k++)
+                    if (sel[k] == v) { v = jj; break; }
+                int k = q;
+                for (; k > 0 && sel[k - 1] > v; k--) sel[k] = sel[k - 1];
+                sel[k] = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    NormView nv = {{a.b.raw + a.b.raw_off[r], 0, a.b.scaling[r], a.b.offset[r]}, a.shift[r], a.scale[r]};
+    float out = 0.f;
     if (n <= S) {  // centred zero padding, left = pad // 2
         const int left = (S - n) / 2;
-        for (int i = 0; i < left; i++) out[i] = 0.f;
-        for (int i = 0; i < n; i++) out[left + i] = (float)nv(lo + i);
-        for (int i = left + n; i < S; i++) out[i] = 0.f;
-    } else {  // S of n samples in time order: Floyd's subset sampling over a counter-based stream, O(S^2)
-        const uint64_t h = mix64((a.seed ^ (a.read_uid[r] * 0x9E3779B97F4A7C15ull)) + (uint64_t)bi * 0xD1B54A32D192ED03ull);
-        int* sel = reinterpret_cast<int*>(out);  // the sorted sample indices live in the output slots first
-        for (int q = 0; q < S; q++) {
-            const int jj = n - S + q;
-            const uint64_t rnd = mix64(h + (uint64_t)q) >> 32;
-            int v = (int)((rnd * (uint64_t)(jj + 1)) >> 32);  // uniform on [0, jj]
-            for (int k = 0; k < q; k++)
-                if (sel[k] == v) { v = jj; break; }
-            int k = q;
-            for (; k > 0 && sel[k - 1] > v; k--) sel[k] = sel[k - 1];
-            sel[k] = v;
-        }
-        for (int k = 0; k < S; k++) out[k] = (float)nv(lo + sel[k]);
+        if (sidx >= left && sidx < left + n) out = (float)nv(lo + (sidx - left));
+    } else {
+        out = (float)nv(lo + sel[sidx]);
     }
+    a.signals[t] = out;
+}
+
+constexpr int kSelWords = 64;  // membership bitset of the subset sampler: bases of up to 2048 samples
+
+// Fast path for signal_len = 4, 8, ..., 256 (a power of two): S/4 adjacent lanes per (site, base) pair, each lane
+// producing four consecutive samples and storing them as one 16-byte vector.
+__global__ __launch_bounds__(256) void dsp_ext_gather4_kernel(GatherArgs a, int log2_lpp) {
+    extern __shared__ int sel_lds[];  // [pairs per workgroup][S]
+    const int S = a.S;
+    const int lpp = 1 << log2_lpp;                 // lanes per pair = S / 4
+    const int ppb = 256 >> log2_lpp;               // pairs per workgroup
+    const int pl = threadIdx.x >> log2_lpp;        // pair within the workgroup
+    const int sub = threadIdx.x & (lpp - 1);       // which four samples of the pair
+    const int64_t pair = (int64_t)blockIdx.x * ppb + pl;
+    const bool live = pair < a.n_sites * a.L;
+    const uint32_t site = live ? (uint32_t)(pair / a.L) : 0;
+    const int j = (int)(pair - (int64_t)site * a.L);
+    int64_t r = 0, bi = 0, e = 0, lo = 0;
+    int n = 0;
+    if (live) {
+        r = a.site_read[site];
+        bi = (int64_t)a.site_loc[site] - (a.L - 1) / 2 + j;
+        e = a.b.ev_off[r] + bi;
+        n = a.base_len[e];
+        lo = a.base_lo[e];
+    }
+    int* sel = sel_lds + pl * S;                                   // sorted sample indices of this pair
+    uint32_t* bits = reinterpret_cast<uint32_t*>(sel_lds + ppb * S) + pl * kSelWords;  // membership bitset, n <= 2048
+    const int nw = (n + 31) >> 5;
+    const bool use_bits = n > S && nw <= kSelWords;
+    if (use_bits)
+        for (int w = sub; w < nw; w += lpp) bits[w] = 0;  // the pair's lanes sit in one wave: LDS order = program order
+    if (live && sub == 0) {
+        a.kmer[pair] = base_code(a.b.ev_base[e]);
+        double m = a.base_mean[e], sd = a.base_std[e];
+        if (a.round_stats) {
+            m = rint(m * 1e6) / 1e6;
+            sd = rint(sd * 1e6) / 1e6;
+        }
+        a.means[pair] = (float)m;
+        a.stds[pair] = (float)sd;
+        a.lens[pair] = n;
+        if (n > S) {  // Floyd's subset sampling, as in the generic kernel
+            const uint64_t h = mix64((a.seed ^ (a.read_uid[r] * 0x9E3779B97F4A7C15ull)) + (uint64_t)bi * 0xD1B54A32D192ED03ull);
+            if (use_bits) {
+                for (int q = 0; q < S; q++) {
+                    const int jj = n - S + q;
+                    const uint64_t rnd = mix64(h + (uint64_t)q) >> 32;
+                    int v = (int)((rnd * (uint64_t)(jj + 1)) >> 32);
+                    if (bits[v >> 5] & (1u << (v & 31))) v = jj;
+                    bits[v >> 5] |= 1u << (v & 31);
+                }
+                int c = 0;
+                for (int w = 0; w < nw; w++) {  // set bits in ascending order = the sorted sample
+                    uint32_t x = bits[w];
+                    while (x) {
+                        sel[c++] = (w << 5) + __ffs((int)x) - 1;
+                        x &= x - 1;
+                    }
+                }
+            } else {
+                for (int q = 0; q < S; q++) {
+                    const int jj = n - S + q;
+                    const uint64_t rnd = mix64(h + (uint64_t)q) >> 32;
+                    int v = (int)((rnd * (uint64_t)(jj + 1)) >> 32);
+                    for (int k = 0; k < q; k++)
+                        if (sel[k] == v) { v = jj; break; }
+                    int k = q;
+                    for (; k > 0 && sel[k - 1] > v; k--) sel[k] = sel[k - 1];
+                    sel[k] = v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    NormView nv = {{a.b.raw + a.b.raw_off[r], 0, a.b.scaling[r], a.b.offset[r]}, a.shift[r], a.scale[r]};
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    const int s0 = sub * 4;
+    if (n <= S) {
+        const int left = (S - n) / 2;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int k = s0 + i - left;
+            if (k >= 0 && k < n) o[i] = (float)nv(lo + k);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i] = (float)nv(lo + sel[s0 + i]);
+    }
+    reinterpret_cast<float4*>(a.signals)[pair * lpp + sub] = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 }  // namespace
@@ -498,19 +625,24 @@ int32_t dsp_extract_normalize(void* stream, const dsp_read_batch* b, int32_t met
     if (!b || !shift || !scale || (method != DSP_NORM_MAD && method != DSP_NORM_ZSCORE))
         return ext_fail(DSP_EINVAL, "dsp_extract_normalize: bad arguments");
     if (b->n_reads == 0) return DSP_OK;
-    hipLaunchKernelGGL(dsp_ext_normalize_kernel, dim3((unsigned)b->n_reads), dim3(256), 0, (hipStream_t)stream, *b,
-                       (int)method, shift, scale);
+    if (method == DSP_NORM_MAD)
+        hipLaunchKernelGGL(dsp_ext_mad_kernel, dim3((unsigned)b->n_reads), dim3(1024), 0, (hipStream_t)stream, *b, shift, scale);
+    else
+        hipLaunchKernelGGL(dsp_ext_zscore_kernel, dim3((unsigned)b->n_reads), dim3(256), 0, (hipStream_t)stream, *b, shift, scale);
     return ext_check_launch("dsp_extract_normalize");
 }
 
 int32_t dsp_extract_base_stats(void* stream, const dsp_read_batch* b, const double* shift, const double* scale,
-                               double* base_mean, double* base_std, int32_t* base_len, int64_t* base_lo) {
-    if (!b || !shift || !scale || !base_mean || !base_std || !base_len || !base_lo)
+                               int64_t* blk_off, double* base_mean, double* base_std, int32_t* base_len,
+                               int64_t* base_lo) {
+    if (!b || !shift || !scale || !blk_off || !base_mean || !base_std || !base_len || !base_lo)
         return ext_fail(DSP_EINVAL, "dsp_extract_base_stats: bad arguments");
-    if (b->n_events == 0) return DSP_OK;
-    const unsigned grid = (unsigned)((b->n_events * 8 + 255) / 256);
+    if (b->n_events == 0 || b->n_reads == 0) return DSP_OK;
+    hipLaunchKernelGGL(dsp_ext_blkoff_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, b->ev_off, b->n_reads, blk_off);
+    // sum over reads of ceil(bases / 256) <= n_events / 256 + n_reads; surplus workgroups exit at once
+    const unsigned grid = (unsigned)(b->n_events / kBasesPerBlock + b->n_reads);
     hipLaunchKernelGGL(dsp_ext_base_stats_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *b, shift, scale,
-                       base_mean, base_std, base_len, base_lo);
+                       (const int64_t*)blk_off, base_mean, base_std, base_len, base_lo);
     return ext_check_launch("dsp_extract_base_stats");
 }
 
@@ -520,7 +652,7 @@ int32_t dsp_extract_gather(void* stream, const dsp_read_batch* b, const double* 
                            int32_t seq_len, int32_t signal_len, int32_t round_stats, uint64_t seed,
                            const uint64_t* read_uid, uint8_t* kmer, float* means, float* stds, int32_t* lens,
                            float* signals) {
-    if (!b || n_sites < 0 || seq_len <= 0 || !(seq_len & 1) || signal_len <= 0)
+    if (!b || n_sites < 0 || seq_len <= 0 || !(seq_len & 1) || signal_len <= 0 || signal_len > 4096)
         return ext_fail(DSP_EINVAL, "dsp_extract_gather: bad arguments (seq_len must be odd)");
     if (n_sites == 0) return DSP_OK;
     if (!shift || !scale || !base_mean || !base_std || !base_len || !base_lo || !site_read || !site_loc || !read_uid ||
@@ -528,8 +660,18 @@ int32_t dsp_extract_gather(void* stream, const dsp_read_batch* b, const double* 
         return ext_fail(DSP_EINVAL, "dsp_extract_gather: NULL array");
     GatherArgs a = {*b, shift, scale, base_mean, base_std, base_len, base_lo, n_sites, site_read, site_loc,
                     (int)seq_len, (int)signal_len, (int)round_stats, seed, read_uid, kmer, means, stds, lens, signals};
-    const int64_t threads = n_sites * seq_len;
-    hipLaunchKernelGGL(dsp_ext_gather_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+    if (signal_len >= 4 && signal_len <= 256 && (signal_len & (signal_len - 1)) == 0 && ((uintptr_t)signals & 15) == 0) {
+        int log2_lpp = 0;
+        while ((4 << log2_lpp) < signal_len) log2_lpp++;
+        const int ppb = 256 >> log2_lpp;
+        const int64_t pairs = n_sites * seq_len;
+        hipLaunchKernelGGL(dsp_ext_gather4_kernel, dim3((unsigned)((pairs + ppb - 1) / ppb)), dim3(256),
+                           (size_t)ppb * (signal_len + kSelWords) * sizeof(int), (hipStream_t)stream, a, log2_lpp);
+        return ext_check_launch("dsp_extract_gather");
+    }
+    const int64_t threads = n_sites * seq_len * (int64_t)signal_len;
+    const size_t lds = (size_t)(256 / signal_len + 2) * signal_len * sizeof(int);
+    hipLaunchKernelGGL(dsp_ext_gather_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), lds,
                        (hipStream_t)stream, a);
     return ext_check_launch("dsp_extract_gather");
 }

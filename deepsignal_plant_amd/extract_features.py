@@ -187,6 +187,7 @@ class FeatureExtractor(object):
             base_mean, base_std = torch.empty(E, **f64), torch.empty(E, **f64)
             base_len = torch.empty(E, dtype=torch.int32, device=dev)
             base_lo = torch.empty(E, dtype=torch.int64, device=dev)
+            blk_off = torch.empty(R + 1, dtype=torch.int64, device=dev)
             out.kmer = torch.empty((n, self.L), dtype=torch.uint8, device=dev)
             out.means = torch.empty((n, self.L), dtype=torch.float32, device=dev)
             out.stds = torch.empty((n, self.L), dtype=torch.float32, device=dev)
@@ -198,7 +199,7 @@ class FeatureExtractor(object):
                 sp = ctypes.c_void_p(st.cuda_stream)
                 ptr = lambda t: ctypes.c_void_p(t.data_ptr())
                 nat.check(L.dsp_extract_normalize(sp, ctypes.byref(batch), self.method, ptr(shift), ptr(scale)))
-                nat.check(L.dsp_extract_base_stats(sp, ctypes.byref(batch), ptr(shift), ptr(scale), ptr(base_mean),
+                nat.check(L.dsp_extract_base_stats(sp, ctypes.byref(batch), ptr(shift), ptr(scale), ptr(blk_off), ptr(base_mean),
                                                    ptr(base_std), ptr(base_len), ptr(base_lo)))
                 if n:
                     d_site_read, d_site_loc = up("site_read", site_read, torch.int32), up("site_loc", site_loc, torch.int32)
@@ -211,7 +212,7 @@ class FeatureExtractor(object):
                                                    ptr(out.signals)))
                     # the inputs must outlive the asynchronous kernels
                     for t in (d_raw, d_raw_off, d_ev_off, d_scaling, d_offset, d_ev_start, d_ev_len, d_ev_base,
-                              base_mean, base_std, base_len, base_lo, d_site_read, d_site_loc, d_uid):
+                              base_mean, base_std, base_len, base_lo, blk_off, d_site_read, d_site_loc, d_uid):
                         t.record_stream(st)
             ev = torch.cuda.Event()
             ev.record(st)

@@ -214,9 +214,10 @@ enum { DSP_NORM_MAD = 0, DSP_NORM_ZSCORE = 1 }; /* --normalize_method, extract_f
 /* per-read shift / scale [n_reads] float64: mad -> (np.median, statsmodels robust.mad), zscore -> (np.mean, np.std) */
 int32_t dsp_extract_normalize(void* stream, const dsp_read_batch* b, int32_t method, double* shift, double* scale);
 /* per-base float64 mean / std of the normalised, 6-decimal-rounded samples, clamped length and first sample
- * index [n_events] */
+ * index [n_events]; blk_off [n_reads+1] int64 is device workspace */
 int32_t dsp_extract_base_stats(void* stream, const dsp_read_batch* b, const double* shift, const double* scale,
-                               double* base_mean, double* base_std, int32_t* base_len, int64_t* base_lo);
+                               int64_t* blk_off, double* base_mean, double* base_std, int32_t* base_len,
+                               int64_t* base_lo);
 /* window gather for n_sites sites (site_read = read index in the batch, site_loc = base index of the targeted
  * base in the read; the caller guarantees seq_len/2 <= loc < n_bases - seq_len/2): kmer u8 [n][L] codes
  * (base2code_dna), means/stds f32 [n][L] (rounded to 6 decimals first when round_stats), lens i32 [n][L],
