@@ -128,6 +128,11 @@ def lib():
                                     [ctypes.c_char_p] + [ctypes.c_int32] * 4 + [ctypes.c_int64, ctypes.c_void_p,
                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)] +
                                     [ctypes.c_void_p] * 4 + [ctypes.c_int32])
+    L.dsp_extract_gather_f64.restype = ctypes.c_int32
+    L.dsp_extract_gather_f64.argtypes = L.dsp_extract_gather.argtypes
+    L.dsp_format_feature_rows.restype = ctypes.c_int64
+    L.dsp_format_feature_rows.argtypes = ([ctypes.c_void_p] * 9 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
+                                          ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32])
     _lib = L
     return L
 

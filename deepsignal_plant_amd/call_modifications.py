@@ -17,7 +17,7 @@ called_label, 5-mer; :175-188, :262-282).  What changed underneath:
 
 Multi-GPU: contiguous byte-range split of the file over ranks (dist.py); per-rank part files concatenated by
 rank 0.  Results do not depend on the number of GPUs or on batching: the in-kernel initial states are keyed
-by the global row index.  The fast5-directory branch (:559-583) is out of scope.
+by the global row index.  The fast5-directory branch (:559-583) extracts features on the GPU from read records (_call_mods_reads).
 """
 from __future__ import annotations
 
@@ -182,6 +182,127 @@ def _call_mods_file(args, rank, local_rank, world):
     return n_rows, part_path, out_path
 
 
+class _ReadsBlock(object):
+    """What the writer needs from one batch of reads: the sites' sampleinfo rows + host k-mer codes."""
+    __slots__ = ("rows",)
+
+
+class _NoRelease(object):
+    def release(self, block):
+        pass
+
+
+def _call_mods_reads(args, rank, local_rank, world):
+    """The fast5-directory branch (call_modifications.py:559-583, :285-470): read records -> features extracted on the
+    GPU (extract_features.py of this build) -> forward -> per-read calls, the features never leaving HBM.
+    Input files: *.fast5 (needs h5py on the host) and *.reads.npz (reads.save_reads).  Files are dealt to ranks
+    in contiguous ranges; output order = file order."""
+    import torch
+    from . import reads as dsp_reads
+    from .extract_features import FeatureExtractor, _read_position_file
+    from .utils.process_utils import get_contig2len
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    model = load_model(args, local_rank)
+    files = dsp_reads.list_read_files(os.path.abspath(args.input_path), str2bool(args.recursively))
+    if rank == 0:
+        print("%d read files in total.." % len(files))
+    lo, hi = (len(files) * rank) // world, (len(files) * (rank + 1)) // world
+    files = files[lo:hi]
+    chrom2len = get_contig2len(args.reference_path) if args.reference_path else None
+    positions = _read_position_file(args.positions) if args.positions else None
+    nthreads = min(max(1, args.nproc if args.nproc > 0 else 1), os.cpu_count() or 1)
+    fx = FeatureExtractor(motifs=args.motifs, mod_loc=args.mod_loc, seq_len=args.seq_len, signal_len=args.signal_len,
+                          normalize_method=args.normalize_method, chrom2len=chrom2len, positions=positions,
+                          region=args.region, methy_label=1, is_dna=str2bool(args.is_dna), device=dev,
+                          seed=getattr(args, "seed", 0), round_stats=False, nthreads=nthreads)
+    out_path = args.result_file
+    if args.gzip and not out_path.endswith(".gz"):
+        out_path += ".gz"
+    part_path = out_path if world == 1 else "%s.part%05d" % (out_path, rank)
+    freq = None
+    if getattr(args, "freq_file", None) and world == 1:
+        from .call_mods_freq import SiteFrequency
+        freq = SiteFrequency(args.prob_cf)
+    writer = _Writer(part_path, args.gzip, nthreads, _NoRelease(), freq)
+    writer.start()
+
+    # loader thread: files -> batches of reads (HDF5 / npz decoding overlaps the GPU work)
+    batch_reads = max(1, int(args.f5_batch_size)) * 8
+    rq = queue.Queue(maxsize=3)
+    failed = [0]
+
+    def load():
+        cur, uids = [], []
+        try:
+            for fi, f in enumerate(files):
+                try:
+                    got = dsp_reads.load_read_file(f, args.corrected_group, args.basecall_subgroup)
+                except Exception:
+                    failed[0] += 1  # like the reference: count and go on (extract_features.py:373-375)
+                    continue
+                cur += got
+                # the sampler key of a read = (global file index, index in file): independent of batching and ranks
+                uids += [((lo + fi) << 20) + i for i in range(len(got))]
+                if len(cur) >= batch_reads:
+                    rq.put((cur, uids))
+                    cur, uids = [], []
+            if cur:
+                rq.put((cur, uids))
+        finally:
+            rq.put(None)
+    loader = threading.Thread(target=load, daemon=True)
+    loader.start()
+
+    stream = torch.cuda.current_stream(dev)
+    n_rows, k = 0, 0
+    ring = [dict(cap=0, ev=None) for _ in range(6)]  # pinned result slots (the writer queue holds at most 4)
+    row_base = rank << 44  # initial-state streams of different ranks never overlap
+    while True:
+        batch = rq.get()
+        if batch is None:
+            break
+        if writer.error is not None:
+            continue
+        ext = fx.extract(batch[0], read_uids=batch[1], stream=stream)
+        n = ext.n
+        if n == 0:
+            continue
+        model.site_offset = row_base + n_rows
+        _logits, probs, labels = model.forward(ext.kmer, ext.means, ext.stds, ext.lens, ext.signals, want_labels=True)
+        slot = ring[k % len(ring)]
+        k += 1
+        if slot["ev"] is not None:
+            slot["ev"].synchronize()  # the writer is done with this slot's previous contents
+        if slot["cap"] < n:
+            cap = n + n // 4
+            slot.update(cap=cap, probs=torch.empty((cap, args.class_num), dtype=torch.float32, pin_memory=True),
+                        labels=torch.empty((cap,), dtype=torch.uint8, pin_memory=True),
+                        kmer=torch.empty((cap, args.seq_len), dtype=torch.uint8, pin_memory=True))
+        h_probs, h_labels, h_kmer = slot["probs"], slot["labels"], slot["kmer"][:n]
+        h_probs[:n].copy_(probs, non_blocking=True)
+        h_labels[:n].copy_(labels, non_blocking=True)
+        h_kmer.copy_(ext.kmer, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        slot["ev"] = ev
+        ext.rows.kmer = h_kmer.numpy()  # valid once `ev` has passed; the writer waits on it first
+        blk = _ReadsBlock()
+        blk.rows = ext.rows
+        writer.q.put((blk, h_probs, h_labels, ev))
+        n_rows += n
+    writer.q.put(None)
+    writer.join()
+    loader.join()
+    torch.cuda.synchronize(dev)
+    if writer.error is not None:
+        raise writer.error
+    if freq is not None:
+        freq.write(args.freq_file, args.freq_sort, args.freq_bed, args.gzip)
+    print("%d of %d read files failed.." % (failed[0], len(files)))  # :440
+    return n_rows, part_path, out_path
+
+
 def _merge_parts(out_path, world):
     with open(out_path, "wb") as wf:
         for r in range(world):
@@ -206,9 +327,6 @@ def call_mods(args):
     input_path = os.path.abspath(args.input_path)
     if not os.path.exists(input_path):
         raise ValueError("--input_path does not exist!")  # :553-554
-    if os.path.isdir(input_path):
-        raise ValueError("--input_path is a directory: calling from fast5 files is outside this build's scope; "
-                         "run `extract` first and pass the feature file")
     if not torch.cuda.is_available():
         raise RuntimeError("no MI355X visible: this build has no CPU path")
 
@@ -225,7 +343,10 @@ def call_mods(args):
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
             else:              # more ranks than visible GPUs (dev box): ranks share GPUs, control plane over gloo
                 dist.init_process_group("gloo")
-    n_rows, part_path, out_path = _call_mods_file(args, rank, local_rank, world)
+    if os.path.isdir(input_path):  # reads in, calls out: extraction + forward on the GPU (:559-583)
+        n_rows, part_path, out_path = _call_mods_reads(args, rank, local_rank, world)
+    else:
+        n_rows, part_path, out_path = _call_mods_file(args, rank, local_rank, world)
     if world > 1:
         import torch.distributed as dist
         cdev = torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else None
@@ -255,9 +376,10 @@ def add_call_mods_args(p):
     plus the build-only flags --init_state / --seed."""
     g = p.add_argument_group("INPUT")
     g.add_argument("--input_path", "-i", type=str, required=True,
-                   help="feature file written by `extract` (plain or .gz), or its binary form written by `pack_features` (.dspf)")
+                   help="feature file written by `extract` (plain or .gz), its binary form written by `pack_features` "
+                        "(.dspf), or a directory of reads (*.fast5 / *.reads.npz) to extract features from on the fly")
     g.add_argument("--f5_batch_size", type=int, default=30,
-                   help="reads per reader batch in the reference (default 30); accepted for compatibility, results do not depend on it")
+                   help="reads per reader batch in the reference (default 30); this build loads 8x as many per GPU batch, results do not depend on it")
     g = p.add_argument_group("CALL")
     g.add_argument("--model_path", "-m", type=str, required=True, help="trained model checkpoint (.ckpt, a state_dict)")
     g.add_argument("--model_type", type=str, default="both_bilstm", choices=["both_bilstm", "seq_bilstm", "signal_bilstm"])
@@ -277,7 +399,7 @@ def add_call_mods_args(p):
     g = p.add_argument_group("OUTPUT")
     g.add_argument("--result_file", "-o", type=str, required=True, help="per-read call file to write")
     g.add_argument("--gzip", action="store_true", default=False, help="gzip the output")
-    g = p.add_argument_group("FAST5_EXTRACTION (accepted for compatibility; the fast5 branch is not part of this build)")
+    g = p.add_argument_group("EXTRACTION (used when --input_path is a directory of *.fast5 [needs h5py] / *.reads.npz files)")
     g.add_argument("--recursively", "-r", type=str, default="yes")
     g.add_argument("--corrected_group", type=str, default="RawGenomeCorrected_000")
     g.add_argument("--basecall_subgroup", type=str, default="BaseCalled_template")

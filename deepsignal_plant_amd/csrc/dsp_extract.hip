@@ -427,7 +427,8 @@ __device__ __forceinline__ uint8_t base_code(uint8_t c) {
     }
 }
 
-struct GatherArgs {
+template <typename T>
+struct GatherArgsT {
     dsp_read_batch b;
     const double *shift, *scale, *base_mean, *base_std;
     const int32_t* base_len;
@@ -438,15 +439,17 @@ struct GatherArgs {
     uint64_t seed;
     const uint64_t* read_uid;
     uint8_t* kmer;
-    float *means, *stds;
+    T *means, *stds;
     int32_t* lens;
-    float* signals;
+    T* signals;
 };
+typedef GatherArgsT<float> GatherArgs;
 
 // One thread per OUTPUT SAMPLE (element of signals[n][L][S]): stores are contiguous across the wave.  The thread
 // of sample 0 of a (site, base) pair is its leader: it writes the pair's k-mer code / mean / std / length and, for
 // a base longer than S, draws the sorted subset into LDS for the pair's other threads.
-__global__ __launch_bounds__(256) void dsp_ext_gather_kernel(GatherArgs a) {
+template <typename T>
+__global__ __launch_bounds__(256) void dsp_ext_gather_kernel(GatherArgsT<T> a) {
     extern __shared__ int sel_lds[];  // [pairs touched by this workgroup][S]
     const int S = a.S;
     const int64_t total = a.n_sites * a.L * (int64_t)S;
@@ -478,8 +481,8 @@ __global__ __launch_bounds__(256) void dsp_ext_gather_kernel(GatherArgs a) {
                 m = rint(m * 1e6) / 1e6;
                 sd = rint(sd * 1e6) / 1e6;
             }
-            a.means[pair] = (float)m;
-            a.stds[pair] = (float)sd;
+            a.means[pair] = (T)m;
+            a.stds[pair] = (T)sd;
             a.lens[pair] = n;
         }
         if (n > S) {  // S of n samples in time order: Floyd's subset sampling over a counter-based stream, O(S^2)
@@ -499,12 +502,12 @@ __global__ __launch_bounds__(256) void dsp_ext_gather_kernel(GatherArgs a) {
     __syncthreads();
     if (!live) return;
     NormView nv = {{a.b.raw + a.b.raw_off[r], 0, a.b.scaling[r], a.b.offset[r]}, a.shift[r], a.scale[r]};
-    float out = 0.f;
+    T out = (T)0;
     if (n <= S) {  // centred zero padding, left = pad // 2
         const int left = (S - n) / 2;
-        if (sidx >= left && sidx < left + n) out = (float)nv(lo + (sidx - left));
+        if (sidx >= left && sidx < left + n) out = (T)nv(lo + (sidx - left));
     } else {
-        out = (float)nv(lo + sel[sidx]);
+        out = (T)nv(lo + sel[sidx]);
     }
     a.signals[t] = out;
 }
@@ -671,9 +674,31 @@ int32_t dsp_extract_gather(void* stream, const dsp_read_batch* b, const double* 
     }
     const int64_t threads = n_sites * seq_len * (int64_t)signal_len;
     const size_t lds = (size_t)(256 / signal_len + 2) * signal_len * sizeof(int);
-    hipLaunchKernelGGL(dsp_ext_gather_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), lds,
+    hipLaunchKernelGGL(dsp_ext_gather_kernel<float>, dim3((unsigned)((threads + 255) / 256)), dim3(256), lds,
                        (hipStream_t)stream, a);
     return ext_check_launch("dsp_extract_gather");
+}
+
+int32_t dsp_extract_gather_f64(void* stream, const dsp_read_batch* b, const double* shift, const double* scale,
+                               const double* base_mean, const double* base_std, const int32_t* base_len,
+                               const int64_t* base_lo, int64_t n_sites, const int32_t* site_read,
+                               const int32_t* site_loc, int32_t seq_len, int32_t signal_len, int32_t round_stats,
+                               uint64_t seed, const uint64_t* read_uid, uint8_t* kmer, double* means, double* stds,
+                               int32_t* lens, double* signals) {
+    if (!b || n_sites < 0 || seq_len <= 0 || !(seq_len & 1) || signal_len <= 0 || signal_len > 4096)
+        return ext_fail(DSP_EINVAL, "dsp_extract_gather_f64: bad arguments (seq_len must be odd)");
+    if (n_sites == 0) return DSP_OK;
+    if (!shift || !scale || !base_mean || !base_std || !base_len || !base_lo || !site_read || !site_loc || !read_uid ||
+        !kmer || !means || !stds || !lens || !signals)
+        return ext_fail(DSP_EINVAL, "dsp_extract_gather_f64: NULL array");
+    GatherArgsT<double> a = {*b, shift, scale, base_mean, base_std, base_len, base_lo, n_sites, site_read, site_loc,
+                             (int)seq_len, (int)signal_len, (int)round_stats, seed, read_uid, kmer, means, stds, lens,
+                             signals};
+    const int64_t threads = n_sites * seq_len * (int64_t)signal_len;
+    const size_t lds = (size_t)(256 / signal_len + 2) * signal_len * sizeof(int);
+    hipLaunchKernelGGL(dsp_ext_gather_kernel<double>, dim3((unsigned)((threads + 255) / 256)), dim3(256), lds,
+                       (hipStream_t)stream, a);
+    return ext_check_launch("dsp_extract_gather_f64");
 }
 
 }  // extern "C"

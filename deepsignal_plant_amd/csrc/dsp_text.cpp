@@ -224,17 +224,18 @@ const char* kFieldName[] = {"", "field count (need 12 tab-separated columns)", "
 // ---- formatter -----------------------------------------------------------------------------------------
 // numpy str(float32): Dragon4 shortest unique digits; positional for 1e-4 <= |x| < 1e16 (and 0) with at least
 // one fractional digit, otherwise scientific d[.ddd]e+XX with the ".0" trimmed.
-int format_f32_numpy(float x, char* out) {
+template <typename T>
+int format_float_numpy(T x, char* out) {
     if (std::isnan(x)) { memcpy(out, "nan", 3); return 3; }
     if (std::isinf(x)) { if (x < 0) { memcpy(out, "-inf", 4); return 4; } memcpy(out, "inf", 3); return 3; }
     char* o = out;
     if (std::signbit(x)) { *o++ = '-'; x = -x; }
-    if (x == 0.0f) { memcpy(o, "0.0", 3); return (int)(o + 3 - out); }
+    if (x == (T)0) { memcpy(o, "0.0", 3); return (int)(o + 3 - out); }
     char sci[48];
     auto res = std::to_chars(sci, sci + sizeof(sci), x, std::chars_format::scientific);  // shortest round-trip
     *res.ptr = 0;
     // sci = d[.ddd]e[+-]XX
-    char digits[24];
+    char digits[32] = {0};
     int nd = 0;
     const char* p = sci;
     for (; *p && *p != 'e'; ++p)
@@ -262,6 +263,10 @@ int format_f32_numpy(float x, char* out) {
     }
     return (int)(o - out);
 }
+
+inline int format_f32_numpy(float x, char* out) { return format_float_numpy<float>(x, out); }
+// str(numpy.float64) == Python's repr(float): same layout rules, 17 significant digits at most
+inline int format_f64_numpy(double x, char* out) { return format_float_numpy<double>(x, out); }
 
 // round(np.float32, 6): numpy multiplies by 1e6, rints (half-even), divides by 1e6 -- all in float32
 inline float np_round6_f32(float x) {
@@ -371,6 +376,64 @@ int64_t dsp_format_calls(const char* text, const uint64_t* row_off, const uint32
             s.append(num, (size_t)snprintf(num, sizeof(num), "%u", (unsigned)labels[r]));
             s.push_back('\t');
             for (int i = k0; i < k1; ++i) s.push_back(code2base[kmer[r * seq_len + i] & 15]);
+            s.push_back('\n');
+        }
+    });
+    size_t total = 0;
+    for (auto& s : parts) total += s.size();
+    if (total > out_cap) return text_fail(DSP_ENOMEM, "output needs %zu bytes, capacity %zu", total, out_cap);
+    size_t pos = 0;
+    for (auto& s : parts) { memcpy(out + pos, s.data(), s.size()); pos += s.size(); }
+    return (int64_t)total;
+}
+
+int dsp_format_f64_(double x, char* out) { return format_f64_numpy(x, out); }  // test hook
+
+int64_t dsp_format_feature_rows(const char* text, const uint64_t* row_off, const uint32_t* info_len, const uint8_t* kmer,
+                                const double* means, const double* stds, const int32_t* lens, const double* signals,
+                                const int32_t* labels, int32_t seq_len, int32_t signal_len, int64_t n, char* out,
+                                size_t out_cap, int32_t nthreads) {
+    if (!text || !row_off || !info_len || !kmer || !means || !stds || !lens || (!signals && signal_len) || !labels ||
+        !out || seq_len < 1 || signal_len < 0)
+        return text_fail(DSP_EINVAL, "bad argument");
+    static const char* code2base = "ACGTNWSMKRYBVDHZ";
+    const int L = seq_len, S = signal_len;
+    if (nthreads < 1) nthreads = 1;
+    std::vector<std::string> parts((size_t)nthreads);
+    run_threads(nthreads, n, [&](int t, int64_t a, int64_t b) {
+        std::string& s = parts[t];
+        s.reserve((size_t)(b - a) * (size_t)(160 + L * (S + 3) * 10));
+        char num[64];
+        for (int64_t r = a; r < b; ++r) {
+            s.append(text + row_off[r], info_len[r]);
+            s.push_back('\t');
+            for (int i = 0; i < L; ++i) s.push_back(code2base[kmer[r * L + i] & 15]);
+            s.push_back('\t');
+            for (int i = 0; i < L; ++i) {
+                if (i) s.push_back(',');
+                s.append(num, (size_t)format_f64_numpy(means[r * L + i], num));
+            }
+            s.push_back('\t');
+            for (int i = 0; i < L; ++i) {
+                if (i) s.push_back(',');
+                s.append(num, (size_t)format_f64_numpy(stds[r * L + i], num));
+            }
+            s.push_back('\t');
+            for (int i = 0; i < L; ++i) {
+                if (i) s.push_back(',');
+                s.append(num, (size_t)snprintf(num, sizeof(num), "%d", (int)lens[r * L + i]));
+            }
+            s.push_back('\t');
+            for (int i = 0; i < L; ++i) {
+                if (i) s.push_back(';');
+                const double* g = signals + ((size_t)r * L + i) * S;
+                for (int k = 0; k < S; ++k) {
+                    if (k) s.push_back(',');
+                    s.append(num, (size_t)format_f64_numpy(g[k], num));
+                }
+            }
+            s.push_back('\t');
+            s.append(num, (size_t)snprintf(num, sizeof(num), "%d", (int)labels[r]));
             s.push_back('\n');
         }
     });

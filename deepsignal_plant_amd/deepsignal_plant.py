@@ -1,10 +1,11 @@
 #!/usr/bin/env python
 """`deepsignal_plant` command line (mirror of deepsignal_plant/deepsignal_plant.py:85-481).
 
-Implemented natively: ``call_mods`` (feature file in, per-read calls out -- the hot path) and ``call_freq``
-(per-read calls in, per-site frequency out -- SURVEY.md 8(f) next-1).  The other sub-commands of the
-reference (extract, train, denoise) are registered so that scripts see the same command set, and exit with a
-clear message (out of scope for this build)."""
+Implemented natively: ``call_mods`` (feature file or reads in, per-read calls out -- the hot path), ``call_freq``
+(per-read calls in, per-site frequency out -- SURVEY.md 8(f) next-1), ``extract`` (reads in, feature rows out --
+next-3) and the build-only ``pack_features`` (feature TSV -> binary container, next-2).  ``train`` and ``denoise``
+are registered so that scripts see the same command set, and exit with a clear message (out of scope
+for this build)."""
 from __future__ import absolute_import
 
 import argparse
@@ -24,6 +25,12 @@ def main_call_freq(args):
     from .call_mods_freq import call_mods_frequency_to_file
     display_args(args)
     call_mods_frequency_to_file(args)
+
+
+def main_extract(args):
+    from .extract_features import extract_features
+    display_args(args)
+    extract_features(args)
 
 
 def main_pack_features(args):
@@ -61,7 +68,11 @@ def main():
                                                            "call_mods reads without parsing (build-only helper)")
     add_pack_features_args(sub_pack)
     sub_pack.set_defaults(func=main_pack_features)
-    for name in ("extract", "train", "denoise"):
+    from .extract_features import add_extract_args
+    sub_extract = sub.add_parser("extract", description="extract features from resquiggled reads (on the GPU)")
+    add_extract_args(sub_extract)
+    sub_extract.set_defaults(func=main_extract)
+    for name in ("train", "denoise"):
         sp = sub.add_parser(name, description="%s (not part of this build)" % name, add_help=True)
         sp.add_argument("rest", nargs=argparse.REMAINDER)
         sp.set_defaults(func=_not_in_this_build(name))

@@ -129,10 +129,12 @@ class FeatureExtractor(object):
             info_len, read_off, read_len = info_len[keep], read_off[keep], read_len[keep]
         return site_read, site_loc, info, row_off, info_len, read_off, read_len
 
-    def extract(self, reads, first_read_uid=0, stream=None):
-        """reads: sequence of reads.ReadRecord -> ExtractedBatch (sites in read order, then position order)."""
+    def extract(self, reads, first_read_uid=0, stream=None, read_uids=None, f64=False):
+        """reads: sequence of reads.ReadRecord -> ExtractedBatch (sites in read order, then position order).
+        read_uids (default first_read_uid + index): 64-bit keys of the subsampler, one per read.
+        f64=True: means / stds / signals as float64 (what the feature TSV prints) instead of the float32 the model eats."""
         torch = self.torch
-        uid_of = {id(r): first_read_uid + i for i, r in enumerate(reads)}
+        uid_of = {id(r): (read_uids[i] if read_uids is not None else first_read_uid + i) for i, r in enumerate(reads)}
         reads, rg_lo, rg_hi = self._select_reads(reads)
         R = len(reads)
         out = ExtractedBatch()
@@ -182,17 +184,18 @@ class FeatureExtractor(object):
             batch = ReadBatchC(R, int(raw_off[-1]), E, d_raw.data_ptr(), d_raw_off.data_ptr(), d_scaling.data_ptr(),
                                d_offset.data_ptr(), d_ev_start.data_ptr(), d_ev_len.data_ptr(), d_ev_base.data_ptr(),
                                d_ev_off.data_ptr())
-            f64 = dict(dtype=torch.float64, device=dev)
-            shift, scale = torch.empty(R, **f64), torch.empty(R, **f64)
-            base_mean, base_std = torch.empty(E, **f64), torch.empty(E, **f64)
+            dbl = dict(dtype=torch.float64, device=dev)
+            shift, scale = torch.empty(R, **dbl), torch.empty(R, **dbl)
+            base_mean, base_std = torch.empty(E, **dbl), torch.empty(E, **dbl)
             base_len = torch.empty(E, dtype=torch.int32, device=dev)
             base_lo = torch.empty(E, dtype=torch.int64, device=dev)
             blk_off = torch.empty(R + 1, dtype=torch.int64, device=dev)
             out.kmer = torch.empty((n, self.L), dtype=torch.uint8, device=dev)
-            out.means = torch.empty((n, self.L), dtype=torch.float32, device=dev)
-            out.stds = torch.empty((n, self.L), dtype=torch.float32, device=dev)
+            fdt = torch.float64 if f64 else torch.float32
+            out.means = torch.empty((n, self.L), dtype=fdt, device=dev)
+            out.stds = torch.empty((n, self.L), dtype=fdt, device=dev)
             out.lens = torch.empty((n, self.L), dtype=torch.int32, device=dev)
-            out.signals = torch.empty((n, self.L, self.S), dtype=torch.float32, device=dev)
+            out.signals = torch.empty((n, self.L, self.S), dtype=fdt, device=dev)
             out.shift, out.scale = shift, scale
             if R:
                 L = nat.lib()
@@ -204,12 +207,12 @@ class FeatureExtractor(object):
                 if n:
                     d_site_read, d_site_loc = up("site_read", site_read, torch.int32), up("site_loc", site_loc, torch.int32)
                     d_uid = up("uid", np.array([uid_of[id(r)] for r in reads], np.uint64).view(np.int64), torch.int64)
-                    nat.check(L.dsp_extract_gather(sp, ctypes.byref(batch), ptr(shift), ptr(scale), ptr(base_mean),
-                                                   ptr(base_std), ptr(base_len), ptr(base_lo), n, ptr(d_site_read),
-                                                   ptr(d_site_loc), self.L, self.S, int(self.round_stats),
-                                                   ctypes.c_uint64(self.seed & ((1 << 64) - 1)), ptr(d_uid),
-                                                   ptr(out.kmer), ptr(out.means), ptr(out.stds), ptr(out.lens),
-                                                   ptr(out.signals)))
+                    gather = L.dsp_extract_gather_f64 if f64 else L.dsp_extract_gather
+                    nat.check(gather(sp, ctypes.byref(batch), ptr(shift), ptr(scale), ptr(base_mean),
+                                     ptr(base_std), ptr(base_len), ptr(base_lo), n, ptr(d_site_read),
+                                     ptr(d_site_loc), self.L, self.S, int(self.round_stats),
+                                     ctypes.c_uint64(self.seed & ((1 << 64) - 1)), ptr(d_uid),
+                                     ptr(out.kmer), ptr(out.means), ptr(out.stds), ptr(out.lens), ptr(out.signals)))
                     # the inputs must outlive the asynchronous kernels
                     for t in (d_raw, d_raw_off, d_ev_off, d_scaling, d_offset, d_ev_start, d_ev_len, d_ev_base,
                               base_mean, base_std, base_len, base_lo, blk_off, d_site_read, d_site_loc, d_uid):
@@ -218,3 +221,131 @@ class FeatureExtractor(object):
             ev.record(st)
             self._stage["_event"] = ev
         return out
+
+
+# ---- `deepsignal_plant extract` (extract_features.py:589-651, :654-767) ---------------------------------------------
+def extract_features(args):
+    """Reads in (a directory of *.fast5 [needs h5py] / *.reads.npz), feature rows out: the reference's `extract`.
+    Output: the feature TSV (plain / --gzip / --w_is_dir batches, byte-compatible with _features_to_str), or the
+    binary container when --write_path ends with .dspf (what call_mods reads fastest)."""
+    import gzip
+    import os
+    import queue
+    import threading
+    import time
+    import torch
+    from . import featfile
+    from . import reads as dsp_reads
+    from .utils.process_utils import get_contig2len, str2bool
+    print("[main] extract_features starts..")
+    start = time.time()
+    if not os.path.isdir(args.fast5_dir):
+        raise ValueError("--fast5_dir is not a directory!")  # :598-599
+    if not torch.cuda.is_available():
+        raise RuntimeError("no MI355X visible: this build has no CPU path")
+    files = dsp_reads.list_read_files(os.path.abspath(args.fast5_dir), str2bool(args.recursively))
+    print("%d read files in total.." % len(files))
+    chrom2len = get_contig2len(args.reference_path) if args.reference_path else None
+    positions = _read_position_file(args.positions) if args.positions else None
+    nthreads = min(max(1, args.nproc), os.cpu_count() or 1)
+    to_dspf = args.write_path.endswith(".dspf")
+    fx = FeatureExtractor(motifs=args.motifs, mod_loc=args.mod_loc, seq_len=args.seq_len, signal_len=args.signal_len,
+                          normalize_method=args.normalize_method, chrom2len=chrom2len, positions=positions,
+                          region=args.region, methy_label=args.methy_label, is_dna=str2bool(args.is_dna), device=0,
+                          seed=getattr(args, "seed", 0), round_stats=True, nthreads=nthreads)
+    batch_reads = max(1, int(args.f5_batch_size)) * 8
+    rq = queue.Queue(maxsize=3)
+    failed = [0]
+
+    def load():
+        cur, uids = [], []
+        try:
+            for fi, f in enumerate(files):
+                try:
+                    got = dsp_reads.load_read_file(f, args.corrected_group, args.basecall_subgroup)
+                except Exception:
+                    failed[0] += 1
+                    continue
+                cur += got
+                uids += [(fi << 20) + i for i in range(len(got))]
+                if len(cur) >= batch_reads:
+                    rq.put((cur, uids))
+                    cur, uids = [], []
+            if cur:
+                rq.put((cur, uids))
+        finally:
+            rq.put(None)
+    threading.Thread(target=load, daemon=True).start()
+
+    is_dir, is_gzip = str2bool(args.w_is_dir), args.gzip
+    n_rows, file_count, batch_count = 0, 0, 0
+    writer = wf = None
+    if to_dspf:
+        writer = featfile.FeatureFileWriter(args.write_path, args.seq_len, args.signal_len)
+    else:
+        op = (lambda p: gzip.open(p, "wb", compresslevel=4)) if is_gzip else (lambda p: open(p, "wb"))
+        if is_dir:  # :474-510
+            if os.path.isfile(args.write_path):
+                raise FileExistsError("{} already exists as a file, please use another write_dir".format(args.write_path))
+            os.makedirs(args.write_path, exist_ok=True)
+            wf = op(os.path.join(args.write_path, "0.tsv" + (".gz" if is_gzip else "")))
+        else:  # :451-471
+            path = args.write_path + (".gz" if is_gzip and not args.write_path.endswith(".gz") else "")
+            wf = op(path)
+    try:
+        while True:
+            item = rq.get()
+            if item is None:
+                break
+            out = fx.extract(item[0], read_uids=item[1], f64=not to_dspf)
+            if out.n == 0:
+                continue
+            rows = out.to_host()
+            if to_dspf:
+                writer.add(rows)
+            else:
+                if is_dir and batch_count >= args.w_batch_num:
+                    wf.close()
+                    file_count += 1
+                    batch_count = 0
+                    wf = op(os.path.join(args.write_path, "%d.tsv%s" % (file_count, ".gz" if is_gzip else "")))
+                wf.write(textio.format_feature_rows(rows, rows.means, rows.stds, rows.signals, nthreads=nthreads))
+                batch_count += 1
+            n_rows += out.n
+    finally:
+        if writer is not None:
+            writer.close()
+        if wf is not None:
+            wf.close()
+    print("%d of %d read files failed.." % (failed[0], len(files)))
+    print("[main] extract_features costs %.1f seconds.. (%d feature rows)" % (time.time() - start, n_rows))
+    return n_rows
+
+
+def add_extract_args(p):
+    """The reference's `extract` flags (extract_features.py:654-745) + --seed of the subsampler."""
+    g = p.add_argument_group("INPUT")
+    g.add_argument("--fast5_dir", "-i", type=str, required=True, help="directory of read files (*.fast5 [needs h5py] / *.reads.npz)")
+    g.add_argument("--recursively", "-r", type=str, default="yes")
+    g.add_argument("--corrected_group", type=str, default="RawGenomeCorrected_000")
+    g.add_argument("--basecall_subgroup", type=str, default="BaseCalled_template")
+    g.add_argument("--is_dna", type=str, default="yes")
+    g.add_argument("--reference_path", type=str, default=None, help="reference .fa (only its contig lengths are used)")
+    g = p.add_argument_group("EXTRACTION")
+    g.add_argument("--normalize_method", type=str, choices=["mad", "zscore"], default="mad")
+    g.add_argument("--methy_label", type=int, choices=[1, 0], default=1)
+    g.add_argument("--seq_len", type=int, default=13)
+    g.add_argument("--signal_len", type=int, default=16)
+    g.add_argument("--motifs", type=str, default="CG")
+    g.add_argument("--mod_loc", type=int, default=0)
+    g.add_argument("--region", type=str, default=None)
+    g.add_argument("--positions", type=str, default=None)
+    g.add_argument("--seed", type=int, default=0, help="seed of the deterministic subsampler of bases longer than --signal_len")
+    g = p.add_argument_group("OUTPUT")
+    g.add_argument("--write_path", "-o", type=str, required=True, help="feature file to write (.dspf = binary container)")
+    g.add_argument("--w_is_dir", type=str, default="no")
+    g.add_argument("--w_batch_num", type=int, default=200)
+    g.add_argument("--gzip", action="store_true", default=False)
+    p.add_argument("--nproc", "-p", type=int, default=10, help="host threads")
+    p.add_argument("--f5_batch_size", type=int, default=30)
+    return p

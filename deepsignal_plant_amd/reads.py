@@ -88,3 +88,52 @@ def from_fast5(path, corrected_group="RawGenomeCorrected_000", basecall_subgroup
                           s(al["mapped_chrom"]), int(al["mapped_start"]), signal, ch["range"] / ch["digitisation"],
                           ch["offset"], ev["start"].astype(np.int64) + int(rel), ev["length"].astype(np.int64),
                           np.frombuffer(b"".join(ev["base"]), np.uint8))
+
+
+# ---- read-record container (.reads.npz): the HDF5-free interchange of this build ------------------------------------
+def save_reads(path, reads):
+    """Write reads as one npz: arrays back to back + CSR offsets + string arrays.  Any tool that can open fast5
+    files can produce this (the fields are ReadRecord's); `load_reads` restores the list."""
+    off = lambda xs: np.concatenate([[0], np.cumsum(xs)]).astype(np.int64)
+    cat = lambda xs, dt: (np.concatenate(xs).astype(dt) if len(xs) else np.zeros(0, dt))
+    np.savez_compressed(
+        path if path.endswith(".npz") else path + ".npz",
+        raw=cat([r.raw for r in reads], np.int16), raw_off=off([len(r.raw) for r in reads]),
+        ev_start=cat([r.ev_start for r in reads], np.int64), ev_len=cat([r.ev_len for r in reads], np.int64),
+        ev_base=cat([r.ev_base for r in reads], np.uint8), ev_off=off([len(r.ev_base) for r in reads]),
+        scaling=np.array([r.scaling for r in reads], np.float64), offset=np.array([r.offset for r in reads], np.float64),
+        chrom_start=np.array([r.chrom_start for r in reads], np.int64),
+        readname=np.array([r.readname for r in reads]), chrom=np.array([r.chrom for r in reads]),
+        strand=np.array([r.strand for r in reads]), alignstrand=np.array([r.alignstrand for r in reads]))
+
+
+def load_reads(path):
+    with np.load(path, allow_pickle=False) as d:
+        ro, eo = d["raw_off"], d["ev_off"]
+        raw, es, el, eb = d["raw"], d["ev_start"], d["ev_len"], d["ev_base"]
+        return [ReadRecord(str(d["readname"][i]), str(d["strand"][i]), str(d["alignstrand"][i]), str(d["chrom"][i]),
+                           int(d["chrom_start"][i]), raw[ro[i]:ro[i + 1]], float(d["scaling"][i]), float(d["offset"][i]),
+                           es[eo[i]:eo[i + 1]], el[eo[i]:eo[i + 1]], eb[eo[i]:eo[i + 1]])
+                for i in range(len(ro) - 1)]
+
+
+def list_read_files(input_dir, recursive=True):
+    """*.fast5 (needs h5py) and *.reads.npz under a directory, sorted (the reference's get_fast5s walks the tree for
+    *.fast5, utils/process_utils.py:148-161)."""
+    import os
+    found = []
+    if recursive:
+        for root, _dirs, files in os.walk(os.path.abspath(input_dir)):
+            found += [os.path.join(root, f) for f in files if f.endswith(".fast5") or f.endswith(".reads.npz")]
+    else:
+        found = [os.path.join(os.path.abspath(input_dir), f) for f in os.listdir(input_dir)
+                 if f.endswith(".fast5") or f.endswith(".reads.npz")]
+    return sorted(found)
+
+
+def load_read_file(path, corrected_group="RawGenomeCorrected_000", basecall_subgroup="BaseCalled_template"):
+    """-> list of ReadRecord.  A fast5 that cannot be parsed raises; the caller counts it as failed like the
+    reference (extract_features.py:373-375)."""
+    if path.endswith(".reads.npz"):
+        return load_reads(path)
+    return [from_fast5(path, corrected_group, basecall_subgroup)]

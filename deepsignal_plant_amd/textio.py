@@ -103,3 +103,27 @@ def format_calls(rows, probs, labels, nthreads=4, start=0, stop=None):
                                    _ptr(out), cap, int(nthreads))
     k = nat.check(int(k))
     return out[:k].tobytes()
+
+
+def format_feature_rows(rows, means, stds, signals, nthreads=4):
+    """bytes of the feature-TSV rows (extract_features.py:381-395) for `rows` (sampleinfo, kmer, lens, labels from
+    the ParsedRows; means / stds / signals as the float64 values the row prints)."""
+    n = rows.n
+    if n <= 0:
+        return b""
+    L, S = rows.seq_len, rows.signal_len
+    means = np.ascontiguousarray(means, np.float64)
+    stds = np.ascontiguousarray(stds, np.float64)
+    signals = np.ascontiguousarray(signals, np.float64)
+    kmer = np.ascontiguousarray(rows.kmer, np.uint8)
+    lens = np.ascontiguousarray(rows.lens, np.int32)
+    labels = np.ascontiguousarray(rows.labels, np.int32)
+    assert means.shape == (n, L) and stds.shape == (n, L) and signals.shape == (n, L, S)
+    cap = int(rows.info_len[:n].sum()) + n * (L + 16 + L * 2 * 26 + L * 12 + L * S * 26)
+    out = np.empty(cap, np.uint8)
+    tp, _, _keep = _buf_ptr(rows.text)
+    k = nat.lib().dsp_format_feature_rows(tp, _ptr(rows.row_off[:n]), _ptr(rows.info_len[:n]), _ptr(kmer), _ptr(means),
+                                          _ptr(stds), _ptr(lens), _ptr(signals), _ptr(labels), L, S, n, _ptr(out), cap,
+                                          int(nthreads))
+    k = nat.check(int(k))
+    return out[:k].tobytes()

@@ -230,6 +230,23 @@ int32_t dsp_extract_gather(void* stream, const dsp_read_batch* b, const double* 
                            int32_t seq_len, int32_t signal_len, int32_t round_stats, uint64_t seed,
                            const uint64_t* read_uid, uint8_t* kmer, float* means, float* stds, int32_t* lens,
                            float* signals);
+/* The same gather with float64 outputs: the values the feature TSV prints (_features_to_str, :381-395, prints
+ * doubles; use round_stats = 1).  Feeds dsp_format_feature_rows. */
+int32_t dsp_extract_gather_f64(void* stream, const dsp_read_batch* b, const double* shift, const double* scale,
+                               const double* base_mean, const double* base_std, const int32_t* base_len,
+                               const int64_t* base_lo, int64_t n_sites, const int32_t* site_read,
+                               const int32_t* site_loc, int32_t seq_len, int32_t signal_len, int32_t round_stats,
+                               uint64_t seed, const uint64_t* read_uid, uint8_t* kmer, double* means, double* stds,
+                               int32_t* lens, double* signals);
+/* HOST: the feature-TSV rows of _features_to_str (extract_features.py:381-395) for n sites:
+ *   sampleinfo \t k-mer \t means(csv) \t stds(csv) \t lens(csv) \t signals(';'-separated csv groups) \t label \n
+ * with every float64 printed like str(numpy.float64) (shortest round-trip digits, positional for
+ * 1e-4 <= |x| < 1e16, else scientific with a two-digit exponent).  Returns the bytes written, DSP_ENOMEM if
+ * out_cap is too small. */
+int64_t dsp_format_feature_rows(const char* text, const uint64_t* row_off, const uint32_t* info_len, const uint8_t* kmer,
+                                const double* means, const double* stds, const int32_t* lens, const double* signals,
+                                const int32_t* labels, int32_t seq_len, int32_t signal_len, int64_t n, char* out,
+                                size_t out_cap, int32_t nthreads);
 /* HOST side of the same stage: motif sites of every read (get_refloc_of_methysite_in_motif,
  * utils/process_utils.py:97-112), the +/- strand coordinates and window bounds of _extract_features
  * (:346-358) and the per-read region bounds [rg_lo, rg_hi) (NULL = no region).  All pointers are HOST pointers.

@@ -107,7 +107,8 @@ def motif_sites(seq, motifset, methyloc=0):
 
 
 def extract_features(reads, normalize_method, motif_seqs, methyloc, chrom2len, kmer_len, signals_len, methy_label,
-                     positions=None, regioninfo=(None, None, None), sampler="python", seed=0, first_read_uid=0):
+                     positions=None, regioninfo=(None, None, None), sampler="python", seed=0, first_read_uid=0,
+                     read_uids=None):
     """reads: iterable of objects with the ReadRecord attributes (deepsignal_plant_amd/reads.py documents them;
     only attribute access is used).  Returns the reference's features_list (tuples, :370-372)."""
     if kmer_len % 2 == 0:
@@ -146,7 +147,8 @@ def extract_features(reads, normalize_method, motif_seqs, methyloc, chrom2len, k
             lens = [len(x) for x in k_signals]
             means = [np.mean(x) for x in k_signals]
             stds = [np.std(x) for x in k_signals]
-            rect = get_signals_rect(k_signals, signals_len, sampler, seed, first_read_uid + ridx, loc - nb)
+            uid = read_uids[ridx] if read_uids is not None else first_read_uid + ridx
+            rect = get_signals_rect(k_signals, signals_len, sampler, seed, uid, loc - nb)
             out.append((chrom, pos, alignstrand, pos_in_strand, rd.readname, rd.strand, k_mer, means, stds, lens,
                         rect, methy_label))
     return out

@@ -58,3 +58,38 @@ def test_unknown_base_in_a_window_is_rejected():
     ev_off = np.array([0, rd.ev_base.shape[0]], np.int64)
     with pytest.raises(ValueError, match="not in the alphabet"):
         fx._sites([rd], rd.ev_base, ev_off, np.zeros(1, np.int64), np.zeros(1, np.int64))
+
+
+def test_feature_row_formatter_reproduces_the_reference_rows():
+    """dsp_format_feature_rows on the float64 features of F6 == the reference's _features_to_str, byte for byte"""
+    import ctypes
+    from deepsignal_plant_amd import _native as nat, textio
+    from tests.test_extract_oracle import F6
+    for c in CASES:
+        g = lambda k: F6["%s/%s" % (c["name"], k)]
+        n = int(g("n_sites"))
+        rows = textio.ParsedRows()
+        info = "".join(g("info").tolist()).encode()
+        lens_info = np.array([len(s.encode()) for s in g("info").tolist()], np.uint32)
+        rows.text, rows.n, rows.seq_len, rows.signal_len = np.frombuffer(info, np.uint8), n, c["k"], c["s"]
+        rows.info_len = lens_info
+        rows.row_off = np.concatenate([[0], np.cumsum(lens_info)[:-1]]).astype(np.uint64)
+        code = {ch: i for i, ch in enumerate("ACGTNWSMKRYBVDHZ")}
+        rows.kmer = np.array([[code[ch] for ch in k] for k in g("kmer").tolist()], np.uint8)
+        rows.lens, rows.labels = g("lens").astype(np.int32), g("labels").astype(np.int32)
+        # the row prints means/stds rounded to 6 decimals, signals as they are
+        got = textio.format_feature_rows(rows, np.around(g("means"), 6), np.around(g("stds"), 6), g("signals"), nthreads=3)
+        assert got.decode().splitlines() == g("rows").tolist()
+    # float64 -> str corner cases against numpy itself
+    L = nat.lib()
+    L.dsp_format_f64_.restype = ctypes.c_int
+    L.dsp_format_f64_.argtypes = [ctypes.c_double, ctypes.c_char_p]
+    buf = ctypes.create_string_buffer(64)
+    rng = np.random.default_rng(0)
+    vals = [0.0, -0.0, 1.0, -1.5, 1e-4, 9.999e-5, 1e-5, 1.5e-7, 123456.789, 1e15, 1e16, 1.2345e17, 5e-324, 1.7976931348623157e308,
+            0.1, 0.30000000000000004, 2.5e-05, float("nan"), float("inf"), -float("inf"), 1e22, 123456789012345680.0]
+    vals += list(np.around(rng.normal(size=3000) * rng.choice([1e-3, 1, 30], size=3000), 6))
+    vals += list(rng.normal(size=2000) * 10.0 ** rng.integers(-12, 20, size=2000))
+    for v in vals:
+        k = L.dsp_format_f64_(float(v), buf)
+        assert buf.raw[:k].decode() == str(np.float64(v)), (v, buf.raw[:k], str(np.float64(v)))

@@ -184,3 +184,112 @@ def test_cli_binary_feature_container_gives_the_same_calls_as_the_tsv(tmp_path):
     open(bad, "wb").write(open(packed, "rb").read()[:5000])
     r = _run_cli(["-i", bad, "-m", ck, "-o", out])
     assert r.returncode != 0 and "dsp_feat_open" in r.stderr and "truncated" in r.stderr
+
+
+def test_cli_directory_of_reads_extracts_on_the_gpu_and_calls(tmp_path):
+    """call_mods -i <dir of read records> (the reference's fast5 branch, call_modifications.py:559-583): features
+    extracted on the GPU (unrounded means/stds, like :285-325) -> forward -> calls.  Expected = oracle extraction
+    of the same reads -> the same model -> the formatter; also 2 ranks == 1 rank."""
+    import socket
+    import torch
+    from deepsignal_plant_amd import reads as R, textio
+    from deepsignal_plant_amd.models import ModelBiLSTM
+    from oracle import extract_np as ox
+    from oracle import forward_np as onp
+    ck = _ckpt(tmp_path)
+    rs = R.synth_reads(9, seed=61, mean_bases=260)
+    d = tmp_path / "reads"
+    (d / "sub").mkdir(parents=True)
+    R.save_reads(str(d / "a.reads.npz"), rs[:4])
+    R.save_reads(str(d / "b.reads.npz"), rs[4:5])
+    R.save_reads(str(d / "sub" / "c.reads.npz"), rs[5:])
+    (d / "broken.fast5").write_bytes(b"not hdf5")  # counted as failed, like an unreadable fast5
+    fa = tmp_path / "ref.fa"
+    fa.write_text(">chr1\n" + "A" * 60 + "\n>chr2\n" + "C" * 50 + "\n")
+    out = str(tmp_path / "calls.tsv")
+    r = _run_cli(["-i", str(d), "-m", ck, "-o", out, "--init_state", "zeros", "--seed", "4", "--reference_path", str(fa),
+                  "--motifs", "CG", "--f5_batch_size", "1"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "1 of 4 read files failed" in r.stdout
+    # expected
+    # sorted file order: a (reads 0-3), b (read 4), broken.fast5, sub/c (reads 5-8); uid = (file index << 20) + i
+    uids = [(0 << 20) + i for i in range(4)] + [1 << 20] + [(3 << 20) + i for i in range(4)]
+    feats = ox.extract_features(rs, "mad", ["CG"], 0, {"chr1": 60, "chr2": 50}, 13, 16, 1, sampler="hash", seed=4,
+                                read_uids=uids)
+    arr = ox.features_to_arrays(feats, 13, 16, round_stats=False)
+    model = ModelBiLSTM(init_state="zeros")
+    w = onp.make_weights(onp.OracleConfig(), 23, 2.0)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    model.cuda(0)
+    t = lambda a: torch.from_numpy(a).cuda()
+    _, probs, labels = model.forward(t(arr["kmer"]), t(arr["means"]), t(arr["stds"]), t(arr["lens"]), t(arr["signals"]),
+                                     want_labels=True)
+    text = ("\n".join(ox.features_to_str(f) for f in feats) + "\n").encode()
+    rows = textio.parse_rows(text, 13, 16)  # only for sampleinfo + k-mers of the expected lines
+    want = textio.format_calls(rows, probs.cpu().numpy(), labels.cpu().numpy())
+    got = open(out, "rb").read()
+    assert got == want and len(feats) > 100
+    # 2 ranks, files dealt in contiguous ranges
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    two = str(tmp_path / "calls2.tsv")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), "-m", "deepsignal_plant_amd.deepsignal_plant", "call_mods",
+           "-i", str(d), "-m", ck, "-o", two, "--init_state", "zeros", "--seed", "4", "--reference_path", str(fa)]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got2 = open(two, "rb").read()
+    assert sorted(got2.splitlines()) == sorted(want.splitlines())
+
+
+def test_extract_cli_writes_the_reference_rows_and_the_binary_container(tmp_path):
+    """deepsignal_plant extract: TSV rows == the oracle's _features_to_str rows (same sampler keys), the --w_is_dir /
+    --gzip flavours hold the same rows, and the .dspf output parses to exactly what the TSV parses to"""
+    from deepsignal_plant_amd import featfile, reads as R, textio
+    from oracle import extract_np as ox
+    rs = R.synth_reads(7, seed=71, mean_bases=240)
+    d = tmp_path / "reads"
+    d.mkdir()
+    R.save_reads(str(d / "a.reads.npz"), rs[:3])
+    R.save_reads(str(d / "b.reads.npz"), rs[3:])
+    uids = [i for i in range(3)] + [(1 << 20) + i for i in range(4)]
+    pos_file = tmp_path / "pos.tsv"
+
+    def run(extra, out):
+        cmd = [sys.executable, "-m", "deepsignal_plant_amd.deepsignal_plant", "extract", "-i", str(d), "-o", out,
+               "--seed", "6", "--f5_batch_size", "1", "-p", "3"] + extra
+        r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return r
+    for method, motifs, k, s in (("mad", "CG", 13, 16), ("zscore", "CHG", 9, 12)):
+        feats = ox.extract_features(rs, method, __import__("deepsignal_plant_amd.utils.process_utils", fromlist=["x"]).get_motif_seqs(motifs),
+                                    0, None, k, s, 0, sampler="hash", seed=6, read_uids=uids)
+        want = [ox.features_to_str(f) for f in feats]
+        out = str(tmp_path / ("f_%s.tsv" % method))
+        flags = ["--normalize_method", method, "--motifs", motifs, "--seq_len", str(k), "--signal_len", str(s), "--methy_label", "0"]
+        r = run(flags, out)
+        assert "0 of 2 read files failed" in r.stdout
+        assert open(out).read().splitlines() == want and len(want) > 50
+        # gzip
+        run(flags + ["--gzip"], out)
+        assert gzip.open(out + ".gz", "rt").read().splitlines() == want
+        # directory of batches
+        ddir = str(tmp_path / ("dir_%s" % method))
+        run(flags + ["--w_is_dir", "yes", "--w_batch_num", "1"], ddir)
+        names = sorted(os.listdir(ddir), key=lambda x: int(x.split(".")[0]))
+        assert len(names) >= 1 and sum((open(os.path.join(ddir, f)).read().splitlines() for f in names), []) == want
+        # binary container == what the TSV parses to
+        packed = str(tmp_path / ("f_%s.dspf" % method))
+        run(flags, packed)
+        rows = textio.parse_rows(open(out, "rb").read(), k, s)
+        with featfile.FeatureFile(packed) as ff:
+            assert (ff.seq_len, ff.signal_len, ff.n_rows) == (k, s, rows.n)
+            got = ff.read_block(0)[0]
+        for key in ("kmer", "means", "stds", "lens", "signals", "labels"):
+            assert np.array_equal(getattr(got, key), getattr(rows, key)), key
+        assert [got.sampleinfo(i) for i in range(got.n)] == [rows.sampleinfo(i) for i in range(rows.n)]
+    # positions filter
+    first = [w.split("\t") for w in open(str(tmp_path / "f_mad.tsv")).read().splitlines()]
+    pos_file.write_text("".join("%s\t%s\t%s\n" % (w[0], w[1], w[2]) for w in first[::3]))
+    out = str(tmp_path / "f_pos.tsv")
+    run(["--positions", str(pos_file), "--methy_label", "0"], out)
+    assert open(out).read().splitlines() == ["\t".join(w) for w in first[::3]]
