@@ -227,28 +227,15 @@ def _call_mods_reads(args, rank, local_rank, world):
     writer = _Writer(part_path, args.gzip, nthreads, _NoRelease(), freq)
     writer.start()
 
-    # loader thread: files -> batches of reads (HDF5 / npz decoding overlaps the GPU work)
-    batch_reads = max(1, int(args.f5_batch_size)) * 8
+    # loader: files -> batches of reads, decoded by a thread pool ahead of the GPU work
+    batches = dsp_reads.ReadBatches(files, max(1, int(args.f5_batch_size)) * 8, args.corrected_group,
+                                    args.basecall_subgroup, first_file_index=lo, workers=min(8, nthreads))
     rq = queue.Queue(maxsize=3)
-    failed = [0]
 
     def load():
-        cur, uids = [], []
         try:
-            for fi, f in enumerate(files):
-                try:
-                    got = dsp_reads.load_read_file(f, args.corrected_group, args.basecall_subgroup)
-                except Exception:
-                    failed[0] += 1  # like the reference: count and go on (extract_features.py:373-375)
-                    continue
-                cur += got
-                # the sampler key of a read = (global file index, index in file): independent of batching and ranks
-                uids += [((lo + fi) << 20) + i for i in range(len(got))]
-                if len(cur) >= batch_reads:
-                    rq.put((cur, uids))
-                    cur, uids = [], []
-            if cur:
-                rq.put((cur, uids))
+            for item in batches:
+                rq.put(item)
         finally:
             rq.put(None)
     loader = threading.Thread(target=load, daemon=True)
@@ -257,6 +244,8 @@ def _call_mods_reads(args, rank, local_rank, world):
     stream = torch.cuda.current_stream(dev)
     n_rows, k = 0, 0
     ring = [dict(cap=0, ev=None) for _ in range(6)]  # pinned result slots (the writer queue holds at most 4)
+    fwd_chunk = 65536
+    model.reserve(fwd_chunk)
     row_base = rank << 44  # initial-state streams of different ranks never overlap
     while True:
         batch = rq.get()
@@ -268,8 +257,6 @@ def _call_mods_reads(args, rank, local_rank, world):
         n = ext.n
         if n == 0:
             continue
-        model.site_offset = row_base + n_rows
-        _logits, probs, labels = model.forward(ext.kmer, ext.means, ext.stds, ext.lens, ext.signals, want_labels=True)
         slot = ring[k % len(ring)]
         k += 1
         if slot["ev"] is not None:
@@ -280,8 +267,13 @@ def _call_mods_reads(args, rank, local_rank, world):
                         labels=torch.empty((cap,), dtype=torch.uint8, pin_memory=True),
                         kmer=torch.empty((cap, args.seq_len), dtype=torch.uint8, pin_memory=True))
         h_probs, h_labels, h_kmer = slot["probs"], slot["labels"], slot["kmer"][:n]
-        h_probs[:n].copy_(probs, non_blocking=True)
-        h_labels[:n].copy_(labels, non_blocking=True)
+        for a in range(0, n, fwd_chunk):  # forward in chunks of the reserved workspace size
+            b = min(n, a + fwd_chunk)
+            model.site_offset = row_base + n_rows + a
+            _logits, probs, labels = model.forward(ext.kmer[a:b], ext.means[a:b], ext.stds[a:b], ext.lens[a:b],
+                                                   ext.signals[a:b], want_labels=True)
+            h_probs[a:b].copy_(probs, non_blocking=True)
+            h_labels[a:b].copy_(labels, non_blocking=True)
         h_kmer.copy_(ext.kmer, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(stream)
@@ -299,7 +291,7 @@ def _call_mods_reads(args, rank, local_rank, world):
         raise writer.error
     if freq is not None:
         freq.write(args.freq_file, args.freq_sort, args.freq_bed, args.gzip)
-    print("%d of %d read files failed.." % (failed[0], len(files)))  # :440
+    print("%d of %d read files failed.." % (batches.failed, len(files)))  # :440
     return n_rows, part_path, out_path
 
 

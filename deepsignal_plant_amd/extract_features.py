@@ -253,26 +253,14 @@ def extract_features(args):
                           normalize_method=args.normalize_method, chrom2len=chrom2len, positions=positions,
                           region=args.region, methy_label=args.methy_label, is_dna=str2bool(args.is_dna), device=0,
                           seed=getattr(args, "seed", 0), round_stats=True, nthreads=nthreads)
-    batch_reads = max(1, int(args.f5_batch_size)) * 8
+    batches = dsp_reads.ReadBatches(files, max(1, int(args.f5_batch_size)) * 8, args.corrected_group,
+                                    args.basecall_subgroup, workers=min(8, nthreads))
     rq = queue.Queue(maxsize=3)
-    failed = [0]
 
     def load():
-        cur, uids = [], []
         try:
-            for fi, f in enumerate(files):
-                try:
-                    got = dsp_reads.load_read_file(f, args.corrected_group, args.basecall_subgroup)
-                except Exception:
-                    failed[0] += 1
-                    continue
-                cur += got
-                uids += [(fi << 20) + i for i in range(len(got))]
-                if len(cur) >= batch_reads:
-                    rq.put((cur, uids))
-                    cur, uids = [], []
-            if cur:
-                rq.put((cur, uids))
+            for item in batches:
+                rq.put(item)
         finally:
             rq.put(None)
     threading.Thread(target=load, daemon=True).start()
@@ -317,7 +305,7 @@ def extract_features(args):
             writer.close()
         if wf is not None:
             wf.close()
-    print("%d of %d read files failed.." % (failed[0], len(files)))
+    print("%d of %d read files failed.." % (batches.failed, len(files)))
     print("[main] extract_features costs %.1f seconds.. (%d feature rows)" % (time.time() - start, n_rows))
     return n_rows
 

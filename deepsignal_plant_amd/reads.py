@@ -91,12 +91,12 @@ def from_fast5(path, corrected_group="RawGenomeCorrected_000", basecall_subgroup
 
 
 # ---- read-record container (.reads.npz): the HDF5-free interchange of this build ------------------------------------
-def save_reads(path, reads):
+def save_reads(path, reads, compress=True):
     """Write reads as one npz: arrays back to back + CSR offsets + string arrays.  Any tool that can open fast5
     files can produce this (the fields are ReadRecord's); `load_reads` restores the list."""
     off = lambda xs: np.concatenate([[0], np.cumsum(xs)]).astype(np.int64)
     cat = lambda xs, dt: (np.concatenate(xs).astype(dt) if len(xs) else np.zeros(0, dt))
-    np.savez_compressed(
+    (np.savez_compressed if compress else np.savez)(
         path if path.endswith(".npz") else path + ".npz",
         raw=cat([r.raw for r in reads], np.int16), raw_off=off([len(r.raw) for r in reads]),
         ev_start=cat([r.ev_start for r in reads], np.int64), ev_len=cat([r.ev_len for r in reads], np.int64),
@@ -108,13 +108,15 @@ def save_reads(path, reads):
 
 
 def load_reads(path):
-    with np.load(path, allow_pickle=False) as d:
-        ro, eo = d["raw_off"], d["ev_off"]
-        raw, es, el, eb = d["raw"], d["ev_start"], d["ev_len"], d["ev_base"]
-        return [ReadRecord(str(d["readname"][i]), str(d["strand"][i]), str(d["alignstrand"][i]), str(d["chrom"][i]),
-                           int(d["chrom_start"][i]), raw[ro[i]:ro[i + 1]], float(d["scaling"][i]), float(d["offset"][i]),
-                           es[eo[i]:eo[i + 1]], el[eo[i]:eo[i + 1]], eb[eo[i]:eo[i + 1]])
-                for i in range(len(ro) - 1)]
+    with np.load(path, allow_pickle=False) as z:
+        d = {k: z[k] for k in z.files}  # NpzFile re-reads a member on every access: pull each one once
+    ro, eo = d["raw_off"], d["ev_off"]
+    raw, es, el, eb = d["raw"], d["ev_start"], d["ev_len"], d["ev_base"]
+    names, strands, astrands, chroms = (d[k].tolist() for k in ("readname", "strand", "alignstrand", "chrom"))
+    cstart, scaling, offset = d["chrom_start"].tolist(), d["scaling"].tolist(), d["offset"].tolist()
+    return [ReadRecord(names[i], strands[i], astrands[i], chroms[i], cstart[i], raw[ro[i]:ro[i + 1]], scaling[i],
+                       offset[i], es[eo[i]:eo[i + 1]], el[eo[i]:eo[i + 1]], eb[eo[i]:eo[i + 1]])
+            for i in range(len(ro) - 1)]
 
 
 def list_read_files(input_dir, recursive=True):
@@ -137,3 +139,54 @@ def load_read_file(path, corrected_group="RawGenomeCorrected_000", basecall_subg
     if path.endswith(".reads.npz"):
         return load_reads(path)
     return [from_fast5(path, corrected_group, basecall_subgroup)]
+
+
+class ReadBatches(object):
+    """Iterate (reads, uids) batches over a list of read files: files are decoded by a small thread pool (HDF5 / zip
+    decoding releases the GIL) with bounded look-ahead and delivered in FILE ORDER; a file that cannot be parsed is
+    counted in .failed and skipped, like the reference (extract_features.py:373-375).  uid of a read =
+    ((first_file_index + file index) << 20) + index in the file: the key of the subsampler, independent of batching
+    and of how files are dealt to ranks."""
+
+    def __init__(self, files, batch_reads, corrected_group="RawGenomeCorrected_000",
+                 basecall_subgroup="BaseCalled_template", first_file_index=0, workers=4, lookahead=8):
+        self.files, self.batch_reads = list(files), max(1, int(batch_reads))
+        self.cg, self.sg, self.first = corrected_group, basecall_subgroup, int(first_file_index)
+        self.workers, self.lookahead = max(1, int(workers)), max(1, int(lookahead))
+        self.failed = 0
+
+    def _load(self, path):
+        try:
+            return load_read_file(path, self.cg, self.sg)
+        except Exception:
+            return None
+
+    def __iter__(self):
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        cur, uids = [], []
+        with ThreadPoolExecutor(self.workers) as pool:
+            pending = deque()
+            it = iter(enumerate(self.files))
+
+            def refill():
+                while len(pending) < self.lookahead:
+                    nxt = next(it, None)
+                    if nxt is None:
+                        return
+                    pending.append((nxt[0], pool.submit(self._load, nxt[1])))
+            refill()
+            while pending:
+                fi, fut = pending.popleft()
+                got = fut.result()
+                refill()
+                if got is None:
+                    self.failed += 1
+                    continue
+                cur += got
+                uids += [((self.first + fi) << 20) + i for i in range(len(got))]
+                if len(cur) >= self.batch_reads:
+                    yield cur, uids
+                    cur, uids = [], []
+        if cur:
+            yield cur, uids

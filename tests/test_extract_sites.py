@@ -93,3 +93,28 @@ def test_feature_row_formatter_reproduces_the_reference_rows():
     for v in vals:
         k = L.dsp_format_f64_(float(v), buf)
         assert buf.raw[:k].decode() == str(np.float64(v)), (v, buf.raw[:k], str(np.float64(v)))
+
+
+def test_read_container_roundtrip_and_ordered_batches(tmp_path):
+    from deepsignal_plant_amd import reads as R
+    rs = R.synth_reads(10, seed=2, mean_bases=100)
+    d = str(tmp_path)
+    R.save_reads(d + "/a.reads.npz", rs[:3])
+    R.save_reads(d + "/b.reads", rs[3:4], compress=False)  # ".npz" appended
+    R.save_reads(d + "/d.reads.npz", rs[4:])
+    open(d + "/c.fast5", "wb").write(b"junk")  # unreadable (and h5py is absent): counted, skipped
+    files = R.list_read_files(d)
+    assert [f.rsplit("/", 1)[1] for f in files] == ["a.reads.npz", "b.reads.npz", "c.fast5", "d.reads.npz"]
+    back = R.load_reads(files[0])
+    for a, b in zip(back, rs[:3]):
+        assert (a.readname, a.strand, a.alignstrand, a.chrom, a.chrom_start, a.scaling, a.offset) == \
+               (b.readname, b.strand, b.alignstrand, b.chrom, b.chrom_start, b.scaling, b.offset)
+        assert np.array_equal(a.raw, b.raw) and np.array_equal(a.ev_start, b.ev_start)
+        assert np.array_equal(a.ev_len, b.ev_len) and np.array_equal(a.ev_base, b.ev_base)
+    bt = R.ReadBatches(files, 4, first_file_index=5, workers=3, lookahead=2)
+    out = list(bt)
+    assert bt.failed == 1 and [len(x[0]) for x in out] == [4, 6]
+    assert [r.readname for x in out for r in x[0]] == [r.readname for r in rs]
+    assert [u for x in out for u in x[1]] == [(5 << 20) + i for i in range(3)] + [6 << 20] + [(8 << 20) + i for i in range(6)]
+    with pytest.raises(RuntimeError, match="h5py"):
+        R.from_fast5(d + "/c.fast5")
