@@ -184,17 +184,5 @@ def main():
         dist.destroy_process_group()
 
 
-def _non_lstm_flops(model):
-    h, L, c = model.hidden_size, model.seq_len, model.num_classes
-    mac = h * 2 * h + c * h
-    if model.module == "both_bilstm":
-        hs = h // 2
-        hg = h - hs
-        mac += L * hs * 2 * hs + L * hg * 2 * hg
-    else:
-        mac += L * h * 2 * h
-    return 2 * mac
-
-
 if __name__ == "__main__":
     main()

@@ -314,28 +314,54 @@ int64_t dsp_parse_feature_rows(const char* text, size_t len, int32_t seq_len, in
                                int32_t* labels, uint64_t* row_off, uint32_t* info_len, uint32_t* read_off,
                                uint32_t* read_len, int32_t nthreads) {
     if (!text || seq_len < 1 || signal_len < 1 || max_rows < 0) return text_fail(DSP_EINVAL, "bad argument");
-    std::vector<const char*> starts;
-    starts.reserve(len / 1024 + 16);
-    const char* p = text;
-    const char* e = text + len;
-    while (p < e) {
-        const char* nl = find_ch(p, e, '\n');
-        starts.push_back(p);
-        p = nl + 1;
+    // Two parallel phases, no serial scan: the text is cut into one byte range per thread, each range moved to the
+    // next line start; phase 1 counts the rows of every range, phase 2 parses them at their global row index.
+    const char* const e = text + len;
+    int nt = nthreads < 1 ? 1 : nthreads;
+    if ((size_t)nt > len / 4096 + 1) nt = (int)(len / 4096 + 1);
+    std::vector<const char*> cut((size_t)nt + 1);
+    cut[0] = text;
+    cut[nt] = e;
+    for (int t = 1; t < nt; ++t) {
+        const char* p = text + len / nt * t;
+        if (p > text && p[-1] != '\n') {
+            const char* nl = find_ch(p, e, '\n');
+            p = nl < e ? nl + 1 : e;
+        }
+        cut[t] = p < cut[t - 1] ? cut[t - 1] : p;
     }
-    const int64_t n = (int64_t)starts.size();
-    if (n > max_rows) return text_fail(DSP_EINVAL, "buffer holds %lld rows but capacity is %lld", (long long)n, (long long)max_rows);
-    starts.push_back(e + 1);
+    std::vector<int64_t> first((size_t)nt + 1, 0);
+    run_threads(nt, nt, [&](int, int64_t a, int64_t b) {
+        for (int64_t t = a; t < b; ++t) {
+            int64_t n = 0;
+            const char* p = cut[t];
+            const char* ce = cut[t + 1];
+            while (p < ce) {
+                const char* nl = find_ch(p, ce, '\n');
+                ++n;
+                p = nl + 1;
+            }
+            first[t + 1] = n;
+        }
+    });
+    for (int t = 0; t < nt; ++t) first[t + 1] += first[t];
+    const int64_t n = first[nt];
+    if (n > max_rows) return text_fail(DSP_ENOMEM, "buffer holds %lld rows but capacity is %lld", (long long)n, (long long)max_rows);
     RowOut o{kmer, means, stds, lens, signals, labels, row_off, info_len, read_off, read_len};
-    std::vector<int64_t> bad_row((size_t)std::max(1, nthreads), -1);
-    std::vector<int> bad_code((size_t)std::max(1, nthreads), 0);
-    run_threads(nthreads, n, [&](int t, int64_t a, int64_t b) {
-        for (int64_t r = a; r < b; ++r) {
-            const char* ls = starts[r];
-            const char* le = starts[r + 1] - 1;  // the '\n' (or end)
-            if (le > e) le = e;
-            const int rc = parse_row(text, ls, le, seq_len, signal_len, r, o);
-            if (rc) { bad_row[t] = r; bad_code[t] = rc; return; }
+    std::vector<int64_t> bad_row((size_t)nt, -1);
+    std::vector<int> bad_code((size_t)nt, 0);
+    run_threads(nt, nt, [&](int, int64_t a, int64_t b) {
+        for (int64_t t = a; t < b; ++t) {
+            int64_t r = first[t];
+            const char* p = cut[t];
+            const char* ce = cut[t + 1];
+            while (p < ce) {
+                const char* nl = find_ch(p, ce, '\n');  // the '\n' (or the end of the range = end of the text)
+                const int rc = parse_row(text, p, nl, seq_len, signal_len, r, o);
+                if (rc) { bad_row[t] = r; bad_code[t] = rc; break; }
+                ++r;
+                p = nl + 1;
+            }
         }
     });
     for (size_t t = 0; t < bad_row.size(); ++t)

@@ -20,7 +20,11 @@ import numpy as np
 from . import dist as dsp_dist
 from . import featfile, textio
 
-BLOCK_BYTES = int(os.environ.get("DSP_BLOCK_BYTES", 0) or (48 << 20))  # ~23k rows of ~2.08 kB per block
+BLOCK_BYTES = int(os.environ.get("DSP_BLOCK_BYTES", 0) or (48 << 20))  # first block: ~23k rows of ~2.08 kB
+# Later blocks are sized to TARGET_ROWS rows from the bytes/row seen so far: 32,768 sites are exactly four full
+# rounds of the LSTM kernels' workgroups on 256 CUs (64 sites x 2 directions per workgroup pair); aiming 2 % low
+# keeps a block from spilling into a fifth round.  DSP_BLOCK_BYTES pins the size instead (tests).
+TARGET_ROWS = 0 if os.environ.get("DSP_BLOCK_BYTES") else int(32768 * 0.98)
 
 
 class Block(object):
@@ -90,10 +94,14 @@ class FeatureReader(threading.Thread):
     # -- producer side
     def _emit(self, data, row0):
         slot = self.free.get()
-        n = textio.count_rows(data)
-        if n > self.cap:  # rows much shorter than expected: grow this slot once (not pinned)
-            slot = textio.alloc_rows(n, self.L, self.S, pinned=False)
-        rows = textio.parse_rows(data, self.L, self.S, nthreads=self.nthreads, out=slot)
+        try:
+            rows = textio.parse_rows(data, self.L, self.S, nthreads=self.nthreads, out=slot)
+        except RuntimeError as e:  # rows much shorter than expected: this block gets its own (unpinned) buffers
+            if "capacity" not in str(e):
+                raise
+            self.free.put(slot)
+            slot = textio.alloc_rows(textio.count_rows(data), self.L, self.S, pinned=False)
+            rows = textio.parse_rows(data, self.L, self.S, nthreads=self.nthreads, out=slot)
         b = Block()
         b.rows, b.first_row, b.slot = rows, row0, slot
         self.q.put(b)
@@ -130,20 +138,26 @@ class FeatureReader(threading.Thread):
         size = os.path.getsize(self.path)
         if size == 0:
             return row
-        with open(self.path, "rb") as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as mm:
-            a, b = self.byte_range if self.byte_range is not None else dsp_dist.byte_range_for_rank(mm, size, self.world, self.rank)
-            pos = a
-            while pos < b:
-                end = min(b, pos + self.block_bytes)
-                if end < b:
-                    nl = mm.rfind(b"\n", pos, end)
-                    if nl < 0:
-                        nl = mm.find(b"\n", end)
-                        nl = b - 1 if nl < 0 else nl
-                    end = min(b, nl + 1)
-                data = mm[pos:end]  # one copy out of the page cache; parsed in place, kept for sampleinfo
-                row += self._emit(data, row)
-                pos = end
+        # the mapping is parsed in place (no copy out of the page cache; the parser threads take the page faults) and
+        # stays referenced by the blocks' sampleinfo views, so it is left to the garbage collector
+        with open(self.path, "rb") as f:
+            mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+        a, b = self.byte_range if self.byte_range is not None else dsp_dist.byte_range_for_rank(mm, size, self.world, self.rank)
+        pos = a
+        while pos < b:
+            end = min(b, pos + self.block_bytes)
+            if end < b:
+                nl = mm.rfind(b"\n", pos, end)
+                if nl < 0:
+                    nl = mm.find(b"\n", end)
+                    nl = b - 1 if nl < 0 else nl
+                end = min(b, nl + 1)
+            data = np.frombuffer(mm, dtype=np.uint8, count=end - pos, offset=pos)
+            n = self._emit(data, row)
+            row += n
+            if TARGET_ROWS and n > 256:
+                self.block_bytes = int(max(1 << 20, (end - pos) / n * min(TARGET_ROWS, 0.95 * self.cap)))
+            pos = end
         return row
 
     def _run_gz(self, row):
