@@ -1,0 +1,232 @@
+// CPU sanitizer harness for the host half of libdsp_amd.so (parser, formatters, feature container, site
+// enumerator, call_freq aggregator): built by tests/test_host_sanitizers.py with -fsanitize=address,undefined and
+// run on the committed fixtures plus mutated / truncated inputs.  It checks invariants, not values (the value
+// checks live in the Python tests); what it is for is memory safety on hostile input.
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "dsp_amd.h"
+
+static std::string g_err;
+extern "C" void dsp_set_error_(const char* msg) { g_err = msg ? msg : ""; }
+extern "C" const char* dsp_last_error(void) { return g_err.c_str(); }
+
+#define CHECK(c) do { if (!(c)) { fprintf(stderr, "CHECK failed %s:%d: %s (last error: %s)\n", __FILE__, __LINE__, #c, g_err.c_str()); exit(1); } } while (0)
+
+static std::string slurp(const char* path) {
+    FILE* f = fopen(path, "rb");
+    CHECK(f != nullptr);
+    std::string s;
+    char buf[1 << 16];
+    size_t k;
+    while ((k = fread(buf, 1, sizeof buf, f)) > 0) s.append(buf, k);
+    fclose(f);
+    return s;
+}
+
+struct Rows {
+    int L, S;
+    int64_t n = 0;
+    std::vector<uint8_t> kmer;
+    std::vector<float> means, stds, signals;
+    std::vector<int32_t> lens, labels;
+    std::vector<uint64_t> row_off;
+    std::vector<uint32_t> info_len, read_off, read_len;
+    Rows(int L_, int S_, int64_t cap) : L(L_), S(S_) {
+        kmer.resize(cap * L); means.resize(cap * L); stds.resize(cap * L); lens.resize(cap * L);
+        signals.resize(cap * L * S); labels.resize(cap); row_off.resize(cap); info_len.resize(cap);
+        read_off.resize(cap); read_len.resize(cap);
+    }
+    int64_t parse(const std::string& text, int nthreads) {
+        // an exact-size heap copy: any read past the end is an ASan report
+        std::vector<char> t(text.begin(), text.end());
+        n = dsp_parse_feature_rows(t.data(), t.size(), L, S, (int64_t)labels.size(), kmer.data(), means.data(), stds.data(),
+                                   lens.data(), signals.data(), labels.data(), row_off.data(), info_len.data(),
+                                   read_off.data(), read_len.data(), nthreads);
+        return n;
+    }
+};
+
+static uint64_t rng_state = 88172645463325252ull;
+static uint64_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return rng_state; }
+
+int main(int argc, char** argv) {
+    CHECK(argc >= 3);
+    const std::string golden = argv[1], tmp = argv[2];
+    const std::string tsv = slurp((golden + "/f2_rows.tsv").c_str());
+    const int64_t nrows = dsp_count_rows(tsv.data(), tsv.size());
+    CHECK(nrows == 200);
+
+    // ---- parser: good input, all thread counts; then truncations and byte mutations (must fail cleanly or parse)
+    Rows rows(13, 16, nrows + 8);
+    for (int nt : {1, 2, 5, 16}) CHECK(rows.parse(tsv, nt) == nrows);
+    CHECK(rows.parse(tsv.substr(0, tsv.size() - 1), 3) == nrows);  // no trailing newline
+    Rows small(13, 16, 10);
+    CHECK(small.parse(tsv, 4) == DSP_ENOMEM);
+    for (int it = 0; it < 300; it++) {
+        std::string m = tsv.substr(0, 200 + rnd() % (tsv.size() - 200));
+        for (int k = 0; k < 1 + (int)(rnd() % 4); k++) m[rnd() % m.size()] = "\t,;\n-e.0A \r\x00\xff"[rnd() % 14];
+        const int64_t r = rows.parse(m, 1 + (int)(rnd() % 4));
+        CHECK(r >= 0 || r == DSP_EPARSE || r == DSP_ENOMEM);
+    }
+    Rows wrong(11, 16, nrows);
+    CHECK(wrong.parse(tsv, 2) == DSP_EPARSE);
+    CHECK(rows.parse(tsv, 4) == nrows);
+
+    // ---- call formatter
+    std::vector<float> probs(nrows * 2);
+    std::vector<uint8_t> labels(nrows);
+    for (int64_t i = 0; i < nrows; i++) {
+        const float p = (float)((rnd() % 2000001) / 2000000.0);
+        probs[2 * i] = p; probs[2 * i + 1] = 1.0f - p; labels[i] = p < 0.5f;
+    }
+    probs[0] = 0.f; probs[1] = 1.f; probs[2] = 1e-7f; probs[3] = 1.f; probs[4] = 0.5f; probs[5] = 0.5f;
+    std::vector<char> out(nrows * 200);
+    const int64_t fb = dsp_format_calls(tsv.data(), rows.row_off.data(), rows.info_len.data(), probs.data(), 2, labels.data(),
+                                        rows.kmer.data(), 13, nrows, out.data(), out.size(), 3);
+    CHECK(fb > 0 && out[fb - 1] == '\n');
+    CHECK(dsp_format_calls(tsv.data(), rows.row_off.data(), rows.info_len.data(), probs.data(), 2, labels.data(),
+                           rows.kmer.data(), 13, nrows, out.data(), 100, 3) == DSP_ENOMEM);
+
+    // ---- feature-row formatter (float64)
+    {
+        std::vector<double> m(nrows * 13), s(nrows * 13), g(nrows * 13 * 16);
+        for (auto& v : m) v = ((int64_t)(rnd() % 4000001) - 2000000) / 1e6;
+        for (auto& v : s) v = (rnd() % 1000001) / 1e6;
+        for (auto& v : g) v = ((int64_t)(rnd() % 8000001) - 4000000) / 1e6;
+        m[0] = 1e-7; m[1] = -0.0; m[2] = 1e22; m[3] = 5e-324; g[0] = 123456789.123456;
+        std::vector<char> o2(nrows * 6000);
+        const int64_t k = dsp_format_feature_rows(tsv.data(), rows.row_off.data(), rows.info_len.data(), rows.kmer.data(),
+                                                  m.data(), s.data(), rows.lens.data(), g.data(), rows.labels.data(), 13, 16,
+                                                  nrows, o2.data(), o2.size(), 4);
+        CHECK(k > 0);
+        // what it writes parses back to the same number of rows
+        Rows back(13, 16, nrows);
+        CHECK(back.parse(std::string(o2.data(), (size_t)k), 3) == nrows);
+        CHECK(dsp_format_feature_rows(tsv.data(), rows.row_off.data(), rows.info_len.data(), rows.kmer.data(), m.data(),
+                                      s.data(), rows.lens.data(), g.data(), rows.labels.data(), 13, 16, nrows, o2.data(), 1000,
+                                      4) == DSP_ENOMEM);
+    }
+
+    // ---- feature container: write (several block sizes), read back, corrupt
+    for (int64_t br : {7, 64, 100000}) {
+        const std::string path = tmp + "/asan.dspf";
+        dsp_feat_writer* w = nullptr;
+        CHECK(dsp_feat_writer_create(path.c_str(), 13, 16, br, &w) == DSP_OK);
+        CHECK(dsp_feat_writer_add(w, nrows, rows.kmer.data(), rows.means.data(), rows.stds.data(), rows.lens.data(),
+                                  rows.signals.data(), rows.labels.data(), tsv.data(), rows.row_off.data(),
+                                  rows.info_len.data(), rows.read_off.data(), rows.read_len.data()) == DSP_OK);
+        CHECK(dsp_feat_writer_add(w, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) == DSP_OK);
+        CHECK(dsp_feat_writer_close(w) == DSP_OK);
+        dsp_feat_file* f = nullptr;
+        CHECK(dsp_feat_open(path.c_str(), &f) == DSP_OK);
+        int32_t L, S; int64_t n, nb;
+        CHECK(dsp_feat_info(f, &L, &S, &n, &nb) == DSP_OK && L == 13 && S == 16 && n == nrows);
+        int64_t seen = 0;
+        for (int64_t b = 0; b < nb; b++) {
+            int64_t bn, first, ib;
+            CHECK(dsp_feat_block_info(f, b, &bn, &first, &ib) == DSP_OK && first == seen);
+            Rows r2(13, 16, bn);
+            std::vector<char> info((size_t)ib + 1);
+            CHECK(dsp_feat_read_block(f, b, bn, r2.kmer.data(), r2.means.data(), r2.stds.data(), r2.lens.data(),
+                                      r2.signals.data(), r2.labels.data(), info.data(), (size_t)ib, r2.row_off.data(),
+                                      r2.info_len.data(), r2.read_off.data(), r2.read_len.data(), 3) == bn);
+            CHECK(memcmp(r2.means.data(), rows.means.data() + seen * 13, (size_t)bn * 13 * 4) == 0);
+            CHECK(dsp_feat_read_block(f, b, bn - 1, r2.kmer.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+                                      nullptr, nullptr, nullptr, nullptr, 1) == DSP_ENOMEM);
+            seen += bn;
+        }
+        CHECK(seen == nrows);
+        CHECK(dsp_feat_block_info(f, nb, nullptr, nullptr, nullptr) == DSP_EINVAL);
+        dsp_feat_close(f);
+        // random corruptions of the file: open/read must fail cleanly or succeed, never crash
+        const std::string blob = slurp(path.c_str());
+        for (int it = 0; it < 60; it++) {
+            std::string m = blob;
+            if (it % 3 == 0) m.resize(rnd() % m.size());
+            else for (int k = 0; k < 8; k++) m[(it % 3 == 1 ? rnd() % 128 : m.size() - 1 - rnd() % 256) % m.size()] = (char)rnd();
+            const std::string p2 = tmp + "/asan_bad.dspf";
+            FILE* fo = fopen(p2.c_str(), "wb"); CHECK(fo); fwrite(m.data(), 1, m.size(), fo); fclose(fo);
+            dsp_feat_file* g = nullptr;
+            if (dsp_feat_open(p2.c_str(), &g) == DSP_OK) {
+                int64_t n2, nb2;
+                dsp_feat_info(g, nullptr, nullptr, &n2, &nb2);
+                for (int64_t b = 0; b < nb2 && b < 4; b++) {
+                    int64_t bn, first, ib;
+                    if (dsp_feat_block_info(g, b, &bn, &first, &ib) != DSP_OK || bn > 1000000 || ib > (1 << 28)) continue;
+                    Rows r2(13, 16, bn);
+                    std::vector<char> info((size_t)ib + 1);
+                    dsp_feat_read_block(g, b, bn, r2.kmer.data(), r2.means.data(), r2.stds.data(), r2.lens.data(),
+                                        r2.signals.data(), r2.labels.data(), info.data(), (size_t)ib, r2.row_off.data(),
+                                        r2.info_len.data(), r2.read_off.data(), r2.read_len.data(), 2);
+                }
+                dsp_feat_close(g);
+            }
+        }
+    }
+
+    // ---- site enumerator
+    {
+        const char* seqs[3] = {"ACGTTCGACGNCGAACGTACGTCGCGCGATATATCGCGACGTTTACGCGAACGCGTTACGACGCGTACGATCGCGAATT", "CG", "TTTTTTTTTTTTTTTTTTTTTTTTTTTT"};
+        std::vector<uint8_t> ev;
+        std::vector<int64_t> off = {0};
+        for (auto s : seqs) { ev.insert(ev.end(), s, s + strlen(s)); off.push_back((int64_t)ev.size()); }
+        const char* chrom[3] = {"chr1", "chrUn_random_2", ""};
+        const char* names[3] = {"read-a", "b", "a-very-long-read-name-0123456789-0123456789-0123456789"};
+        const int64_t cstart[3] = {100, 0, 99999999999ll}, clen[3] = {5000, -1, 100000000000ll};
+        for (int k : {1, 5, 13}) for (int nt : {1, 3}) {
+            size_t need = 0;
+            const int64_t n = dsp_extract_sites(3, ev.data(), off.data(), chrom, names, "tct", "+-+", cstart, clen, nullptr, nullptr,
+                                                "CGCAGCCGCTG", k == 5 ? 1 : 4, k == 5 ? 2 : 3 - (k == 13), 0, k, 0, nullptr, nullptr,
+                                                nullptr, 0, &need, nullptr, nullptr, nullptr, nullptr, nt);
+            CHECK(n >= 0);
+            std::vector<int32_t> sr(n + 1), sl(n + 1);
+            std::vector<char> info(need + 1);
+            std::vector<uint64_t> ro(n + 1);
+            std::vector<uint32_t> il(n + 1), rdo(n + 1), rdl(n + 1);
+            CHECK(dsp_extract_sites(3, ev.data(), off.data(), chrom, names, "tct", "+-+", cstart, clen, nullptr, nullptr,
+                                    "CGCAGCCGCTG", k == 5 ? 1 : 4, k == 5 ? 2 : 3 - (k == 13), 0, k, n, sr.data(), sl.data(),
+                                    info.data(), need, nullptr, ro.data(), il.data(), rdo.data(), rdl.data(), nt) == n);
+            if (n > 0) CHECK(ro[n - 1] + il[n - 1] == need);
+            if (n > 1) CHECK(dsp_extract_sites(3, ev.data(), off.data(), chrom, names, "tct", "+-+", cstart, clen, nullptr, nullptr,
+                                               "CGCAGCCGCTG", k == 5 ? 1 : 4, k == 5 ? 2 : 3 - (k == 13), 0, k, n - 1, sr.data(),
+                                               sl.data(), info.data(), need, nullptr, ro.data(), il.data(), rdo.data(),
+                                               rdl.data(), nt) == DSP_ENOMEM);
+        }
+        CHECK(dsp_extract_sites(3, ev.data(), off.data(), chrom, names, "tct", "+-+", cstart, clen, nullptr, nullptr, "CG", 1, 2, 0,
+                                12, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1) == DSP_EINVAL);
+    }
+
+    // ---- call_freq aggregator on the formatter's own output, on mutated text, and through add_block
+    {
+        dsp_freq* fq = dsp_freq_create(0.1);
+        CHECK(fq != nullptr);
+        CHECK(dsp_freq_add_calls_text(fq, out.data(), (size_t)fb, nullptr) >= 0);
+        CHECK(dsp_freq_add_block(fq, tsv.data(), rows.row_off.data(), rows.info_len.data(), probs.data(), 2, labels.data(),
+                                 rows.kmer.data(), 13, nrows) >= 0);
+        for (int it = 0; it < 200; it++) {
+            std::string m(out.data(), (size_t)fb);
+            m.resize(1 + rnd() % m.size());
+            for (int k = 0; k < 3; k++) m[rnd() % m.size()] = "\t\n-e.9 \r\x00"[rnd() % 9];
+            std::vector<char> t(m.begin(), m.end());
+            dsp_freq_add_calls_text(fq, t.data(), t.size(), it % 5 == 0 ? "chr1" : nullptr);
+        }
+        int64_t c, u, s;
+        dsp_freq_counts(fq, &c, &u, &s);
+        CHECK(c >= u && s >= 0);
+        for (int sort = 0; sort < 2; sort++) for (int bed = 0; bed < 2; bed++) {
+            const int64_t need = dsp_freq_format(fq, sort, bed, nullptr, 0);
+            CHECK(need >= 0);
+            std::vector<char> o3((size_t)need + 1);
+            CHECK(dsp_freq_format(fq, sort, bed, o3.data(), (size_t)need) == need);
+        }
+        dsp_freq_destroy(fq);
+    }
+    printf("host_asan: ok\n");
+    return 0;
+}
