@@ -12,7 +12,7 @@ def find(d, pat):
 
 
 def short(name):
-    return name.split("(")[0][:60]
+    return name.replace("(anonymous namespace)::", "").split("(")[0][:60]
 
 
 def trace(d, out):
