@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 
 BATCH = 65536
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-CPU_BASELINE_TARGET_S = 15.0
+CPU_BASELINE_TARGET_S = float(os.environ.get("DSP_CPU_BASELINE_S", 15.0))  # bounded sample: ~15 s of host work
 
 
 def cpu_baseline(model_cfg_kwargs, sd_numpy, seed):

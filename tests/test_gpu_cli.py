@@ -293,3 +293,26 @@ def test_extract_cli_writes_the_reference_rows_and_the_binary_container(tmp_path
     out = str(tmp_path / "f_pos.tsv")
     run(["--positions", str(pos_file), "--methy_label", "0"], out)
     assert open(out).read().splitlines() == ["\t".join(w) for w in first[::3]]
+
+
+def test_bench_line_keeps_the_driver_contract():
+    """bench.py prints ONE JSON line with the contract's keys, the roofline and (when asked) cpu_baseline objects"""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "8192"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900, env=dict(os.environ, DSP_CPU_BASELINE_S="2"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                 ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                 ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(d[k], t), (k, d[k])
+    assert d["vs_baseline"] is None and d["n_gpus"] == 1 and d["steps"] == 2 and d["scaling"] == "weak" and d["dtype"] == "f32"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert 0.3 < rf["frac"] < 1.0 and "traffic" in rf
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "sites/s" and cb["sample"]
+    assert abs(d["value"] - 2 * 8192 / (d["ms_per_step"] * 2e-3)) / d["value"] < 0.01
