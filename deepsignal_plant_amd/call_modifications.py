@@ -138,6 +138,7 @@ def _call_mods_file(args, rank, local_rank, world):
     reader.start()
     writer.start()
     stream = torch.cuda.current_stream(dev)
+    copy_stream = torch.cuda.Stream(dev)
     nout = 4
     out_probs = [torch.empty((cap, args.class_num), dtype=torch.float32, pin_memory=True) for _ in range(nout)]
     out_labels = [torch.empty((cap,), dtype=torch.uint8, pin_memory=True) for _ in range(nout)]
@@ -160,8 +161,15 @@ def _call_mods_file(args, rank, local_rank, world):
         def dev_t(name):
             src = tt[name][:n] if tt is not None else torch.from_numpy(getattr(rows, name))
             return src.to(dev, non_blocking=True)
-        kmer, means, stds = dev_t("kmer"), dev_t("means"), dev_t("stds")
-        lens, signals = dev_t("lens"), dev_t("signals")
+        # uploads go down their own stream so that block k+1's H2D runs under block k's forward
+        with torch.cuda.stream(copy_stream):
+            kmer, means, stds = dev_t("kmer"), dev_t("means"), dev_t("stds")
+            lens, signals = dev_t("lens"), dev_t("signals")
+            up_done = torch.cuda.Event()
+            up_done.record(copy_stream)
+        stream.wait_event(up_done)
+        for t_in in (kmer, means, stds, lens, signals):
+            t_in.record_stream(stream)
         model.site_offset = block.first_row
         _logits, probs, labels = model.forward(kmer, means, stds, lens, signals, want_labels=True)
         slot = k % nout
