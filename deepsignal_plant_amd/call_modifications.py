@@ -312,8 +312,42 @@ def _merge_parts(out_path, world):
             os.remove(part)
 
 
+def _self_launch(args, argv=None):
+    """The reference starts --nproc_gpu model processes itself and deals them to the visible GPUs round-robin
+    (call_modifications.py:523-529, :613-621).  Here: when call_mods is started plainly (no torch.distributed
+    launcher) on a node with several GPUs and --nproc_gpu > 1, it starts min(nproc_gpu, GPUs) ranks of itself under
+    torch.distributed.run as a CHILD process (nothing has touched the GPU yet in this one) and returns its exit
+    code; None = carry on in this process."""
+    import socket
+    import subprocess
+    import torch
+    if "RANK" in os.environ or "WORLD_SIZE" in os.environ or os.environ.get("DSP_NO_SELF_LAUNCH"):
+        return None
+    n = min(int(getattr(args, "nproc_gpu", 1) or 1), torch.cuda.device_count())  # device_count() does not initialise the GPU
+    if n <= 1:
+        return None
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if argv and argv[0] == "call_mods":
+        argv = argv[1:]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), "-m", "deepsignal_plant_amd.deepsignal_plant", "call_mods"] + argv
+    print("[main] %d GPUs visible, --nproc_gpu %s: starting %d ranks (one per GPU)" % (torch.cuda.device_count(),
+                                                                                     args.nproc_gpu, n))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def call_mods(args):
-    """Main function of calling modifications (mirror of call_modifications.py:532-640, TSV branch)."""
+    """Main function of calling modifications (mirror of call_modifications.py:532-640)."""
+    rc = _self_launch(args)
+    if rc is not None:
+        if rc != 0:
+            raise RuntimeError("call_mods: the multi-GPU child run failed with exit code %d" % rc)
+        return None
     print("[main] call_mods starts..")
     start = time.time()
     import torch
@@ -412,7 +446,8 @@ def add_call_mods_args(p):
     g.add_argument("--reference_path", type=str, default=None)
     p.add_argument("--nproc", "-p", type=int, default=10, help="host threads for parsing/formatting, default 10")
     p.add_argument("--nproc_gpu", type=int, default=2,
-                   help="model processes per run in the reference; this build runs one process per GPU (torch.distributed.run)")
+                   help="model processes in the reference (default 2); here: GPUs to use -- started plainly on a node "
+                        "with several GPUs, call_mods runs min(nproc_gpu, GPUs) ranks of itself, one per GPU")
     g = p.add_argument_group("MI355X build")
     g.add_argument("--init_state", type=str, default="randn", choices=["randn", "zeros"],
                    help="LSTM initial states: 'randn' = N(0,1) like the reference's init_hidden (in-kernel Philox), 'zeros'")

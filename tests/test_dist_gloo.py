@@ -120,3 +120,35 @@ def test_reader_surfaces_parse_errors(tmp_path):
     with pytest.raises(ValueError):
         for _ in rd:
             pass
+
+
+def test_plain_start_on_a_multi_gpu_node_launches_one_rank_per_gpu(monkeypatch):
+    """call_mods started without a launcher: min(--nproc_gpu, visible GPUs) ranks under torch.distributed.run, as a
+    child process (the reference starts its own model processes, call_modifications.py:613-621)"""
+    import argparse
+    import subprocess
+    import sys
+    import torch
+    from deepsignal_plant_amd import call_modifications as cm
+    calls = []
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: calls.append((cmd, env)) or 0)
+    for k in ("RANK", "WORLD_SIZE", "DSP_NO_SELF_LAUNCH"):
+        monkeypatch.delenv(k, raising=False)
+    args = argparse.Namespace(nproc_gpu=4)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    assert cm._self_launch(args, ["call_mods", "-i", "x.tsv", "-o", "y.tsv", "--nproc_gpu", "4"]) == 0
+    cmd, env = calls[-1]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert cmd[-8:] == ["deepsignal_plant_amd.deepsignal_plant", "call_mods", "-i", "x.tsv", "-o", "y.tsv", "--nproc_gpu", "4"]
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    cm._self_launch(args, ["-i", "x.tsv"])
+    assert calls[-1][0][calls[-1][0].index("--nproc-per-node") + 1] == "2"
+    n = len(calls)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    assert cm._self_launch(args, []) is None  # one GPU: stay in this process
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    assert cm._self_launch(argparse.Namespace(nproc_gpu=1), []) is None
+    monkeypatch.setenv("RANK", "0")
+    assert cm._self_launch(args, []) is None  # already under a launcher
+    assert len(calls) == n
