@@ -17,8 +17,12 @@ for _ in range(R): m(*ins)
 torch.cuda.synchronize()
 pr = m.profile_read()
 n = len(pr) // R
-mac = {1: 2*13*4*128*(7+128), 2: 2*13*4*128*(16+128), 5: 2*13*4*256*(256+256), 6: 2*13*4*256*(512+256), 7: 2*13*4*256*(512+256)}
+# algorithmic MACs per site of every launch, in launch order
+macs = [("pack", 0), ("lstm_seq", 2*13*4*128*(7+128)), ("fc_seq", 13*128*256), ("lstm_signal", 2*13*4*128*(16+128)),
+        ("fc_signal", 13*128*256), ("lstm_comb", 2*13*4*256*(256+256)), ("lstm_comb", 2*13*4*256*(512+256)),
+        ("lstm_comb", 2*13*4*256*(512+256)), ("head", 256*512 + 2*256)]
 for i in range(n):
     ms = sum(pr[i + r*n][1] for r in range(R)) / R
-    tf = (" %6.1f TFLOP/s" % (2*mac[i]*B/ms/1e9)) if i in mac else ""
+    name, mac = macs[i] if i < len(macs) and macs[i][0] == pr[i][0] else (pr[i][0], 0)
+    tf = (" %6.1f TFLOP/s" % (2*mac*B/ms/1e9)) if mac else ""
     print("%d %-12s %8.3f ms%s" % (i, pr[i][0], ms, tf))
