@@ -375,6 +375,7 @@ __global__ __launch_bounds__(256) void dsp_ext_base_stats_kernel(dsp_read_batch 
                                                                  const int64_t* blk_off, double* base_mean,
                                                                  double* base_std, int32_t* base_len, int64_t* base_lo) {
     __shared__ PwStack stacks[32];
+    __shared__ double cache[32][32];
     const int64_t blk = blockIdx.x;
     if (blk >= blk_off[b.n_reads]) return;
     int64_t rlo = 0, rhi = b.n_reads;  // last r with blk_off[r] <= blk (uniform: scalar loads)
@@ -396,9 +397,20 @@ __global__ __launch_bounds__(256) void dsp_ext_base_stats_kernel(dsp_read_batch 
         lo = lo < 0 ? 0 : (lo > n_raw ? n_raw : lo);
         hi = hi < lo ? lo : (hi > n_raw ? n_raw : hi);
         const int64_t n = hi - lo;
-        const double mean = np_sum8(nv, lo, n, l8, &stacks[grp]) / (double)n;  // n == 0 -> nan, like np.mean([])
-        auto dev2 = [&](int64_t i) { const double d = nv(i) - mean; return d * d; };
-        const double var = np_sum8(dev2, lo, n, l8, &stacks[grp]) / (double)n;
+        double mean, var;
+        if (n <= 32) {
+            // a short base (one numpy block): every sample is normalised once (two f64 divisions) by the lane that owns it in
+            // both passes, and parked in LDS between the mean and the variance pass
+            double* c = cache[grp];
+            auto first = [&](int64_t i) { const double v = nv(i); c[i - lo] = v; return v; };
+            mean = np_sum8(first, lo, n, l8, &stacks[grp]) / (double)n;  // n == 0 -> nan, like np.mean([])
+            auto dev2 = [&](int64_t i) { const double d = c[i - lo] - mean; return d * d; };
+            var = np_sum8(dev2, lo, n, l8, &stacks[grp]) / (double)n;
+        } else {
+            mean = np_sum8(nv, lo, n, l8, &stacks[grp]) / (double)n;
+            auto dev2 = [&](int64_t i) { const double d = nv(i) - mean; return d * d; };
+            var = np_sum8(dev2, lo, n, l8, &stacks[grp]) / (double)n;
+        }
         if (l8 == 0) {
             base_mean[e] = mean;
             base_std[e] = sqrt(var);
