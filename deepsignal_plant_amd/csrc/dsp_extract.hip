@@ -39,6 +39,11 @@ struct NormView {
         if (scale != 0.0) v = (v - shift) / scale;
         return rint(v * 1e6) / 1e6;
     }
+    __device__ __forceinline__ double of_code(int16_t code) const {  // the same for a DAQ code already in a register
+        double v = rd.scaling * ((double)code + rd.offset);
+        if (scale != 0.0) v = (v - shift) / scale;
+        return rint(v * 1e6) / 1e6;
+    }
 };
 
 // ---- numpy pairwise summation -------------------------------------------------------------------------------
@@ -524,7 +529,9 @@ __global__ __launch_bounds__(256) void dsp_ext_gather_kernel(GatherArgsT<T> a) {
     a.signals[t] = out;
 }
 
-constexpr int kSelWords = 64;  // membership bitset of the subset sampler: bases of up to 2048 samples
+constexpr int kSelWords = 16;  // membership bitset of the subset sampler: bases of up to 512 samples
+constexpr int kLongMax = kSelWords * 32;
+constexpr int kSampleMaxS = 64;  // widest signal_len the sampling pass serves (LDS index columns)
 
 // Fast path for signal_len = 4, 8, ..., 256 (a power of two): S/4 adjacent lanes per (site, base) pair, each lane
 // producing four consecutive samples and storing them as one 16-byte vector.
@@ -548,12 +555,8 @@ __global__ __launch_bounds__(256) void dsp_ext_gather4_kernel(GatherArgs a, int 
         n = a.base_len[e];
         lo = a.base_lo[e];
     }
-    int* sel = sel_lds + pl * S;                                   // sorted sample indices of this pair
-    uint32_t* bits = reinterpret_cast<uint32_t*>(sel_lds + ppb * S) + pl * kSelWords;  // membership bitset, n <= 2048
-    const int nw = (n + 31) >> 5;
-    const bool use_bits = n > S && nw <= kSelWords;
-    if (use_bits)
-        for (int w = sub; w < nw; w += lpp) bits[w] = 0;  // the pair's lanes sit in one wave: LDS order = program order
+    const int long_max = S <= kSampleMaxS ? kLongMax : 0;  // 0: no sampling pass, every long base is drawn here
+    int* sel = sel_lds + pl * S;  // sorted sample indices of this pair (only for bases beyond the sampling pass)
     if (live && sub == 0) {
         a.kmer[pair] = base_code(a.b.ev_base[e]);
         double m = a.base_mean[e], sd = a.base_std[e];
@@ -564,41 +567,24 @@ __global__ __launch_bounds__(256) void dsp_ext_gather4_kernel(GatherArgs a, int 
         a.means[pair] = (float)m;
         a.stds[pair] = (float)sd;
         a.lens[pair] = n;
-        if (n > S) {  // Floyd's subset sampling, as in the generic kernel
+        if (n > long_max) {  // a stall of more than 512 samples (or signal_len > 64): Floyd's subset sampling with a sorted list, O(S^2)
             const uint64_t h = mix64((a.seed ^ (a.read_uid[r] * 0x9E3779B97F4A7C15ull)) + (uint64_t)bi * 0xD1B54A32D192ED03ull);
-            if (use_bits) {
-                for (int q = 0; q < S; q++) {
-                    const int jj = n - S + q;
-                    const uint64_t rnd = mix64(h + (uint64_t)q) >> 32;
-                    int v = (int)((rnd * (uint64_t)(jj + 1)) >> 32);
-                    if (bits[v >> 5] & (1u << (v & 31))) v = jj;
-                    bits[v >> 5] |= 1u << (v & 31);
-                }
-                int c = 0;
-                for (int w = 0; w < nw; w++) {  // set bits in ascending order = the sorted sample
-                    uint32_t x = bits[w];
-                    while (x) {
-                        sel[c++] = (w << 5) + __ffs((int)x) - 1;
-                        x &= x - 1;
-                    }
-                }
-            } else {
-                for (int q = 0; q < S; q++) {
-                    const int jj = n - S + q;
-                    const uint64_t rnd = mix64(h + (uint64_t)q) >> 32;
-                    int v = (int)((rnd * (uint64_t)(jj + 1)) >> 32);
-                    for (int k = 0; k < q; k++)
-                        if (sel[k] == v) { v = jj; break; }
-                    int k = q;
-                    for (; k > 0 && sel[k - 1] > v; k--) sel[k] = sel[k - 1];
-                    sel[k] = v;
-                }
+            for (int q = 0; q < S; q++) {
+                const int jj = n - S + q;
+                const uint64_t rnd = mix64(h + (uint64_t)q) >> 32;
+                int v = (int)((rnd * (uint64_t)(jj + 1)) >> 32);
+                for (int k = 0; k < q; k++)
+                    if (sel[k] == v) { v = jj; break; }
+                int k = q;
+                for (; k > 0 && sel[k - 1] > v; k--) sel[k] = sel[k - 1];
+                sel[k] = v;
             }
         }
     }
     __syncthreads();
     if (!live) return;
     NormView nv = {{a.b.raw + a.b.raw_off[r], 0, a.b.scaling[r], a.b.offset[r]}, a.shift[r], a.scale[r]};
+    if (n > S && n <= long_max) return;  // S < n <= 512: written by dsp_ext_sample_kernel, all lanes busy
     float o[4] = {0.f, 0.f, 0.f, 0.f};
     const int s0 = sub * 4;
     if (n <= S) {
@@ -613,6 +599,88 @@ __global__ __launch_bounds__(256) void dsp_ext_gather4_kernel(GatherArgs a, int 
         for (int i = 0; i < 4; i++) o[i] = (float)nv(lo + sel[s0 + i]);
     }
     reinterpret_cast<float4*>(a.signals)[pair * lpp + sub] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// Subsampling pass of the fast path: 15 % of the (site, base) pairs are longer than S but nearly every wave of the
+// gather holds one, so drawing them there leaves 3 of 4 (or 63 of 64) lanes idle for the whole serial draw.  Here a
+// wave scans 64 pairs at a time (their lengths were just written to `lens`), queues the long ones in LDS and, as
+// soon as 64 are waiting, draws them with every lane busy: Floyd's subset sampling with a per-lane membership
+// bitset in LDS, whose set bits in ascending order are the sorted sample.
+constexpr int kPairsPerWave = 512;
+
+__device__ void sample_one(const GatherArgs& a, int64_t pair, uint32_t* bits /* [kSelWords][64], this lane's column */,
+                           int* idx /* [kSampleMaxS][64], this lane's column */) {
+    const int S = a.S;
+    const int64_t site = pair / a.L;
+    const int j = (int)(pair - site * a.L);
+    const int64_t r = a.site_read[site];
+    const int64_t bi = (int64_t)a.site_loc[site] - (a.L - 1) / 2 + j;
+    const int64_t e = a.b.ev_off[r] + bi;
+    const int n = a.base_len[e];
+    const int64_t lo = a.base_lo[e];
+    const int nw = (n + 31) >> 5;
+    for (int w = 0; w < nw; w++) bits[w * 64] = 0;
+    const uint64_t h = mix64((a.seed ^ (a.read_uid[r] * 0x9E3779B97F4A7C15ull)) + (uint64_t)bi * 0xD1B54A32D192ED03ull);
+    for (int q = 0; q < S; q++) {
+        const int jj = n - S + q;
+        const uint64_t rnd = mix64(h + (uint64_t)q) >> 32;
+        int v = (int)((rnd * (uint64_t)(jj + 1)) >> 32);  // uniform on [0, jj]
+        if (bits[(v >> 5) * 64] & (1u << (v & 31))) v = jj;
+        bits[(v >> 5) * 64] |= 1u << (v & 31);
+    }
+    // set bits in ascending order = the sorted sample; the indices go through LDS so that the 4 sample loads of
+    // an output vector are independent (a pop-load-store loop would serialise S scattered loads)
+    int c = 0;
+    for (int w = 0; w < nw; w++) {
+        uint32_t x = bits[w * 64];
+        while (x) {
+            idx[(c++) * 64] = (w << 5) + __ffs((int)x) - 1;
+            x &= x - 1;
+        }
+    }
+    const NormView nv = {{a.b.raw + a.b.raw_off[r], 0, a.b.scaling[r], a.b.offset[r]}, a.shift[r], a.scale[r]};
+    float4* out = reinterpret_cast<float4*>(a.signals + pair * S);
+    for (int k = 0; k < S; k += 4) {
+        const int i0 = idx[k * 64], i1 = idx[(k + 1) * 64], i2 = idx[(k + 2) * 64], i3 = idx[(k + 3) * 64];
+        const int16_t r0 = nv.rd.raw[lo + i0], r1 = nv.rd.raw[lo + i1], r2 = nv.rd.raw[lo + i2], r3 = nv.rd.raw[lo + i3];
+        out[k >> 2] = make_float4((float)nv.of_code(r0), (float)nv.of_code(r1), (float)nv.of_code(r2), (float)nv.of_code(r3));
+    }
+}
+
+__global__ __launch_bounds__(256) void dsp_ext_sample_kernel(GatherArgs a) {
+    __shared__ uint32_t bits_lds[4][kSelWords * 64];
+    __shared__ int64_t queue_lds[4][128];
+    extern __shared__ int idx_lds[];  // [4 waves][S][64]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t* bits = bits_lds[w] + lane;
+    int* idx = idx_lds + (size_t)w * a.S * 64 + lane;
+    int64_t* queue = queue_lds[w];
+    const int64_t total = a.n_sites * a.L;
+    const int64_t p0 = ((int64_t)blockIdx.x * 4 + w) * kPairsPerWave;
+    int qn = 0;  // wave-uniform
+    int len[kPairsPerWave / 64];  // all length loads of this wave's pairs in flight at once
+#pragma unroll
+    for (int c = 0; c < kPairsPerWave / 64; c++) {
+        const int64_t pair = p0 + c * 64 + lane;
+        len[c] = pair < total ? a.lens[pair] : 0;
+    }
+#pragma unroll
+    for (int c = 0; c < kPairsPerWave / 64; c++) {
+        const int64_t pair = p0 + c * 64 + lane;
+        const bool is_long = len[c] > a.S && len[c] <= kLongMax;
+        const uint64_t m = __ballot(is_long);
+        if (is_long) queue[qn + __popcll(m & ((1ull << lane) - 1))] = pair;
+        qn += __popcll(m);
+        if (qn >= 64) {
+            sample_one(a, queue[lane], bits, idx);
+            qn -= 64;
+            if (lane < qn) {
+                const int64_t keep = queue[64 + lane];
+                queue[lane] = keep;
+            }
+        }
+    }
+    if (lane < qn) sample_one(a, queue[lane], bits, idx);
 }
 
 }  // namespace
@@ -681,7 +749,11 @@ int32_t dsp_extract_gather(void* stream, const dsp_read_batch* b, const double* 
         const int ppb = 256 >> log2_lpp;
         const int64_t pairs = n_sites * seq_len;
         hipLaunchKernelGGL(dsp_ext_gather4_kernel, dim3((unsigned)((pairs + ppb - 1) / ppb)), dim3(256),
-                           (size_t)ppb * (signal_len + kSelWords) * sizeof(int), (hipStream_t)stream, a, log2_lpp);
+                           (size_t)ppb * signal_len * sizeof(int), (hipStream_t)stream, a, log2_lpp);
+        const int64_t per_block = 4 * (int64_t)kPairsPerWave;
+        if (signal_len <= kSampleMaxS)
+            hipLaunchKernelGGL(dsp_ext_sample_kernel, dim3((unsigned)((pairs + per_block - 1) / per_block)), dim3(256),
+                               (size_t)4 * signal_len * 64 * sizeof(int), (hipStream_t)stream, a);
         return ext_check_launch("dsp_extract_gather");
     }
     const int64_t threads = n_sites * seq_len * (int64_t)signal_len;
