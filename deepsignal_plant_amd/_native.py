@@ -85,6 +85,8 @@ def lib():
                                    ctypes.c_size_t, ctypes.c_int32]
     L.dsp_freq_create.restype = ctypes.c_void_p
     L.dsp_freq_create.argtypes = [ctypes.c_double]
+    L.dsp_freq_set_threads.restype = None
+    L.dsp_freq_set_threads.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     L.dsp_freq_destroy.restype = None
     L.dsp_freq_destroy.argtypes = [ctypes.c_void_p]
     L.dsp_freq_add_calls_text.restype = ctypes.c_int64

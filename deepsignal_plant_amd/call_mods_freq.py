@@ -23,10 +23,14 @@ from . import _native as nat
 class SiteFrequency(object):
     """Streaming per-site aggregator (sites keyed by chromosome + pos, txt_formater.py:12)."""
 
-    def __init__(self, prob_cf=0.5):
+    def __init__(self, prob_cf=0.5, nthreads=None):
         self._h = ctypes.c_void_p(nat.lib().dsp_freq_create(float(prob_cf)))
         if not self._h:
             raise MemoryError("dsp_freq_create failed")
+        if nthreads is None:
+            import os
+            nthreads = min(16, os.cpu_count() or 1)
+        nat.lib().dsp_freq_set_threads(self._h, int(nthreads))
 
     def __del__(self):
         try:

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -39,23 +40,54 @@ int freq_fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// strand and k-mer of a site are short ("+", a 5-mer): kept inline so that creating a site allocates nothing; longer
+// ones (malformed or exotic input) spill into dsp_freq::long_text.
 struct Site {
-    std::string chrom;
+    uint32_t chrom;  // index into dsp_freq::chroms
+    uint8_t strand_len, kmer_len;  // 255 = spilled
+    char strand[6];
+    char kmer[20];
     long long pos;
-    std::string strand, kmer;
     long long pos_in_strand;
     double prob0 = 0.0, prob1 = 0.0;
     long long met = 0, unmet = 0, coverage = 0;
+    uint64_t first_use;  // global sequence number of the record that created the site (= Python dict order)
 };
 
-struct Key {
-    std::string chrom;
-    long long pos;
-    bool operator==(const Key& o) const { return pos == o.pos && chrom == o.chrom; }
-};
-struct KeyHash {
-    size_t operator()(const Key& k) const {
-        return std::hash<std::string>()(k.chrom) * 1000003u ^ std::hash<long long>()(k.pos);
+// (chromosome id, pos) -> site index: open addressing, linear probing, no per-entry allocation
+struct SiteIndex {
+    struct Slot { long long pos; uint32_t chrom; uint32_t idx; };  // idx == UINT32_MAX: empty
+    std::vector<Slot> slots;
+    size_t used = 0, mask = 0;
+    static uint64_t hash(uint32_t chrom, long long pos) {  // splitmix64 finaliser
+        uint64_t x = (uint64_t)pos * 0x9E3779B97F4A7C15ull + ((uint64_t)chrom << 48) + chrom;
+        x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+        x ^= x >> 27; x *= 0x94D049BB133111EBull;
+        x ^= x >> 31;
+        return x;
+    }
+    void rehash(size_t cap) {
+        std::vector<Slot> old;
+        old.swap(slots);
+        slots.assign(cap, Slot{0, 0, UINT32_MAX});
+        mask = cap - 1;
+        for (const Slot& s : old)
+            if (s.idx != UINT32_MAX) {
+                size_t i = hash(s.chrom, s.pos) & mask;
+                while (slots[i].idx != UINT32_MAX) i = (i + 1) & mask;
+                slots[i] = s;
+            }
+    }
+    // returns the slot of (chrom, pos); *found tells whether it holds a site already
+    Slot* find_or_slot(uint32_t chrom, long long pos, bool* found) {
+        if (slots.empty() || (used + 1) * 10 > slots.size() * 6) rehash(slots.empty() ? 1024 : slots.size() * 2);
+        size_t i = hash(chrom, pos) & mask;
+        while (slots[i].idx != UINT32_MAX) {
+            if (slots[i].pos == pos && slots[i].chrom == chrom) { *found = true; return &slots[i]; }
+            i = (i + 1) & mask;
+        }
+        *found = false;
+        return &slots[i];
     }
 };
 
@@ -77,50 +109,200 @@ bool parse_ll(const char* p, const char* e, long long* out) {
     return true;
 }
 
-bool parse_double(const char* p, const char* e, double* out) {  // Python float(): correctly rounded
-    char tmp[96];
+// Python float(): correctly rounded.  Fast exact path (Clinger): up to 15 significant digits and a decimal exponent
+// within +-22 -- the integer mantissa and the power of ten are both exact doubles, so one multiply or divide is
+// correctly rounded; everything else goes to strtod.
+bool parse_double(const char* p, const char* e, double* out) {
+    static const double kPow10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                                      1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
     while (p < e && is_space(*p)) ++p;
     while (e > p && is_space(e[-1])) --e;
+    if (p >= e) return false;
+    const char* q = p;
+    bool neg = false;
+    if (*q == '+' || *q == '-') { neg = *q == '-'; ++q; }
+    uint64_t mant = 0;
+    int digits = 0, frac = 0;
+    bool any = false, dot = false, fast = true;
+    for (; q < e; ++q) {
+        if (*q >= '0' && *q <= '9') {
+            any = true;
+            if (mant || *q != '0') {
+                if (++digits > 15) { fast = false; break; }
+                mant = mant * 10 + (uint64_t)(*q - '0');
+            }
+            if (dot) ++frac;
+        } else if (*q == '.' && !dot) {
+            dot = true;
+        } else {
+            break;
+        }
+    }
+    if (fast && any) {
+        int ex = 0;
+        if (q < e && (*q == 'e' || *q == 'E')) {
+            const char* r = q + 1;
+            bool eneg = false;
+            if (r < e && (*r == '+' || *r == '-')) { eneg = *r == '-'; ++r; }
+            if (r >= e) fast = false;
+            int v = 0;
+            for (; r < e && fast; ++r) {
+                if (*r < '0' || *r > '9' || v > 1000) fast = false;
+                else v = v * 10 + (*r - '0');
+            }
+            ex = eneg ? -v : v;
+            q = r;
+        }
+        if (fast && q == e) {
+            const int e10 = ex - frac;
+            if (e10 >= -22 && e10 <= 22) {
+                double v = (double)mant;
+                v = e10 < 0 ? v / kPow10[-e10] : v * kPow10[e10];
+                *out = neg ? -v : v;
+                return true;
+            }
+        }
+    }
+    char tmp[96];
     const size_t n = (size_t)(e - p);
     if (n == 0 || n >= sizeof(tmp)) return false;
     memcpy(tmp, p, n);
     tmp[n] = 0;
+    if (memchr(tmp, 'x', n) || memchr(tmp, 'X', n)) return false;  // strtod takes hex floats, Python's float() does not
     char* endp = nullptr;
     *out = strtod(tmp, &endp);
     return endp == tmp + n;
 }
 
+// one parsed per-read call line; the string fields point into the caller's text
+struct Rec {
+    const char *chrom, *strand, *kmer;
+    uint32_t chrom_len, strand_len, kmer_len;
+    long long pos, pis, label;
+    double p0, p1;
+    uint32_t cid;  // interned chromosome, filled by the sequential interning pass
+};
+
+// 0 = ok, 1 = fewer than 10 columns, 2 = bad number
+int parse_call_line(const char* ls, const char* le, Rec* r) {
+    while (ls < le && is_space(*ls)) ++ls;
+    while (le > ls && is_space(le[-1])) --le;
+    const char* fs[10];
+    const char* fe[10];
+    int nf = 0;
+    for (const char* q = ls; nf < 10;) {
+        const char* t = (const char*)memchr(q, '\t', (size_t)(le - q));
+        if (!t) t = le;
+        fs[nf] = q; fe[nf] = t; ++nf;
+        if (t == le) break;
+        q = t + 1;
+    }
+    if (nf < 10) return 1;
+    if (!parse_ll(fs[1], fe[1], &r->pos) || !parse_ll(fs[3], fe[3], &r->pis) || !parse_double(fs[6], fe[6], &r->p0) ||
+        !parse_double(fs[7], fe[7], &r->p1) || !parse_ll(fs[8], fe[8], &r->label))
+        return 2;
+    r->chrom = fs[0]; r->chrom_len = (uint32_t)(fe[0] - fs[0]);
+    r->strand = fs[2]; r->strand_len = (uint32_t)(fe[2] - fs[2]);
+    r->kmer = fs[9]; r->kmer_len = (uint32_t)(fe[9] - fs[9]);
+    return 0;
+}
+
 }  // namespace
 
-struct dsp_freq {
-    double prob_cf;
-    std::vector<Site> sites;  // insertion order = order of first used record (Python dict order)
-    std::unordered_map<Key, size_t, KeyHash> index;
-    long long count = 0, used = 0;
+// The table is split into kParts partitions by key hash.  A record only ever touches the partition of its site, so
+// partitions can be filled by different threads, each scanning the records in order: every site still sees its
+// records in file order (the double sums associate exactly like a sequential pass) and remembers the sequence
+// number of the record that created it, from which the global insertion order is rebuilt.  The partition count is
+// fixed, so the result does not depend on the number of threads.
+constexpr int kParts = 16;
 
-    void add(const char* chrom, size_t chrom_len, long long pos, const char* strand, size_t strand_len,
-             long long pos_in_strand, double p0, double p1, long long label, const char* kmer, size_t kmer_len) {
-        ++count;
-        if (std::fabs(p0 - p1) < prob_cf) return;  // txt_formater.py:23-26
-        Key k{std::string(chrom, chrom_len), pos};
-        auto it = index.find(k);
+struct Partition {
+    std::vector<Site> sites;
+    SiteIndex index;
+    std::unordered_map<size_t, std::pair<std::string, std::string>> long_text;  // spilled strand / k-mer by site index
+    long long used = 0;
+
+    void apply(uint32_t cid, long long pos, const char* strand, size_t strand_len, long long pos_in_strand, double p0,
+               double p1, long long label, const char* kmer, size_t kmer_len, uint64_t seq) {
+        bool found;
+        SiteIndex::Slot* slot = index.find_or_slot(cid, pos, &found);
         size_t idx;
-        if (it == index.end()) {
+        if (!found) {
             idx = sites.size();
             Site s;
-            s.chrom = k.chrom; s.pos = pos;
-            s.strand.assign(strand, strand_len); s.kmer.assign(kmer, kmer_len);
-            s.pos_in_strand = pos_in_strand;
-            sites.push_back(std::move(s));
-            index.emplace(std::move(k), idx);
+            s.chrom = cid; s.pos = pos; s.pos_in_strand = pos_in_strand; s.first_use = seq;
+            if (strand_len <= sizeof(s.strand) && kmer_len <= sizeof(s.kmer)) {
+                s.strand_len = (uint8_t)strand_len; s.kmer_len = (uint8_t)kmer_len;
+                memcpy(s.strand, strand, strand_len);
+                memcpy(s.kmer, kmer, kmer_len);
+            } else {
+                s.strand_len = s.kmer_len = 255;
+                long_text.emplace(idx, std::make_pair(std::string(strand, strand_len), std::string(kmer, kmer_len)));
+            }
+            sites.push_back(s);
+            slot->pos = pos; slot->chrom = cid; slot->idx = (uint32_t)idx;
+            ++index.used;
         } else {
-            idx = it->second;
+            idx = slot->idx;
         }
         Site& s = sites[idx];
         s.prob0 += p0; s.prob1 += p1;
         s.coverage += 1;
         if (label == 1) s.met += 1; else s.unmet += 1;
         ++used;
+    }
+    std::string strand_of(size_t i) const {
+        const Site& s = sites[i];
+        return s.strand_len == 255 ? long_text.at(i).first : std::string(s.strand, s.strand_len);
+    }
+    std::string kmer_of(size_t i) const {
+        const Site& s = sites[i];
+        return s.kmer_len == 255 ? long_text.at(i).second : std::string(s.kmer, s.kmer_len);
+    }
+};
+
+inline int part_of(uint32_t cid, long long pos) { return (int)(SiteIndex::hash(cid, pos) >> 60) & (kParts - 1); }
+
+struct dsp_freq {
+    double prob_cf;
+    int nthreads = 1;
+    std::vector<std::string> chroms;
+    std::unordered_map<std::string, uint32_t> chrom_id;
+    uint32_t last_chrom = 0;  // chromosome of the previous record (records of a read share it)
+    Partition parts[kParts];
+    long long count = 0;
+    uint64_t seq = 0;  // records seen so far (sequence numbers of first_use)
+
+    uint32_t intern(const char* chrom, size_t n) {
+        if (!chroms.empty() && chroms[last_chrom].size() == n && memcmp(chroms[last_chrom].data(), chrom, n) == 0)
+            return last_chrom;
+        std::string key(chrom, n);
+        auto it = chrom_id.find(key);
+        if (it == chrom_id.end()) {
+            it = chrom_id.emplace(key, (uint32_t)chroms.size()).first;
+            chroms.push_back(std::move(key));
+        }
+        return last_chrom = it->second;
+    }
+    long long used() const {
+        long long u = 0;
+        for (const Partition& p : parts) u += p.used;
+        return u;
+    }
+    size_t n_sites() const {
+        size_t n = 0;
+        for (const Partition& p : parts) n += p.sites.size();
+        return n;
+    }
+
+    // one record, sequential feeders (dsp_freq_add_block)
+    void add(const char* chrom, size_t chrom_len, long long pos, const char* strand, size_t strand_len,
+             long long pos_in_strand, double p0, double p1, long long label, const char* kmer, size_t kmer_len) {
+        ++count;
+        const uint64_t my_seq = seq++;
+        if (std::fabs(p0 - p1) < prob_cf) return;  // txt_formater.py:23-26
+        const uint32_t cid = intern(chrom, chrom_len);
+        parts[part_of(cid, pos)].apply(cid, pos, strand, strand_len, pos_in_strand, p0, p1, label, kmer, kmer_len, my_seq);
     }
 };
 
@@ -134,40 +316,100 @@ dsp_freq* dsp_freq_create(double prob_cf) {
 
 void dsp_freq_destroy(dsp_freq* f) { delete f; }
 
+int dsp_parse_double_(const char* p, size_t n, double* out) { return parse_double(p, p + n, out) ? 1 : 0; }  // test hook
+
+void dsp_freq_set_threads(dsp_freq* f, int32_t nthreads) {
+    if (f) f->nthreads = nthreads < 1 ? 1 : (nthreads > 64 ? 64 : nthreads);
+}
+
+// Lines are parsed by f->nthreads threads (byte ranges moved to line starts), then applied to the table by one
+// thread in line order: the double sums are associated exactly like a sequential pass.
 int64_t dsp_freq_add_calls_text(dsp_freq* f, const char* text, size_t len, const char* contig) {
     if (!f || (!text && len)) return freq_fail(DSP_EINVAL, "NULL argument");
     const size_t clen = contig ? strlen(contig) : 0;
-    const char* p = text;
-    const char* e = text + len;
-    int64_t nline = 0;
-    while (p < e) {
-        const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
-        const char* le = nl ? nl : e;
-        const char* ls = p;
-        p = nl ? nl + 1 : e;
-        while (ls < le && is_space(*ls)) ++ls;
-        while (le > ls && is_space(le[-1])) --le;
-        const char* fs[10];
-        const char* fe[10];
-        int nf = 0;
-        for (const char* q = ls; nf < 10;) {
-            const char* t = (const char*)memchr(q, '\t', (size_t)(le - q));
-            if (!t) t = le;
-            fs[nf] = q; fe[nf] = t; ++nf;
-            if (t == le) break;
-            q = t + 1;
+    const char* const e = text + len;
+    int nt = f->nthreads;
+    if ((size_t)nt > len / 65536 + 1) nt = (int)(len / 65536 + 1);
+    std::vector<const char*> cut((size_t)nt + 1);
+    cut[0] = text;
+    cut[nt] = e;
+    for (int t = 1; t < nt; ++t) {
+        const char* p = text + len / nt * t;
+        if (p > text && p[-1] != '\n') {
+            const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
+            p = nl ? nl + 1 : e;
         }
-        if (nf < 10) return freq_fail(DSP_EPARSE, "malformed call line %lld: need 10 tab-separated columns", (long long)nline);
-        long long pos, pis, label;
-        double p0, p1;
-        if (!parse_ll(fs[1], fe[1], &pos) || !parse_ll(fs[3], fe[3], &pis) || !parse_double(fs[6], fe[6], &p0) ||
-            !parse_double(fs[7], fe[7], &p1) || !parse_ll(fs[8], fe[8], &label))
-            return freq_fail(DSP_EPARSE, "malformed call line %lld: bad number", (long long)nline);
-        ++nline;
-        if (contig && !((size_t)(fe[0] - fs[0]) == clen && memcmp(fs[0], contig, clen) == 0)) continue;
-        f->add(fs[0], (size_t)(fe[0] - fs[0]), pos, fs[2], (size_t)(fe[2] - fs[2]), pis, p0, p1, label, fs[9],
-               (size_t)(fe[9] - fs[9]));
+        cut[t] = p < cut[t - 1] ? cut[t - 1] : p;
     }
+    std::vector<std::vector<Rec>> recs((size_t)nt);
+    std::vector<int> bad_code((size_t)nt, 0);
+    std::vector<int64_t> bad_line((size_t)nt, 0);
+    auto work = [&](int t) {
+        std::vector<Rec>& out = recs[t];
+        out.reserve((size_t)(cut[t + 1] - cut[t]) / 56 + 16);
+        const char* p = cut[t];
+        const char* ce = cut[t + 1];
+        while (p < ce) {
+            const char* nl = (const char*)memchr(p, '\n', (size_t)(ce - p));
+            const char* le = nl ? nl : ce;
+            Rec r;
+            const int rc = parse_call_line(p, le, &r);
+            if (rc) { bad_code[t] = rc; bad_line[t] = (int64_t)out.size(); return; }
+            out.push_back(r);
+            p = nl ? nl + 1 : ce;
+        }
+    };
+    if (nt == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
+    }
+    // sequential: how many records count (everything before the first malformed line), chromosome interning
+    int64_t nline = 0;
+    int bad_t = -1;
+    for (int t = 0; t < nt; ++t) {
+        for (Rec& r : recs[t]) r.cid = f->intern(r.chrom, r.chrom_len);
+        nline += (int64_t)recs[t].size();
+        if (bad_code[t]) { bad_t = t; break; }
+    }
+    const int t_end = bad_t >= 0 ? bad_t + 1 : nt;
+    const uint32_t contig_id = contig ? f->intern(contig, clen) : 0;
+    const uint64_t seq0 = f->seq;
+    // parallel over partitions, every worker scanning all records in order
+    const int workers = f->nthreads < kParts ? f->nthreads : kParts;
+    auto apply = [&](int wk) {
+        uint64_t seq = seq0;
+        for (int t = 0; t < t_end; ++t)
+            for (const Rec& r : recs[t]) {
+                const uint64_t my_seq = seq++;
+                if (contig && r.cid != contig_id) continue;
+                if (std::fabs(r.p0 - r.p1) < f->prob_cf) continue;
+                const int part = part_of(r.cid, r.pos);
+                if (part % workers != wk) continue;
+                f->parts[part].apply(r.cid, r.pos, r.strand, r.strand_len, r.pis, r.p0, r.p1, r.label, r.kmer, r.kmer_len, my_seq);
+            }
+    };
+    if (workers <= 1) {
+        apply(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int wk = 1; wk < workers; ++wk) th.emplace_back(apply, wk);
+        apply(0);
+        for (auto& x : th) x.join();
+    }
+    f->seq += (uint64_t)nline;
+    if (contig) {  // `count` counts the records of the requested contig only (call_mods_freq.py:53-56)
+        for (int t = 0; t < t_end; ++t)
+            for (const Rec& r : recs[t]) f->count += r.cid == contig_id;
+    } else {
+        f->count += nline;
+    }
+    if (bad_t >= 0)  // everything before the bad line has been applied, like a sequential pass that stops there
+        return freq_fail(DSP_EPARSE, bad_code[bad_t] == 1 ? "malformed call line %lld: need 10 tab-separated columns"
+                                                          : "malformed call line %lld: bad number", (long long)nline);
     return nline;
 }
 
@@ -204,10 +446,11 @@ int64_t dsp_freq_add_block(dsp_freq* f, const char* text, const uint64_t* row_of
         const float z0 = dsp_np_round6_f32_(q);
         volatile float om = 1.0f - z0;
         const float z1 = dsp_np_round6_f32_(om);
-        num[dsp_format_prob_f32_(z0, num)] = 0;
-        const double p0 = strtod(num, nullptr);
-        num[dsp_format_prob_f32_(z1, num)] = 0;
-        const double p1 = strtod(num, nullptr);
+        double p0 = 0.0, p1 = 0.0;
+        int k = dsp_format_prob_f32_(z0, num);
+        parse_double(num, num + k, &p0);
+        k = dsp_format_prob_f32_(z1, num);
+        parse_double(num, num + k, &p1);
         for (int i = k0; i < k1; ++i) k5[i - k0] = code2base[kmer[r * seq_len + i] & 15];
         f->add(fs[0], (size_t)(fe[0] - fs[0]), pos, fs[2], (size_t)(fe[2] - fs[2]), pis, p0, p1, (long long)labels[r], k5,
                (size_t)(k1 - k0));
@@ -218,47 +461,55 @@ int64_t dsp_freq_add_block(dsp_freq* f, const char* text, const uint64_t* row_of
 void dsp_freq_counts(const dsp_freq* f, int64_t* count, int64_t* used, int64_t* sites) {
     if (!f) return;
     if (count) *count = f->count;
-    if (used) *used = f->used;
-    if (sites) *sites = (int64_t)f->sites.size();
+    if (used) *used = f->used();
+    if (sites) *sites = (int64_t)f->n_sites();
 }
 
 // write_sitekey2stats (call_mods_freq.py:77-122).  Returns bytes needed; writes at most cap bytes.
 int64_t dsp_freq_format(const dsp_freq* f, int32_t is_sort, int32_t is_bed, char* out, size_t cap) {
     if (!f) return freq_fail(DSP_EINVAL, "NULL argument");
-    std::vector<size_t> order(f->sites.size());
-    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
-    if (is_sort)  // sorted(keys, key=split_key): (chrom str, pos int)
-        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
-            const Site& x = f->sites[a];
-            const Site& y = f->sites[b];
-            const int c = x.chrom.compare(y.chrom);
+    // global insertion order: merge the partitions by the sequence number of each site's first record
+    struct Ref { uint64_t first_use; uint32_t part; uint32_t idx; };
+    std::vector<Ref> order;
+    order.reserve(f->n_sites());
+    for (int p = 0; p < kParts; ++p)
+        for (size_t i = 0; i < f->parts[p].sites.size(); ++i)
+            order.push_back(Ref{f->parts[p].sites[i].first_use, (uint32_t)p, (uint32_t)i});
+    std::sort(order.begin(), order.end(), [](const Ref& a, const Ref& b) { return a.first_use < b.first_use; });
+    if (is_sort)  // sorted(keys, key=split_key): (chrom str, pos int); stable, like Python's sorted
+        std::stable_sort(order.begin(), order.end(), [&](const Ref& a, const Ref& b) {
+            const Site& x = f->parts[a.part].sites[a.idx];
+            const Site& y = f->parts[b.part].sites[b.idx];
+            const int c = x.chrom == y.chrom ? 0 : f->chroms[x.chrom].compare(f->chroms[y.chrom]);
             return c != 0 ? c < 0 : x.pos < y.pos;
         });
     std::string s;
     s.reserve(order.size() * 72);
     char buf[512];
-    for (size_t i : order) {
-        const Site& t = f->sites[i];
+    for (const Ref& ref : order) {
+        const Partition& part = f->parts[ref.part];
+        const Site& t = part.sites[ref.idx];
         if (t.coverage <= 0) continue;
+        const std::string strand = part.strand_of(ref.idx), kmer = part.kmer_of(ref.idx);
         const double rmet = (double)t.met / (double)t.coverage;
         int k;
         if (is_bed) {
             const long long pct = (long long)std::nearbyint(rmet * 100 + 0.001);  // int(round(rmet*100+0.001, 0)), :110
-            k = snprintf(buf, sizeof(buf), "%s\t%lld\t%lld\t.\t%lld\t%s\t%lld\t%lld\t0,0,0\t%lld\t%lld\n", t.chrom.c_str(),
-                         t.pos, t.pos + 1, t.coverage, t.strand.c_str(), t.pos, t.pos + 1, t.coverage, pct);
+            k = snprintf(buf, sizeof(buf), "%s\t%lld\t%lld\t.\t%lld\t%s\t%lld\t%lld\t0,0,0\t%lld\t%lld\n", f->chroms[t.chrom].c_str(),
+                         t.pos, t.pos + 1, t.coverage, strand.c_str(), t.pos, t.pos + 1, t.coverage, pct);
         } else {
-            k = snprintf(buf, sizeof(buf), "%s\t%lld\t%s\t%lld\t%.3f\t%.3f\t%lld\t%lld\t%lld\t%.4f\t%s\n", t.chrom.c_str(), t.pos,
-                         t.strand.c_str(), t.pos_in_strand, t.prob0, t.prob1, t.met, t.unmet, t.coverage, rmet,
-                         t.kmer.c_str());
+            k = snprintf(buf, sizeof(buf), "%s\t%lld\t%s\t%lld\t%.3f\t%.3f\t%lld\t%lld\t%lld\t%.4f\t%s\n", f->chroms[t.chrom].c_str(), t.pos,
+                         strand.c_str(), t.pos_in_strand, t.prob0, t.prob1, t.met, t.unmet, t.coverage, rmet,
+                         kmer.c_str());
         }
         if (k < 0 || (size_t)k >= sizeof(buf)) {  // very long contig names: format into a growing string
-            std::string big(1024 + t.chrom.size() * 2 + t.kmer.size(), '\0');
-            k = is_bed ? snprintf(&big[0], big.size(), "%s\t%lld\t%lld\t.\t%lld\t%s\t%lld\t%lld\t0,0,0\t%lld\t%lld\n", t.chrom.c_str(),
-                                  t.pos, t.pos + 1, t.coverage, t.strand.c_str(), t.pos, t.pos + 1, t.coverage,
+            std::string big(1024 + f->chroms[t.chrom].size() * 2 + kmer.size(), '\0');
+            k = is_bed ? snprintf(&big[0], big.size(), "%s\t%lld\t%lld\t.\t%lld\t%s\t%lld\t%lld\t0,0,0\t%lld\t%lld\n", f->chroms[t.chrom].c_str(),
+                                  t.pos, t.pos + 1, t.coverage, strand.c_str(), t.pos, t.pos + 1, t.coverage,
                                   (long long)std::nearbyint(rmet * 100 + 0.001))
-                       : snprintf(&big[0], big.size(), "%s\t%lld\t%s\t%lld\t%.3f\t%.3f\t%lld\t%lld\t%lld\t%.4f\t%s\n", t.chrom.c_str(),
-                                  t.pos, t.strand.c_str(), t.pos_in_strand, t.prob0, t.prob1, t.met, t.unmet, t.coverage, rmet,
-                                  t.kmer.c_str());
+                       : snprintf(&big[0], big.size(), "%s\t%lld\t%s\t%lld\t%.3f\t%.3f\t%lld\t%lld\t%lld\t%.4f\t%s\n", f->chroms[t.chrom].c_str(),
+                                  t.pos, strand.c_str(), t.pos_in_strand, t.prob0, t.prob1, t.met, t.unmet, t.coverage, rmet,
+                                  kmer.c_str());
             s.append(big.data(), (size_t)k);
         } else {
             s.append(buf, (size_t)k);

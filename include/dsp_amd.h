@@ -276,6 +276,9 @@ int64_t dsp_extract_sites(int64_t n_reads, const uint8_t* ev_base, const int64_t
 typedef struct dsp_freq dsp_freq;
 dsp_freq* dsp_freq_create(double prob_cf);
 void dsp_freq_destroy(dsp_freq* f);
+/* host threads that parse the lines of dsp_freq_add_calls_text (default 1); the table is always updated by one
+ * thread in line order, so the result does not depend on the thread count */
+void dsp_freq_set_threads(dsp_freq* f, int32_t nthreads);
 int64_t dsp_freq_add_calls_text(dsp_freq* f, const char* text, size_t len, const char* contig);
 int64_t dsp_freq_add_block(dsp_freq* f, const char* text, const uint64_t* row_off, const uint32_t* info_len,
                            const float* probs, int32_t num_classes, const uint8_t* labels, const uint8_t* kmer,

@@ -206,6 +206,7 @@ int main(int argc, char** argv) {
     {
         dsp_freq* fq = dsp_freq_create(0.1);
         CHECK(fq != nullptr);
+        dsp_freq_set_threads(fq, 3);
         CHECK(dsp_freq_add_calls_text(fq, out.data(), (size_t)fb, nullptr) >= 0);
         CHECK(dsp_freq_add_block(fq, tsv.data(), rows.row_off.data(), rows.info_len.data(), probs.data(), 2, labels.data(),
                                  rows.kmer.data(), 13, nrows) >= 0);

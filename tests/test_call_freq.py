@@ -83,3 +83,48 @@ def test_call_freq_rejects_malformed_lines():
         a.add_calls_text(b"chr1\t10\t+\t10\tr\tt\t0.9\n")
     with pytest.raises(ValueError):
         a.add_calls_text(b"chr1\tx\t+\t10\tr\tt\t0.9\t0.1\t0\tAACGT\n")
+
+
+def test_thread_count_does_not_change_the_result_and_numbers_parse_like_python():
+    import ctypes
+    import random
+    from deepsignal_plant_amd import _native as nat
+    from deepsignal_plant_amd.call_mods_freq import SiteFrequency
+    text = open(os.path.join(GOLDEN, "f5_calls.tsv"), "rb").read() * 3
+    outs = []
+    for nt in (1, 2, 7, 16):
+        agg = SiteFrequency(0.1, nthreads=nt)
+        agg.add_calls_text(text)
+        outs.append((agg.format(False, False), agg.format(True, True), agg.counts()))
+    assert all(o == outs[0] for o in outs[1:]) and outs[0][2][0] == text.count(b"\n")
+    # a malformed line: everything before it is applied, then the error (like a sequential pass)
+    lines = text.splitlines(keepends=True)
+    bad = b"".join(lines[:1000]) + b"chr1\t12\t+\t12\tr\tt\t0.4\tx\t1\tACGTA\n" + b"".join(lines[1000:])
+    agg = SiteFrequency(0.1, nthreads=5)
+    with pytest.raises(ValueError, match="line 1000"):
+        agg.add_calls_text(bad)
+    assert agg.counts()[0] == 1000
+    # decimal -> double, bit for bit like float()
+    L = nat.lib()
+    L.dsp_parse_double_.restype = ctypes.c_int
+    L.dsp_parse_double_.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_double)]
+    rng = random.Random(4)
+    cases = ["0", "0.0", "-0.0", "1", "1.0", "1e-05", "9.9e-05", "0.000001", "0.123457", "1.", ".5", "+3.25", "1E5", "1e+22", "1e23",
+             "123456789012345", "1234567890123456", "0.1234567890123456789", "1e-22", "1e-23", "5e-324", "1.7976931348623157e308",
+             " 0.25 ", "0.500000", "00012.50", "1e0005"]
+    for _ in range(20000):
+        d = rng.randint(1, 19)
+        m = str(rng.randint(0, 10 ** d - 1))
+        k = rng.randint(0, len(m))
+        t = m[:k] + "." + m[k:] if rng.random() < 0.8 else m
+        if rng.random() < 0.3:
+            t += "e%+d" % rng.randint(-30, 30)
+        cases.append(t)
+    out = ctypes.c_double()
+    for t in cases:
+        b = t.encode()
+        assert L.dsp_parse_double_(b, len(b), ctypes.byref(out)) == 1, t
+        assert out.value == float(t) and (out.value != 0 or str(out.value) == str(float(t))), (t, out.value, float(t))
+    for t in ("", "abc", "1e", "1.2.3", "--1", "1e+", "0x10"):
+        b = t.encode()
+        assert L.dsp_parse_double_(b, len(b), ctypes.byref(out)) == 0, t
