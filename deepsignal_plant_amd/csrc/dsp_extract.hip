@@ -376,11 +376,100 @@ __global__ __launch_bounds__(1024) void dsp_ext_blkoff_kernel(const int64_t* ev_
     }
 }
 
+// numpy's recursion over one chunk (n <= 8192), walked by ONE thread: first to list the leaf blocks (<= 128 samples
+// each, in order), later to add up their sums in numpy's association
+struct LeafList {
+    int lo[128], n[128];
+    double sum[128];
+    int count;
+    double result;
+};
+
+struct WalkScratch {  // stacks of the single-thread walks; in LDS so that they cost the kernel no registers
+    int lo[16], n[16], phase[16];
+    double left[16];
+};
+
+__device__ void chunk_leaves(int n, LeafList* L, WalkScratch* w) {
+    int sp = 0, cnt = 0;
+    w->lo[0] = 0; w->n[0] = n;
+    while (sp >= 0) {  // pre-order, left child first = leaves in sample order
+        const int clo = w->lo[sp], cn = w->n[sp];
+        sp--;
+        if (cn <= 128) {
+            L->lo[cnt] = clo; L->n[cnt] = cn; cnt++;
+        } else {
+            int n2 = cn / 2;
+            n2 -= n2 % 8;
+            w->lo[sp + 1] = clo + n2; w->n[sp + 1] = cn - n2;  // right below left on the stack
+            w->lo[sp + 2] = clo;      w->n[sp + 2] = n2;
+            sp += 2;
+        }
+    }
+    L->count = cnt;
+}
+
+__device__ double chunk_combine(int n, const LeafList* L, WalkScratch* w) {  // sum(n) = n <= 128 ? leaf : sum(left) + sum(right)
+    int next = 0;
+    if (n <= 128) return L->sum[next];
+    int sp = 0;
+    w->n[0] = n; w->phase[0] = 0;
+    double ret = 0.0;
+    bool have = false;
+    while (true) {
+        if (!have) {
+            const int cn = w->n[sp];
+            if (cn <= 128) { ret = L->sum[next++]; have = true; sp--; }
+            else { int n2 = cn / 2; n2 -= n2 % 8; w->phase[sp] = 1; w->n[sp + 1] = n2; w->phase[sp + 1] = 0; sp++; }
+        } else {
+            if (sp < 0) return ret;
+            const int cn = w->n[sp];
+            if (w->phase[sp] == 1) {
+                int n2 = cn / 2; n2 -= n2 % 8;
+                w->left[sp] = ret; w->phase[sp] = 2;
+                w->n[sp + 1] = cn - n2; w->phase[sp + 1] = 0; sp++;
+                have = false;
+            } else { ret = w->left[sp] + ret; sp--; }
+        }
+    }
+}
+
+// np.add.reduce of f(lo .. lo+n) by a whole 256-thread workgroup: the leaf blocks of every chunk are summed by the
+// 32 eight-lane groups in parallel and combined by thread 0; every thread returns the same value.
+template <class F>
+__device__ double np_sum_wg(const F& f, int64_t lo, int64_t n, LeafList* L, WalkScratch* w) {
+    const int grp = threadIdx.x >> 3, l8 = threadIdx.x & 7;
+    double total = 0.0;
+    for (int64_t c = 0; c < n; c += kChunk) {
+        const int m = (int)((n - c) < kChunk ? (n - c) : kChunk);
+        __syncthreads();
+        if (threadIdx.x == 0) chunk_leaves(m, L, w);
+        __syncthreads();
+        for (int j = grp; j < L->count; j += 32) {
+            const double v = pw_block8(f, lo + c + L->lo[j], L->n[j], l8);
+            if (l8 == 0) L->sum[j] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            total = total + chunk_combine(m, L, w);
+            L->result = total;
+        }
+    }
+    __syncthreads();
+    total = L->result;
+    __syncthreads();
+    return total;
+}
+
 __global__ __launch_bounds__(256) void dsp_ext_base_stats_kernel(dsp_read_batch b, const double* shift, const double* scale,
                                                                  const int64_t* blk_off, double* base_mean,
                                                                  double* base_std, int32_t* base_len, int64_t* base_lo) {
     __shared__ PwStack stacks[32];
     __shared__ double cache[32][32];
+    __shared__ LeafList leaves;
+    __shared__ WalkScratch walk;
+    __shared__ int n_long;
+    __shared__ int long_e[kBasesPerBlock];  // bases of more than one numpy block, left to the whole workgroup
     const int64_t blk = blockIdx.x;
     if (blk >= blk_off[b.n_reads]) return;
     int64_t rlo = 0, rhi = b.n_reads;  // last r with blk_off[r] <= blk (uniform: scalar loads)
@@ -393,15 +482,25 @@ __global__ __launch_bounds__(256) void dsp_ext_base_stats_kernel(dsp_read_batch 
     const int64_t e0 = b.ev_off[r], n_ev = b.ev_off[r + 1] - e0;
     const int64_t n_raw = b.raw_off[r + 1] - b.raw_off[r];
     const NormView nv = {{b.raw + b.raw_off[r], n_raw, b.scaling[r], b.offset[r]}, shift[r], scale[r]};
+    if (threadIdx.x == 0) n_long = 0;
+    __syncthreads();
     for (int round = 0; round < kBasesPerBlock / 32; round++) {
         const int64_t e_local = (blk - blk_off[r]) * kBasesPerBlock + round * 32 + grp;
-        if (e_local >= n_ev) return;  // whole 8-lane groups leave together
+        if (e_local >= n_ev) break;  // whole 8-lane groups leave together
         const int64_t e = e0 + e_local;
         // norm_signals[start:start+length] with Python's clamping of the slice ends
         int64_t lo = b.ev_start[e], hi = lo + b.ev_len[e];
         lo = lo < 0 ? 0 : (lo > n_raw ? n_raw : lo);
         hi = hi < lo ? lo : (hi > n_raw ? n_raw : hi);
         const int64_t n = hi - lo;
+        if (l8 == 0) {
+            base_len[e] = (int32_t)n;
+            base_lo[e] = lo;
+        }
+        if (n > 128) {  // a stall: 1 % of the bases, a third of the samples -- it would hold this wave's other groups up
+            if (l8 == 0) long_e[atomicAdd(&n_long, 1)] = (int)e_local;
+            continue;
+        }
         double mean, var;
         if (n <= 32) {
             // a short base (one numpy block): every sample is normalised once (two f64 divisions) by the lane that owns it in
@@ -419,8 +518,22 @@ __global__ __launch_bounds__(256) void dsp_ext_base_stats_kernel(dsp_read_batch 
         if (l8 == 0) {
             base_mean[e] = mean;
             base_std[e] = sqrt(var);
-            base_len[e] = (int32_t)n;
-            base_lo[e] = lo;
+        }
+    }
+    __syncthreads();
+    const int nl = n_long;
+    for (int k = 0; k < nl; k++) {  // uniform: the whole workgroup takes the long bases one by one
+        const int64_t e = e0 + long_e[k];
+        int64_t lo = b.ev_start[e], hi = lo + b.ev_len[e];
+        lo = lo < 0 ? 0 : (lo > n_raw ? n_raw : lo);
+        hi = hi < lo ? lo : (hi > n_raw ? n_raw : hi);
+        const int64_t n = hi - lo;
+        const double mean = np_sum_wg(nv, lo, n, &leaves, &walk) / (double)n;
+        auto dev2 = [&](int64_t i) { const double d = nv(i) - mean; return d * d; };
+        const double var = np_sum_wg(dev2, lo, n, &leaves, &walk) / (double)n;
+        if (threadIdx.x == 0) {
+            base_mean[e] = mean;
+            base_std[e] = sqrt(var);
         }
     }
 }
