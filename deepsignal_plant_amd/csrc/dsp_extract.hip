@@ -301,28 +301,189 @@ __device__ double np_median(const int16_t* raw, int64_t n, const K& key, const V
 }
 
 // ---- kernel 1: per-read shift / scale (extract_features.py:179-185); one workgroup per read ----------------------
+//
+// Fast MAD path (scaling > 0, i.e. pA non-decreasing in the DAQ code): two streamed passes instead of ~12.
+//   pass 1  histogram of the codes' high bytes -> where the median lies;
+//   pass 2  fine histogram of the 32,768 codes around it (LDS), codes outside only counted;
+//   median  = order statistics read off the prefix sums of the fine histogram;
+//   MAD     = order statistics of dev(v) = |x(v) - med| read off the same histogram by LEVELS: level a holds the
+//             codes m1 - a and m2 + a (m1 <= m2 the median codes).  dev is non-decreasing in a on either side, and
+//             consecutive levels are one code step (= scaling, guarded to be >> rounding) apart, so the k-th
+//             smallest deviation sits in the level where the cumulative count passes k; the at most two distinct
+//             codes of that level are ordered by their float deviations.
+// Anything the window cannot decide (codes outside it that the ranks reach, a degenerate scaling) falls back to
+// the generic radix select below.
+constexpr int kWin = 32768;
+
+struct MadLds {
+    uint32_t wave_sum[16];
+    uint32_t below, above;
+    int found_bin[2];
+    int ok;
+};
+
+// exclusive prefix of `val` over the 1024 threads of the workgroup (thread order)
+__device__ uint32_t block_excl_scan(uint32_t val, MadLds* m, uint32_t* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t x = val;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    __syncthreads();
+    if (lane == 63) m->wave_sum[w] = x;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    for (int i = 0; i < 16; i++) {
+        const uint32_t v = m->wave_sum[i];
+        if (i < w) base += v;
+        tot += v;
+    }
+    *total = tot;
+    return base + x - val;
+}
+
+__device__ bool mad_by_histogram(const int16_t* raw, int64_t n, double scaling, double offset, uint32_t* fine, SelectLds* sel,
+                                 MadLds* m, double* shift_out, double* scale_out) {
+    const int64_t k1 = (n - 1) / 2, k2 = n / 2;
+    auto kraw = [](int16_t c) { return (uint64_t)(uint16_t)(c ^ (int16_t)0x8000); };
+    // pass 1: high byte of the lower median
+    select_pass(raw, n, kraw, 0, 8, 8, sel);
+    select_pick(sel, k1, 1);
+    const int hb = (int)sel->sel[0];
+    int ub0 = hb * 256 + 128 - kWin / 2;  // window [ub0, ub0 + kWin) in biased-code space 0..65535
+    ub0 = ub0 < 0 ? 0 : (ub0 > 65536 - kWin ? 65536 - kWin : ub0);
+    // pass 2: fine histogram
+    for (int i = threadIdx.x; i < kWin; i += blockDim.x) fine[i] = 0;
+    if (threadIdx.x == 0) { m->below = 0; m->above = 0; m->ok = 1; }
+    __syncthreads();
+    {
+        const int lane = threadIdx.x & 63;
+        uint32_t lo_cnt = 0, hi_cnt = 0;
+        auto take = [&](int16_t c) {
+            const int d = (int)(uint16_t)(c ^ (int16_t)0x8000) - ub0;
+            if (d < 0) lo_cnt++;
+            else if (d >= kWin) hi_cnt++;
+            else atomicAdd(&fine[d], 1u);
+        };
+        int64_t head = (int64_t)((16 - ((uintptr_t)raw & 15)) & 15) >> 1;
+        if (head > n) head = n;
+        const int64_t nvec = (n - head) >> 3;
+        const int64_t tail0 = head + (nvec << 3);
+        if ((int64_t)threadIdx.x < head) take(raw[threadIdx.x]);
+        else if ((int64_t)threadIdx.x - head < n - tail0) take(raw[tail0 + threadIdx.x - head]);
+        const int4* vec = reinterpret_cast<const int4*>(raw + head);
+        for (int64_t g = threadIdx.x; g < nvec; g += blockDim.x) {
+            const int4 v = vec[g];
+            const int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 8; e++) take((int16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffff)));
+        }
+        for (int d = 32; d >= 1; d >>= 1) { lo_cnt += __shfl_xor(lo_cnt, d); hi_cnt += __shfl_xor(hi_cnt, d); }
+        if (lane == 0) { if (lo_cnt) atomicAdd(&m->below, lo_cnt); if (hi_cnt) atomicAdd(&m->above, hi_cnt); }
+    }
+    __syncthreads();
+    const uint32_t below = m->below, above = m->above;
+    // median codes: thread t owns bins [32 t, 32 t + 32)
+    const int t32 = threadIdx.x * 32;
+    uint32_t mine = 0;
+    for (int i = 0; i < 32; i++) mine += fine[t32 + i];
+    uint32_t in_window;
+    const uint32_t off = block_excl_scan(mine, m, &in_window) + below;
+    for (int q = 0; q < 2; q++) {
+        const int64_t k = q ? k2 : k1;
+        if (k < (int64_t)below || k >= (int64_t)below + in_window) { if (threadIdx.x == 0) m->ok = 0; }
+        else if ((int64_t)off <= k && k < (int64_t)off + mine) {
+            int64_t c = off;
+            for (int i = 0; i < 32; i++) {
+                c += fine[t32 + i];
+                if (k < c) { m->found_bin[q] = t32 + i; break; }
+            }
+        }
+    }
+    __syncthreads();
+    if (!m->ok) return false;
+    const int m1 = m->found_bin[0], m2 = m->found_bin[1];
+    auto x_of = [&](int bin) { return scaling * ((double)(int16_t)((uint16_t)(ub0 + bin) ^ 0x8000u) + offset); };
+    const double shift = (n & 1) ? x_of(m1) : ((0.0 + x_of(m1)) + x_of(m2)) / 2.0;
+    // level spacing (one code step) must dwarf the rounding of the deviations
+    if (!(scaling > 1e-9 * (fabs(x_of(m1)) + fabs(x_of(m2)) + fabs(shift) + 1.0))) return false;
+    // levels: thread t owns levels [32 t, 32 t + 32)
+    auto cnt_l = [&](int a) { const int v = m1 - a; return v >= 0 ? fine[v] : 0u; };
+    auto cnt_r = [&](int a) { const int v = m2 + a; return v < kWin ? fine[v] : 0u; };
+    auto level = [&](int a) { return (a == 0 && m1 == m2) ? fine[m1] : cnt_l(a) + cnt_r(a); };
+    uint32_t lmine = 0;
+    for (int i = 0; i < 32; i++) lmine += level(t32 + i);
+    uint32_t covered;
+    const uint32_t loff = block_excl_scan(lmine, m, &covered);
+    __syncthreads();
+    if (threadIdx.x == 0) { m->found_bin[0] = -1; m->found_bin[1] = -1; }
+    __syncthreads();
+    for (int q = 0; q < 2; q++) {
+        const int64_t k = q ? k2 : k1;
+        if ((int64_t)loff <= k && k < (int64_t)loff + lmine) {
+            int64_t c = loff;
+            for (int i = 0; i < 32; i++) {
+                const int64_t c0 = c;
+                c += level(t32 + i);
+                if (k < c) { m->found_bin[q] = t32 + i; sel->k[q] = k - c0; break; }
+            }
+        }
+    }
+    __syncthreads();
+    double e[2];
+    for (int q = 0; q < 2; q++) {
+        const int a = m->found_bin[q];
+        if (a < 0) return false;  // the rank reaches codes outside the window
+        // a level is decided only if neither side of it (nor of the levels before) hides samples outside the window
+        if ((below && m1 - a < 0) || (above && m2 + a >= kWin)) return false;
+        const int64_t r = sel->k[q];
+        double dev;
+        if (a == 0 && m1 == m2) {
+            dev = fabs(x_of(m1) - shift);
+        } else {
+            const uint32_t cl = cnt_l(a), cr = cnt_r(a);
+            const double dl = cl ? fabs(x_of(m1 - a) - shift) : 0.0, dr = cr ? fabs(x_of(m2 + a) - shift) : 0.0;
+            if (!cl) dev = dr;
+            else if (!cr) dev = dl;
+            else if (dl <= dr) dev = r < (int64_t)cl ? dl : dr;
+            else dev = r < (int64_t)cr ? dr : dl;
+        }
+        e[q] = dev / kMadC;
+    }
+    *shift_out = shift;
+    *scale_out = (n & 1) ? e[0] : ((0.0 + e[0]) + e[1]) / 2.0;
+    return true;
+}
+
 __global__ __launch_bounds__(1024) void dsp_ext_mad_kernel(dsp_read_batch b, double* shift_out, double* scale_out) {
+    extern __shared__ uint32_t fine_lds[];  // kWin bins
     __shared__ SelectLds sel;
+    __shared__ MadLds mad;
     const int64_t r = blockIdx.x;
     const int16_t* raw = b.raw + b.raw_off[r];
     const int64_t n = b.raw_off[r + 1] - b.raw_off[r];
     const double scaling = b.scaling[r], offset = b.offset[r];
     double shift = 0.0, scale = 0.0;
     if (n > 0) {
-        if (scaling > 0.0) {
-            // pA is a non-decreasing function of the DAQ code: take the order statistics on the 16-bit codes
-            auto kraw = [](int16_t c) { return (uint64_t)(uint16_t)(c ^ (int16_t)0x8000); };
-            auto vraw = [&](uint64_t u) { return scaling * ((double)(int16_t)((uint16_t)u ^ 0x8000u) + offset); };
-            shift = np_median(raw, n, kraw, vraw, 8, &sel);
-        } else {
-            auto kx = [&](int16_t c) { return ord_bits(scaling * ((double)c + offset)); };
-            auto vx = [](uint64_t u) { return ord_value(u); };
-            shift = np_median(raw, n, kx, vx, 56, &sel);
+        const bool fast = scaling > 0.0 && n < (1ll << 31) &&
+                          mad_by_histogram(raw, n, scaling, offset, fine_lds, &sel, &mad, &shift, &scale);
+        if (!fast) {
+            if (scaling > 0.0) {
+                // pA is a non-decreasing function of the DAQ code: take the order statistics on the 16-bit codes
+                auto kraw = [](int16_t c) { return (uint64_t)(uint16_t)(c ^ (int16_t)0x8000); };
+                auto vraw = [&](uint64_t u) { return scaling * ((double)(int16_t)((uint16_t)u ^ 0x8000u) + offset); };
+                shift = np_median(raw, n, kraw, vraw, 8, &sel);
+            } else {
+                auto kx = [&](int16_t c) { return ord_bits(scaling * ((double)c + offset)); };
+                auto vx = [](uint64_t u) { return ord_value(u); };
+                shift = np_median(raw, n, kx, vx, 56, &sel);
+            }
+            // median(|x - med| / c): x / c is monotone in x, so select on |x - med| and divide the selected values
+            auto ke = [&](int16_t c) { return ord_bits(fabs(scaling * ((double)c + offset) - shift)); };
+            auto ve = [](uint64_t u) { return ord_value(u) / kMadC; };
+            scale = np_median(raw, n, ke, ve, 56, &sel);
         }
-        // median(|x - med| / c): x / c is monotone in x, so select on |x - med| and divide the selected values
-        auto ke = [&](int16_t c) { return ord_bits(fabs(scaling * ((double)c + offset) - shift)); };
-        auto ve = [](uint64_t u) { return ord_value(u) / kMadC; };
-        scale = np_median(raw, n, ke, ve, 56, &sel);
     }
     if (threadIdx.x == 0) {
         shift_out[r] = shift;
@@ -822,7 +983,16 @@ int32_t dsp_extract_normalize(void* stream, const dsp_read_batch* b, int32_t met
         return ext_fail(DSP_EINVAL, "dsp_extract_normalize: bad arguments");
     if (b->n_reads == 0) return DSP_OK;
     if (method == DSP_NORM_MAD)
-        hipLaunchKernelGGL(dsp_ext_mad_kernel, dim3((unsigned)b->n_reads), dim3(1024), 0, (hipStream_t)stream, *b, shift, scale);
+    {
+        static bool attr_set = false;  // 128 KB of dynamic LDS needs the opt-in (set once; idempotent if raced)
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)dsp_ext_mad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWin * 4) != hipSuccess)
+                return ext_fail(DSP_EHIP, "dsp_extract_normalize: cannot reserve LDS for the MAD kernel");
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(dsp_ext_mad_kernel, dim3((unsigned)b->n_reads), dim3(1024), (size_t)kWin * 4, (hipStream_t)stream, *b,
+                           shift, scale);
+    }
     else
         hipLaunchKernelGGL(dsp_ext_zscore_kernel, dim3((unsigned)b->n_reads), dim3(256), 0, (hipStream_t)stream, *b, shift, scale);
     return ext_check_launch("dsp_extract_normalize");

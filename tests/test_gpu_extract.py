@@ -142,3 +142,35 @@ def test_extracted_features_drive_call_mods_like_the_tsv_route(tmp_path):
     _, p_tsv = model.forward(t(rows.kmer), t(rows.means), t(rows.stds), t(rows.lens), t(rows.signals))
     _, p_dev = model.forward(out.kmer, out.means, out.stds, out.lens, out.signals)
     assert torch.equal(p_tsv, p_dev) and p_dev.shape == (len(feats), 2)
+
+
+def test_mad_fast_path_and_its_fallbacks_match_numpy():
+    """the windowed-histogram MAD (two passes) and the generic radix select it falls back to, on reads built to hit
+    each: ordinary DAQ ranges (odd / even lengths, ties at the median), codes spread over the whole int16 range, a
+    bimodal read whose medians lie 40,000 codes apart (outside any window), negative scaling, a constant read"""
+    rng = np.random.default_rng(5)
+    base = R.synth_reads(1, seed=9, mean_bases=60)[0]
+
+    def read_with(raw, scaling=0.18, offset=7.0):
+        r = R.ReadRecord("r", "t", "+", "chr1", 0, raw, scaling, offset, base.ev_start[:5], base.ev_len[:5], base.ev_base[:5])
+        return r
+    raws = [
+        rng.integers(300, 700, size=9999),                      # odd length
+        rng.integers(300, 700, size=10000),                     # even length
+        np.repeat(np.array([500, 501]), 5000),                   # medians straddle two codes, massive ties
+        np.full(4096, 512),                                      # constant: scale 0
+        rng.integers(-32768, 32768, size=20001),                 # whole int16 range: MAD level beyond the window
+        np.concatenate([rng.integers(-32768, -20000, size=6000), rng.integers(20000, 32768, size=6000)]),  # bimodal
+        np.concatenate([rng.integers(400, 600, size=50000), rng.integers(-30000, 30000, size=300)]),       # outliers outside the window
+        rng.integers(0, 8192, size=131077),
+        np.array([5]), np.array([5, 9]), np.array([9, 5, 7]),
+    ]
+    reads = [read_with(x.astype(np.int16)) for x in raws]
+    reads.append(read_with(raws[1].astype(np.int16), scaling=-0.18))   # decreasing pA: generic path
+    reads.append(read_with(raws[1].astype(np.int16), scaling=1e-30))   # degenerate spacing: guarded -> generic path
+    out = ef.FeatureExtractor(normalize_method="mad").extract(reads)
+    shift, scale = out.shift.cpu().numpy(), out.scale.cpu().numpy()
+    for i, r in enumerate(reads):
+        x = ox.rescale_signals(r.raw, r.scaling, r.offset)
+        want = (np.median(x), float(ox.mad(x)))
+        assert (shift[i], scale[i]) == want, (i, len(r.raw), shift[i], scale[i], want)
