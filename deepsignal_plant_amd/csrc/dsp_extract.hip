@@ -7,11 +7,14 @@
 //   * np.add.reduce over a contiguous float64 array = 0.0 + pairwise sums of 8192-element buffer chunks, each chunk
 //     summed by numpy's pairwise scheme (blocks of <= 128 with 8 accumulators, halves rounded down to a multiple
 //     of 8 above that);
-//   * np.median = k-th order statistic (mean of the two middle ones for even n), found here with an 8-pass
-//     radix select over the order-preserving 64-bit image of the doubles -- no sort, no scratch arrays;
+//   * np.median = k-th order statistic (mean of the two middle ones for even n): read off code histograms in two
+//     streamed passes when pA is monotone in the DAQ code (dsp_ext_mad_kernel), else found with an 8-pass radix
+//     select over the order-preserving 64-bit image of the doubles -- no sort, no scratch arrays;
 //   * np.around(x, 6) = rint(x * 1e6) / 1e6.
-// HBM-bound integer/byte work: one workgroup per read for the read statistics, one thread per base for the base
-// statistics, one thread per (site, base) for the window gather; no MFMA.
+// HBM-bound integer/byte work, no MFMA: one 1024-thread workgroup per read for the read statistics; 8 adjacent
+// lanes per base for the base statistics (lane j = accumulator r[j] of numpy's unrolled loop; stalls of more than
+// 128 samples by the whole workgroup); 4 output samples per lane (one 16-byte store) for the window gather, the bases
+// longer than signal_len compacted into full waves for the subset draw.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
