@@ -12,6 +12,7 @@ MODULE_CODE = {"both_bilstm": 0, "seq_bilstm": 1, "signal_bilstm": 2}
 DT_F32, DT_U8, DT_U16, DT_I32 = 0, 1, 2, 3
 INIT_ZEROS, INIT_EXPLICIT, INIT_PHILOX = 0, 1, 2
 NORM_MAD, NORM_ZSCORE = 0, 1
+PRECISION = {"fp32": 0, "bf16x6": 6, "bf16x9": 9}
 
 
 class ModelCfg(ctypes.Structure):
@@ -72,6 +73,8 @@ def lib():
     L.dsp_profile_read.restype = ctypes.c_int32
     L.dsp_profile_read.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t,
                                    ctypes.POINTER(ctypes.c_float), ctypes.c_int32]
+    L.dsp_model_set_precision.restype = ctypes.c_int32
+    L.dsp_model_set_precision.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     L.dsp_model_destroy.restype = None
     L.dsp_model_destroy.argtypes = [ctypes.c_void_p]
     L.dsp_count_rows.restype = ctypes.c_int64

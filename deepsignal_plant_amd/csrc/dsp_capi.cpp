@@ -124,7 +124,7 @@ std::vector<int> map_bidir(int H, int Hp) {  // [fwd Hp | bwd Hp] -> [fwd H | bw
     return m;
 }
 
-struct DevLstmLayer { int Ipad, Iused, H, Hp; float* wpk[2]; float* sbias[2]; };
+struct DevLstmLayer { int Ipad, Iused, H, Hp; float* wpk[2]; float* sbias[2]; float* wsplit[2]; };  // wsplit: see pack_lstm_dir_split
 struct DevLinear { int Fin, ORT; float* wpk; float* bias; };
 
 // A fragments for gates^T = W * act^T :  [UT][NQ][4 gates][64 lanes][4]
@@ -156,6 +156,56 @@ void pack_lstm_dir(const float* wih, const float* whh, const float* bih, const f
                 }
     for (int g = 0; g < 4; ++g)
         for (int unit = 0; unit < H; ++unit) bias[(size_t)g * Hp + unit] = bih[g * H + unit] + bhh[g * H + unit];
+}
+
+// Split-bf16 A fragments of the same Wcat for dsp_lstm6_kernel (v_mfma_f32_32x32x16_bf16):
+//   [UT][(Ipad+Hp)/16 k-stages][4 gates][3 pieces][64 lanes][8 bf16]
+//   piece p of Wcat[g*H + u*32 + (lane&31)][16q + 8*(lane>>5) + j];  hi + mid + lo == the fp32 weight exactly
+inline uint16_t bf16_rne(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    return (uint16_t)u;
+}
+inline float bf16_to_f32(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+void pack_lstm_dir_split(const float* wih, const float* whh, int I, int H, int Hp, const std::vector<int>& in_map,
+                         std::vector<float>& out) {
+    const int Ipad = (int)in_map.size();
+    const int UT = Hp / 32, NQ = (Ipad + Hp) / 16;
+    std::vector<uint16_t> pk((size_t)UT * NQ * 4 * 3 * 64 * 8, 0);
+    for (int u = 0; u < UT; ++u)
+        for (int q = 0; q < NQ; ++q)
+            for (int g = 0; g < 4; ++g)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int unit = u * 32 + (lane & 31);
+                    if (unit >= H) continue;
+                    const size_t row = (size_t)g * H + unit;
+                    for (int j = 0; j < 8; ++j) {
+                        const int kk = 16 * q + 8 * (lane >> 5) + j;
+                        float v = 0.f;
+                        if (kk < Ipad) {
+                            const int col = in_map[kk];
+                            if (col >= 0) v = wih[row * I + col];
+                        } else {
+                            const int hk = kk - Ipad;
+                            if (hk < H) v = whh[row * H + hk];
+                        }
+                        const uint16_t hi = bf16_rne(v);
+                        const float r1 = v - bf16_to_f32(hi);
+                        const uint16_t mid = bf16_rne(r1);
+                        const uint16_t lo = bf16_rne(r1 - bf16_to_f32(mid));
+                        const uint16_t piece[3] = {hi, mid, lo};
+                        for (int p = 0; p < 3; ++p)
+                            pk[((((((size_t)u * NQ + q) * 4 + g) * 3 + p) * 64 + lane) * 8) + j] = piece[p];
+                    }
+                }
+    out.resize(pk.size() / 2);
+    memcpy(out.data(), pk.data(), pk.size() * 2);
 }
 
 // A fragments for out^T = W * act^T : [ORT][Fin/8][64][4]
@@ -195,6 +245,7 @@ struct dsp_model {
     int hseq_p = 0, hsig_p = 0, Hp = 0, Fseq = 0, Fsig = 0, Fcomb = 0, Fwide = 0;
     std::vector<int> comb_in_map;  // padded comb-input feature -> reference feature
     int lstm_kernel = 4;           // 4 = dsp_lstm4_kernel (2 waves/SIMD, default); 3 = dsp_lstm3_kernel (1 wave/SIMD)
+    int precision = DSP_PREC_FP32; // products of the combined stack: fp32 MFMA, or split-bf16 emulation (dsp_lstm6_kernel)
     // scratch
     void* ws = nullptr;
     int64_t ws_sites = 0;
@@ -221,7 +272,7 @@ int upload(dsp_model* m, const std::vector<float>& h, float** out) {
 }
 
 int build_stack(dsp_model* m, const float* const* w, int in, int hid, int layers, std::vector<int> in_map0,
-                std::vector<DevLstmLayer>& out) {
+                std::vector<DevLstmLayer>& out, bool with_split = false) {
     const int Hp = pad_hidden(hid);
     for (int k = 0; k < layers; ++k) {
         const int I = k == 0 ? in : 2 * hid;
@@ -245,6 +296,13 @@ int build_stack(dsp_model* m, const float* const* w, int in, int hid, int layers
             }
             rc = upload(m, sb, &L.sbias[d]);
             if (rc) return rc;
+            L.wsplit[d] = nullptr;
+            if (with_split && L.Ipad % 16 == 0 && Hp % 16 == 0 && Hp / 32 <= 8 && L.Ipad >= 16) {
+                std::vector<float> ws;
+                pack_lstm_dir_split(p[0], p[1], I, hid, Hp, in_map, ws);
+                rc = upload(m, ws, &L.wsplit[d]);
+                if (rc) return rc;
+            }
         }
         out.push_back(L);
     }
@@ -346,7 +404,15 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
             if (hipMalloc((void**)&dbg, 16 * 8 * sizeof(unsigned long long)) == hipSuccess) hipMemset(dbg, 0, 16 * 8 * 8);
             a.dbg = dbg;
         }
-        L.run(name, [&] { return k4 ? dsp_k_lstm4(&a, L.s) : dsp_k_lstm3(&a, upw, L.s); });
+        const bool split = k4 && m->precision != DSP_PREC_FP32 && ly.wsplit[0] && ly.wsplit[1];
+        if (split) {  // same geometry as lstm4; weights and k-stage count of the split-bf16 kernel
+            a.wpk0 = ly.wsplit[0]; a.wpk1 = ly.wsplit[1];
+            a.NQ = (ly.Ipad + ly.Hp) / 16;
+        }
+        L.run(name, [&] {
+            return split ? dsp_k_lstm6(&a, m->precision == DSP_PREC_BF16X9 ? 9 : 6, L.s)
+                         : (k4 ? dsp_k_lstm4(&a, L.s) : dsp_k_lstm3(&a, upw, L.s));
+        });
         if (dbg) {
             unsigned long long h[16 * 8];
             hipStreamSynchronize(L.s);
@@ -437,6 +503,8 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
     if (!m) { hipSetDevice(prev); return fail(DSP_ENOMEM, "out of host memory"); }
     m->cfg = *cfg; m->d = d; m->device = device;
     if (const char* v = getenv("DSP_LSTM_KERNEL")) m->lstm_kernel = atoi(v) == 3 ? 3 : 4;  // A/B switch
+    if (const char* v = getenv("DSP_PRECISION"))
+        m->precision = !strcmp(v, "bf16x6") ? DSP_PREC_BF16X6 : (!strcmp(v, "bf16x9") ? DSP_PREC_BF16X9 : DSP_PREC_FP32);
     m->hseq_p = d.hseq ? pad_hidden(d.hseq) : 0;
     m->hsig_p = d.hsig ? pad_hidden(d.hsig) : 0;
     m->Hp = pad_hidden(d.H);
@@ -478,7 +546,7 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
         rc = upload(m, bias, &m->fc_sig.bias); if (rc) return done(rc);
         wi += 2;
     }
-    rc = build_stack(m, w + wi, d.H, d.H, d.l1, m->comb_in_map, m->comb); if (rc) return done(rc);
+    rc = build_stack(m, w + wi, d.H, d.H, d.l1, m->comb_in_map, m->comb, true); if (rc) return done(rc);
     wi += 8 * d.l1;
     {
         std::vector<float> wpk, bias;
@@ -634,6 +702,13 @@ int32_t dsp_profile_read(dsp_model* m, char* names, size_t names_cap, float* ms,
     m->prof_entries.clear();
     m->event_used = 0;
     return k;
+}
+
+int32_t dsp_model_set_precision(dsp_model* m, int32_t precision) {
+    if (!m || (precision != DSP_PREC_FP32 && precision != DSP_PREC_BF16X6 && precision != DSP_PREC_BF16X9))
+        return fail(DSP_EINVAL, "dsp_model_set_precision: bad arguments");
+    m->precision = precision;
+    return DSP_OK;
 }
 
 void dsp_model_destroy(dsp_model* m) {

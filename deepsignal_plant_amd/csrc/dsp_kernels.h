@@ -74,6 +74,7 @@ int dsp_k_init(void);
 int dsp_k_pack(const PackArgs* a, hipStream_t s);
 int dsp_k_lstm3(const LstmArgs* a, int upw, hipStream_t s);
 int dsp_k_lstm4(const LstmArgs* a, hipStream_t s);
+int dsp_k_lstm6(const LstmArgs* a, int nprod, hipStream_t s);
 int dsp_k_linear(const LinArgs* a, hipStream_t s);
 int dsp_k_head(const HeadArgs* a, hipStream_t s);
 #ifdef __cplusplus

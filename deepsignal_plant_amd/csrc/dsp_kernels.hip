@@ -583,6 +583,190 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm4_kernel(LstmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// dsp_lstm6_kernel<NPROD> (opt-in, DSP_PRECISION=bf16x6 | bf16x9): dsp_lstm4_kernel with every fp32 product
+// emulated on the bf16 matrix cores.  Both operands are split into three bf16 pieces (hi + mid + lo == x exactly
+// for an fp32 x); a product keeps the NPROD largest piece products (9 = all of them, exact; 6 = without ml, lm,
+// ll, i.e. about 2^-24 relative -- below the rounding of an fp32 accumulation), smallest first, accumulated in
+// fp32 by v_mfma_f32_32x32x16_bf16 (8x the fp32 MFMA rate per piece product).  Weights come pre-split from the
+// host ([unit tile][k-stage of 16][gate][piece][lane] 16 B); activations stay fp32 in the K4 layout -- nothing
+// changes for the other kernels -- and are split in registers after the load.  Same wave/tile mapping, cell phase,
+// h exchange and initial-state handling as dsp_lstm4_kernel; one k-stage = 16 k = 4 K4 groups.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// 8 fp32 (two float4 = the lane's 8 consecutive k of a k-stage) -> hi / mid / lo as packed bf16x8
+__device__ __forceinline__ void split_bf16x3(const f32x4 x0, const f32x4 x1, u32x4& hi, u32x4& mid, u32x4& lo) {
+    const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = x[2 * i], b = x[2 * i + 1];
+        const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a, b}, bf16x2_t));  // RNE
+        const float ra = a - __builtin_bit_cast(float, hp << 16), rb = b - __builtin_bit_cast(float, hp & 0xffff0000u);
+        const unsigned mp = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){ra, rb}, bf16x2_t));
+        const float sa = ra - __builtin_bit_cast(float, mp << 16), sb = rb - __builtin_bit_cast(float, mp & 0xffff0000u);
+        const unsigned lp = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){sa, sb}, bf16x2_t));
+        hi[i] = hp; mid[i] = mp; lo[i] = lp;
+    }
+}
+
+template <int NPROD>
+__global__ __launch_bounds__(512, 2) void dsp_lstm6_kernel(LstmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* c_lds = (f32x4*)smem;           // [2 site tiles][4 groups][512 threads] float4
+    f32x4* b_lds = c_lds + 8 * 512;        // [unit tile][aa][gate][half] float4
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const uint32_t voff = (uint32_t)lane * 16u;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int u = w % a.UT, sg = w / a.UT;
+    const int dir = blockIdx.x & 1;
+    const int grp = blockIdx.x >> 1;
+    const int half = lane >> 5, ls = lane & 31;
+    const int HQ = a.Hp >> 2;
+    const int nqx = a.Ipad >> 4, NQ = a.NQ;  // k-stages of 16: x part, total
+    const int T = a.T;
+    const int F4 = a.Fout >> 2;
+    const uint32_t xrow = (uint32_t)(a.Ipad >> 2) * 512u;
+    const uint32_t orow = (uint32_t)F4 * 512u;
+    // the lane's two K4 groups of a stage: 2*half and 2*half+1 (k = 8*half + j inside the 16-wide stage)
+    const uint32_t xvoff = (uint32_t)half * 1024u + (uint32_t)ls * 16u;
+
+    const long long gt0 = (long long)grp * (a.SG * 2) + sg * 2;
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc((const char*)(dir ? a.wpk1 : a.wpk0) + (size_t)u * NQ * 12288);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)a.x + (size_t)gt0 * T * xrow);
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)a.out + (size_t)gt0 * T * orow + (size_t)dir * HQ * 512);
+    const __amdgpu_buffer_rsrc_t rh0 = make_rsrc((const char*)a.h0buf + (size_t)gt0 * orow + (size_t)dir * HQ * 512);
+    const f32x4* bias4 = (const f32x4*)(dir ? a.sbias1 : a.sbias0);
+
+    for (int i = tid; i < a.Hp; i += blockDim.x) {
+        const int h = i & 1, g = (i >> 1) & 3, aa = (i >> 3) & 3, ut = i >> 5;
+        b_lds[i] = bias4[g * HQ + ut * 8 + 2 * aa + h];
+    }
+    const f32x4* b_my = b_lds + (size_t)u * 32 + half;  // + aa*8 + gate*2
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const long long site = (gt0 + m) * 32 + ls;
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa) {
+            const int k4 = u * 8 + 2 * aa + half;
+            f32x4 hv = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
+            if (a.init_mode != 0) {
+                hv = init_state4(a.h0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, a.site_offset,
+                                 (uint32_t)(a.stream_base + dir * 2 + 0));
+                cv = init_state4(a.c0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, a.site_offset,
+                                 (uint32_t)(a.stream_base + dir * 2 + 1));
+            }
+            bst16(rh0, voff + aa * 1024u, (uint32_t)m * orow + (uint32_t)u * 4096u, hv);
+            c_lds[(m * 4 + aa) * 512 + tid] = cv;
+        }
+    }
+    __syncthreads();  // h0 stored (vmcnt drained) before any wave reads it back
+
+    __amdgpu_buffer_rsrc_t rhp = rh0;
+    uint32_t xo[2], ho[2];
+    auto set_bases = [&](int step) __attribute__((always_inline)) {
+        const int t = dir ? (T - 1 - step) : step;
+        const int tp = dir ? (t + 1) : (t - 1);
+        rhp = step == 0 ? rh0 : ro;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            xo[m] = (uint32_t)(m * T + t) * xrow;
+            ho[m] = (step == 0 ? (uint32_t)m * orow : (uint32_t)(m * T + tp) * orow) - (uint32_t)nqx * 2048u;
+        }
+    };
+
+    u32x4 A[4][3];
+    f32x4 X[2][2];
+    f32x16 acc[4][2];
+    auto loadX = [&](int q) __attribute__((always_inline)) {
+        const bool isx = q < nqx;
+        const __amdgpu_buffer_rsrc_t r = isx ? rx : rhp;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const uint32_t so = (isx ? xo[m] : ho[m]) + (uint32_t)q * 2048u;
+            X[m][0] = bld16(r, xvoff, so);
+            X[m][1] = bld16(r, xvoff + 512u, so);
+        }
+    };
+    auto loadA1 = [&](int g, int q) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            A[g][p] = __builtin_bit_cast(u32x4, bld16(rw, voff, (uint32_t)((q * 4 + g) * 3 + p) * 1024u));
+    };
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // piece products, smallest first: (ll, lm, ml,) mm, lh, hl, mh, hm, hh
+    constexpr int pa[9] = {2, 2, 1, 1, 2, 0, 1, 0, 0}, pb[9] = {2, 1, 2, 1, 0, 2, 0, 1, 0};
+    // one k-stage: split the activations loaded a stage ago, request the next ones, then per gate fragment the
+    // NPROD x 2 MFMAs followed by the (late) refill of that fragment for the next stage
+    auto stage = [&](int q, int qn, auto first) __attribute__((always_inline)) {
+        u32x4 B[2][3];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) split_bf16x3(X[m][0], X[m][1], B[m][0], B[m][1], B[m][2]);
+        loadX(qn);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int k = 9 - NPROD; k < 9; ++k) {
+                const bf16x8 av = __builtin_bit_cast(bf16x8, A[g][pa[k]]);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const bf16x8 bv = __builtin_bit_cast(bf16x8, B[m][pb[k]]);
+                    if (decltype(first)::value && k == 9 - NPROD)
+                        acc[g][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, zero16, 0, 0, 0);
+                    else
+                        acc[g][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[g][m], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            loadA1(g, qn);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    set_bases(0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) loadA1(g, 0);
+    loadX(0);
+
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? (T - 1 - step) : step;
+        if (step > 0) __syncthreads();  // h_{t-1} of every wave stored (vmcnt(0) + barrier) before anyone reads it back
+        stage(0, 1, std::true_type{});
+        for (int q = 1; q < NQ - 1; ++q) stage(q, q + 1, std::false_type{});
+        set_bases(step + 1 < T ? step + 1 : step);  // the activation request of the last stage belongs to the next step
+        stage(NQ - 1, 0, std::false_type{});
+
+        // LSTM cell (see lstm3): pre-scaled biases folded into the exp2 arguments
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa) {
+            const f32x4 bi = b_my[aa * 8 + 0], bf = b_my[aa * 8 + 2], bg = b_my[aa * 8 + 4], bo = b_my[aa * 8 + 6];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                f32x4 cv = c_lds[(m * 4 + aa) * 512 + tid];
+                f32x4 hv;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 4 * aa + i;
+                    const float ig = sigmoid_pre(acc[0][m][r], bi[i]);
+                    const float fg = sigmoid_pre(acc[1][m][r], bf[i]);
+                    const float gg = tanh_pre(acc[2][m][r], bg[i]);
+                    const float og = sigmoid_pre(acc[3][m][r], bo[i]);
+                    const float cn = __builtin_fmaf(fg, cv[i], ig * gg);
+                    cv[i] = cn;
+                    hv[i] = og * fast_tanh(cn);
+                }
+                c_lds[(m * 4 + aa) * 512 + tid] = cv;
+                bst16(ro, voff + aa * 1024u, (uint32_t)(m * T + t) * orow + (uint32_t)u * 4096u, hv);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // linear_kernel: out[., out_off + o] = act( W[o,:] . x[., :] + b[o] ) on K4 activations, per (tile, t)
 // column block of 32 sites.  Used for fc_seq / fc_signal (+ReLU; models.py:199-201, :215-217).
 // ------------------------------------------------------------------------------------------------
@@ -738,6 +922,10 @@ extern "C" int dsp_k_init(void) {
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)dsp_lstm4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)dsp_lstm6_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)dsp_lstm6_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)dsp_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     return (int)e;
 }
@@ -765,6 +953,16 @@ extern "C" int dsp_k_lstm4(const LstmArgs* a, hipStream_t s) {
     const bool sparse = a->nqx_used < (a->Ipad >> 3) || a->NQ > ((a->Ipad + a->Hp) >> 3);
     if (sparse) hipLaunchKernelGGL(dsp_lstm4_kernel<true>, dim3(groups * 2), dim3(waves * 64), lds, s, *a);
     else hipLaunchKernelGGL(dsp_lstm4_kernel<false>, dim3(groups * 2), dim3(waves * 64), lds, s, *a);
+    return (int)hipGetLastError();
+}
+
+// split-bf16 variant: a->wpk0/1 = split weights, a->NQ = k-stages of 16, nprod = 6 or 9
+extern "C" int dsp_k_lstm6(const LstmArgs* a, int nprod, hipStream_t s) {
+    const int waves = a->UT * a->SG;
+    const unsigned groups = (unsigned)(a->NTp / (a->SG * 2));
+    const size_t lds = (size_t)8 * 512 * 16 + (size_t)a->Hp * 16;
+    if (nprod == 9) hipLaunchKernelGGL(dsp_lstm6_kernel<9>, dim3(groups * 2), dim3(waves * 64), lds, s, *a);
+    else hipLaunchKernelGGL(dsp_lstm6_kernel<6>, dim3(groups * 2), dim3(waves * 64), lds, s, *a);
     return (int)hipGetLastError();
 }
 

@@ -51,6 +51,7 @@ class ModelBiLSTM(object):
         # parameters start as zeros; real values come from load_state_dict (call_modifications.py:219-223)
         self._params = OrderedDict((k, torch.zeros(shp, dtype=torch.float32)) for k, shp in self._spec)
         self._handle = None
+        self._precision = None
         self._training = True
 
     # ---- reference-compatible surface -------------------------------------------------------------
@@ -130,6 +131,19 @@ class ModelBiLSTM(object):
         nat.check(L.dsp_model_create(ctypes.byref(self._cfg), ptrs, numels, len(tensors), self._device_index(),
                                      ctypes.byref(h)))
         self._handle = h
+        if self._precision is not None:
+            nat.check(L.dsp_model_set_precision(h, nat.PRECISION[self._precision]))
+
+    def set_precision(self, precision):
+        """How the fp32 products of the combined BiLSTM stack are evaluated: "fp32" (fp32 MFMA, the default),
+        "bf16x9" / "bf16x6" (split-bf16 emulation on the bf16 matrix cores, include/dsp_amd.h).  None = whatever
+        DSP_PRECISION says (default fp32)."""
+        if precision is not None and precision not in nat.PRECISION:
+            raise ValueError("precision must be one of %s" % sorted(nat.PRECISION))
+        self._precision = precision
+        if self._handle is not None and precision is not None:
+            nat.check(nat.lib().dsp_model_set_precision(self._handle, nat.PRECISION[precision]))
+        return self
 
     def _release(self):
         if self._handle is not None:

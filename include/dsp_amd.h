@@ -126,6 +126,16 @@ int32_t dsp_debug_read_activation(dsp_model* m, void* stream, int32_t which, int
 int32_t dsp_profile_enable(dsp_model* m, int32_t on);
 int32_t dsp_profile_read(dsp_model* m, char* names, size_t names_cap, float* ms, int32_t cap);
 
+/* How the fp32 products of the combined BiLSTM stack (92 % of the FLOPs) are evaluated.  DSP_PREC_FP32 (default):
+ * v_mfma_f32_32x32x2_f32.  DSP_PREC_BF16X9 / DSP_PREC_BF16X6: every operand is split into three bf16 pieces
+ * (hi + mid + lo == x exactly) and a product becomes 9 (all: exact) or 6 (without the three smallest: ~2^-24
+ * relative, below the rounding of an fp32 accumulation) piece products on v_mfma_f32_32x32x16_bf16, accumulated in
+ * fp32.  Inputs, outputs, layouts and every other kernel are unchanged.  Also settable at creation through the
+ * environment variable DSP_PRECISION = fp32 | bf16x6 | bf16x9.  (No reference counterpart: torch.nn.LSTM on CPU is
+ * fp32 throughout, models.py:137-157.) */
+enum { DSP_PREC_FP32 = 0, DSP_PREC_BF16X6 = 6, DSP_PREC_BF16X9 = 9 };
+int32_t dsp_model_set_precision(dsp_model* m, int32_t precision);
+
 void dsp_model_destroy(dsp_model* m);
 
 /* ---- host-side text I/O of the path (plain C++, multi-threaded; no GPU involved) ------------------------

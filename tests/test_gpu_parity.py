@@ -208,3 +208,40 @@ def test_empty_batch():
     z = [torch.zeros((0, 13), device="cuda:0")] * 4 + [torch.zeros((0, 13, 16), device="cuda:0")]
     logits, probs = m(*z)
     assert logits.shape == (0, 2) and probs.shape == (0, 2)
+
+
+@pytest.mark.parametrize("precision", ["bf16x9", "bf16x6"])
+def test_split_bf16_product_emulation_stays_within_the_fp32_path(precision):
+    """opt-in split-bf16 evaluation of the combined stack's products (include/dsp_amd.h, DSP_PREC_*): against the
+    fixtures captured from the reference it has to meet the same bound as the fp32 path, and it must agree with
+    the fp32 path itself far below the 1e-4 contract -- also with sharp (x3) weights and Philox states at full
+    batch"""
+    torch = _torch()
+    from deepsignal_plant_amd.models import ModelBiLSTM
+    for name in ("both_default", "both_sharp", "seq_cfg3"):
+        f = load_f1(name)
+        model = build_model(f["cfg"], f["w"])
+        st = {k: torch.from_numpy(v).cuda(0) for k, v in f["states"].items()}
+        ins = to_dev(f["inputs"])
+        _, p32 = model.forward(*ins, init_states=st)
+        model.set_precision(precision)
+        _, ps = model.forward(*ins, init_states=st)
+        err_ref = float(np.abs(ps.cpu().numpy() - f["probs"]).max())
+        err_32 = float((ps - p32).abs().max())
+        print(name, precision, "vs reference %.2e, vs fp32 path %.2e" % (err_ref, err_32))
+        assert err_ref <= TOL_TIGHT and err_32 <= 5e-6, (name, precision, err_ref, err_32)
+        model.set_precision("fp32")
+        _, again = model.forward(*ins, init_states=st)
+        assert torch.equal(again, p32)
+    # full batch, in-kernel Philox states
+    from deepsignal_plant_amd import synth
+    model = ModelBiLSTM(init_state="randn", seed=3)
+    model.load_state_dict(synth.random_state_dict(model, seed=5, scale=2.0))
+    model.cuda(0)
+    ins = synth.feature_batch(65536 + 77, device="cuda:0", seed=9)
+    _, p32 = model.forward(*ins)
+    model.set_precision(precision)
+    _, ps = model.forward(*ins)
+    assert float((ps - p32).abs().max()) <= 5e-6
+    with pytest.raises(ValueError):
+        model.set_precision("fp16")
