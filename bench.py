@@ -55,6 +55,10 @@ def main():
     ap.add_argument("--layernum1", type=int, default=3)
     ap.add_argument("--hid_rnn", type=int, default=256)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--precision", default=os.environ.get("DSP_PRECISION", "fp32"), choices=["fp32", "bf16x6", "bf16x9"],
+                    help="products of the combined stack: fp32 MFMA (default, what `value` is measured in) or the opt-in "
+                         "split-bf16 emulation (include/dsp_amd.h DSP_PREC_*)")
+    ap.add_argument("--no_alt", action="store_true", help="skip the extra bf16x6 measurement reported under alt_precision")
     ap.add_argument("--gather", action="store_true", help="optional final RCCL all_gather of per-site probs")
     args = ap.parse_args()
 
@@ -91,6 +95,7 @@ def main():
     sd = synth.random_state_dict(model, seed=1234)
     model.load_state_dict(sd)
     model.cuda(local_rank).eval()
+    model.set_precision(args.precision)
     model.reserve(B)
     flops_site = model.flops_per_site()
 
@@ -132,6 +137,29 @@ def main():
             dist.all_gather(gathered, src)
     assert outs is not None and bool(torch.isfinite(outs[1]).all())
 
+    # opt-in mode, reported next to the headline (never as `value`): the same steps with the combined stack's fp32
+    # products emulated by 6 bf16 piece products (include/dsp_amd.h), and how far its probabilities are from fp32's
+    alt = None
+    if world == 1 and args.precision == "fp32" and not args.no_alt and K > 0:
+        ka = min(K, 40)
+        model.site_offset = site0
+        ref = model(*batches[0])[1].clone()
+        model.set_precision("bf16x6")
+        for i in range(2):
+            step(i)
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        for i in range(ka):
+            step(i)
+        torch.cuda.synchronize()
+        ta = time.perf_counter() - ta
+        model.site_offset = site0
+        dmax = float((model(*batches[0])[1] - ref).abs().max())
+        model.set_precision("fp32")
+        alt = {"dtype": "f32 via bf16x6 (3 bf16 pieces per operand, 6 piece products, f32 accumulate)",
+               "value": round(ka * B / ta, 1), "unit": "sites/s", "steps": ka, "ms_per_step": round(ta / ka * 1e3, 3),
+               "max_abs_dprob_vs_fp32_path": dmax, "how": "python bench.py --precision bf16x6"}
+
     if rank == 0:
         total_sites = world * K * B
         value = total_sites / dt
@@ -145,7 +173,10 @@ def main():
         n_lstm = max(len(comb_ms), 1)
         avg_ms = sum(comb_ms) / n_lstm
         flops_per_launch = comb_flops_site * B * K / n_lstm
-        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        nprod = {"fp32": 1, "bf16x6": 6, "bf16x9": 9}[args.precision]
+        # split-bf16 modes execute nprod bf16 piece products per fp32 product: price those against the bf16 peak
+        peak = FP32_MATRIX_PEAK_TFLOPS if nprod == 1 else 16 * FP32_MATRIX_PEAK_TFLOPS
+        achieved = nprod * flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         lstm_ms = comb_ms
         traffic = None
         try:  # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/)
@@ -157,7 +188,9 @@ def main():
         line = {
             "metric": "methylation sites/sec, %s bn13_sn16" % args.model_type, "value": round(value, 1), "unit": "sites/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / max(K, 1) * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if nprod == 1 else "f32 via %s (3 bf16 pieces per operand, %d piece products, f32 accumulate)" % (args.precision, nprod),
+            "data": "synthetic",
             "config": {"workload": "%d synthetic sites, %s bn13_sn16 fp32, batch %d on %dxMI355X (BASELINE.json configs[%d])"
                                    % (total_sites, args.model_type, B, world,
                                       2 if args.model_type == "seq_bilstm" else (1 if world == 1 else 3)),
@@ -165,14 +198,16 @@ def main():
                        "init_state": "in-kernel Philox N(0,1) (stand-in for torch.randn, models.py:169-176)",
                        "weights": "seeded random state_dict, PyTorch default-init scale", "parallelism": "range-shard x%d" % world,
                        "flops_per_site": flops_site},
-            "roofline": {"bound": "mfma", "kernel": "dsp_lstm4_kernel<false>", "achieved": round(achieved, 2),
-                         "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4),
-                         "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches": len(lstm_ms),
+            "roofline": {"bound": "mfma", "kernel": "dsp_lstm4_kernel<false>" if nprod == 1 else "dsp_lstm6_kernel<%d>" % nprod,
+                         "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                         "traffic": traffic if nprod == 1 else None, "avg_launch_ms": round(avg_ms, 4), "launches": len(lstm_ms),
                          "flops_per_launch": flops_per_launch,
                          "whole_forward_tflops": round(value / world * flops_site / 1e12, 2),
                          "hbm_gbps_algorithmic": round(value / world * 1048 / 1e9, 3),
                          "kernel_time_frac_of_wall": round(all_ms * 1e-3 / dt, 4)},
         }
+        if alt is not None:
+            line["alt_precision"] = alt
         if not args.no_cpu_baseline and world == 1:
             try:
                 kw = dict(num_layers1=args.layernum1, hidden_size=args.hid_rnn, module=args.model_type)

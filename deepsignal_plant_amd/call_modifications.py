@@ -59,6 +59,8 @@ def load_model(args, device):
     model.load_state_dict(model_dict)
     model.cuda(device)
     model.eval()
+    if getattr(args, "precision", None):
+        model.set_precision(args.precision)
     return model
 
 
@@ -452,6 +454,10 @@ def add_call_mods_args(p):
     g.add_argument("--init_state", type=str, default="randn", choices=["randn", "zeros"],
                    help="LSTM initial states: 'randn' = N(0,1) like the reference's init_hidden (in-kernel Philox), 'zeros'")
     g.add_argument("--seed", type=int, default=0, help="seed of the in-kernel initial-state generator")
+    g.add_argument("--precision", type=str, default=None, choices=["fp32", "bf16x6", "bf16x9"],
+                   help="how the fp32 products of the combined BiLSTM stack are evaluated: fp32 matrix cores (default), or "
+                        "split into bf16 pieces on the bf16 matrix cores (bf16x9: all nine piece products, exact; bf16x6: "
+                        "without the three smallest, ~1.4x faster, probabilities within 1e-7 of the fp32 path)")
     g.add_argument("--freq_file", type=str, default=None,
                    help="also write the per-site modification frequency (what `call_freq` computes from the result file) "
                         "without re-reading the per-read calls")

@@ -223,6 +223,7 @@ def test_split_bf16_product_emulation_stays_within_the_fp32_path(precision):
         model = build_model(f["cfg"], f["w"])
         st = {k: torch.from_numpy(v).cuda(0) for k, v in f["states"].items()}
         ins = to_dev(f["inputs"])
+        model.set_precision("fp32")  # whatever DSP_PRECISION says
         _, p32 = model.forward(*ins, init_states=st)
         model.set_precision(precision)
         _, ps = model.forward(*ins, init_states=st)
@@ -239,6 +240,7 @@ def test_split_bf16_product_emulation_stays_within_the_fp32_path(precision):
     model.load_state_dict(synth.random_state_dict(model, seed=5, scale=2.0))
     model.cuda(0)
     ins = synth.feature_batch(65536 + 77, device="cuda:0", seed=9)
+    model.set_precision("fp32")
     _, p32 = model.forward(*ins)
     model.set_precision(precision)
     _, ps = model.forward(*ins)
