@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--layernum1", type=int, default=3)
     ap.add_argument("--hid_rnn", type=int, default=256)
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--precision", default=os.environ.get("DSP_PRECISION", "fp32"), choices=["fp32", "bf16x6", "bf16x9"],
+    ap.add_argument("--precision", default=os.environ.get("DSP_PRECISION", "fp32"), choices=["fp32", "bf16x6", "bf16x9", "fp16x3"],
                     help="products of the combined stack: fp32 MFMA (default, what `value` is measured in) or the opt-in "
                          "split-bf16 emulation (include/dsp_amd.h DSP_PREC_*)")
     ap.add_argument("--no_alt", action="store_true", help="skip the extra bf16x6 measurement reported under alt_precision")
@@ -173,7 +173,7 @@ def main():
         n_lstm = max(len(comb_ms), 1)
         avg_ms = sum(comb_ms) / n_lstm
         flops_per_launch = comb_flops_site * B * K / n_lstm
-        nprod = {"fp32": 1, "bf16x6": 6, "bf16x9": 9}[args.precision]
+        nprod = {"fp32": 1, "bf16x6": 6, "bf16x9": 9, "fp16x3": 3}[args.precision]
         # split-bf16 modes execute nprod bf16 piece products per fp32 product: price those against the bf16 peak
         peak = FP32_MATRIX_PEAK_TFLOPS if nprod == 1 else 16 * FP32_MATRIX_PEAK_TFLOPS
         achieved = nprod * flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
@@ -189,7 +189,8 @@ def main():
             "metric": "methylation sites/sec, %s bn13_sn16" % args.model_type, "value": round(value, 1), "unit": "sites/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / max(K, 1) * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if nprod == 1 else "f32 via %s (3 bf16 pieces per operand, %d piece products, f32 accumulate)" % (args.precision, nprod),
+            "dtype": "f32" if nprod == 1 else "f32 via %s (%s pieces per operand, %d piece products, f32 accumulate)" % (
+                args.precision, "2 fp16" if nprod == 3 else "3 bf16", nprod),
             "data": "synthetic",
             "config": {"workload": "%d synthetic sites, %s bn13_sn16 fp32, batch %d on %dxMI355X (BASELINE.json configs[%d])"
                                    % (total_sites, args.model_type, B, world,

@@ -12,7 +12,7 @@ MODULE_CODE = {"both_bilstm": 0, "seq_bilstm": 1, "signal_bilstm": 2}
 DT_F32, DT_U8, DT_U16, DT_I32 = 0, 1, 2, 3
 INIT_ZEROS, INIT_EXPLICIT, INIT_PHILOX = 0, 1, 2
 NORM_MAD, NORM_ZSCORE = 0, 1
-PRECISION = {"fp32": 0, "bf16x6": 6, "bf16x9": 9}
+PRECISION = {"fp32": 0, "fp16x3": 3, "bf16x6": 6, "bf16x9": 9}
 
 
 class ModelCfg(ctypes.Structure):

@@ -454,7 +454,7 @@ def add_call_mods_args(p):
     g.add_argument("--init_state", type=str, default="randn", choices=["randn", "zeros"],
                    help="LSTM initial states: 'randn' = N(0,1) like the reference's init_hidden (in-kernel Philox), 'zeros'")
     g.add_argument("--seed", type=int, default=0, help="seed of the in-kernel initial-state generator")
-    g.add_argument("--precision", type=str, default=None, choices=["fp32", "bf16x6", "bf16x9"],
+    g.add_argument("--precision", type=str, default=None, choices=["fp32", "bf16x6", "bf16x9", "fp16x3"],
                    help="how the fp32 products of the combined BiLSTM stack are evaluated: fp32 matrix cores (default), or "
                         "split into bf16 pieces on the bf16 matrix cores (bf16x9: all nine piece products, exact; bf16x6: "
                         "without the three smallest, ~1.4x faster, probabilities within 1e-7 of the fp32 path)")

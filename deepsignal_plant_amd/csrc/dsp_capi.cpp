@@ -124,7 +124,7 @@ std::vector<int> map_bidir(int H, int Hp) {  // [fwd Hp | bwd Hp] -> [fwd H | bw
     return m;
 }
 
-struct DevLstmLayer { int Ipad, Iused, H, Hp; float* wpk[2]; float* sbias[2]; float* wsplit[2]; };  // wsplit: see pack_lstm_dir_split
+struct DevLstmLayer { int Ipad, Iused, H, Hp; float* wpk[2]; float* sbias[2]; float* wsplit[2]; float* wsplit16[2]; };  // wsplit: see pack_lstm_dir_split
 struct DevLinear { int Fin, ORT; float* wpk; float* bias; };
 
 // A fragments for gates^T = W * act^T :  [UT][NQ][4 gates][64 lanes][4]
@@ -173,11 +173,13 @@ inline float bf16_to_f32(uint16_t h) {
     memcpy(&f, &u, 4);
     return f;
 }
+// fp16 = true: two fp16 pieces (hi = fp16(w), lo = fp16(w - hi)) instead of three bf16 pieces
 void pack_lstm_dir_split(const float* wih, const float* whh, int I, int H, int Hp, const std::vector<int>& in_map,
-                         std::vector<float>& out) {
+                         std::vector<float>& out, bool fp16 = false) {
     const int Ipad = (int)in_map.size();
     const int UT = Hp / 32, NQ = (Ipad + Hp) / 16;
-    std::vector<uint16_t> pk((size_t)UT * NQ * 4 * 3 * 64 * 8, 0);
+    const int NP = fp16 ? 2 : 3;
+    std::vector<uint16_t> pk((size_t)UT * NQ * 4 * NP * 64 * 8, 0);
     for (int u = 0; u < UT; ++u)
         for (int q = 0; q < NQ; ++q)
             for (int g = 0; g < 4; ++g)
@@ -195,13 +197,20 @@ void pack_lstm_dir_split(const float* wih, const float* whh, int I, int H, int H
                             const int hk = kk - Ipad;
                             if (hk < H) v = whh[row * H + hk];
                         }
-                        const uint16_t hi = bf16_rne(v);
-                        const float r1 = v - bf16_to_f32(hi);
-                        const uint16_t mid = bf16_rne(r1);
-                        const uint16_t lo = bf16_rne(r1 - bf16_to_f32(mid));
-                        const uint16_t piece[3] = {hi, mid, lo};
-                        for (int p = 0; p < 3; ++p)
-                            pk[((((((size_t)u * NQ + q) * 4 + g) * 3 + p) * 64 + lane) * 8) + j] = piece[p];
+                        uint16_t piece[3];
+                        if (fp16) {
+                            const _Float16 h = (_Float16)v;  // round to nearest even, subnormals kept
+                            const _Float16 l = (_Float16)(v - (float)h);
+                            memcpy(&piece[0], &h, 2);
+                            memcpy(&piece[1], &l, 2);
+                        } else {
+                            piece[0] = bf16_rne(v);
+                            const float r1 = v - bf16_to_f32(piece[0]);
+                            piece[1] = bf16_rne(r1);
+                            piece[2] = bf16_rne(r1 - bf16_to_f32(piece[1]));
+                        }
+                        for (int p = 0; p < NP; ++p)
+                            pk[((((((size_t)u * NQ + q) * 4 + g) * NP + p) * 64 + lane) * 8) + j] = piece[p];
                     }
                 }
     out.resize(pk.size() / 2);
@@ -296,11 +305,14 @@ int build_stack(dsp_model* m, const float* const* w, int in, int hid, int layers
             }
             rc = upload(m, sb, &L.sbias[d]);
             if (rc) return rc;
-            L.wsplit[d] = nullptr;
+            L.wsplit[d] = L.wsplit16[d] = nullptr;
             if (with_split && L.Ipad % 16 == 0 && Hp % 16 == 0 && Hp / 32 <= 8 && L.Ipad >= 16) {
                 std::vector<float> ws;
                 pack_lstm_dir_split(p[0], p[1], I, hid, Hp, in_map, ws);
                 rc = upload(m, ws, &L.wsplit[d]);
+                if (rc) return rc;
+                pack_lstm_dir_split(p[0], p[1], I, hid, Hp, in_map, ws, true);
+                rc = upload(m, ws, &L.wsplit16[d]);
                 if (rc) return rc;
             }
         }
@@ -405,12 +417,13 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
             a.dbg = dbg;
         }
         const bool split = k4 && m->precision != DSP_PREC_FP32 && ly.wsplit[0] && ly.wsplit[1];
-        if (split) {  // same geometry as lstm4; weights and k-stage count of the split-bf16 kernel
-            a.wpk0 = ly.wsplit[0]; a.wpk1 = ly.wsplit[1];
+        if (split) {  // same geometry as lstm4; weights and k-stage count of the split kernel
+            const bool f16 = m->precision == DSP_PREC_FP16X3;
+            a.wpk0 = f16 ? ly.wsplit16[0] : ly.wsplit[0]; a.wpk1 = f16 ? ly.wsplit16[1] : ly.wsplit[1];
             a.NQ = (ly.Ipad + ly.Hp) / 16;
         }
         L.run(name, [&] {
-            return split ? dsp_k_lstm6(&a, m->precision == DSP_PREC_BF16X9 ? 9 : 6, L.s)
+            return split ? dsp_k_lstm6(&a, m->precision, L.s)
                          : (k4 ? dsp_k_lstm4(&a, L.s) : dsp_k_lstm3(&a, upw, L.s));
         });
         if (dbg) {
@@ -504,7 +517,8 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
     m->cfg = *cfg; m->d = d; m->device = device;
     if (const char* v = getenv("DSP_LSTM_KERNEL")) m->lstm_kernel = atoi(v) == 3 ? 3 : 4;  // A/B switch
     if (const char* v = getenv("DSP_PRECISION"))
-        m->precision = !strcmp(v, "bf16x6") ? DSP_PREC_BF16X6 : (!strcmp(v, "bf16x9") ? DSP_PREC_BF16X9 : DSP_PREC_FP32);
+        m->precision = !strcmp(v, "bf16x6") ? DSP_PREC_BF16X6 : (!strcmp(v, "bf16x9") ? DSP_PREC_BF16X9 :
+                       (!strcmp(v, "fp16x3") ? DSP_PREC_FP16X3 : DSP_PREC_FP32));
     m->hseq_p = d.hseq ? pad_hidden(d.hseq) : 0;
     m->hsig_p = d.hsig ? pad_hidden(d.hsig) : 0;
     m->Hp = pad_hidden(d.H);
@@ -705,7 +719,8 @@ int32_t dsp_profile_read(dsp_model* m, char* names, size_t names_cap, float* ms,
 }
 
 int32_t dsp_model_set_precision(dsp_model* m, int32_t precision) {
-    if (!m || (precision != DSP_PREC_FP32 && precision != DSP_PREC_BF16X6 && precision != DSP_PREC_BF16X9))
+    if (!m || (precision != DSP_PREC_FP32 && precision != DSP_PREC_BF16X6 && precision != DSP_PREC_BF16X9 &&
+               precision != DSP_PREC_FP16X3))
         return fail(DSP_EINVAL, "dsp_model_set_precision: bad arguments");
     m->precision = precision;
     return DSP_OK;

@@ -594,6 +594,8 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm4_kernel(LstmArgs a) {
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -612,8 +614,25 @@ __device__ __forceinline__ void split_bf16x3(const f32x4 x0, const f32x4 x1, u32
     }
 }
 
+// 8 fp32 -> hi / lo as packed fp16x8 (NPROD == 3: two fp16 pieces, 11 + 11 mantissa bits, products lh + hl + hh:
+// about 2^-22 relative; activations and weights must stay inside the fp16 range, which saturates visibly to inf)
+__device__ __forceinline__ void split_f16x2(const f32x4 x0, const f32x4 x1, u32x4& hi, u32x4& lo) {
+    const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = x[2 * i], b = x[2 * i + 1];
+        const f16x2_t hp = __builtin_convertvector((f32x2_t){a, b}, f16x2_t);  // RNE
+        const f32x2_t hf = __builtin_convertvector(hp, f32x2_t);
+        const f16x2_t lp = __builtin_convertvector((f32x2_t){a - hf[0], b - hf[1]}, f16x2_t);
+        hi[i] = __builtin_bit_cast(unsigned, hp);
+        lo[i] = __builtin_bit_cast(unsigned, lp);
+    }
+}
+
 template <int NPROD>
 __global__ __launch_bounds__(512, 2) void dsp_lstm6_kernel(LstmArgs a) {
+    constexpr bool F16 = NPROD == 3;     // two fp16 pieces instead of three bf16 pieces
+    constexpr int NP = F16 ? 2 : 3;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* c_lds = (f32x4*)smem;           // [2 site tiles][4 groups][512 threads] float4
     f32x4* b_lds = c_lds + 8 * 512;        // [unit tile][aa][gate][half] float4
@@ -635,7 +654,7 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm6_kernel(LstmArgs a) {
     const uint32_t xvoff = (uint32_t)half * 1024u + (uint32_t)ls * 16u;
 
     const long long gt0 = (long long)grp * (a.SG * 2) + sg * 2;
-    const __amdgpu_buffer_rsrc_t rw = make_rsrc((const char*)(dir ? a.wpk1 : a.wpk0) + (size_t)u * NQ * 12288);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc((const char*)(dir ? a.wpk1 : a.wpk0) + (size_t)u * NQ * (4096 * NP));
     const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)a.x + (size_t)gt0 * T * xrow);
     const __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)a.out + (size_t)gt0 * T * orow + (size_t)dir * HQ * 512);
     const __amdgpu_buffer_rsrc_t rh0 = make_rsrc((const char*)a.h0buf + (size_t)gt0 * orow + (size_t)dir * HQ * 512);
@@ -678,7 +697,7 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm6_kernel(LstmArgs a) {
         }
     };
 
-    u32x4 A[4][3];
+    u32x4 A[4][NP];
     f32x4 X[2][2];
     f32x16 acc[4][2];
     auto loadX = [&](int q) __attribute__((always_inline)) {
@@ -693,32 +712,41 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm6_kernel(LstmArgs a) {
     };
     auto loadA1 = [&](int g, int q) __attribute__((always_inline)) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-            A[g][p] = __builtin_bit_cast(u32x4, bld16(rw, voff, (uint32_t)((q * 4 + g) * 3 + p) * 1024u));
+        for (int p = 0; p < NP; ++p)
+            A[g][p] = __builtin_bit_cast(u32x4, bld16(rw, voff, (uint32_t)((q * 4 + g) * NP + p) * 1024u));
     };
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // piece products, smallest first: (ll, lm, ml,) mm, lh, hl, mh, hm, hh
-    constexpr int pa[9] = {2, 2, 1, 1, 2, 0, 1, 0, 0}, pb[9] = {2, 1, 2, 1, 0, 2, 0, 1, 0};
+    // piece products, smallest first.  bf16 (pieces h, m, l = 0, 1, 2): (ll, lm, ml,) mm, lh, hl, mh, hm, hh;
+    // fp16 (pieces h, l = 0, 1): lh, hl, hh
+    constexpr int pa9[9] = {2, 2, 1, 1, 2, 0, 1, 0, 0}, pb9[9] = {2, 1, 2, 1, 0, 2, 0, 1, 0};
+    constexpr int pa3[3] = {1, 0, 0}, pb3[3] = {0, 1, 0};
     // one k-stage: split the activations loaded a stage ago, request the next ones, then per gate fragment the
     // NPROD x 2 MFMAs followed by the (late) refill of that fragment for the next stage
     auto stage = [&](int q, int qn, auto first) __attribute__((always_inline)) {
-        u32x4 B[2][3];
+        u32x4 B[2][NP];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) split_bf16x3(X[m][0], X[m][1], B[m][0], B[m][1], B[m][2]);
+        for (int m = 0; m < 2; ++m) {
+            if constexpr (F16) split_f16x2(X[m][0], X[m][1], B[m][0], B[m][1]);
+            else split_bf16x3(X[m][0], X[m][1], B[m][0], B[m][1], B[m][NP - 1]);
+        }
         loadX(qn);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
 #pragma unroll
-            for (int k = 9 - NPROD; k < 9; ++k) {
-                const bf16x8 av = __builtin_bit_cast(bf16x8, A[g][pa[k]]);
+            for (int k = 0; k < NPROD; ++k) {
+                const int ia = F16 ? pa3[k] : pa9[9 - NPROD + k], ib = F16 ? pb3[k] : pb9[9 - NPROD + k];
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    const bf16x8 bv = __builtin_bit_cast(bf16x8, B[m][pb[k]]);
-                    if (decltype(first)::value && k == 9 - NPROD)
-                        acc[g][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, zero16, 0, 0, 0);
+                    const bool z = decltype(first)::value && k == 0;
+                    if constexpr (F16)
+                        acc[g][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[g][ia]),
+                                                                             __builtin_bit_cast(f16x8, B[m][ib]),
+                                                                             z ? zero16 : acc[g][m], 0, 0, 0);
                     else
-                        acc[g][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[g][m], 0, 0, 0);
+                        acc[g][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[g][ia]),
+                                                                              __builtin_bit_cast(bf16x8, B[m][ib]),
+                                                                              z ? zero16 : acc[g][m], 0, 0, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -926,6 +954,8 @@ extern "C" int dsp_k_init(void) {
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)dsp_lstm6_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)dsp_lstm6_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute((const void*)dsp_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     return (int)e;
 }
@@ -956,12 +986,13 @@ extern "C" int dsp_k_lstm4(const LstmArgs* a, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-// split-bf16 variant: a->wpk0/1 = split weights, a->NQ = k-stages of 16, nprod = 6 or 9
+// split variants: a->wpk0/1 = split weights, a->NQ = k-stages of 16, nprod = 6 / 9 (bf16 pieces) or 3 (fp16 pieces)
 extern "C" int dsp_k_lstm6(const LstmArgs* a, int nprod, hipStream_t s) {
     const int waves = a->UT * a->SG;
     const unsigned groups = (unsigned)(a->NTp / (a->SG * 2));
     const size_t lds = (size_t)8 * 512 * 16 + (size_t)a->Hp * 16;
     if (nprod == 9) hipLaunchKernelGGL(dsp_lstm6_kernel<9>, dim3(groups * 2), dim3(waves * 64), lds, s, *a);
+    else if (nprod == 3) hipLaunchKernelGGL(dsp_lstm6_kernel<3>, dim3(groups * 2), dim3(waves * 64), lds, s, *a);
     else hipLaunchKernelGGL(dsp_lstm6_kernel<6>, dim3(groups * 2), dim3(waves * 64), lds, s, *a);
     return (int)hipGetLastError();
 }

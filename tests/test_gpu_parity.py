@@ -210,7 +210,7 @@ def test_empty_batch():
     assert logits.shape == (0, 2) and probs.shape == (0, 2)
 
 
-@pytest.mark.parametrize("precision", ["bf16x9", "bf16x6"])
+@pytest.mark.parametrize("precision", ["bf16x9", "bf16x6", "fp16x3"])
 def test_split_bf16_product_emulation_stays_within_the_fp32_path(precision):
     """opt-in split-bf16 evaluation of the combined stack's products (include/dsp_amd.h, DSP_PREC_*): against the
     fixtures captured from the reference it has to meet the same bound as the fp32 path, and it must agree with
@@ -246,4 +246,4 @@ def test_split_bf16_product_emulation_stays_within_the_fp32_path(precision):
     _, ps = model.forward(*ins)
     assert float((ps - p32).abs().max()) <= 5e-6
     with pytest.raises(ValueError):
-        model.set_precision("fp16")
+        model.set_precision("fp8")

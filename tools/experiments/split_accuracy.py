@@ -32,6 +32,20 @@ def split3(x):
 ORDER = [(0, 0), (0, 1), (1, 0), (0, 2), (2, 0), (1, 1), (1, 2), (2, 1), (2, 2)]  # decreasing magnitude
 
 
+def split2_f16(x, scale=1.0):
+    """two fp16 pieces (11 + 11 mantissa bits) of scale * x"""
+    x = (x.astype(np.float32) * np.float32(scale))
+    hi = x.astype(np.float16).astype(np.float32)
+    lo = (x - hi).astype(np.float16).astype(np.float32)
+    return [hi.astype(np.float64), lo.astype(np.float64)]
+
+
+def split_matmul_f16(a, bt, wscale):
+    """3 products hh + hl + lh on fp16 pieces; the weights (bt) are pre-scaled by a power of two"""
+    A, B = split2_f16(a), split2_f16(bt, wscale)
+    return (A[1] @ B[0] + A[0] @ B[1] + A[0] @ B[0]) / wscale
+
+
 def split_matmul(a, bt, nprod):
     """a [n,K] @ bt[K,m] with every scalar product replaced by its NPROD largest piece products"""
     A, B = split3(a), split3(bt)
@@ -59,7 +73,10 @@ def forward_split(cfg, w, ins, states, nprod):
                 h = h0[2 * k + d].astype(dtype)
                 c = c0[2 * k + d].astype(dtype)
                 for t in (range(L) if d == 0 else range(L - 1, -1, -1)):
-                    g = split_matmul(inp[:, t, :], wih.T, nprod) + split_matmul(h, whh.T, nprod) + b
+                    if nprod < 0:  # fp16x3 with weights pre-scaled by 2^-nprod
+                        g = split_matmul_f16(inp[:, t, :], wih.T, 2.0 ** -nprod) + split_matmul_f16(h, whh.T, 2.0 ** -nprod) + b
+                    else:
+                        g = split_matmul(inp[:, t, :], wih.T, nprod) + split_matmul(h, whh.T, nprod) + b
                     i_, f_, g_, o_ = g[:, :hid], g[:, hid:2 * hid], g[:, 2 * hid:3 * hid], g[:, 3 * hid:]
                     c = onp._sigmoid(f_) * c + onp._sigmoid(i_) * np.tanh(g_)
                     h = onp._sigmoid(o_) * np.tanh(c)
@@ -86,6 +103,9 @@ def main():
         for nprod in (9, 6, 3):
             _, p = forward_split(cfg, w, ins, states, nprod)
             print("weights x%.0f: bf16x%d products (float64 accumulate) max|dprob| = %.2e" % (scale, nprod, np.abs(p - ref).max()))
+        for sh in (-1, -5, -9):  # weight pre-scale 2^0 (encoded -1 -> 2^1 .. keep simple), 2^5, 2^9
+            _, p = forward_split(cfg, w, ins, states, sh)
+            print("weights x%.0f: fp16x3 products, weights pre-scaled 2^%d  max|dprob| = %.2e" % (scale, -sh, np.abs(p - ref).max()))
 
 
 if __name__ == "__main__":
