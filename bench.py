@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("DSP_PRECISION", "fp32"), choices=["fp32", "bf16x6", "bf16x9", "fp16x3"],
                     help="products of the combined stack: fp32 MFMA (default, what `value` is measured in) or the opt-in "
                          "split-bf16 emulation (include/dsp_amd.h DSP_PREC_*)")
-    ap.add_argument("--no_alt", action="store_true", help="skip the extra bf16x6 measurement reported under alt_precision")
+    ap.add_argument("--no_alt", action="store_true", help="skip the extra fp16x3 measurement reported under alt_precision")
     ap.add_argument("--gather", action="store_true", help="optional final RCCL all_gather of per-site probs")
     args = ap.parse_args()
 
@@ -137,14 +137,15 @@ def main():
             dist.all_gather(gathered, src)
     assert outs is not None and bool(torch.isfinite(outs[1]).all())
 
-    # opt-in mode, reported next to the headline (never as `value`): the same steps with the combined stack's fp32
-    # products emulated by 6 bf16 piece products (include/dsp_amd.h), and how far its probabilities are from fp32's
+    # opt-in mode, reported next to the headline (never as `value`): the same steps with the LSTMs' fp32 products
+    # emulated by split low-precision pieces on the fast matrix pipes (include/dsp_amd.h DSP_PREC_FP16X3), and how far
+    # its probabilities are from the fp32 path's
     alt = None
     if world == 1 and args.precision == "fp32" and not args.no_alt and K > 0:
         ka = min(K, 40)
         model.site_offset = site0
         ref = model(*batches[0])[1].clone()
-        model.set_precision("bf16x6")
+        model.set_precision("fp16x3")
         for i in range(2):
             step(i)
         torch.cuda.synchronize()
@@ -156,9 +157,9 @@ def main():
         model.site_offset = site0
         dmax = float((model(*batches[0])[1] - ref).abs().max())
         model.set_precision("fp32")
-        alt = {"dtype": "f32 via bf16x6 (3 bf16 pieces per operand, 6 piece products, f32 accumulate)",
+        alt = {"dtype": "f32 via fp16x3 (2 fp16 pieces per operand, 3 piece products, f32 accumulate; front ends bf16x6)",
                "value": round(ka * B / ta, 1), "unit": "sites/s", "steps": ka, "ms_per_step": round(ta / ka * 1e3, 3),
-               "max_abs_dprob_vs_fp32_path": dmax, "how": "python bench.py --precision bf16x6"}
+               "max_abs_dprob_vs_fp32_path": dmax, "how": "python bench.py --precision fp16x3"}
 
     if rank == 0:
         total_sites = world * K * B

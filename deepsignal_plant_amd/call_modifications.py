@@ -456,8 +456,9 @@ def add_call_mods_args(p):
     g.add_argument("--seed", type=int, default=0, help="seed of the in-kernel initial-state generator")
     g.add_argument("--precision", type=str, default=None, choices=["fp32", "bf16x6", "bf16x9", "fp16x3"],
                    help="how the fp32 products of the combined BiLSTM stack are evaluated: fp32 matrix cores (default), or "
-                        "split into bf16 pieces on the bf16 matrix cores (bf16x9: all nine piece products, exact; bf16x6: "
-                        "without the three smallest, ~1.4x faster, probabilities within 1e-7 of the fp32 path)")
+                        "split into low-precision pieces on the fast matrix pipes with fp32 accumulation (bf16x9: nine bf16 "
+                        "piece products, exact; bf16x6: without the three smallest, 1.5x; fp16x3: two fp16 pieces, three "
+                        "products, 2.4x; probabilities within 1e-6 of the fp32 path)")
     g.add_argument("--freq_file", type=str, default=None,
                    help="also write the per-site modification frequency (what `call_freq` computes from the result file) "
                         "without re-reading the per-read calls")

@@ -218,10 +218,12 @@ void pack_lstm_dir_split(const float* wih, const float* whh, int I, int H, int H
 }
 
 // A fragments for out^T = W * act^T : [ORT][Fin/8][64][4]
-void pack_linear(const float* w, const float* b, int O, int K, const std::vector<int>& in_map, std::vector<float>& wpk,
-                 std::vector<float>& bias) {
+// Opad = padded output width the kernels iterate over (row tiles Opad/32); rows O..Opad-1 keep zero weights and
+// zero bias, so the padding features come out as exact zeros
+void pack_linear(const float* w, const float* b, int O, int Opad, int K, const std::vector<int>& in_map,
+                 std::vector<float>& wpk, std::vector<float>& bias) {
     const int Fin = (int)in_map.size();
-    const int ORT = rup(O, 32) / 32, NQ = Fin / 8;
+    const int ORT = rup(Opad > O ? Opad : O, 32) / 32, NQ = Fin / 8;
     wpk.assign((size_t)ORT * NQ * 64 * 4, 0.f);
     bias.assign((size_t)ORT * 32, 0.f);
     for (int rt = 0; rt < ORT; ++rt)
@@ -281,7 +283,7 @@ int upload(dsp_model* m, const std::vector<float>& h, float** out) {
 }
 
 int build_stack(dsp_model* m, const float* const* w, int in, int hid, int layers, std::vector<int> in_map0,
-                std::vector<DevLstmLayer>& out, bool with_split = false) {
+                std::vector<DevLstmLayer>& out, int with_split = 0 /* 1: bf16 pieces, 2: + fp16 pieces */) {
     const int Hp = pad_hidden(hid);
     for (int k = 0; k < layers; ++k) {
         const int I = k == 0 ? in : 2 * hid;
@@ -311,9 +313,11 @@ int build_stack(dsp_model* m, const float* const* w, int in, int hid, int layers
                 pack_lstm_dir_split(p[0], p[1], I, hid, Hp, in_map, ws);
                 rc = upload(m, ws, &L.wsplit[d]);
                 if (rc) return rc;
-                pack_lstm_dir_split(p[0], p[1], I, hid, Hp, in_map, ws, true);
-                rc = upload(m, ws, &L.wsplit16[d]);
-                if (rc) return rc;
+                if (with_split >= 2) {
+                    pack_lstm_dir_split(p[0], p[1], I, hid, Hp, in_map, ws, true);
+                    rc = upload(m, ws, &L.wsplit16[d]);
+                    if (rc) return rc;
+                }
             }
         }
         out.push_back(L);
@@ -379,6 +383,11 @@ struct Launcher {
         const int e = f();
         if (e != 0) { rc = fail(DSP_EHIP, "launch %s failed: %s", name, hipGetErrorString((hipError_t)e)); return; }
         if (m->prof) { hipEventRecord(eb, s); m->prof_entries.push_back({name, ea, eb}); }
+        if (getenv("DSP_SYNC_EACH")) {  // debugging aid: attribute an asynchronous GPU fault to its launch
+            fprintf(stderr, "[launch] %s ...", name);
+            const hipError_t se = hipStreamSynchronize(s);
+            fprintf(stderr, " %s\n", se == hipSuccess ? "ok" : hipGetErrorString(se));
+        }
     }
 };
 
@@ -416,14 +425,21 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
             if (hipMalloc((void**)&dbg, 16 * 8 * sizeof(unsigned long long)) == hipSuccess) hipMemset(dbg, 0, 16 * 8 * 8);
             a.dbg = dbg;
         }
-        const bool split = k4 && m->precision != DSP_PREC_FP32 && ly.wsplit[0] && ly.wsplit[1];
+        // fp16 pieces are only safe where the operands are bounded: the combined stack eats relu(fc(h)) and h in (-1, 1);
+        // the front ends eat raw features (a signal mean of 1e6 is a legal row), so they take the bf16 variant, whose
+        // pieces have fp32's range
+        const int prec = (lstm_id != 2 && m->precision == DSP_PREC_FP16X3) ? DSP_PREC_BF16X6 : m->precision;
+        const bool split = k4 && prec != DSP_PREC_FP32 && ly.wsplit[0] && ly.wsplit[1];
         if (split) {  // same geometry as lstm4; weights and k-stage count of the split kernel
-            const bool f16 = m->precision == DSP_PREC_FP16X3;
+            const bool f16 = prec == DSP_PREC_FP16X3;
             a.wpk0 = f16 ? ly.wsplit16[0] : ly.wsplit[0]; a.wpk1 = f16 ? ly.wsplit16[1] : ly.wsplit[1];
             a.NQ = (ly.Ipad + ly.Hp) / 16;
         }
+        if (getenv("DSP_DEBUG_LSTM"))
+            fprintf(stderr, "[lstm] %s k=%zu split=%d Ipad=%d H=%d Hp=%d UT=%d SG=%d NQ=%d NTp=%lld n=%lld T=%d Fout=%d x=%p out=%p\n", name, k,
+                    (int)split, a.Ipad, a.H, a.Hp, a.UT, a.SG, a.NQ, a.NTp, a.n, a.T, a.Fout, (const void*)a.x, (void*)a.out);
         L.run(name, [&] {
-            return split ? dsp_k_lstm6(&a, m->precision, L.s)
+            return split ? dsp_k_lstm6(&a, prec, L.s)
                          : (k4 ? dsp_k_lstm4(&a, L.s) : dsp_k_lstm3(&a, upw, L.s));
         });
         if (dbg) {
@@ -541,30 +557,30 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
         std::vector<float> emb(w[wi], w[wi] + (size_t)d.V * d.E);
         rc = upload(m, emb, &m->embed); if (rc) return done(rc);
         ++wi;
-        rc = build_stack(m, w + wi, d.Iseq, d.hseq, d.l2, map_pad(d.Iseq, m->Fseq), m->seq); if (rc) return done(rc);
+        rc = build_stack(m, w + wi, d.Iseq, d.hseq, d.l2, map_pad(d.Iseq, m->Fseq), m->seq, 1); if (rc) return done(rc);
         wi += 8 * d.l2;
         std::vector<float> wpk, bias;
-        pack_linear(w[wi], w[wi + 1], d.hseq, 2 * d.hseq, map_bidir(d.hseq, m->hseq_p), wpk, bias);
+        pack_linear(w[wi], w[wi + 1], d.hseq, m->hseq_p, 2 * d.hseq, map_bidir(d.hseq, m->hseq_p), wpk, bias);
         m->fc_seq.Fin = 2 * m->hseq_p; m->fc_seq.ORT = m->hseq_p / 32;
         rc = upload(m, wpk, &m->fc_seq.wpk); if (rc) return done(rc);
         rc = upload(m, bias, &m->fc_seq.bias); if (rc) return done(rc);
         wi += 2;
     }
     if (d.hsig) {
-        rc = build_stack(m, w + wi, d.S, d.hsig, d.l2, map_pad(d.S, m->Fsig), m->sig); if (rc) return done(rc);
+        rc = build_stack(m, w + wi, d.S, d.hsig, d.l2, map_pad(d.S, m->Fsig), m->sig, 1); if (rc) return done(rc);
         wi += 8 * d.l2;
         std::vector<float> wpk, bias;
-        pack_linear(w[wi], w[wi + 1], d.hsig, 2 * d.hsig, map_bidir(d.hsig, m->hsig_p), wpk, bias);
+        pack_linear(w[wi], w[wi + 1], d.hsig, m->hsig_p, 2 * d.hsig, map_bidir(d.hsig, m->hsig_p), wpk, bias);
         m->fc_sig.Fin = 2 * m->hsig_p; m->fc_sig.ORT = m->hsig_p / 32;
         rc = upload(m, wpk, &m->fc_sig.wpk); if (rc) return done(rc);
         rc = upload(m, bias, &m->fc_sig.bias); if (rc) return done(rc);
         wi += 2;
     }
-    rc = build_stack(m, w + wi, d.H, d.H, d.l1, m->comb_in_map, m->comb, true); if (rc) return done(rc);
+    rc = build_stack(m, w + wi, d.H, d.H, d.l1, m->comb_in_map, m->comb, 2); if (rc) return done(rc);
     wi += 8 * d.l1;
     {
         std::vector<float> wpk, bias;
-        pack_linear(w[wi], w[wi + 1], d.H, 2 * d.H, map_bidir(d.H, m->Hp), wpk, bias);
+        pack_linear(w[wi], w[wi + 1], d.H, m->Hp, 2 * d.H, map_bidir(d.H, m->Hp), wpk, bias);
         m->fc1.Fin = 2 * m->Hp; m->fc1.ORT = m->Hp / 32;
         rc = upload(m, wpk, &m->fc1.wpk); if (rc) return done(rc);
         rc = upload(m, bias, &m->fc1.bias); if (rc) return done(rc);

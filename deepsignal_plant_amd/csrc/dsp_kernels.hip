@@ -693,7 +693,7 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm6_kernel(LstmArgs a) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             xo[m] = (uint32_t)(m * T + t) * xrow;
-            ho[m] = (step == 0 ? (uint32_t)m * orow : (uint32_t)(m * T + tp) * orow) - (uint32_t)nqx * 2048u;
+            ho[m] = step == 0 ? (uint32_t)m * orow : (uint32_t)(m * T + tp) * orow;
         }
     };
 
@@ -705,7 +705,8 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm6_kernel(LstmArgs a) {
         const __amdgpu_buffer_rsrc_t r = isx ? rx : rhp;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            const uint32_t so = (isx ? xo[m] : ho[m]) + (uint32_t)q * 2048u;
+            // never form a negative intermediate: the buffer unit adds voffset + soffset + imm without wrapping at 32 bits
+            const uint32_t so = isx ? xo[m] + (uint32_t)q * 2048u : ho[m] + (uint32_t)(q - nqx) * 2048u;
             X[m][0] = bld16(r, xvoff, so);
             X[m][1] = bld16(r, xvoff + 512u, so);
         }

@@ -247,3 +247,25 @@ def test_split_bf16_product_emulation_stays_within_the_fp32_path(precision):
     assert float((ps - p32).abs().max()) <= 5e-6
     with pytest.raises(ValueError):
         model.set_precision("fp8")
+
+
+@pytest.mark.parametrize("hidden", [160, 192, 80])
+def test_hidden_sizes_whose_padding_adds_row_tiles(hidden):
+    """hid_rnn 160 / 192 / 80: the per-branch width (80 / 96 / 40) is padded to more 32-row tiles than it fills; the
+    padding rows of fc_seq / fc_signal / fc1 must be packed as zeros (they once were not packed at all and the
+    kernels read past the weight buffers) -- all precision modes against the oracle"""
+    torch = _torch()
+    from deepsignal_plant_amd.models import ModelBiLSTM
+    from oracle import c_oracle as oc
+    from oracle import forward_np as onp
+    cfg = onp.OracleConfig(hidden_size=hidden, num_layers1=2)
+    w = onp.make_weights(cfg, 31, 2.0)
+    n = 300
+    ins = onp.make_inputs(cfg, n, 32)
+    m = build_model(cfg, w)
+    m.init_state, m.seed = "randn", 17
+    _, po = oc.forward(cfg, w, *ins, init_mode="philox", seed=17)
+    for precision in ("fp32", "bf16x6", "fp16x3"):
+        m.set_precision(precision)
+        _, probs = m.forward(*to_dev(ins))
+        assert np.abs(probs.cpu().numpy() - po).max() <= TOL_TIGHT, precision
