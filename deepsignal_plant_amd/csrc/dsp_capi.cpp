@@ -217,6 +217,24 @@ void pack_lstm_dir_split(const float* wih, const float* whh, int I, int H, int H
     memcpy(out.data(), pk.data(), pk.size() * 2);
 }
 
+// fp16x3 splits operands into fp16 pieces, which saturate at 65504.  The combined stack's operands are its weights,
+// h in (-1, 1) and relu(fc(h)) <= max_i (sum_j |w_ij| + |b_i|): both bounds are checked against this margin.
+constexpr double kFp16Safe = 3.0e4;
+inline double max_abs(const float* w, size_t n) {
+    double m = 0.0;
+    for (size_t i = 0; i < n; ++i) { const double a = std::fabs((double)w[i]); if (!(a <= m)) m = a; }  // NaN -> kept
+    return m;
+}
+inline double fc_out_bound(const float* w, const float* b, int O, int K) {
+    double m = 0.0;
+    for (int o = 0; o < O; ++o) {
+        double s = std::fabs((double)b[o]);
+        for (int k = 0; k < K; ++k) s += std::fabs((double)w[(size_t)o * K + k]);
+        if (!(s <= m)) m = s;
+    }
+    return m;
+}
+
 // A fragments for out^T = W * act^T : [ORT][Fin/8][64][4]
 // Opad = padded output width the kernels iterate over (row tiles Opad/32); rows O..Opad-1 keep zero weights and
 // zero bias, so the padding features come out as exact zeros
@@ -256,6 +274,7 @@ struct dsp_model {
     int hseq_p = 0, hsig_p = 0, Hp = 0, Fseq = 0, Fsig = 0, Fcomb = 0, Fwide = 0;
     std::vector<int> comb_in_map;  // padded comb-input feature -> reference feature
     int lstm_kernel = 4;           // 4 = dsp_lstm4_kernel (2 waves/SIMD, default); 3 = dsp_lstm3_kernel (1 wave/SIMD)
+    bool fp16_safe = true;         // every operand of the combined stack provably inside the fp16 range (fp16x3 only then)
     int precision = DSP_PREC_FP32; // products of the combined stack: fp32 MFMA, or split-bf16 emulation (dsp_lstm6_kernel)
     // scratch
     void* ws = nullptr;
@@ -561,6 +580,7 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
         wi += 8 * d.l2;
         std::vector<float> wpk, bias;
         pack_linear(w[wi], w[wi + 1], d.hseq, m->hseq_p, 2 * d.hseq, map_bidir(d.hseq, m->hseq_p), wpk, bias);
+        if (!(fc_out_bound(w[wi], w[wi + 1], d.hseq, 2 * d.hseq) <= kFp16Safe)) m->fp16_safe = false;
         m->fc_seq.Fin = 2 * m->hseq_p; m->fc_seq.ORT = m->hseq_p / 32;
         rc = upload(m, wpk, &m->fc_seq.wpk); if (rc) return done(rc);
         rc = upload(m, bias, &m->fc_seq.bias); if (rc) return done(rc);
@@ -571,12 +591,21 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
         wi += 8 * d.l2;
         std::vector<float> wpk, bias;
         pack_linear(w[wi], w[wi + 1], d.hsig, m->hsig_p, 2 * d.hsig, map_bidir(d.hsig, m->hsig_p), wpk, bias);
+        if (!(fc_out_bound(w[wi], w[wi + 1], d.hsig, 2 * d.hsig) <= kFp16Safe)) m->fp16_safe = false;
         m->fc_sig.Fin = 2 * m->hsig_p; m->fc_sig.ORT = m->hsig_p / 32;
         rc = upload(m, wpk, &m->fc_sig.wpk); if (rc) return done(rc);
         rc = upload(m, bias, &m->fc_sig.bias); if (rc) return done(rc);
         wi += 2;
     }
+    for (int k = 0; k < d.l1; ++k)  // weight_ih, weight_hh of both directions of every combined layer
+        for (int dd = 0; dd < 2; ++dd) {
+            const int I = k == 0 ? d.H : 2 * d.H;
+            if (!(max_abs(w[wi + (k * 2 + dd) * 4], (size_t)4 * d.H * I) <= kFp16Safe) ||
+                !(max_abs(w[wi + (k * 2 + dd) * 4 + 1], (size_t)4 * d.H * d.H) <= kFp16Safe))
+                m->fp16_safe = false;
+        }
     rc = build_stack(m, w + wi, d.H, d.H, d.l1, m->comb_in_map, m->comb, 2); if (rc) return done(rc);
+    if (m->precision == DSP_PREC_FP16X3 && !m->fp16_safe) m->precision = DSP_PREC_BF16X6;  // DSP_PRECISION asked for it
     wi += 8 * d.l1;
     {
         std::vector<float> wpk, bias;
@@ -738,6 +767,9 @@ int32_t dsp_model_set_precision(dsp_model* m, int32_t precision) {
     if (!m || (precision != DSP_PREC_FP32 && precision != DSP_PREC_BF16X6 && precision != DSP_PREC_BF16X9 &&
                precision != DSP_PREC_FP16X3))
         return fail(DSP_EINVAL, "dsp_model_set_precision: bad arguments");
+    if (precision == DSP_PREC_FP16X3 && !m->fp16_safe)
+        return fail(DSP_EINVAL, "dsp_model_set_precision: this checkpoint's combined-stack operands are not provably inside the "
+                                "fp16 range (weights or fc outputs above 3e4): use bf16x6");
     m->precision = precision;
     return DSP_OK;
 }

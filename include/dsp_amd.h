@@ -132,7 +132,9 @@ int32_t dsp_profile_read(dsp_model* m, char* names, size_t names_cap, float* ms,
  * relative, below the rounding of an fp32 accumulation) piece products on v_mfma_f32_32x32x16_bf16, accumulated in
  * fp32.  DSP_PREC_FP16X3: two fp16 pieces per operand (11 + 11 mantissa bits) and the three products lh, hl, hh on
  * v_mfma_f32_32x32x16_f16: ~2^-22 relative, half the matrix work of BF16X6; operands beyond the fp16 range (6.5e4)
- * saturate to inf, visibly.  Inputs, outputs, layouts and every other kernel are unchanged.  Also settable at creation through the
+ * would saturate: the mode is therefore used for the combined stack only (the front ends, which eat raw features,
+ * take bf16 pieces) and dsp_model_set_precision returns DSP_EINVAL for a checkpoint whose combined-stack weights or fc
+ * output bounds exceed 3e4.  Inputs, outputs, layouts and every other kernel are unchanged.  Also settable at creation through the
  * environment variable DSP_PRECISION = fp32 | bf16x6 | bf16x9 | fp16x3.  (No reference counterpart: torch.nn.LSTM on CPU is
  * fp32 throughout, models.py:137-157.) */
 enum { DSP_PREC_FP32 = 0, DSP_PREC_FP16X3 = 3, DSP_PREC_BF16X6 = 6, DSP_PREC_BF16X9 = 9 };

@@ -247,6 +247,19 @@ def test_split_bf16_product_emulation_stays_within_the_fp32_path(precision):
     assert float((ps - p32).abs().max()) <= 5e-6
     with pytest.raises(ValueError):
         model.set_precision("fp8")
+    # a checkpoint whose fc outputs could leave the fp16 range is refused fp16 pieces (bf16 pieces have fp32's range)
+    sd = synth.random_state_dict(model, seed=5)
+    sd["fc_seq.weight"] = sd["fc_seq.weight"] * 1e4
+    big = ModelBiLSTM(init_state="zeros")
+    big.load_state_dict(sd)
+    big.cuda(0)
+    with pytest.raises(ValueError, match="fp16 range"):
+        big.set_precision("fp16x3")
+    big.set_precision("bf16x6")
+    _, pb = big.forward(*synth.feature_batch(64, device="cuda:0", seed=2))
+    big.set_precision("fp32")
+    _, pf = big.forward(*synth.feature_batch(64, device="cuda:0", seed=2))
+    assert bool(torch.isfinite(pb).all()) and float((pb - pf).abs().max()) <= 1e-4
 
 
 @pytest.mark.parametrize("hidden", [160, 192, 80])
