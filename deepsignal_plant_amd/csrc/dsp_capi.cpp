@@ -41,9 +41,12 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 inline int rup(int x, int m) { return (x + m - 1) / m * m; }
-// hidden sizes are zero-padded to whole unit tiles: 32 units, or pairs of them (64) above 32 so that every
-// wave of the lstm2 kernel owns two unit tiles
+// hidden sizes are zero-padded to whole unit tiles: 32 units, or pairs of them (64) above 32 so that a wave of the
+// <2,1> tiling (dsp_kernels.hip) can own two unit tiles
 inline int pad_hidden(int h) { return h <= 32 ? 32 : rup(h, 64); }
+// one workgroup (at most 8 waves: two per SIMD, 256 registers each, one unit tile of 32 hidden units per wave) holds a
+// direction's whole hidden state, which its waves exchange every step through a workgroup barrier
+constexpr int kMaxHidden = 256;
 
 struct Dims {
     int T, S, H, C, V, E, l1, l2;
@@ -57,8 +60,9 @@ int derive(const dsp_model_cfg* c, Dims* d) {
     if (c->seq_len < 1 || c->signal_len < 1 || c->num_layers1 < 1 || c->num_layers2 < 1 || c->num_classes < 1 ||
         c->hidden_size < 2 || c->vocab_size < 1 || c->embedding_size < 1)
         return fail(DSP_EINVAL, "non-positive model dimension");
-    if (c->hidden_size > 256)
-        return fail(DSP_EINVAL, "hidden_size %d > 256 is not supported by this build", c->hidden_size);
+    if (c->hidden_size > kMaxHidden)
+        return fail(DSP_EINVAL, "hidden_size %d > %d is not supported by this build (one workgroup of 8 waves x 32 units holds a "
+                                "direction's whole hidden state)", c->hidden_size, kMaxHidden);
     if (c->num_classes > 64) return fail(DSP_EINVAL, "num_classes %d > 64 is not supported", c->num_classes);
     if (c->num_layers1 > 15 || c->num_layers2 > 15) return fail(DSP_EINVAL, "too many LSTM layers");
     d->T = c->seq_len; d->S = c->signal_len; d->H = c->hidden_size; d->C = c->num_classes;
@@ -273,13 +277,13 @@ struct dsp_model {
     float* w2 = nullptr; float* b2 = nullptr;
     int hseq_p = 0, hsig_p = 0, Hp = 0, Fseq = 0, Fsig = 0, Fcomb = 0, Fwide = 0;
     std::vector<int> comb_in_map;  // padded comb-input feature -> reference feature
-    int lstm_kernel = 4;           // 4 = dsp_lstm4_kernel (2 waves/SIMD, default); 3 = dsp_lstm3_kernel (1 wave/SIMD)
+    int trace_launch = -1, lstm_launch_no = 0;  // DSP_TRACE_LAUNCH: index of the LSTM launch (within a forward) to stamp
+    int sg_override = 0;  // DSP_LSTM_SG: site groups per LSTM workgroup (0 = default policy)
     bool fp16_safe = true;         // every operand of the combined stack provably inside the fp16 range (fp16x3 only then)
     int precision = DSP_PREC_FP32; // products of the combined stack: fp32 MFMA, or split-bf16 emulation (dsp_lstm6_kernel)
     // scratch
     void* ws = nullptr;
     int64_t ws_sites = 0;
-    long long NTp = 0;
     float *xseq = nullptr, *xsig = nullptr, *bufA = nullptr, *bufB = nullptr, *comb_in = nullptr, *h0buf = nullptr;
     float* last_out = nullptr;
     // profiling
@@ -379,13 +383,13 @@ int ensure_ws(dsp_model* m, int64_t sites, hipStream_t stream) {
     m->bufA = (float*)(b + off[2]); m->bufB = (float*)(b + off[3]); m->comb_in = (float*)(b + off[4]);
     m->h0buf = (float*)(b + off[5]);
     m->ws_sites = (int64_t)NTp * 32;
-    m->NTp = NTp;
     return 0;
 }
 
 struct Launcher {
     dsp_model* m;
     hipStream_t s;
+    long long NTp;  // padded tile count of THIS call (launch geometry is per call, never stored in the handle)
     int rc = 0;
     template <class F> void run(const char* name, F&& f) {
         if (rc) return;
@@ -410,6 +414,16 @@ struct Launcher {
     }
 };
 
+// site groups per workgroup of one LSTM layer launch (a wave owns one unit tile x two site tiles; at most 8 waves per
+// workgroup).  Front ends (4 unit tiles at the default sizes): one site group = 4-wave workgroups, two of which share a
+// CU independently (measured +1 % on those launches over one 8-wave workgroup).  DSP_LSTM_SG overrides (A/B switch).
+int pick_site_groups(const dsp_model* m, int UT) {
+    const int gmax = 8 / UT > 0 ? 8 / UT : 1;
+    int g = m->sg_override;
+    if (g < 1 || g > gmax || (g & (g - 1))) g = UT <= 4 ? 4 / UT : 1;
+    return g;
+}
+
 // run one BiLSTM stack; returns the buffer holding the last layer's output
 float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>& layers, int lstm_id, const float* x,
                  int64_t n, const dsp_init_state* init, const float* h0, const float* c0) {
@@ -422,55 +436,38 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
         LstmArgs a{};
         a.x = cur; a.out = dst;
         a.wpk0 = ly.wpk[0]; a.wpk1 = ly.wpk[1]; a.sbias0 = ly.sbias[0]; a.sbias1 = ly.sbias[1];
-        a.n = n; a.NTp = m->NTp;
+        a.n = n; a.NTp = L.NTp;
         a.Ipad = ly.Ipad; a.H = ly.H; a.Hp = ly.Hp; a.T = m->d.T; a.Fout = 2 * ly.Hp;
         a.NQ = rup((ly.Ipad + ly.Hp) / 8, 4);
         a.nqx_used = (ly.Iused + 7) / 8;
         a.h0buf = m->h0buf;
         a.UT = ly.Hp / 32;
-        const bool k4 = m->lstm_kernel == 4 && a.UT <= 8;
-        const int upw = k4 ? 1 : (a.UT == 1 ? 1 : 2);  // lstm4: 1 unit tile per wave, 8 waves (2 per SIMD)
-        a.SG = (k4 ? 8 : 4) / (a.UT / upw);
-        if (a.SG < 1) a.SG = 1;
+        a.SG = pick_site_groups(m, a.UT);
         a.init_mode = init ? init->mode : DSP_INIT_ZEROS;
         a.seed = init ? init->seed : 0; a.site_offset = init ? init->site_offset : 0;
         a.stream_base = lstm_id * 64 + (int)k * 4;
+        a.flags = 0;
+        if (m->trace_launch >= 0 && m->trace_launch == m->lstm_launch_no) a.flags |= 256;  // DSP_TRACE builds
+        ++m->lstm_launch_no;
         if (a.init_mode == DSP_INIT_EXPLICIT) {
             a.h0 = h0 + (size_t)(2 * k) * (size_t)n * ly.H;
             a.c0 = c0 + (size_t)(2 * k) * (size_t)n * ly.H;
-        }
-        unsigned long long* dbg = nullptr;
-        if (getenv("DSP_TIMING_DUMP") && k + 1 == layers.size() && lstm_id == 2) {  // last combined layer
-            if (hipMalloc((void**)&dbg, 16 * 8 * sizeof(unsigned long long)) == hipSuccess) hipMemset(dbg, 0, 16 * 8 * 8);
-            a.dbg = dbg;
         }
         // fp16 pieces are only safe where the operands are bounded: the combined stack eats relu(fc(h)) and h in (-1, 1);
         // the front ends eat raw features (a signal mean of 1e6 is a legal row), so they take the bf16 variant, whose
         // pieces have fp32's range
         const int prec = (lstm_id != 2 && m->precision == DSP_PREC_FP16X3) ? DSP_PREC_BF16X6 : m->precision;
-        const bool split = k4 && prec != DSP_PREC_FP32 && ly.wsplit[0] && ly.wsplit[1];
-        if (split) {  // same geometry as lstm4; weights and k-stage count of the split kernel
+        const bool split = prec != DSP_PREC_FP32 && ly.wsplit[0] && ly.wsplit[1];
+        if (split) {  // the split kernels run 8-wave workgroups; their own weights and k-stage count
             const bool f16 = prec == DSP_PREC_FP16X3;
             a.wpk0 = f16 ? ly.wsplit16[0] : ly.wsplit[0]; a.wpk1 = f16 ? ly.wsplit16[1] : ly.wsplit[1];
             a.NQ = (ly.Ipad + ly.Hp) / 16;
+            a.SG = 8 / a.UT;
         }
         if (getenv("DSP_DEBUG_LSTM"))
             fprintf(stderr, "[lstm] %s k=%zu split=%d Ipad=%d H=%d Hp=%d UT=%d SG=%d NQ=%d NTp=%lld n=%lld T=%d Fout=%d x=%p out=%p\n", name, k,
                     (int)split, a.Ipad, a.H, a.Hp, a.UT, a.SG, a.NQ, a.NTp, a.n, a.T, a.Fout, (const void*)a.x, (void*)a.out);
-        L.run(name, [&] {
-            return split ? dsp_k_lstm6(&a, prec, L.s)
-                         : (k4 ? dsp_k_lstm4(&a, L.s) : dsp_k_lstm3(&a, upw, L.s));
-        });
-        if (dbg) {
-            unsigned long long h[16 * 8];
-            hipStreamSynchronize(L.s);
-            hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
-            hipFree(dbg);
-            for (int st = 0; st < m->d.T && st < 16; ++st)
-                fprintf(stderr, "[timing] step %2d: bias %6llu  main %8llu  tail %7llu  cell %6llu  barrier %6llu  (total %8llu)\n", st,
-                        h[st * 8 + 1] - h[st * 8], h[st * 8 + 2] - h[st * 8 + 1], h[st * 8 + 3] - h[st * 8 + 2],
-                        h[st * 8 + 4] - h[st * 8 + 3], h[st * 8 + 5] - h[st * 8 + 4], h[st * 8 + 5] - h[st * 8]);
-        }
+        L.run(name, [&] { return split ? dsp_k_lstm6(&a, prec, L.s) : dsp_k_lstm(&a, L.s); });
         cur = dst;
     }
     return dst;
@@ -550,7 +547,8 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
     dsp_model* m = new (std::nothrow) dsp_model();
     if (!m) { hipSetDevice(prev); return fail(DSP_ENOMEM, "out of host memory"); }
     m->cfg = *cfg; m->d = d; m->device = device;
-    if (const char* v = getenv("DSP_LSTM_KERNEL")) m->lstm_kernel = atoi(v) == 3 ? 3 : 4;  // A/B switch
+    if (const char* v = getenv("DSP_TRACE_LAUNCH")) m->trace_launch = atoi(v);
+    if (const char* v = getenv("DSP_LSTM_SG")) m->sg_override = atoi(v);  // A/B switch
     if (const char* v = getenv("DSP_PRECISION"))
         m->precision = !strcmp(v, "bf16x6") ? DSP_PREC_BF16X6 : (!strcmp(v, "bf16x9") ? DSP_PREC_BF16X9 :
                        (!strcmp(v, "fp16x3") ? DSP_PREC_FP16X3 : DSP_PREC_FP32));
@@ -558,7 +556,7 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
     m->hsig_p = d.hsig ? pad_hidden(d.hsig) : 0;
     m->Hp = pad_hidden(d.H);
     // front-end inputs are padded to >= 32 features so that the first four k-groups of every step are
-    // x-part groups (lstm3 requests them before h_t exists)
+    // x-part groups: the LSTM kernel requests them before h_t exists (dsp_kernels.hip, SPARSE note)
     m->Fseq = d.hseq ? std::max(32, rup(d.Iseq, 8)) : 0;
     m->Fsig = d.hsig ? std::max(32, rup(d.S, 8)) : 0;
     m->Fcomb = m->hseq_p + m->hsig_p;
@@ -667,12 +665,11 @@ int32_t dsp_forward(dsp_model* m, void* stream, int64_t n, const void* kmer, int
     if (rc) { if (prev != m->device) hipSetDevice(prev); return rc; }
     // use the tile count of THIS call (padded to 16 tiles), not the capacity
     const long long NTp = (((n + 31) / 32) + 15) / 16 * 16;
-    const long long cap_NTp = m->NTp;
-    m->NTp = NTp;
 
     // profiling entries accumulate across forwards until dsp_profile_read() drains them
     if (!m->prof) { m->prof_entries.clear(); m->event_used = 0; }
-    Launcher L{m, s};
+    Launcher L{m, s, NTp};
+    m->lstm_launch_no = 0;
 
     PackArgs p{};
     p.kmer = kmer; p.means = means; p.stds = stds; p.lens = lens; p.signals = signals; p.embed = m->embed;
@@ -706,7 +703,6 @@ int32_t dsp_forward(dsp_model* m, void* stream, int64_t n, const void* kmer, int
     h.logits = logits; h.probs = probs; h.labels = labels; h.n = n; h.Hp = m->Hp; h.T = d.T; h.C = d.C;
     L.run("head", [&] { return dsp_k_head(&h, s); });
 
-    m->NTp = cap_NTp;
     if (prev != m->device) hipSetDevice(prev);
     return L.rc;
 }

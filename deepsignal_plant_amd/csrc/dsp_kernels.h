@@ -32,17 +32,17 @@ struct LstmArgs {
     const float* sbias1;   // backward
     const float* h0;       // EXPLICIT: reference layout, already offset to this layer: [2 dirs][n][H]
     const float* c0;
-    unsigned long long* dbg;  // optional per-step phase timestamps of (block 0, wave 0) [T][8] (DSP_TIMING builds)
-    float* h0buf;          // lstm3: K4 scratch [NTp][Fout/4][32][4] holding h0 (read by step 0 as "h_{-1}")
+    float* h0buf;          // K4 scratch [NTp][Fout/4][32][4] holding h0 (read by step 0 as "h_{-1}")
     long long n;
     long long NTp;
     unsigned long long seed, site_offset;
     int Ipad, H, Hp, T, Fout;
     int nqx_used;          // x-part k-groups that carry real features (the rest of Ipad/8 is zero padding)
     int NQ;                // k-groups per unit tile in wpk: (Ipad+Hp)/8 padded to a multiple of 4 (zero weights)
-    int UT, SG;            // unit tiles (Hp/32), site groups per workgroup; block = 64*(UT/UPW)*SG threads
+    int UT, SG;            // unit tiles (Hp/32), site groups (of two 32-site tiles) per workgroup; block = 64*UT*SG threads
     int init_mode;         // DSP_INIT_*
     int stream_base;       // philox stream of (lstm, layer, dir=0, h): lstm*64 + layer*4
+    int flags;             // bit 8: stamp this launch (DSP_TRACE builds only)
 };
 
 struct LinArgs {
@@ -72,8 +72,7 @@ extern "C" {
 #endif
 int dsp_k_init(void);
 int dsp_k_pack(const PackArgs* a, hipStream_t s);
-int dsp_k_lstm3(const LstmArgs* a, int upw, hipStream_t s);
-int dsp_k_lstm4(const LstmArgs* a, hipStream_t s);
+int dsp_k_lstm(const LstmArgs* a, hipStream_t s);
 int dsp_k_lstm6(const LstmArgs* a, int nprod, hipStream_t s);
 int dsp_k_linear(const LinArgs* a, hipStream_t s);
 int dsp_k_head(const HeadArgs* a, hipStream_t s);

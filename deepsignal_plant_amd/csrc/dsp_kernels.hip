@@ -173,30 +173,44 @@ __device__ __forceinline__ f32x4 init_state4(const float* src, int mode, long lo
 }
 
 // ------------------------------------------------------------------------------------------------
-// dsp_lstm3_kernel: one direction of one LSTM layer, all T steps, for 64*SG sites per workgroup.
-// blockIdx.x & 1 = direction: with the observed block -> XCD (b % 8) placement even XCDs run the forward and
-// odd XCDs the backward direction, so each XCD's 4 MiB L2 holds one direction's weights.
-// (History: the first kernel of this round -- 8 waves, h in LDS, one-deep prefetch -- reached 76 % of the
-// fp32 MFMA peak; ablation showed operand loads, not MFMA issue, cost ~25 %.  This is the restructured form.)
-//   * ONE wave per SIMD (<= 4 waves, up to 512 registers each); a wave owns UPW unit tiles (32 hidden units x
-//     4 gates each) x 2 site tiles = UPW*8 accumulator tiles (256 AGPRs), 64 MFMAs per k-group (8 k).
-//   * EVERY operand is a coalesced global load: weights (A), x_t (B) and also h_{t-1} (B), which is read
-//     back from the K4 output the workgroup itself stored one step earlier (same CU, visible after the
-//     per-step workgroup barrier; L2-resident).  No LDS at all, so no flat/LDS/global mixing and the
-//     compiler can count vmcnt exactly.
-//   * Register rings, four k-groups deep: an A fragment (weights of one unit tile x gate, 4 VGPRs) is
-//     re-requested for k-group q+4 after its 8 MFMAs of group q; B fragments likewise.  The k-group count is
-//     padded to a multiple of 4 with zero weights (host side), so the loop body is branch-free with exact
-//     vmcnt counts; the last groups of step t request the first groups of step t+1 (weights and x_{t+1},
-//     which do not depend on h_t) before the cell phase.
+// dsp_lstm_kernel<SPARSE, UPW, SPW>: one direction of one LSTM layer, all T steps, for 32*SPW*SG sites per
+// workgroup.  blockIdx.x & 1 = direction: with the observed block -> XCD (b % 8) placement even XCDs run the
+// forward and odd XCDs the backward direction, so each XCD's 4 MiB L2 holds one direction's weights.
+// (History, all measured on MI355X: first kernel -- 8 waves, h in LDS, one-deep prefetch -- 76 % of the fp32 MFMA
+// peak; ablation showed operand loads, not MFMA issue, cost ~25 %.  One wave per SIMD with register rings 90.4 %;
+// two waves per SIMD 93.6 %; profiles/README.md.)
+//   * TWO waves per SIMD, 256 registers each.  A wave owns UPW unit tiles (32 hidden units x 4 gates each) x SPW
+//     site tiles (32 sites each), UPW*SPW = 2: 8 accumulator tiles (128 registers), 32 MFMAs per k-group (8 k).
+//       <1,2>: a weight fragment feeds 8 MFMAs; a workgroup needs UT waves per 64 sites (UT = Hp/32 unit tiles).
+//       <2,1>: a weight fragment feeds 4 MFMAs (twice the weight stream out of L2), but a workgroup needs only
+//              UT/2 waves per 32 sites: for UT = 8 that is FOUR waves, so TWO INDEPENDENT workgroups share a CU
+//              (one wave of each per SIMD).  Measured in round 2: +0.6 % on the combined-stack launches, but with
+//              non-zero initial states the h0 read-back of the second wave of a SIMD came out wrong for sites 12-15 /
+//              28-31 of a tile, non-deterministically (not root-caused: an explicit vmcnt(0) before the barriers, L1
+//              invalidation, sc0 loads and a different MFMA order all left it unchanged) -- NOT INSTANTIATED.
+//   * EVERY operand is a coalesced BUFFER load: a wave-uniform 128-bit descriptor (SGPRs) + a wave-uniform byte
+//     offset (SGPR soffset) + lane*16 (the only address VGPR of the kernel): weights (A), x_t (B) and also h_{t-1}
+//     (B), which is read back from the K4 output the workgroup itself stored one step earlier (same CU, visible
+//     after the per-step workgroup barrier; L2-resident).  Compared with flat/global addressing this removes all
+//     64-bit VALU address arithmetic from the MFMA stream (measured: ~5 % of the MFMA issue rate).
+//   * Register rings: an A fragment (weights of one unit tile x gate, 4 VGPRs) is re-requested for k-group q+DA
+//     after the MFMAs of the NEXT fragment of group q (one fragment late, so the load never writes registers
+//     that the MFMA issued just before it is still reading: a WAR interlock that otherwise stalls the in-order
+//     issue); B fragments four k-groups deep.  The k-group count is padded to a multiple of 4 with zero weights
+//     (host side), so the loop body is branch-free with exact vmcnt counts; the last groups of step t request the
+//     first groups of step t+1 (weights and x_{t+1} do not depend on h_t) before the cell phase.
 //   * The cell state c and the (pre-scaled) biases live in LDS (own-lane float4 slots, conflict-free), the
 //     accumulators start from literal zero (first MFMA of a step takes C = 0) and the biases are folded into
-//     the exp2 arguments of the activations.
+//     the exp2 arguments of the activations; the per-step cost that does not scale with K is ~4.5 us
+//     (transcendental-bound: 10 v_exp/v_rcp per element, tools/micro/trans_rate.hip).
+// SPARSE = true (front-end layers): k-groups that are pure zero padding -- the x part padded from 8/16 to 32
+// features so that the first four k-groups never depend on h_t, and the tail padded to a multiple of four -- keep
+// their (branch-free) operand requests but skip their MFMAs behind a wave-uniform test.
+// The padding to four x-part k-groups is a CORRECTNESS requirement, not a convenience: the B ring requests four
+// k-groups across a step boundary, i.e. before the cell phase of step t has stored h_t.  A request that touched an
+// h_t row early would pull its stale lines into this CU's vector L1, and the re-request after the barrier would hit
+// them (measured in round 2: sites 12-15 / 28-31 of a tile wrong, non-deterministically, at full batch only).
 // ------------------------------------------------------------------------------------------------
-// Every global access of lstm3 is a BUFFER access: a wave-uniform 128-bit descriptor (SGPRs) + a
-// wave-uniform byte offset (SGPR soffset) + lane*16 (the only address VGPR of the kernel).  Compared with
-// flat/global addressing this removes all 64-bit VALU address arithmetic from the MFMA stream (measured: the
-// refills cost ~5 % of the MFMA issue rate with global_load + v_lshl_add_u64/v_addc chains).
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7ffffff0, 0x00020000);
@@ -208,19 +222,50 @@ __device__ __forceinline__ void bst16(__amdgpu_buffer_rsrc_t r, uint32_t voff, u
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, (int)soff, 0);
 }
 
-template <int UPW>
-__global__ __launch_bounds__(256, 1) void dsp_lstm3_kernel(LstmArgs a) {
-    // LDS: the cell state c (own-lane scratch, [UPW*2*4 groups][256 threads] float4, conflict-free) and the
-    // pre-scaled biases [4][Hp].  Keeping c out of the VGPRs leaves them to the fragment rings (no spills).
+template <int N> using ic = std::integral_constant<int, N>;
+
+// Workgroup barrier of the h exchange through global memory.  hipcc's __syncthreads() is a workgroup-scope release /
+// acquire; not being in threadgroup-split mode it emits NO s_waitcnt vmcnt(0) before s_barrier (checked in the ISA):
+// the waves of a workgroup share one CU's vector memory pipeline and L1, which keeps a wave's buffer_store ahead of
+// another wave's buffer_load issued after the barrier.  An explicit vmcnt(0) was measured (round 2): -2 % on the
+// combined-stack launches and no change in any result, so it is not inserted; determinism at full batch is tested
+// (tests/test_gpu_parity.py).
+__device__ __forceinline__ void barrier_after_global_stores() { __syncthreads(); }
+
+// DSP_TRACE builds only (make trace -> libdsp_amd_trace.so, tools/trace_lstm.py): shader-clock stamps of wave 0 of
+// every workgroup of ONE chosen LSTM launch, at the start / after the k-loop / after the cell phase of every step
+#ifdef DSP_TRACE
+#define DSP_TRACE_WGS 8192
+__device__ unsigned long long g_trace[DSP_TRACE_WGS][16][4];
+__device__ unsigned int g_trace_hw[DSP_TRACE_WGS][4];
+#define TSTAMP(k) do { if ((a.flags & 256) && tid == 0 && blockIdx.x < DSP_TRACE_WGS && step < 16) g_trace[blockIdx.x][step][k] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int dsp_k_trace_read(unsigned long long* t, unsigned int* hw) {
+    hipError_t e = hipMemcpyFromSymbol(t, HIP_SYMBOL(g_trace), sizeof(g_trace));
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(hw, HIP_SYMBOL(g_trace_hw), sizeof(g_trace_hw));
+    return (int)e;
+}
+#else
+#define TSTAMP(k) do { } while (0)
+#endif
+
+template <bool SPARSE, int UPW, int SPW>
+__global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
+    static_assert(UPW * SPW == 2, "a wave owns 8 accumulator tiles");
+    // (a <1,1> variant -- 4 accumulator tiles, four waves per SIMD, 128 registers -- was measured on the front ends:
+    // +3 % on those two launches, i.e. 0.1 % of the forward; not kept)
+    constexpr int NF = UPW * 4;            // A fragments per k-group
+    constexpr int DA = UPW == 1 ? 4 : 2;   // A ring depth in k-groups (64 registers either way)
+    constexpr int DB = 4;                  // B ring depth
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    f32x4* c_lds = (f32x4*)smem;
-    f32x4* b_lds = c_lds + UPW * 8 * 256;
+    const int nthr = blockDim.x;
+    f32x4* c_lds = (f32x4*)smem;           // [UPW*SPW*4 groups][nthr] float4
+    f32x4* b_lds = c_lds + UPW * SPW * 4 * nthr;  // [unit tile][aa][gate][half] float4
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const uint32_t voff = (uint32_t)lane * 16u;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int UTP = a.UT / UPW;
-    const int ug = w % UTP, sg = w / UTP;
+    const int UTW = a.UT / UPW;            // waves per site group
+    const int ug = w % UTW, sg = w / UTW;
     const int dir = blockIdx.x & 1;
     const int grp = blockIdx.x >> 1;
     const int half = lane >> 5, ls = lane & 31;
@@ -230,23 +275,26 @@ __global__ __launch_bounds__(256, 1) void dsp_lstm3_kernel(LstmArgs a) {
     const int F4 = a.Fout >> 2;
     const uint32_t xrow = (uint32_t)(a.Ipad >> 2) * 512u;  // bytes of one (tile, t) block of the input
     const uint32_t orow = (uint32_t)F4 * 512u;             // bytes of one (tile, t) block of the output
+    const uint32_t wstride = (uint32_t)NQ * 4096u;         // bytes between the unit tiles of a wave
 
-    // first site tile of this wave; its two tiles are adjacent, so one descriptor per buffer serves both
-    const long long gt0 = (long long)grp * (a.SG * 2) + sg * 2;
+    // first site tile of this wave; its SPW tiles are adjacent, so one descriptor per buffer serves them
+    const long long gt0 = ((long long)grp * a.SG + sg) * SPW;
     const __amdgpu_buffer_rsrc_t rw = make_rsrc((const char*)(dir ? a.wpk1 : a.wpk0) + (size_t)(ug * UPW) * NQ * 4096);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)a.x + (size_t)gt0 * T * xrow);
     const __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)a.out + (size_t)gt0 * T * orow + (size_t)dir * HQ * 512);
     const __amdgpu_buffer_rsrc_t rh0 = make_rsrc((const char*)a.h0buf + (size_t)gt0 * orow + (size_t)dir * HQ * 512);
-    const uint32_t wstride = (uint32_t)NQ * 4096u;  // bytes between the unit tiles of this wave
     const f32x4* bias4 = (const f32x4*)(dir ? a.sbias1 : a.sbias0);
 
     // ---- initial state: c0 -> LDS, h0 -> the K4 scratch that step 0 reads as "h_{-1}"; biases -> LDS
-    for (int i = tid; i < a.Hp; i += blockDim.x) b_lds[i] = bias4[i];
+    for (int i = tid; i < a.Hp; i += nthr) {
+        const int h = i & 1, g = (i >> 1) & 3, aa = (i >> 3) & 3, ut = i >> 5;
+        b_lds[i] = bias4[g * HQ + ut * 8 + 2 * aa + h];
+    }
 #pragma unroll
     for (int uu = 0; uu < UPW; ++uu) {
         const int u = ug * UPW + uu;
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+        for (int m = 0; m < SPW; ++m) {
             const long long site = (gt0 + m) * 32 + ls;
 #pragma unroll
             for (int aa = 0; aa < 4; ++aa) {
@@ -258,133 +306,130 @@ __global__ __launch_bounds__(256, 1) void dsp_lstm3_kernel(LstmArgs a) {
                     cv = init_state4(a.c0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, a.site_offset,
                                      (uint32_t)(a.stream_base + dir * 2 + 1));
                 }
-                bst16(rh0, voff, (uint32_t)m * orow + (uint32_t)(u * 8 + 2 * aa) * 512u, hv);
-                c_lds[((uu * 2 + m) * 4 + aa) * 256 + tid] = cv;
+                bst16(rh0, voff + aa * 1024u, (uint32_t)m * orow + (uint32_t)u * 4096u, hv);
+                c_lds[((uu * SPW + m) * 4 + aa) * nthr + tid] = cv;
             }
         }
     }
-    __syncthreads();  // h0 stored (vmcnt drained) before any wave reads it back
+    barrier_after_global_stores();  // h0 stored before any wave reads it back
 
     // B-operand source of a step (all uniform): x_t from rx, h_{t-1} from the K4 output of the previous step
     // (ro) or, at step 0, from the h0 scratch (rh0).  Offsets are biased so that both parts are "base + q*1024".
     __amdgpu_buffer_rsrc_t rhp = rh0;
-    uint32_t xo[2], ho[2];
-    auto set_bases = [&](int step) {
+    uint32_t xo[SPW], ho[SPW];
+    auto set_bases = [&](int step) __attribute__((always_inline)) {
         const int t = dir ? (T - 1 - step) : step;
         const int tp = dir ? (t + 1) : (t - 1);
         rhp = step == 0 ? rh0 : ro;
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+        for (int m = 0; m < SPW; ++m) {
             xo[m] = (uint32_t)(m * T + t) * xrow;
             ho[m] = (step == 0 ? (uint32_t)m * orow : (uint32_t)(m * T + tp) * orow) - (uint32_t)nqx * 1024u;
         }
     };
 
-    // register rings: A and B four k-groups deep
-#define ARING 4
-    f32x4 A0[UPW][4], A1[UPW][4], A2[UPW][4], A3[UPW][4], B0[2], B1[2], B2[2], B3[2];
-    f32x16 acc[UPW][4][2];
-    auto loadB = [&](f32x4 (&B)[2], int q) {
+    f32x4 A[DA][NF], B[DB][SPW];
+    f32x16 acc[UPW][4][SPW];
+    auto loadB = [&](f32x4 (&Bs)[SPW], int q) __attribute__((always_inline)) {
         const int qc = q < nq ? q : nq - 1;  // padded k-groups have zero weights: any finite B will do
         const bool isx = qc < nqx;
         const __amdgpu_buffer_rsrc_t r = isx ? rx : rhp;
 #pragma unroll
-        for (int m = 0; m < 2; ++m) B[m] = bld16(r, voff, (isx ? xo[m] : ho[m]) + (uint32_t)qc * 1024u);
+        for (int m = 0; m < SPW; ++m) Bs[m] = bld16(r, voff, (isx ? xo[m] : ho[m]) + (uint32_t)qc * 1024u);
     };
-    auto loadA = [&](f32x4 (&A)[UPW][4], int q) {
-#pragma unroll
-        for (int uu = 0; uu < UPW; ++uu)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) A[uu][g] = bld16(rw, voff, (uint32_t)uu * wstride + (uint32_t)q * 4096u + g * 1024u);
+    auto ldA = [&](int j, int q) __attribute__((always_inline)) {  // fragment j = (unit tile j/4, gate j%4) of k-group q
+        return bld16(rw, voff + (uint32_t)(j & 3) * 1024u, (uint32_t)(j >> 2) * wstride + (uint32_t)q * 4096u);
     };
-    // one k-group: 8 MFMAs per (unit tile, gate).  After the MFMAs of fragment j the fragment j-1 is refilled
-    // (for k-group qa); fragment UPW*4-1 of the PREVIOUS stage's ring slot Ap is refilled after j = 0 (for
-    // k-group qp).  Refilling one fragment late keeps the load from writing registers that the MFMA issued
-    // just before it is still reading (a WAR interlock that otherwise stalls the in-order issue).
-    // first = true: the very first k-step of a time step accumulates onto literal zero (no accumulator init;
-    // the biases are folded into the activation arguments of the cell phase instead)
+#define QW(x) ((x) < NQ ? (x) : (x) - NQ)
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto stage = [&](f32x4 (&A)[UPW][4], const f32x4 (&B)[2], int qa, f32x4 (&Ap)[UPW][4], int qp, auto first) {
+    const int nqx_used = a.nqx_used;
+    // one k-group (ring slots are compile-time: QS = q mod 4): the MFMAs of fragment j, then the refill of fragment
+    // j-1 for k-group q+DA; the last fragment of the PREVIOUS stage's slot is refilled after fragment 0.
+    // first = true: the very first k-step of a time step accumulates onto literal zero.
+    auto stage = [&](auto qs, int q, auto first) __attribute__((always_inline)) {
+        constexpr int QS = decltype(qs)::value;
+        constexpr int sa = QS % DA, sp = (QS + DA - 1) % DA, sb = QS % DB;
+        const int qa = QW(q + DA), qp = QW(q + DA - 1);
+        const bool live = !SPARSE || q < nqx_used || (q >= nqx && q < nq);  // wave-uniform
+        // fragments are processed in groups of FG with the k-steps outermost, so that consecutive MFMAs never share an
+        // accumulator: FG = 1 for SPW = 2 (the two site tiles alternate), FG = 2 for SPW = 1 (two gates alternate)
+        constexpr int FG = SPW == 1 ? 2 : 1;
 #pragma unroll
-        for (int uu = 0; uu < UPW; ++uu)
+        for (int j0 = 0; j0 < NF; j0 += FG) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int i = 0; i < 4; ++i) {
+                if (SPARSE && !live) break;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (decltype(first)::value && i == 0) {
-                        acc[uu][g][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[uu][g][i], B[0][i], zero16, 0, 0, 0);
-                        acc[uu][g][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[uu][g][i], B[1][i], zero16, 0, 0, 0);
-                    } else {
-                        acc[uu][g][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[uu][g][i], B[0][i], acc[uu][g][0], 0, 0, 0);
-                        acc[uu][g][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[uu][g][i], B[1][i], acc[uu][g][1], 0, 0, 0);
+                for (int f = 0; f < FG; ++f) {
+                    const int j = j0 + f;
+#pragma unroll
+                    for (int m = 0; m < SPW; ++m) {
+                        if (decltype(first)::value && i == 0)
+                            acc[j >> 2][j & 3][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[sa][j][i], B[sb][m][i], zero16, 0, 0, 0);
+                        else
+                            acc[j >> 2][j & 3][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[sa][j][i], B[sb][m][i], acc[j >> 2][j & 3][m], 0, 0, 0);
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);  // keep "8 MFMAs, then one refill" in program order
-                const int j = uu * 4 + g;
-                if (j == 0) Ap[UPW - 1][3] = bld16(rw, voff, (uint32_t)(UPW - 1) * wstride + (uint32_t)qp * 4096u + 3 * 1024u);
-                else A[(j - 1) >> 2][(j - 1) & 3] = bld16(rw, voff, (uint32_t)((j - 1) >> 2) * wstride + (uint32_t)qa * 4096u + ((j - 1) & 3) * 1024u);
-                __builtin_amdgcn_sched_barrier(0);
             }
+            __builtin_amdgcn_sched_barrier(0);  // keep "MFMAs of a fragment group, then its refills" in program order
+#pragma unroll
+            for (int f = 0; f < FG; ++f) {
+                if (j0 == 0) A[sp][NF - FG + f] = ldA(NF - FG + f, qp);
+                else A[sa][j0 - FG + f] = ldA(j0 - FG + f, qa);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto stage4 = [&](int q, auto first) __attribute__((always_inline)) {
+        stage(ic<0>{}, q + 0, first); loadB(B[0 % DB], QW(q + 0 + DB)); __builtin_amdgcn_sched_barrier(0);
+        stage(ic<1>{}, q + 1, std::false_type{}); loadB(B[1 % DB], QW(q + 1 + DB)); __builtin_amdgcn_sched_barrier(0);
+        stage(ic<2>{}, q + 2, std::false_type{}); loadB(B[2 % DB], QW(q + 2 + DB)); __builtin_amdgcn_sched_barrier(0);
+        stage(ic<3>{}, q + 3, std::false_type{}); loadB(B[3 % DB], QW(q + 3 + DB)); __builtin_amdgcn_sched_barrier(0);
     };
 
     set_bases(0);
-    loadA(A0, 0); loadB(B0, 0);
-    loadA(A1, 1); loadB(B1, 1);
-    loadA(A2, 2); loadA(A3, 3);
-    loadB(B2, 2); loadB(B3, 3);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        if (d < DA) {
+#pragma unroll
+            for (int j = 0; j < NF; ++j) A[d][j] = ldA(j, d);
+        }
+        if (d < DB) loadB(B[d], d);
+    }
 
-#ifdef DSP_TIMING
-#define TSTAMP(k) do { if (a.dbg && blockIdx.x == 0 && tid == 0) a.dbg[step * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define TSTAMP(k) do { } while (0)
+#ifdef DSP_TRACE
+    if ((a.flags & 256) && tid == 0 && blockIdx.x < DSP_TRACE_WGS) {
+        g_trace_hw[blockIdx.x][0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+        g_trace_hw[blockIdx.x][1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+    }
 #endif
     for (int step = 0; step < T; ++step) {
         const int t = dir ? (T - 1 - step) : step;
         TSTAMP(0);
-        // stage(q): slot q%ARING is refilled for k-group q+ARING; the last fragment of the previous stage's
-        // slot is refilled (for k-group q-1+ARING) after this stage's first fragment.  k-groups >= NQ wrap to
-        // the next step.
-#define QW(x) ((x) < NQ ? (x) : (x) - NQ)
-        stage(A0, B0, 0 + ARING, A3, QW(NQ - 1 + ARING), std::true_type{}); loadB(B0, 4); __builtin_amdgcn_sched_barrier(0);
-        stage(A1, B1, 1 + ARING, A0, 0 + ARING, std::false_type{}); loadB(B1, 5); __builtin_amdgcn_sched_barrier(0);
-        stage(A2, B2, 2 + ARING, A1, 1 + ARING, std::false_type{}); loadB(B2, 6); __builtin_amdgcn_sched_barrier(0);
-        stage(A3, B3, 3 + ARING, A2, 2 + ARING, std::false_type{}); loadB(B3, 7); __builtin_amdgcn_sched_barrier(0);
-        for (int q = 4; q < NQ - 4; q += 4) {
-            stage(A0, B0, q + 0 + ARING, A3, q - 1 + ARING, std::false_type{}); loadB(B0, q + 4); __builtin_amdgcn_sched_barrier(0);
-            stage(A1, B1, q + 1 + ARING, A0, q + 0 + ARING, std::false_type{}); loadB(B1, q + 5); __builtin_amdgcn_sched_barrier(0);
-            stage(A2, B2, q + 2 + ARING, A1, q + 1 + ARING, std::false_type{}); loadB(B2, q + 6); __builtin_amdgcn_sched_barrier(0);
-            stage(A3, B3, q + 3 + ARING, A2, q + 2 + ARING, std::false_type{}); loadB(B3, q + 7); __builtin_amdgcn_sched_barrier(0);
-        }
+        if (step > 0) barrier_after_global_stores();  // h_{t-1} of every wave stored before anyone reads it back
+        TSTAMP(1);
+        stage4(0, std::true_type{});
+        for (int q = 4; q < NQ - 4; q += 4) stage4(q, std::false_type{});
+        set_bases(step + 1 < T ? step + 1 : step);  // B requests from here on belong to the next step
+        stage4(NQ - 4, std::false_type{});
+        // (stage NQ-1 leaves the last fragment of its ring slot, for the next step's k-group DA-1, to "the next
+        // stage": request it here, ahead of the cell phase)
+#pragma unroll
+        for (int f = SPW == 1 ? NF - 2 : NF - 1; f < NF; ++f) A[DA - 1][f] = ldA(f, DA - 1);
         TSTAMP(2);
-        // last four k-groups of the step; refills wrap to the first groups of step+1 (weights and x_{t+1} do
-        // not depend on h_t, so they are requested before the cell phase).  On the last step the wrapped
-        // requests re-read the same step (valid addresses, results unused): no branches in the stream.
-        stage(A0, B0, QW(NQ - 4 + ARING), A3, QW(NQ - 5 + ARING), std::false_type{});
-        stage(A1, B1, QW(NQ - 3 + ARING), A0, QW(NQ - 4 + ARING), std::false_type{});
-        set_bases(step + 1 < T ? step + 1 : step);
-        loadB(B0, 0);
-        loadB(B1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        stage(A2, B2, QW(NQ - 2 + ARING), A1, QW(NQ - 3 + ARING), std::false_type{});
-        loadB(B2, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        stage(A3, B3, QW(NQ - 1 + ARING), A2, QW(NQ - 2 + ARING), std::false_type{});
-        loadB(B3, 3);
-        __builtin_amdgcn_sched_barrier(0);
-        TSTAMP(3);
 
         // LSTM cell.  b_lds holds the PRE-SCALED biases (-log2e*b for i,f,o; -2*log2e*b for g), so
         // sigmoid(x+b) = rcp(1 + exp2(fma(x, -log2e, b'))) costs no extra instruction for the bias.
 #pragma unroll
         for (int uu = 0; uu < UPW; ++uu) {
             const int u = ug * UPW + uu;
+            const f32x4* b_my = b_lds + (size_t)u * 32 + half;  // + aa*8 + gate*2
 #pragma unroll
             for (int aa = 0; aa < 4; ++aa) {
-                const int k4 = u * 8 + 2 * aa + half;
-                const f32x4 bi = b_lds[0 * HQ + k4], bf = b_lds[1 * HQ + k4], bg = b_lds[2 * HQ + k4], bo = b_lds[3 * HQ + k4];
+                const f32x4 bi = b_my[aa * 8 + 0], bf = b_my[aa * 8 + 2], bg = b_my[aa * 8 + 4], bo = b_my[aa * 8 + 6];
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    f32x4 cv = c_lds[((uu * 2 + m) * 4 + aa) * 256 + tid];
+                for (int m = 0; m < SPW; ++m) {
+                    f32x4 cv = c_lds[((uu * SPW + m) * 4 + aa) * nthr + tid];
                     f32x4 hv;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -397,187 +442,12 @@ __global__ __launch_bounds__(256, 1) void dsp_lstm3_kernel(LstmArgs a) {
                         cv[i] = cn;
                         hv[i] = og * fast_tanh(cn);
                     }
-                    c_lds[((uu * 2 + m) * 4 + aa) * 256 + tid] = cv;
-                    bst16(ro, voff, (uint32_t)(m * T + t) * orow + (uint32_t)(u * 8 + 2 * aa) * 512u, hv);
+                    c_lds[((uu * SPW + m) * 4 + aa) * nthr + tid] = cv;
+                    bst16(ro, voff + aa * 1024u, (uint32_t)(m * T + t) * orow + (uint32_t)u * 4096u, hv);
                 }
             }
         }
-        TSTAMP(4);
-        __syncthreads();  // h_t stored by every wave (vmcnt(0) + barrier) before the next step reads it
-        TSTAMP(5);
-    }
-#undef QW
-#undef ARING
-}
-
-// ------------------------------------------------------------------------------------------------
-// dsp_lstm4_kernel (the default): the same math, K4 layout and operand scheme as dsp_lstm3_kernel (buffer loads
-// with SGPR offsets, register rings, h_{t-1} read back from the K4 output, zero-C first MFMA, biases folded into
-// the activations, cell state in LDS), but TWO waves per SIMD:
-//   * 8 waves x 256 registers: a wave owns ONE unit tile (4 gates) x 2 site tiles = 8 accumulator tiles (128
-//     registers); A ring 4 x 16 VGPRs, B ring 4 x 8 VGPRs.  Weight traffic per site is unchanged (a fragment
-//     still feeds 8 MFMAs).
-//   * The per-step cost that does not scale with K (the transcendental-bound cell phase; intercept of launch
-//     time vs k-groups) drops from 8.2 us (lstm3, one wave per SIMD) to 4.5 us: each wave's cell phase covers
-//     half the elements and the two waves of a SIMD interleave their v_exp/v_rcp streams (a single wave reaches
-//     only 64 % of the TRANS issue rate, tools/micro/trans_rate.hip); the MFMA stream stays at 97 % of peak.
-//   * Tried and measured null: placing the per-step rendezvous at different k-groups for the two waves of a SIMD
-//     (so that they run 4..24 k-groups apart and one wave's cell phase meets the other's MFMAs): with half-size
-//     cell phases already sharing the VALU there is nothing left to win (18.15 ms for every skew incl. 0).
-// ------------------------------------------------------------------------------------------------
-// SPARSE = true (front-end layers): k-groups that are pure zero padding -- the x part padded from 8/16 to 32
-// features so that the first four k-groups never depend on h_t, and the tail padded to a multiple of four -- keep
-// their (branch-free) operand requests but skip their MFMAs behind a wave-uniform test.
-template <bool SPARSE>
-__global__ __launch_bounds__(512, 2) void dsp_lstm4_kernel(LstmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    f32x4* c_lds = (f32x4*)smem;           // [2 site tiles][4 groups][512 threads] float4
-    f32x4* b_lds = c_lds + 8 * 512;        // [unit tile][aa][gate][half] float4
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const uint32_t voff = (uint32_t)lane * 16u;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int u = w % a.UT, sg = w / a.UT;
-    const int dir = blockIdx.x & 1;
-    const int grp = blockIdx.x >> 1;
-    const int half = lane >> 5, ls = lane & 31;
-    const int HQ = a.Hp >> 2;
-    const int nqx = a.Ipad >> 3, nq = nqx + (a.Hp >> 3), NQ = a.NQ;
-    const int T = a.T;
-    const int F4 = a.Fout >> 2;
-    const uint32_t xrow = (uint32_t)(a.Ipad >> 2) * 512u;
-    const uint32_t orow = (uint32_t)F4 * 512u;
-
-    const long long gt0 = (long long)grp * (a.SG * 2) + sg * 2;
-    const __amdgpu_buffer_rsrc_t rw = make_rsrc((const char*)(dir ? a.wpk1 : a.wpk0) + (size_t)u * NQ * 4096);
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)a.x + (size_t)gt0 * T * xrow);
-    const __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)a.out + (size_t)gt0 * T * orow + (size_t)dir * HQ * 512);
-    const __amdgpu_buffer_rsrc_t rh0 = make_rsrc((const char*)a.h0buf + (size_t)gt0 * orow + (size_t)dir * HQ * 512);
-    const f32x4* bias4 = (const f32x4*)(dir ? a.sbias1 : a.sbias0);
-
-    for (int i = tid; i < a.Hp; i += blockDim.x) {
-        const int h = i & 1, g = (i >> 1) & 3, aa = (i >> 3) & 3, ut = i >> 5;
-        b_lds[i] = bias4[g * HQ + ut * 8 + 2 * aa + h];
-    }
-    const f32x4* b_my = b_lds + (size_t)u * 32 + half;  // + aa*8 + gate*2
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const long long site = (gt0 + m) * 32 + ls;
-#pragma unroll
-        for (int aa = 0; aa < 4; ++aa) {
-            const int k4 = u * 8 + 2 * aa + half;
-            f32x4 hv = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
-            if (a.init_mode != 0) {
-                hv = init_state4(a.h0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, a.site_offset,
-                                 (uint32_t)(a.stream_base + dir * 2 + 0));
-                cv = init_state4(a.c0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, a.site_offset,
-                                 (uint32_t)(a.stream_base + dir * 2 + 1));
-            }
-            bst16(rh0, voff + aa * 1024u, (uint32_t)m * orow + (uint32_t)u * 4096u, hv);
-            c_lds[(m * 4 + aa) * 512 + tid] = cv;
-        }
-    }
-    __syncthreads();  // h0 stored (vmcnt drained) before any wave reads it back
-
-    __amdgpu_buffer_rsrc_t rhp = rh0;
-    uint32_t xo[2], ho[2];
-    auto set_bases = [&](int step) __attribute__((always_inline)) {
-        const int t = dir ? (T - 1 - step) : step;
-        const int tp = dir ? (t + 1) : (t - 1);
-        rhp = step == 0 ? rh0 : ro;
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            xo[m] = (uint32_t)(m * T + t) * xrow;
-            ho[m] = (step == 0 ? (uint32_t)m * orow : (uint32_t)(m * T + tp) * orow) - (uint32_t)nqx * 1024u;
-        }
-    };
-
-    f32x4 A0[4], A1[4], A2[4], A3[4], B0[2], B1[2], B2[2], B3[2];
-    f32x16 acc[4][2];
-    auto loadB = [&](f32x4 (&B)[2], int q) __attribute__((always_inline)) {
-        const int qc = q < nq ? q : nq - 1;  // padded k-groups have zero weights: any finite B will do
-        const bool isx = qc < nqx;
-        const __amdgpu_buffer_rsrc_t r = isx ? rx : rhp;
-#pragma unroll
-        for (int m = 0; m < 2; ++m) B[m] = bld16(r, voff, (isx ? xo[m] : ho[m]) + (uint32_t)qc * 1024u);
-    };
-    auto loadA = [&](f32x4 (&A)[4], int q) __attribute__((always_inline)) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) A[g] = bld16(rw, voff + g * 1024u, (uint32_t)q * 4096u);
-    };
-#define QW(x) ((x) < NQ ? (x) : (x) - NQ)
-    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // one k-group: 8 MFMAs per gate fragment; fragment g-1 is re-requested (k-group q+4) after the MFMAs of
-    // fragment g, fragment 3 of the previous stage's slot after fragment 0 (late refill, see lstm3)
-    const int nqx_used = a.nqx_used;
-    auto stage = [&](f32x4 (&A)[4], const f32x4 (&B)[2], f32x4 (&Ap)[4], int q, auto first) __attribute__((always_inline)) {
-        const int qa = QW(q + 4), qp = QW(q + 3);
-        const bool live = !SPARSE || q < nqx_used || (q >= nqx && q < nq);  // wave-uniform
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (SPARSE && !live) break;
-                if (decltype(first)::value && i == 0) {
-                    acc[g][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g][i], B[0][i], zero16, 0, 0, 0);
-                    acc[g][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g][i], B[1][i], zero16, 0, 0, 0);
-                } else {
-                    acc[g][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g][i], B[0][i], acc[g][0], 0, 0, 0);
-                    acc[g][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g][i], B[1][i], acc[g][1], 0, 0, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (g == 0) Ap[3] = bld16(rw, voff + 3 * 1024u, (uint32_t)qp * 4096u);
-            else A[g - 1] = bld16(rw, voff + (g - 1) * 1024u, (uint32_t)qa * 4096u);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    auto stage4 = [&](int q, auto first) __attribute__((always_inline)) {
-        stage(A0, B0, A3, q + 0, first); loadB(B0, QW(q + 4)); __builtin_amdgcn_sched_barrier(0);
-        stage(A1, B1, A0, q + 1, std::false_type{}); loadB(B1, QW(q + 5)); __builtin_amdgcn_sched_barrier(0);
-        stage(A2, B2, A1, q + 2, std::false_type{}); loadB(B2, QW(q + 6)); __builtin_amdgcn_sched_barrier(0);
-        stage(A3, B3, A2, q + 3, std::false_type{}); loadB(B3, QW(q + 7)); __builtin_amdgcn_sched_barrier(0);
-    };
-
-    set_bases(0);
-    loadA(A0, 0); loadB(B0, 0);
-    loadA(A1, 1); loadB(B1, 1);
-    loadA(A2, 2); loadB(B2, 2);
-    loadA(A3, 3); loadB(B3, 3);
-
-    for (int step = 0; step < T; ++step) {
-        const int t = dir ? (T - 1 - step) : step;
-        if (step > 0) __syncthreads();  // h_{t-1} of every wave stored (vmcnt(0) + barrier) before anyone reads it back
-        stage4(0, std::true_type{});
-        for (int q = 4; q < NQ - 4; q += 4) stage4(q, std::false_type{});
-        set_bases(step + 1 < T ? step + 1 : step);  // B requests from here on belong to the next step
-        stage4(NQ - 4, std::false_type{});
-        // (stage NQ-1 leaves the last fragment of A3, for the next step's k-group 3, to "the next stage")
-        A3[3] = bld16(rw, voff + 3 * 1024u, 3u * 4096u);
-
-        // LSTM cell (see lstm3): pre-scaled biases folded into the exp2 arguments
-#pragma unroll
-        for (int aa = 0; aa < 4; ++aa) {
-            const f32x4 bi = b_my[aa * 8 + 0], bf = b_my[aa * 8 + 2], bg = b_my[aa * 8 + 4], bo = b_my[aa * 8 + 6];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                f32x4 cv = c_lds[(m * 4 + aa) * 512 + tid];
-                f32x4 hv;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = 4 * aa + i;
-                    const float ig = sigmoid_pre(acc[0][m][r], bi[i]);
-                    const float fg = sigmoid_pre(acc[1][m][r], bf[i]);
-                    const float gg = tanh_pre(acc[2][m][r], bg[i]);
-                    const float og = sigmoid_pre(acc[3][m][r], bo[i]);
-                    const float cn = __builtin_fmaf(fg, cv[i], ig * gg);
-                    cv[i] = cn;
-                    hv[i] = og * fast_tanh(cn);
-                }
-                c_lds[(m * 4 + aa) * 512 + tid] = cv;
-                bst16(ro, voff + aa * 1024u, (uint32_t)(m * T + t) * orow + (uint32_t)u * 4096u, hv);
-            }
-        }
+        TSTAMP(3);
     }
 #undef QW
 }
@@ -597,7 +467,6 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // 8 fp32 (two float4 = the lane's 8 consecutive k of a k-stage) -> hi / mid / lo as packed bf16x8
 __device__ __forceinline__ void split_bf16x3(const f32x4 x0, const f32x4 x1, u32x4& hi, u32x4& mid, u32x4& lo) {
@@ -682,7 +551,7 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm6_kernel(LstmArgs a) {
             c_lds[(m * 4 + aa) * 512 + tid] = cv;
         }
     }
-    __syncthreads();  // h0 stored (vmcnt drained) before any wave reads it back
+    barrier_after_global_stores();  // h0 stored before any wave reads it back
 
     __amdgpu_buffer_rsrc_t rhp = rh0;
     uint32_t xo[2], ho[2];
@@ -763,7 +632,7 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm6_kernel(LstmArgs a) {
 
     for (int step = 0; step < T; ++step) {
         const int t = dir ? (T - 1 - step) : step;
-        if (step > 0) __syncthreads();  // h_{t-1} of every wave stored (vmcnt(0) + barrier) before anyone reads it back
+        if (step > 0) barrier_after_global_stores();  // h_{t-1} of every wave stored before anyone reads it back
         stage(0, 1, std::true_type{});
         for (int q = 1; q < NQ - 1; ++q) stage(q, q + 1, std::false_type{});
         set_bases(step + 1 < T ? step + 1 : step);  // the activation request of the last stage belongs to the next step
@@ -801,21 +670,26 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm6_kernel(LstmArgs a) {
 // ------------------------------------------------------------------------------------------------
 // A wave computes 4 row tiles (128 output rows) x 2 column blocks (2 x 32 sites): 8 accumulator tiles, 32 MFMAs
 // per k-group against 6 fragment loads (the first version -- one tile per wave, 4 MFMAs per 2 loads -- was bound
-// by the L1 fill rate at 32 B/clk/CU and reached 88 TFLOP/s).  Fragments of k-group q+1 are requested before the
-// MFMAs of group q.
+// by the L1 fill rate at 32 B/clk/CU and reached 88 TFLOP/s).  Operands come through the same buffer-load register
+// rings as in dsp_lstm_kernel: the weights (L2-resident) two k-groups deep, the activations four -- they stream
+// from HBM (the LSTM layer's [B,13,2H] output is 0.87 GB, beyond the 256 MiB Infinity Cache), and with the first
+// version's one-deep prefetch every k-group waited out part of an HBM round trip (66 % of the MFMA peak).
 __global__ __launch_bounds__(256, 2) void dsp_linear_kernel(LinArgs a) {
     const int lane = threadIdx.x & 63;
+    const uint32_t voff = (uint32_t)lane * 16u;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rt0 = blockIdx.y * 4;
     const int half = lane >> 5, ls = lane & 31;
     const long long col0 = ((long long)blockIdx.x * 4 + w) * 2;
     if (col0 >= a.ncols) return;
     const bool two = col0 + 1 < a.ncols;
-    const int nq = a.Fin >> 3;
+    const int nq = a.Fin >> 3;   // a multiple of 8 (Fin = 2*Hp, Hp a multiple of 32)
     const int nrt = a.ORT - rt0 < 4 ? a.ORT - rt0 : 4;
-    const f32x4* wq = (const f32x4*)a.wpk + (size_t)rt0 * nq * 64 + lane;  // + r*nq*64 + q*64
-    const f32x4* xb0 = (const f32x4*)a.x + ((size_t)col0 * (a.Fin >> 2) + half) * 32 + ls;
-    const f32x4* xb1 = two ? xb0 + (size_t)(a.Fin >> 2) * 32 : xb0;
+    const uint32_t xrow = (uint32_t)(a.Fin >> 2) * 512u;  // bytes of one column block of the input
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc((const char*)a.wpk + (size_t)rt0 * nq * 1024);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)a.x + (size_t)col0 * xrow);
+    const uint32_t wrow = (uint32_t)nq * 1024u;           // bytes between row tiles
+    const uint32_t x1 = two ? xrow : 0u;                  // a lone last column block is computed twice, stored once
     const f32x4* bias4 = (const f32x4*)a.bias;
     f32x16 acc[4][2];
 #pragma unroll
@@ -826,27 +700,46 @@ __global__ __launch_bounds__(256, 2) void dsp_linear_kernel(LinArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) { acc[r][0][4 * aa + i] = b[i]; acc[r][1][4 * aa + i] = b[i]; }
         }
-    f32x4 An[4], Bn[2];
+    uint32_t ro[4];  // row tiles beyond ORT re-read tile 0 (results dropped)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) An[r] = wq[(size_t)(r < nrt ? r : 0) * nq * 64];
-    Bn[0] = xb0[0]; Bn[1] = xb1[0];
-    for (int q = 0; q < nq; ++q) {
-        f32x4 A[4], B[2];
+    for (int r = 0; r < 4; ++r) ro[r] = (uint32_t)(r < nrt ? r : 0) * wrow;
+    f32x4 A[2][4], B[4][2];
+    auto ldA = [&](int r, int q) __attribute__((always_inline)) { return bld16(rw, voff, ro[r] + (uint32_t)q * 1024u); };
+    auto ldB = [&](f32x4 (&Bs)[2], int q) __attribute__((always_inline)) {
+        Bs[0] = bld16(rx, voff, (uint32_t)q * 1024u);
+        Bs[1] = bld16(rx, voff, x1 + (uint32_t)q * 1024u);
+    };
+#define QC(x) ((x) < nq ? (x) : nq - 1)
+    auto stage = [&](auto qs, int q) __attribute__((always_inline)) {
+        constexpr int QS = decltype(qs)::value;
+        constexpr int sa = QS % 2, sp = (QS + 1) % 2, sb = QS % 4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) A[r] = An[r];
-        B[0] = Bn[0]; B[1] = Bn[1];
-        const int qn = q + 1 < nq ? q + 1 : q;
+        for (int r = 0; r < 4; ++r) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) An[r] = wq[(size_t)(r < nrt ? r : 0) * nq * 64 + (size_t)qn * 64];
-        Bn[0] = xb0[(size_t)qn * 64]; Bn[1] = xb1[(size_t)qn * 64];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc[r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[r][i], B[0][i], acc[r][0], 0, 0, 0);
-                acc[r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[r][i], B[1][i], acc[r][1], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) {
+                acc[r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[sa][r][i], B[sb][0][i], acc[r][0], 0, 0, 0);
+                acc[r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[sa][r][i], B[sb][1][i], acc[r][1], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (r == 0) A[sp][3] = ldA(3, QC(q + 1));
+            else A[sa][r - 1] = ldA(r - 1, QC(q + 2));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        ldB(B[sb], QC(q + 4));
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        if (d < 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A[d][r] = ldA(r, d);
+        }
+        ldB(B[d], d);
     }
+    for (int q = 0; q < nq; q += 4) {
+        stage(ic<0>{}, q); stage(ic<1>{}, q + 1); stage(ic<2>{}, q + 2); stage(ic<3>{}, q + 3);
+    }
+#undef QC
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         if (c == 1 && !two) break;
@@ -943,22 +836,13 @@ __global__ __launch_bounds__(256) void dsp_head_kernel(HeadArgs a) {
 // launch wrappers (called from dsp_capi.cpp; keep all <<<>>> syntax in this translation unit)
 // ------------------------------------------------------------------------------------------------
 extern "C" int dsp_k_init(void) {
-    hipError_t e = hipFuncSetAttribute((const void*)dsp_lstm3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)dsp_lstm3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)dsp_lstm4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)dsp_lstm4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)dsp_lstm6_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)dsp_lstm6_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)dsp_lstm6_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)dsp_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    return (int)e;
+    const void* fns[] = {(const void*)dsp_lstm_kernel<false, 1, 2>, (const void*)dsp_lstm_kernel<true, 1, 2>,
+                         (const void*)dsp_lstm6_kernel<6>, (const void*)dsp_lstm6_kernel<9>, (const void*)dsp_lstm6_kernel<3>};
+    for (const void* f : fns) {
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+    }
+    return (int)hipFuncSetAttribute((const void*)dsp_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
 }
 
 extern "C" int dsp_k_pack(const PackArgs* a, hipStream_t s) {
@@ -968,22 +852,16 @@ extern "C" int dsp_k_pack(const PackArgs* a, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-extern "C" int dsp_k_lstm3(const LstmArgs* a, int upw, hipStream_t s) {
-    const int waves = (a->UT / upw) * a->SG;
+// a wave owns one unit tile x two site tiles; a->SG site groups (of two tiles) per workgroup
+extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
+    const int threads = a->UT * a->SG * 64;
     const unsigned groups = (unsigned)(a->NTp / (a->SG * 2));
-    const size_t lds = (size_t)upw * 8 * 256 * 16 + (size_t)a->Hp * 16;
-    if (upw == 2) hipLaunchKernelGGL(dsp_lstm3_kernel<2>, dim3(groups * 2), dim3(waves * 64), lds, s, *a);
-    else hipLaunchKernelGGL(dsp_lstm3_kernel<1>, dim3(groups * 2), dim3(waves * 64), lds, s, *a);
-    return (int)hipGetLastError();
-}
-
-extern "C" int dsp_k_lstm4(const LstmArgs* a, hipStream_t s) {
-    const int waves = a->UT * a->SG;
-    const unsigned groups = (unsigned)(a->NTp / (a->SG * 2));
-    const size_t lds = (size_t)8 * 512 * 16 + (size_t)a->Hp * 16;
+    const size_t lds = (size_t)8 * threads * 16 + (size_t)a->Hp * 16;
+    if ((a->Ipad >> 3) < 4 || threads > 512) return (int)hipErrorInvalidValue;  // see the SPARSE note: four x-part k-groups are required
     const bool sparse = a->nqx_used < (a->Ipad >> 3) || a->NQ > ((a->Ipad + a->Hp) >> 3);
-    if (sparse) hipLaunchKernelGGL(dsp_lstm4_kernel<true>, dim3(groups * 2), dim3(waves * 64), lds, s, *a);
-    else hipLaunchKernelGGL(dsp_lstm4_kernel<false>, dim3(groups * 2), dim3(waves * 64), lds, s, *a);
+    const dim3 g(groups * 2), b(threads);
+    if (sparse) hipLaunchKernelGGL((dsp_lstm_kernel<true, 1, 2>), g, b, lds, s, *a);
+    else hipLaunchKernelGGL((dsp_lstm_kernel<false, 1, 2>), g, b, lds, s, *a);
     return (int)hipGetLastError();
 }
 

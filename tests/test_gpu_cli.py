@@ -316,3 +316,39 @@ def test_bench_line_keeps_the_driver_contract():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "sites/s" and cb["sample"]
     assert abs(d["value"] - 2 * 8192 / (d["ms_per_step"] * 2e-3)) / d["value"] < 0.01
+    assert cb["reference_proper"]["call_mods_default_flags_sites_per_s"] == 237.0
+    assert d["config"]["rank_site_ranges"] == [[0, 2 * 8192]]
+    for a in d["alt_precision"]:  # opt-in modes: reported beside the fp32 headline, never as `value`
+        assert a["value"] is None or a["max_abs_dprob_vs_fp32_path"] < 1e-4
+
+
+def test_bench_started_plainly_with_gpus_2_starts_two_ranks_itself():
+    """`python bench.py --gpus 2` (no launcher) starts 2 ranks as a fresh child before any GPU call; on this 1-GPU box
+    they share the GPU and the control plane runs over gloo.  n_gpus, the site total and the per-rank ranges of the
+    global site index space are those of a 2-rank job."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "8192", "--no_cpu_baseline", "--gather"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["sites"] == 2 * 2 * 8192
+    assert d["config"]["rank_site_ranges"] == [[0, 2 * 8192], [2 * 8192, 4 * 8192]]
+    assert abs(d["value"] - 4 * 8192 / (d["ms_per_step"] * 2e-3)) / d["value"] < 0.01
+    assert "cpu_baseline" not in d and d["vs_baseline"] is None
+
+
+def test_bench_config3_seq_only_line():
+    """BASELINE.json configs[2]: seq-only branch, hid 256 x 2 combined layers"""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model_type", "seq_bilstm", "--layernum1", "2",
+                        "--steps", "2", "--warmup", "1", "--batch", "8192", "--no_cpu_baseline", "--no_alt"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["config"]["flops_per_site"] == 85832704 and "configs[2]" in d["config"]["workload"]
+    assert d["roofline"]["launches"] == 2 * 2 and 0.3 < d["roofline"]["frac"] < 1.0

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Shader-clock trace of one LSTM launch (DSP_TRACE build: `make -C deepsignal_plant_amd/csrc trace`).
+usage: DSP_AMD_LIB=deepsignal_plant_amd/libdsp_amd_trace.so DSP_TRACE_LAUNCH=<i> python3 tools/trace_lstm.py [--batch B]
+Prints, per CU sample, the step timeline of the workgroups that ran on it (k-loop / cell / barrier wait, cycles)."""
+import argparse
+import ctypes
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from deepsignal_plant_amd import _native as nat
+from deepsignal_plant_amd import synth
+from deepsignal_plant_amd.models import ModelBiLSTM
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=65536)
+ap.add_argument("--model_type", default="both_bilstm")
+ap.add_argument("--layernum1", type=int, default=3)
+ap.add_argument("--cus", type=int, default=2)
+a = ap.parse_args()
+m = ModelBiLSTM(13, 16, a.layernum1, 1, 2, 0, 256, 16, 4, True, True, module=a.model_type, device=0, init_state="randn")
+m.load_state_dict(synth.random_state_dict(m)); m.cuda(0)
+ins = synth.feature_batch(a.batch, device="cuda:0", seed=1)
+for _ in range(3): m(*ins)
+torch.cuda.synchronize()
+W = 8192
+t = np.zeros((W, 16, 4), np.uint64); hw = np.zeros((W, 4), np.uint32)
+L = nat.lib()
+rc = L.dsp_k_trace_read(t.ctypes.data_as(ctypes.c_void_p), hw.ctypes.data_as(ctypes.c_void_p))
+assert rc == 0, rc
+used = np.nonzero(t[:, 0, 1])[0]
+print("traced workgroups: %d" % len(used))
+hwid, xcc = hw[:, 0], hw[:, 1] & 0xf
+cu = (hwid >> 8) & 0xf; sh = (hwid >> 12) & 1; se = (hwid >> 13) & 7; simd = (hwid >> 4) & 3; wid = hwid & 0xf
+key = (xcc.astype(np.int64) << 16) | (se.astype(np.int64) << 8) | (sh.astype(np.int64) << 4) | cu
+t = t.astype(np.int64)
+shown = 0
+for k in np.unique(key[used]):
+    wg = [i for i in used if key[i] == k]
+    wg.sort(key=lambda i: t[i, 0, 0])
+    t0 = t[wg[0], 0, 0]
+    print("== CU key %06x: %d workgroups" % (k, len(wg)))
+    for i in wg[:6]:
+        steps = []
+        for s in range(13):
+            steps.append("%d:%d+%d+%d" % (s, t[i, s, 1] - t[i, s, 0], t[i, s, 2] - t[i, s, 1], t[i, s, 3] - t[i, s, 2]))
+        print(" wg %5d dir %d simd %d wave %2d start %9d end %9d | step: barrier+kloop+cell | %s" % (
+            i, i & 1, simd[i], wid[i], t[i, 0, 0] - t0, t[i, 12, 3] - t0, " ".join(steps)))
+    shown += 1
+    if shown >= a.cus:
+        break
+# aggregate over all traced workgroups: median per-phase cycles of the middle steps
+mid = t[used][:, 2:12, :]
+bar = np.median(mid[:, :, 1] - mid[:, :, 0]); kl = np.median(mid[:, :, 2] - mid[:, :, 1]); ce = np.median(mid[:, :, 3] - mid[:, :, 2])
+step = np.median(mid[:, 1:, 0] - mid[:, :-1, 0])
+print("median cycles per step %d = barrier wait %d + k-loop %d + cell %d (+ stamp overhead)" % (step, bar, kl, ce))
