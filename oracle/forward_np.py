@@ -140,6 +140,30 @@ def make_inputs(cfg: OracleConfig, n: int, seed: int, wide_alphabet: bool = Fals
     return kmer, means, stds, lens_i.astype(np.float32), signals
 
 
+def make_extreme_inputs(cfg: OracleConfig, n: int, seed: int):
+    """Legal but extreme feature rows (what `extract` can emit, extract_features.py:232-251, :381-395): the whole IUPAC
+    alphabet; bases of 1 sample and stalls of 130..420 samples; per-base means / signals that are ordinary, tiny, or
+    huge (|x| 1e3..1e6, e.g. an un-normalised read) of both signs; stds from 0 to 1e3; signal rectangles that are all
+    padding but one sample.  Saturates the front-end LSTM gates (exp2 overflow / underflow of the activations)."""
+    rng = np.random.default_rng(seed)
+    L, S = cfg.seq_len, cfg.signal_len
+    kmer = rng.integers(0, cfg.vocab_size, size=(n, L)).astype(np.float32)
+    kmer[:, L // 2] = 1.0
+    kind = rng.integers(0, 4, size=(n, L))                       # 0 ordinary, 1 tiny, 2 huge, 3 huge negative
+    scale = np.choose(kind, [1.0, 1e-6, 1.0, 1.0])
+    shift = np.choose(kind, [0.0, 0.0, 1.0, -1.0]) * 10.0 ** rng.uniform(3, 6, size=(n, L))
+    means = np.around(rng.standard_normal((n, L)) * scale + shift, 6).astype(np.float32)
+    stds = np.around(np.abs(rng.normal(0.25, 0.1, size=(n, L))) * np.choose(kind, [1.0, 0.0, 1e3, 40.0]), 6).astype(np.float32)
+    lens_i = np.where(rng.random((n, L)) < 0.15, rng.integers(130, 421, size=(n, L)),
+                      np.where(rng.random((n, L)) < 0.2, 1, rng.integers(2, 40, size=(n, L))))
+    sig = np.around(rng.standard_normal((n, L, S)) * scale[:, :, None] + shift[:, :, None], 6)
+    idx = np.arange(S)[None, None, :]
+    ln = np.minimum(lens_i, S)[:, :, None]
+    left = (S - ln) // 2
+    signals = np.where((idx >= left) & (idx < left + ln), sig, 0.0).astype(np.float32)
+    return kmer, means, stds, lens_i.astype(np.float32), signals
+
+
 def init_state_shapes(cfg: OracleConfig, n: int):
     """Shapes and draw order of init_hidden: models.py:169-176, called at :196-198, :212-214, :226-228."""
     shp = []

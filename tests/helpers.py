@@ -24,7 +24,10 @@ def load_f1(name):
     w = onp.make_weights(cfg, int(d["wseed"]), float(d["wscale"]))
     wsum = float(sum(float(np.abs(v.astype(np.float64)).sum()) for v in w.values()))
     assert abs(wsum - float(d["wsum"])) <= 1e-9 * abs(wsum), "weight generator drifted"
-    inputs = onp.make_inputs(cfg, n, int(d["iseed"]), wide_alphabet=("wide" in name))
+    if "extreme" in name:
+        inputs = onp.make_extreme_inputs(cfg, n, int(d["iseed"]))
+    else:
+        inputs = onp.make_inputs(cfg, n, int(d["iseed"]), wide_alphabet=("wide" in name))
     if "isum" in d.files:
         isum = float(sum(np.abs(a.astype(np.float64)).sum() for a in inputs))
         assert abs(isum - float(d["isum"])) <= 1e-9 * abs(isum), "input generator drifted"
@@ -37,3 +40,18 @@ def load_f1(name):
     inter = {k[6:]: d[k] for k in d.files if k.startswith("inter_")}
     return dict(cfg=cfg, w=w, inputs=inputs, states=states, logits=d["logits"], probs=d["probs"], inter=inter,
                 n=n, raw=d)
+
+
+def f1_tolerances(name):
+    """(oracle-vs-reference, HIP-vs-reference) bounds on |dprob| for fixture `name`.  Default: 1e-6 for the CPU
+    restatements and 2e-5 for the HIP path (regression guards far inside the 1e-4 contract).  The saturating-weight
+    fixtures (x5, x8) amplify fp32 summation-order differences: the reference's own fp32 result is 8e-5 away from the
+    float64 evaluation of the same model on both_x8_n96 (make_golden.py printout), so there only the contract itself
+    (1e-4, BASELINE.json north_star) can be asserted, for the oracle and for the HIP path alike."""
+    if "_x8" in name:
+        return 1e-4, 1e-4
+    if "_x5" in name:
+        return 1e-5, 1e-4
+    if "_x4" in name or "_x3" in name:
+        return 2e-6, 2e-5
+    return 1e-6, 2e-5

@@ -4,7 +4,7 @@ within 1e-4 (fp32) of the reference forward on identical feature rows with pinne
 import numpy as np
 import pytest
 
-from tests.helpers import f1_names, load_f1
+from tests.helpers import f1_names, f1_tolerances, load_f1
 
 pytestmark = pytest.mark.gpu
 
@@ -43,9 +43,10 @@ def test_hip_matches_reference_fixture(name):
     torch.cuda.synchronize()
     dp = np.abs(probs.cpu().numpy() - f["probs"]).max()
     dl = np.abs(logits.cpu().numpy() - f["logits"]).max()
-    print(name, "max|dprob| %.2e max|dlogit| %.2e" % (dp, dl))
-    assert dp <= TOL_PROB
-    assert dp <= TOL_TIGHT
+    print(name, "HIP vs reference: max|dprob| %.2e max|dlogit| %.2e (n = %d, p1 in [%.4g, %.4g])" % (
+        dp, dl, f["n"], f["probs"][:, -1].min(), f["probs"][:, -1].max()))
+    assert dp <= TOL_PROB                   # the contract
+    assert dp <= f1_tolerances(name)[1]     # regression guard (= the contract for the saturating-weight fixtures)
     # labels identical except where |p1 - 0.5| < 1e-4
     ref_lab = f["probs"].argmax(1)
     sure = np.abs(f["probs"][:, 1] - 0.5) >= 1e-4 if f["probs"].shape[1] == 2 else np.ones(len(ref_lab), bool)
@@ -173,15 +174,16 @@ def test_random_model_shapes_match_oracle(case):
     assert np.abs(logits.cpu().numpy() - lo).max() <= 1e-4
 
 
-def test_full_batch_properties():
-    """BASELINE size (65,536 + a ragged tail): size-independent properties -- determinism, permutation
-    equivariance under pinned zero states, split invariance, finite normalised probabilities -- plus an oracle
-    spot check on a strided sample of the same batch"""
+@pytest.mark.parametrize("which", ["configs1_both_bilstm", "configs2_seq_only_hid256x2"])
+def test_full_batch_properties(which):
+    """BASELINE size (65,536 + a ragged tail), for the models of BASELINE.json configs[1] and configs[2]:
+    size-independent properties -- determinism, permutation equivariance under pinned zero states, split invariance,
+    finite normalised probabilities -- plus an oracle spot check on a strided sample of the same batch"""
     torch = _torch()
     from deepsignal_plant_amd import synth
     from oracle import c_oracle as oc
     from oracle import forward_np as onp
-    cfg = onp.OracleConfig()
+    cfg = onp.OracleConfig() if which.startswith("configs1") else onp.OracleConfig(module="seq_bilstm", num_layers1=2)
     w = onp.make_weights(cfg, 51, 2.0)
     n = 65536 + 1234
     ins = synth.feature_batch(n, device="cuda:0", seed=52)

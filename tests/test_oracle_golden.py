@@ -5,7 +5,7 @@ import pytest
 
 from oracle import c_oracle as oc
 from oracle import forward_np as onp
-from tests.helpers import f1_names, load_f1
+from tests.helpers import f1_names, f1_tolerances, load_f1
 
 
 @pytest.mark.parametrize("name", f1_names())
@@ -13,8 +13,10 @@ def test_numpy_oracle_matches_reference_fixture(name):
     f = load_f1(name)
     lo, po, inter = onp.forward(f["cfg"], f["w"], *f["inputs"], f["states"], dtype=np.float64,
                                 want_intermediates=True)
-    assert np.abs(po - f["probs"]).max() <= 1e-6
-    assert np.abs(lo - f["logits"]).max() <= 5e-6
+    tol = f1_tolerances(name)[0]
+    print(name, "numpy f64 oracle vs reference: max|dprob| %.2e (bound %.0e)" % (np.abs(po - f["probs"]).max(), tol))
+    assert np.abs(po - f["probs"]).max() <= tol
+    assert np.abs(lo - f["logits"]).max() <= 5e-6 * (tol / 1e-6)
     # intermediates recorded through forward hooks in the reference (first 8 sites)
     m = {"relu_seq": "out_seq", "relu_signal": "out_signal", "lstm_comb": "lstm_comb"}
     for k, v in f["inter"].items():
@@ -25,8 +27,10 @@ def test_numpy_oracle_matches_reference_fixture(name):
 def test_c_oracle_matches_reference_fixture(name):
     f = load_f1(name)
     lo, po = oc.forward(f["cfg"], f["w"], *f["inputs"], states=f["states"], init_mode="explicit")
-    assert np.abs(po - f["probs"]).max() <= 1e-6
-    assert np.abs(lo - f["logits"]).max() <= 5e-6
+    tol = f1_tolerances(name)[0]
+    print(name, "C fp32 oracle vs reference: max|dprob| %.2e (bound %.0e)" % (np.abs(po - f["probs"]).max(), tol))
+    assert np.abs(po - f["probs"]).max() <= tol
+    assert np.abs(lo - f["logits"]).max() <= 5e-6 * (tol / 1e-6)
 
 
 def test_randn_capture_documents_draw_order():
