@@ -101,6 +101,25 @@ def lib():
     L.dsp_freq_counts.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int64)] * 3
     L.dsp_freq_format.restype = ctypes.c_int64
     L.dsp_freq_format.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_size_t]
+    L.dsp_freq_block_keys.restype = ctypes.c_int64
+    L.dsp_freq_block_keys.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int32, ctypes.c_int64] + [ctypes.c_void_p] * 3
+    L.dsp_freq_dev_encode.restype = ctypes.c_int32
+    L.dsp_freq_dev_encode.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+    L.dsp_freq_dev_count_sites.restype = ctypes.c_int32
+    L.dsp_freq_dev_count_sites.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+    L.dsp_freq_dev_reduce.restype = ctypes.c_int32
+    L.dsp_freq_dev_reduce.argtypes = [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 5 + [ctypes.c_int64] + [ctypes.c_void_p] * 8
+    L.dsp_freq_add_sites.restype = ctypes.c_int64
+    L.dsp_freq_add_sites.argtypes = [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 8
+    L.dsp_freq_add_counts.restype = None
+    L.dsp_freq_add_counts.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+    L.dsp_freq_chrom_count.restype = ctypes.c_int32
+    L.dsp_freq_chrom_count.argtypes = [ctypes.c_void_p]
+    L.dsp_freq_chrom_name.restype = ctypes.c_int64
+    L.dsp_freq_chrom_name.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_size_t]
+    L.dsp_freq_intern_chrom.restype = ctypes.c_int32
+    L.dsp_freq_intern_chrom.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
     L.dsp_feat_writer_create.restype = ctypes.c_int32
     L.dsp_feat_writer_create.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
                                          ctypes.POINTER(ctypes.c_void_p)]

@@ -71,7 +71,8 @@ class _Writer(threading.Thread):
         super().__init__(daemon=True)
         self.q = queue.Queue(maxsize=4)
         self.path, self.is_gzip, self.nthreads, self.reader = path, is_gzip, nthreads, reader
-        self.freq = freq  # optional SiteFrequency fed straight from the GPU results (fused call_freq)
+        self.freq = freq  # optional SiteFrequency (host) fed straight from the GPU results (fused call_freq)
+        self.freq_dev = None  # optional (DeviceSiteFrequency, stream, first-row getter): the reads branch feeds it from here
         self.error = None
         self.rows = 0
 
@@ -90,6 +91,9 @@ class _Writer(threading.Thread):
                     wf.write(textio.format_calls(block.rows, probs, labels, nthreads=self.nthreads))
                     if self.freq is not None:
                         self.freq.add_block(block.rows, probs, labels)
+                    if self.freq_dev is not None:
+                        agg, side_stream = self.freq_dev
+                        agg.add_block(block.rows, probs, labels, block.first_row, stream=side_stream)
                     self.rows += block.rows.n
                     self.reader.release(block)
         except BaseException as e:
@@ -130,10 +134,7 @@ def _call_mods_file(args, rank, local_rank, world):
 
     reader = feed.FeatureReader(input_path, args.seq_len, args.signal_len, rank=rank, world=world, nthreads=nthreads,
                                 nbuf=4, first_row=first_row, byte_range=byte_range)
-    freq = None
-    if getattr(args, "freq_file", None) and world == 1:
-        from .call_mods_freq import SiteFrequency
-        freq = SiteFrequency(args.prob_cf)
+    freq, freq_dev = _make_freq(args, dev, world, nthreads)
     writer = _Writer(part_path, args.gzip, nthreads, reader, freq)
     cap = reader.cap
     model.reserve(cap)
@@ -174,6 +175,8 @@ def _call_mods_file(args, rank, local_rank, world):
             t_in.record_stream(stream)
         model.site_offset = block.first_row
         _logits, probs, labels = model.forward(kmer, means, stds, lens, signals, want_labels=True)
+        if freq_dev is not None:  # the calls go into the device-side call_freq records straight from HBM
+            freq_dev.add_block(rows, probs, labels, block.first_row, stream=stream)
         slot = k % nout
         out_events[slot].synchronize()  # the writer is done with this slot's previous contents
         out_probs[slot][:n].copy_(probs, non_blocking=True)
@@ -187,14 +190,34 @@ def _call_mods_file(args, rank, local_rank, world):
     torch.cuda.synchronize(dev)
     if writer.error is not None:
         raise writer.error
-    if freq is not None:
-        freq.write(args.freq_file, args.freq_sort, args.freq_bed, args.gzip)
+    _finish_freq(args, freq, freq_dev, rank, world)
     return n_rows, part_path, out_path
+
+
+def _make_freq(args, dev, world, nthreads):
+    """--freq_file: (host aggregator, device aggregator).  Device (default): the calls stay in HBM as records and are
+    reduced there, sharded over the ranks (call_mods_freq.DeviceSiteFrequency).  Host (--freq_on host): the native host
+    table; with several ranks it is fed from the merged per-read file by rank 0."""
+    if not getattr(args, "freq_file", None):
+        return None, None
+    from .call_mods_freq import DeviceSiteFrequency, SiteFrequency
+    if getattr(args, "freq_on", "device") == "device":
+        return None, DeviceSiteFrequency(args.prob_cf, dev, nthreads)
+    return (SiteFrequency(args.prob_cf) if world == 1 else None), None
+
+
+def _finish_freq(args, freq, freq_dev, rank, world):
+    if freq_dev is not None:
+        table = freq_dev.finish(rank, world)  # collective: every rank takes part
+        if table is not None:
+            table.write(args.freq_file, args.freq_sort, args.freq_bed, args.gzip)
+    elif freq is not None:
+        freq.write(args.freq_file, args.freq_sort, args.freq_bed, args.gzip)
 
 
 class _ReadsBlock(object):
     """What the writer needs from one batch of reads: the sites' sampleinfo rows + host k-mer codes."""
-    __slots__ = ("rows",)
+    __slots__ = ("rows", "first_row")
 
 
 class _NoRelease(object):
@@ -230,11 +253,10 @@ def _call_mods_reads(args, rank, local_rank, world):
     if args.gzip and not out_path.endswith(".gz"):
         out_path += ".gz"
     part_path = out_path if world == 1 else "%s.part%05d" % (out_path, rank)
-    freq = None
-    if getattr(args, "freq_file", None) and world == 1:
-        from .call_mods_freq import SiteFrequency
-        freq = SiteFrequency(args.prob_cf)
+    freq, freq_dev = _make_freq(args, dev, world, nthreads)
     writer = _Writer(part_path, args.gzip, nthreads, _NoRelease(), freq)
+    if freq_dev is not None:  # fed from the writer thread (the k-mer codes reach the host with the results)
+        writer.freq_dev = (freq_dev, torch.cuda.Stream(dev))
     writer.start()
 
     # loader: files -> batches of reads, decoded by a thread pool ahead of the GPU work
@@ -291,6 +313,7 @@ def _call_mods_reads(args, rank, local_rank, world):
         ext.rows.kmer = h_kmer.numpy()  # valid once `ev` has passed; the writer waits on it first
         blk = _ReadsBlock()
         blk.rows = ext.rows
+        blk.first_row = row_base + n_rows
         writer.q.put((blk, h_probs, h_labels, ev))
         n_rows += n
     writer.q.put(None)
@@ -299,8 +322,7 @@ def _call_mods_reads(args, rank, local_rank, world):
     torch.cuda.synchronize(dev)
     if writer.error is not None:
         raise writer.error
-    if freq is not None:
-        freq.write(args.freq_file, args.freq_sort, args.freq_bed, args.gzip)
+    _finish_freq(args, freq, freq_dev, rank, world)
     print("%d of %d read files failed.." % (batches.failed, len(files)))  # :440
     return n_rows, part_path, out_path
 
@@ -390,9 +412,9 @@ def call_mods(args):
         dist.barrier()
         if rank == 0:
             _merge_parts(out_path, world)
-            if getattr(args, "freq_file", None):
-                # sites span ranks: aggregate the merged per-read calls in file order so that the double sums
-                # are associated exactly like the reference's (single pass, native text path)
+            if getattr(args, "freq_file", None) and getattr(args, "freq_on", "device") == "host":
+                # --freq_on host with several ranks: aggregate the merged per-read calls in file order (the default,
+                # --freq_on device, has already reduced them on the GPUs: DeviceSiteFrequency.finish)
                 from .call_mods_freq import SiteFrequency
                 agg = SiteFrequency(args.prob_cf)
                 agg.add_calls_file(out_path)
@@ -441,6 +463,9 @@ def add_call_mods_args(p):
     g.add_argument("--basecall_subgroup", type=str, default="BaseCalled_template")
     g.add_argument("--is_dna", type=str, default="yes")
     g.add_argument("--normalize_method", type=str, choices=["mad", "zscore"], default="mad")
+    g.add_argument("--methy_label", type=int, choices=[1, 0], default=1, help=argparse.SUPPRESS)  # commented out in the
+    # reference's call_mods parsers (deepsignal_plant.py:280-283, call_modifications.py:721); accepted and ignored here so
+    # that a command line carrying it (it is an `extract` flag, deepsignal_plant.py:150) still runs
     g.add_argument("--motifs", type=str, default="CG")
     g.add_argument("--mod_loc", type=int, default=0)
     g.add_argument("--region", type=str, default=None)
@@ -462,6 +487,10 @@ def add_call_mods_args(p):
     g.add_argument("--freq_file", type=str, default=None,
                    help="also write the per-site modification frequency (what `call_freq` computes from the result file) "
                         "without re-reading the per-read calls")
+    g.add_argument("--freq_on", type=str, default="device", choices=["device", "host"],
+                   help="where --freq_file is aggregated: 'device' (default) keeps the calls in HBM as records, deals them to "
+                        "the ranks by site (one RCCL all_to_all) and reduces them there; 'host' = the native host table "
+                        "(with several ranks: rank 0 re-reads the merged per-read file).  Same bytes either way")
     g.add_argument("--prob_cf", type=float, default=0.5, help="call_freq threshold on abs(prob1-prob0), default 0.5")
     g.add_argument("--freq_bed", action="store_true", default=False, help="--freq_file in bedMethyl format")
     g.add_argument("--freq_sort", action="store_true", default=False, help="sort --freq_file by chromosome and position")

@@ -99,6 +99,183 @@ class SiteFrequency(object):
         return result_file
 
 
+class DeviceSiteFrequency(object):
+    """`call_freq` fed from HBM and sharded over ranks (include/dsp_amd.h, "call_freq on the device").
+
+    add_block() keeps every per-read call of this rank on its GPU as a 32-byte record (site key, packed printed
+    probabilities + label + first-record metadata, pos_in_strand, global row index).  finish() then
+      1. agrees on global chromosome ids (an all_gather of the name lists),
+      2. deals the records to ranks by a hash of the site key -- ONE all_to_all over RCCL/xGMI, the only exchange
+         step of the whole call_mods path; chunks arrive in rank order = file order,
+      3. sorts them by site key with a stable sort and reduces every site on the device with the reference's own
+         sequence of double additions (csrc/dsp_freq_dev.hip),
+      4. gathers the per-site results (72 B per site) to rank 0, which prints them with the host formatter
+         (insertion order = global row of the site's first used record, or sorted).
+    Bytes are identical to `call_freq` run on the merged per-read file (tests/test_gpu_cli.py, tests/test_gpu_freq.py)."""
+
+    UNUSED = 0x7fffffffffffffff
+
+    def __init__(self, prob_cf, device, nthreads=None):
+        import torch
+        self.torch = torch
+        self.dev = torch.device(device)
+        self.prob_cf = float(prob_cf)
+        self.host = SiteFrequency(prob_cf, nthreads)   # chromosome dictionary + final table / formatter
+        self.keys, self.packed, self.pis, self.rows = [], [], [], []
+        self.count = 0
+
+    def add_block(self, rows, probs_dev, labels_dev, first_row, start=0, stop=None, stream=None):
+        """rows: the parsed block (host); probs_dev [n, C] float32 and labels_dev [n] uint8: the forward's outputs,
+        still on the GPU; first_row: global index of rows[start]."""
+        torch = self.torch
+        stop = rows.n if stop is None else stop
+        n = stop - start
+        if n <= 0:
+            return 0
+        key = np.empty(n, np.int64)
+        pis = np.empty(n, np.int64)
+        meta = np.empty(n, np.uint32)
+        text = rows.text if isinstance(rows.text, np.ndarray) else np.frombuffer(memoryview(rows.text), np.uint8)
+        p = ctypes.c_void_p
+        L = nat.lib()
+        nat.check(int(L.dsp_freq_block_keys(self.host._h, p(text.ctypes.data), p(rows.row_off[start:stop].ctypes.data),
+                                            p(rows.info_len[start:stop].ctypes.data), p(rows.kmer[start:stop].ctypes.data),
+                                            rows.seq_len, n, p(key.ctypes.data), p(pis.ctypes.data), p(meta.ctypes.data))))
+        s = stream if stream is not None else torch.cuda.current_stream(self.dev)
+        with torch.cuda.stream(s):
+            if not torch.is_tensor(probs_dev):   # host copies (the reads branch feeds from its writer thread): 9 B per row up
+                probs_dev = torch.from_numpy(np.ascontiguousarray(probs_dev[start:stop], np.float32)).to(self.dev)
+                labels_dev = torch.from_numpy(np.ascontiguousarray(labels_dev[start:stop], np.uint8)).to(self.dev)
+            key_d = torch.from_numpy(key).to(self.dev, non_blocking=True)
+            meta_d = torch.from_numpy(meta.view(np.int32)).to(self.dev, non_blocking=True)
+            pis_d = torch.from_numpy(pis).to(self.dev, non_blocking=True)
+            key_o = torch.empty(n, dtype=torch.int64, device=self.dev)
+            packed = torch.empty(n, dtype=torch.int64, device=self.dev)
+            probs_dev = probs_dev.contiguous()
+            nat.check(int(L.dsp_freq_dev_encode(p(s.cuda_stream), n, p(probs_dev.data_ptr()), int(probs_dev.shape[1]),
+                                                p(labels_dev.data_ptr()), p(key_d.data_ptr()), p(meta_d.data_ptr()),
+                                                self.prob_cf, p(key_o.data_ptr()), p(packed.data_ptr()))))
+            row = torch.arange(first_row, first_row + n, dtype=torch.int64, device=self.dev)
+        for t in (key_d, meta_d, probs_dev, labels_dev):
+            t.record_stream(s)
+        self.keys.append(key_o); self.packed.append(packed); self.pis.append(pis_d); self.rows.append(row)
+        self.count += n
+        self._keep = (key, meta, pis)  # pageable sources of the async copies stay alive until the next block
+        return n
+
+    # ---- collectives (RCCL on GPUs; gloo when ranks share a GPU on the dev box) -------------------------------
+    def _chrom_names(self):
+        L = nat.lib()
+        out = []
+        for i in range(L.dsp_freq_chrom_count(self.host._h)):
+            k = int(L.dsp_freq_chrom_name(self.host._h, i, None, 0))
+            buf = ctypes.create_string_buffer(max(k, 1))
+            L.dsp_freq_chrom_name(self.host._h, i, buf, k)
+            out.append(buf.raw[:k])
+        return out
+
+    def _exchange(self, cols, dest, world, dist):
+        """deal the record columns to ranks by `dest`; what arrives is ordered by source rank, then source order"""
+        torch = self.torch
+        order = torch.sort(dest, stable=True)[1]
+        counts = torch.bincount(dest, minlength=world)
+        cols = [c[order] for c in cols]
+        if dist.get_backend() == "nccl":
+            recv_counts = torch.empty_like(counts)
+            dist.all_to_all_single(recv_counts, counts)
+            ins, outs = counts.tolist(), recv_counts.tolist()
+            got = []
+            for c in cols:
+                o = torch.empty(sum(outs), dtype=c.dtype, device=c.device)
+                dist.all_to_all_single(o, c.contiguous(), outs, ins)
+                got.append(o)
+            return got
+        # gloo has no all_to_all: every rank publishes its columns, everybody keeps its own share (dev box only)
+        rank = dist.get_rank()
+        objs = [None] * world
+        dist.all_gather_object(objs, (counts.cpu(), [c.cpu() for c in cols]))
+        got = []
+        for j in range(len(cols)):
+            parts = []
+            for src in range(world):
+                cnt, cc = objs[src]
+                off = int(cnt[:rank].sum())
+                parts.append(cc[j][off:off + int(cnt[rank])])
+            got.append(torch.cat(parts).to(self.dev))
+        return got
+
+    def finish(self, rank=0, world=1):
+        """-> the SiteFrequency holding every site on rank 0 (None on the other ranks)"""
+        torch = self.torch
+        L = nat.lib()
+        p = ctypes.c_void_p
+        dev = self.dev
+        cat = lambda xs, dt: torch.cat(xs) if xs else torch.empty(0, dtype=dt, device=dev)
+        key, packed = cat(self.keys, torch.int64), cat(self.packed, torch.int64)
+        pis, row = cat(self.pis, torch.int64), cat(self.rows, torch.int64)
+        self.keys, self.packed, self.pis, self.rows = [], [], [], []
+        live = key != self.UNUSED
+        key, packed, pis, row = key[live], packed[live], pis[live], row[live]
+        names = self._chrom_names()
+        total = self.count
+        if world > 1:
+            import torch.distributed as dist
+            lists = [None] * world
+            dist.all_gather_object(lists, names)
+            glob, ids = [], {}
+            for lst in lists:
+                for nm in lst:
+                    if nm not in ids:
+                        ids[nm] = len(glob)
+                        glob.append(nm)
+            if len(glob) >= (1 << 22):
+                raise ValueError("more than 2^22 chromosomes: use the host aggregator (--freq_on host)")
+            remap = torch.tensor([ids[nm] for nm in names] or [0], dtype=torch.int64, device=dev)
+            key = (remap[key >> 40] << 40) | (key & ((1 << 40) - 1))
+            mixed = (key * -7046029254386353131) >> 24            # 0x9E3779B97F4A7C15 as int64; wraps like uint64
+            dest = (mixed & 0xffffff) % world
+            key, packed, pis, row = self._exchange([key, packed, pis, row], dest, world, dist)
+            t = torch.tensor([total], dtype=torch.int64, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t)
+            total = int(t.item())
+            names = glob
+        n = int(key.numel())
+        s = torch.cuda.current_stream(dev)
+        key, perm = torch.sort(key, stable=True)   # file order inside a site survives
+        packed, pis, row = packed[perm], pis[perm], row[perm]
+        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        nat.check(int(L.dsp_freq_dev_count_sites(p(s.cuda_stream), n, p(key.data_ptr()), p(cnt.data_ptr()))))
+        ns = int(cnt.item())
+        out_i = [torch.empty(ns, dtype=torch.int64, device=dev) for _ in range(6)]  # key, first_row, packed, pis, met, cov
+        out_d = [torch.empty(ns, dtype=torch.float64, device=dev) for _ in range(2)]
+        nat.check(int(L.dsp_freq_dev_reduce(p(s.cuda_stream), n, p(key.data_ptr()), p(packed.data_ptr()), p(pis.data_ptr()),
+                                            p(row.data_ptr()), p(cnt.data_ptr()), ns, p(out_i[0].data_ptr()),
+                                            p(out_i[1].data_ptr()), p(out_i[2].data_ptr()), p(out_i[3].data_ptr()),
+                                            p(out_d[0].data_ptr()), p(out_d[1].data_ptr()), p(out_i[4].data_ptr()),
+                                            p(out_i[5].data_ptr()))))
+        cols = out_i + [o.view(torch.int64) for o in out_d]   # doubles travel as their bit patterns
+        if world > 1:
+            import torch.distributed as dist
+            from . import dist as dsp_dist
+            gathered = dsp_dist.gather_columns(cols, world, dev if dist.get_backend() == "nccl" else None)
+            if rank != 0:
+                return None
+            cols = gathered
+        host = [c.cpu().numpy() for c in cols]
+        order = np.argsort(host[1], kind="stable")   # by first row: deterministic whatever order the slots were taken in
+        host = [np.ascontiguousarray(h[order]) for h in host]
+        table = SiteFrequency(self.prob_cf)
+        for nm in names:
+            L.dsp_freq_intern_chrom(table._h, nm, len(nm))
+        m = len(host[0])
+        nat.check(int(L.dsp_freq_add_sites(table._h, m, p(host[0].ctypes.data), p(host[1].ctypes.data), p(host[2].ctypes.data),
+                                           p(host[3].ctypes.data), p(host[6].view(np.float64).ctypes.data),
+                                           p(host[7].view(np.float64).ctypes.data), p(host[4].ctypes.data),
+                                           p(host[5].ctypes.data))))
+        L.dsp_freq_add_counts(table._h, total)
+        return table
+
+
 def _contig_names(spec):
     """--contigs: genome fasta, a file of names, or a comma list (call_mods_freq.py:253-263)"""
     if os.path.isfile(spec):

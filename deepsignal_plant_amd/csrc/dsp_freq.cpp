@@ -458,6 +458,122 @@ int64_t dsp_freq_add_block(dsp_freq* f, const char* text, const uint64_t* row_of
     return n;
 }
 
+// ---- device-side / sharded aggregation (dsp_freq_dev.hip does the sums; this is its host side) ---------------
+// Record encoding shared with the kernels:
+//   key    = chrom_id << 40 | pos                      (int64, >= 0; INT64_MAX marks an unused record)
+//   meta   = strand code (0 '+', 1 '-') | kmer5 << 2   (5 bases x 4 bits: codes of process_utils.base2code_dna)
+//   packed = k0 | k1 << 20 | label==1 << 40 | meta << 41,  k = printed probability in units of 1e-6
+static const char* const kCode2Base = "ACGTNWSMKRYBVDHZ";
+
+int64_t dsp_freq_block_keys(dsp_freq* f, const char* text, const uint64_t* row_off, const uint32_t* info_len,
+                            const uint8_t* kmer, int32_t seq_len, int64_t n, int64_t* key, int64_t* pis, uint32_t* meta) {
+    if (!f || !text || !row_off || !info_len || !kmer || !key || !pis || !meta || seq_len < 1)
+        return freq_fail(DSP_EINVAL, "NULL / bad argument");
+    const int center = seq_len / 2;
+    const int k0 = center - 2 >= 0 ? center - 2 : 0;
+    const int k1 = center + 3 <= seq_len ? center + 3 : seq_len;
+    if (k1 - k0 != 5) return freq_fail(DSP_EINVAL, "the device aggregator needs a 5-mer (seq_len >= 5)");
+    struct Chrom { const char* p; uint32_t len; };
+    std::vector<Chrom> chrom((size_t)n);
+    int nt = f->nthreads;
+    if ((int64_t)nt > n / 4096 + 1) nt = (int)(n / 4096 + 1);
+    std::vector<int64_t> bad((size_t)nt, -1);
+    std::vector<int> why((size_t)nt, 0);
+    auto work = [&](int t) {
+        const int64_t a = n * t / nt, b = n * (t + 1) / nt;
+        for (int64_t r = a; r < b; ++r) {
+            const char* ls = text + row_off[r];
+            const char* le = ls + info_len[r];
+            const char* fs[4];
+            const char* fe[4];
+            int nf = 0;
+            for (const char* q = ls; nf < 4;) {
+                const char* tb = (const char*)memchr(q, '\t', (size_t)(le - q));
+                if (!tb) tb = le;
+                fs[nf] = q; fe[nf] = tb; ++nf;
+                if (tb == le) break;
+                q = tb + 1;
+            }
+            long long pos, ps;
+            if (nf < 4 || !parse_ll(fs[1], fe[1], &pos) || !parse_ll(fs[3], fe[3], &ps)) { bad[t] = r; why[t] = 1; return; }
+            const size_t sl = (size_t)(fe[2] - fs[2]);
+            if (pos < 0 || pos >= (1ll << 40) || sl != 1 || (fs[2][0] != '+' && fs[2][0] != '-')) { bad[t] = r; why[t] = 2; return; }
+            uint32_t m = fs[2][0] == '-' ? 1u : 0u;
+            for (int i = k0; i < k1; ++i) m |= (uint32_t)(kmer[r * seq_len + i] & 15) << (2 + 4 * (i - k0));
+            chrom[r] = Chrom{fs[0], (uint32_t)(fe[0] - fs[0])};
+            key[r] = pos;
+            pis[r] = ps;
+            meta[r] = m;
+        }
+    };
+    if (nt <= 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
+    }
+    for (int t = 0; t < nt; ++t)
+        if (bad[t] >= 0)
+            return why[t] == 1 ? freq_fail(DSP_EPARSE, "row %lld: bad pos / pos_in_strand column", (long long)bad[t])
+                               : freq_fail(DSP_EINVAL, "row %lld: strand / position outside the device aggregator's encoding "
+                                                       "('+'/'-', 0 <= pos < 2^40): use the host aggregator", (long long)bad[t]);
+    for (int64_t r = 0; r < n; ++r) {  // sequential: chromosome interning (records of a read share it: one memcmp)
+        const uint32_t cid = f->intern(chrom[r].p, chrom[r].len);
+        if (cid >= (1u << 22)) return freq_fail(DSP_EINVAL, "more than 2^22 chromosomes: use the host aggregator");
+        key[r] |= (int64_t)cid << 40;
+    }
+    return n;
+}
+
+int32_t dsp_freq_chrom_count(const dsp_freq* f) { return f ? (int32_t)f->chroms.size() : 0; }
+
+int64_t dsp_freq_chrom_name(const dsp_freq* f, int32_t id, char* out, size_t cap) {
+    if (!f || id < 0 || (size_t)id >= f->chroms.size()) return freq_fail(DSP_EINVAL, "chromosome id out of range");
+    const std::string& s = f->chroms[(size_t)id];
+    if (out && cap) memcpy(out, s.data(), std::min(cap, s.size()));
+    return (int64_t)s.size();
+}
+
+int32_t dsp_freq_intern_chrom(dsp_freq* f, const char* name, size_t len) {
+    if (!f || !name) return freq_fail(DSP_EINVAL, "NULL argument");
+    return (int32_t)f->intern(name, len);
+}
+
+void dsp_freq_add_counts(dsp_freq* f, int64_t count) {
+    if (f) f->count += count;
+}
+
+// finished sites (sums taken on the device in record order) into the table that dsp_freq_format prints
+int64_t dsp_freq_add_sites(dsp_freq* f, int64_t n, const int64_t* key, const int64_t* first_row, const int64_t* packed_first,
+                           const int64_t* pis, const double* sum0, const double* sum1, const int64_t* met, const int64_t* cov) {
+    if (!f || (n && (!key || !first_row || !packed_first || !pis || !sum0 || !sum1 || !met || !cov)))
+        return freq_fail(DSP_EINVAL, "NULL argument");
+    for (int64_t i = 0; i < n; ++i) {
+        const uint32_t cid = (uint32_t)((uint64_t)key[i] >> 40);
+        const long long pos = (long long)((uint64_t)key[i] & ((1ull << 40) - 1));
+        if (cid >= f->chroms.size()) return freq_fail(DSP_EINVAL, "site %lld: unknown chromosome id %u", (long long)i, cid);
+        const uint32_t meta = (uint32_t)((uint64_t)packed_first[i] >> 41);
+        Partition& part = f->parts[part_of(cid, pos)];
+        bool found;
+        SiteIndex::Slot* slot = part.index.find_or_slot(cid, pos, &found);
+        if (found) return freq_fail(DSP_EINVAL, "site %lld: (chromosome, pos) added twice", (long long)i);
+        Site s;
+        s.chrom = cid; s.pos = pos; s.pos_in_strand = pis[i]; s.first_use = (uint64_t)first_row[i];
+        s.strand_len = 1; s.strand[0] = (meta & 1) ? '-' : '+';
+        s.kmer_len = 5;
+        for (int b = 0; b < 5; ++b) s.kmer[b] = kCode2Base[(meta >> (2 + 4 * b)) & 15];
+        s.prob0 = sum0[i]; s.prob1 = sum1[i];
+        s.met = met[i]; s.coverage = cov[i]; s.unmet = cov[i] - met[i];
+        slot->pos = pos; slot->chrom = cid; slot->idx = (uint32_t)part.sites.size();
+        part.sites.push_back(s);
+        ++part.index.used;
+        part.used += cov[i];
+    }
+    return n;
+}
+
 void dsp_freq_counts(const dsp_freq* f, int64_t* count, int64_t* used, int64_t* sites) {
     if (!f) return;
     if (count) *count = f->count;

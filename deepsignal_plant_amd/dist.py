@@ -74,3 +74,23 @@ def gather_probs(probs, world, dst=0):
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad)
     return [o[:s] for o, s in zip(out, sizes)] if dist.get_rank() == dst else None
+
+
+def gather_columns(cols, world, device=None):
+    """Ragged gather of equally long 1-D int64 columns to rank 0: sizes exchanged first, then one padded all_gather
+    per column (RCCL when `device` is a GPU).  Returns the concatenated columns on rank 0, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    n = int(cols[0].numel())
+    sizes = all_gather_ints(n, world, device)
+    mx = max(max(sizes), 1)
+    out = []
+    for c in cols:
+        src = c if device is not None else c.cpu()
+        pad = torch.zeros(mx, dtype=src.dtype, device=src.device)
+        pad[:n] = src
+        got = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(got, pad)
+        if dist.get_rank() == 0:
+            out.append(torch.cat([g[:k] for g, k in zip(got, sizes)]))
+    return out if dist.get_rank() == 0 else None

@@ -300,6 +300,40 @@ int64_t dsp_freq_add_block(dsp_freq* f, const char* text, const uint64_t* row_of
 void dsp_freq_counts(const dsp_freq* f, int64_t* count, int64_t* used, int64_t* sites);
 int64_t dsp_freq_format(const dsp_freq* f, int32_t is_sort, int32_t is_bed, char* out, size_t cap);
 
+/* ---- `call_freq` on the device and over several ranks ----------
+ * Records stay in HBM as (key, packed, pos_in_strand, global row) and are reduced there.  Encoding:
+ *   key    = chromosome id << 40 | pos   (ids from the handle's dictionary; INT64_MAX = record not used)
+ *   meta   = strand code (0 '+', 1 '-') | 5-mer << 2 (4 bits per base, codes of process_utils.base2code_dna)
+ *   packed = k0 | k1 << 20 | (label == 1) << 40 | meta << 41,  k = the printed probability in units of 1e-6
+ * dsp_freq_block_keys (HOST): key / pos_in_strand / meta of the rows of a parsed call_mods block (multi-threaded).
+ *   DSP_EINVAL when a row cannot be encoded (strand other than +/-, pos outside [0, 2^40), > 2^22 chromosomes):
+ *   the caller must fall back to the host aggregator, loudly.
+ * dsp_freq_dev_encode (DEVICE): probabilities + labels of the block (still in HBM after dsp_forward) -> key_out
+ *   (INT64_MAX where |p0 - p1| < prob_cf, txt_formater.py:23-26) and packed_out.
+ * dsp_freq_dev_count_sites / dsp_freq_dev_reduce (DEVICE): on records STABLY sorted by key: the number of sites, then
+ *   per site (in no particular order; slot_counter is device scratch) its key, the global row / packed word /
+ *   pos_in_strand of its first record, the double sums of p0 and p1 taken sequentially in record order, the
+ *   methylated count and the coverage.
+ * dsp_freq_add_sites (HOST): finished sites into the table dsp_freq_format prints; dsp_freq_add_counts adds to the
+ *   number of records seen; dsp_freq_chrom_count / _name / dsp_freq_intern_chrom expose the chromosome dictionary
+ *   so that ranks can agree on global ids. */
+int64_t dsp_freq_block_keys(dsp_freq* f, const char* text, const uint64_t* row_off, const uint32_t* info_len,
+                            const uint8_t* kmer, int32_t seq_len, int64_t n, int64_t* key, int64_t* pis, uint32_t* meta);
+int32_t dsp_freq_dev_encode(void* stream, int64_t n, const float* probs, int32_t num_classes, const uint8_t* labels,
+                            const int64_t* key_in, const uint32_t* meta_in, double prob_cf, int64_t* key_out,
+                            int64_t* packed_out);
+int32_t dsp_freq_dev_count_sites(void* stream, int64_t n, const int64_t* key_sorted, int64_t* n_sites);
+int32_t dsp_freq_dev_reduce(void* stream, int64_t n, const int64_t* key_sorted, const int64_t* packed_sorted,
+                            const int64_t* pis_sorted, const int64_t* row_sorted, int64_t* slot_counter, int64_t cap,
+                            int64_t* site_key, int64_t* site_first_row, int64_t* site_packed, int64_t* site_pis,
+                            double* sum0, double* sum1, int64_t* met, int64_t* cov);
+int64_t dsp_freq_add_sites(dsp_freq* f, int64_t n, const int64_t* key, const int64_t* first_row, const int64_t* packed_first,
+                           const int64_t* pis, const double* sum0, const double* sum1, const int64_t* met, const int64_t* cov);
+void dsp_freq_add_counts(dsp_freq* f, int64_t count);
+int32_t dsp_freq_chrom_count(const dsp_freq* f);
+int64_t dsp_freq_chrom_name(const dsp_freq* f, int32_t id, char* out, size_t cap);
+int32_t dsp_freq_intern_chrom(dsp_freq* f, const char* name, size_t len);
+
 const char* dsp_last_error(void);
 int32_t dsp_abi_version(void);
 

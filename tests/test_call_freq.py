@@ -128,3 +128,113 @@ def test_thread_count_does_not_change_the_result_and_numbers_parse_like_python()
     for t in ("", "abc", "1e", "1.2.3", "--1", "1e+", "0x10"):
         b = t.encode()
         assert L.dsp_parse_double_(b, len(b), ctypes.byref(out)) == 0, t
+
+
+def test_printed_probability_of_a_rounded_float32_is_k_over_1e6_exactly():
+    """The device aggregator (csrc/dsp_freq_dev.hip) never formats or parses text: it keeps k = rint(x * 1e6) and adds
+    float(k) / 1e6.  That is only the reference's value if, for EVERY k in [0, 10^6], (a) str(np.float32(k / 1e6)) --
+    what call_mods prints (call_modifications.py:177-187) -- is the decimal k * 1e-6, and (b) Python's float() of it
+    (txt_formater.py:14-15) is the correctly rounded quotient k / 1e6.  Checked exhaustively."""
+    k = np.arange(0, 1000001, dtype=np.float32)
+    z = (k / np.float32(1e6)).astype(np.float32)               # np.round(x, 6) of a float32 ends with this division
+    want = np.arange(0, 1000001, dtype=np.float64) / 1e6
+    got = np.array([float(str(v)) for v in z])                 # str(np.float32) -> float(): the reference's round trip
+    assert np.array_equal(got, want)
+    # and the native formatter / parser pair used by the host aggregator agrees on a sample
+    import ctypes
+    from deepsignal_plant_amd import _native as nat
+    L = nat.lib()
+    L.dsp_format_prob_f32_.restype = ctypes.c_int
+    L.dsp_format_prob_f32_.argtypes = [ctypes.c_float, ctypes.c_char_p]
+    buf = ctypes.create_string_buffer(64)
+    for i in list(range(0, 1000001, 997)) + [1, 9, 10, 99, 100, 999999, 1000000]:
+        n = L.dsp_format_prob_f32_(float(z[i]), buf)
+        assert float(buf.raw[:n].decode()) == want[i]
+
+
+def _rows_from_calls(lines):
+    """ParsedRows-like block (sampleinfo text + k-mer codes of a 5-mer window) and the float32 probabilities that print
+    as the call lines' prob_0 / prob_1"""
+    code = {b: i for i, b in enumerate("ACGTNWSMKRYBVDHZ")}
+    info, probs, labels, kmer = [], [], [], []
+    for l in lines:
+        w = l.rstrip("\n").split("\t")
+        info.append("\t".join(w[:6]))
+        p0 = np.float32(w[6])
+        probs.append((p0, np.float32(1.0) - p0))
+        labels.append(int(w[8]))
+        kmer.append([code[c] for c in w[9]])
+    n = len(info)
+    text = "\n".join(info).encode()
+    offs, lens, pos = np.zeros(n, np.uint64), np.zeros(n, np.uint32), 0
+    for i, s in enumerate(info):
+        offs[i], lens[i] = pos, len(s)
+        pos += len(s) + 1
+    r = textio.ParsedRows()
+    r.text, r.n, r.row_off, r.info_len, r.seq_len, r.signal_len = np.frombuffer(text, np.uint8), n, offs, lens, 5, 16
+    r.kmer = np.array(kmer, np.uint8)
+    return r, np.array(probs, np.float32), np.array(labels, np.uint8)
+
+
+@pytest.mark.parametrize("tag,kw", [("tsv", {}), ("bed_sorted", dict(bed=True, sort=True)), ("tsv_cf0", dict(prob_cf=0.0)),
+                                    ("bed_cf02", dict(bed=True, prob_cf=0.2))])
+def test_host_side_of_the_device_aggregator_on_the_reference_outputs(tag, kw):
+    """dsp_freq_block_keys + the record encoding + dsp_freq_add_sites, with the two device kernels (encode, sequential
+    per-site reduce after a stable sort) restated in numpy: byte-identical to the reference's call_freq outputs (F5).
+    The kernels themselves are checked against the same files in tests/test_gpu_freq.py."""
+    import ctypes
+    from deepsignal_plant_amd import _native as nat
+    L = nat.lib()
+    p = ctypes.c_void_p
+    lines = open(CALLS).read().splitlines()
+    r, probs, labels = _rows_from_calls(lines)
+    cfv = kw.get("prob_cf", 0.5)
+    agg = cf.SiteFrequency(cfv, nthreads=3)
+    n = r.n
+    key, pis, meta = np.empty(n, np.int64), np.empty(n, np.int64), np.empty(n, np.uint32)
+    assert L.dsp_freq_block_keys(agg._h, p(r.text.ctypes.data), p(r.row_off.ctypes.data), p(r.info_len.ctypes.data),
+                                 p(r.kmer.ctypes.data), 5, n, p(key.ctypes.data), p(pis.ctypes.data), p(meta.ctypes.data)) == n
+    # encode (dsp_freq_dev.hip: freq_encode_kernel)
+    a, b = probs[:, 0], probs[:, 1]
+    q = (a / (a + b)).astype(np.float32)
+    k0 = np.rint(q * np.float32(1e6)).astype(np.float32)
+    z0 = (k0 / np.float32(1e6)).astype(np.float32)
+    k1 = np.rint((np.float32(1.0) - z0) * np.float32(1e6)).astype(np.float32)
+    k0, k1 = k0.astype(np.int64), k1.astype(np.int64)
+    used = np.abs(k0 / 1e6 - k1 / 1e6) >= cfv
+    packed = k0 | (k1 << 20) | ((labels == 1).astype(np.int64) << 40) | (meta.astype(np.int64) << 41)
+    row = np.arange(n, dtype=np.int64)
+    key, packed, pis, row = key[used], packed[used], pis[used], row[used]
+    # stable sort + sequential per-site reduce (freq_reduce_kernel)
+    order = np.argsort(key, kind="stable")
+    key, packed, pis, row = key[order], packed[order], pis[order], row[order]
+    heads = np.nonzero(np.r_[True, key[1:] != key[:-1]])[0] if len(key) else np.zeros(0, np.int64)
+    ends = np.r_[heads[1:], len(key)]
+    s0, s1, met, cov = [], [], [], []
+    for h, e in zip(heads, ends):
+        x0 = x1 = 0.0
+        for j in range(h, e):
+            x0 += float(packed[j] & 0xfffff) / 1e6
+            x1 += float((packed[j] >> 20) & 0xfffff) / 1e6
+        s0.append(x0); s1.append(x1)
+        met.append(int(((packed[h:e] >> 40) & 1).sum())); cov.append(int(e - h))
+    arr = lambda x, dt: np.ascontiguousarray(np.array(x, dt))
+    sk, fr, pk, sp = arr(key[heads], np.int64), arr(row[heads], np.int64), arr(packed[heads], np.int64), arr(pis[heads], np.int64)
+    s0, s1, met, cov = arr(s0, np.float64), arr(s1, np.float64), arr(met, np.int64), arr(cov, np.int64)
+    by_first = np.argsort(fr, kind="stable")
+    cols = [np.ascontiguousarray(c[by_first]) for c in (sk, fr, pk, sp, s0, s1, met, cov)]
+    table = cf.SiteFrequency(cfv)
+    for i in range(L.dsp_freq_chrom_count(agg._h)):
+        k = int(L.dsp_freq_chrom_name(agg._h, i, None, 0))
+        buf = ctypes.create_string_buffer(max(k, 1))
+        L.dsp_freq_chrom_name(agg._h, i, buf, k)
+        assert L.dsp_freq_intern_chrom(table._h, buf.raw[:k], k) == i
+    assert L.dsp_freq_add_sites(table._h, len(cols[0]), *[p(c.ctypes.data) for c in cols]) == len(cols[0])
+    L.dsp_freq_add_counts(table._h, n)
+    assert table.format(kw.get("sort", False), kw.get("bed", False)) == open(os.path.join(GOLDEN, "f5_freq_%s.txt" % tag), "rb").read()
+    assert table.counts()[0] == n and table.counts()[1] == int(used.sum())
+    # rows the compact encoding cannot hold are refused loudly (the caller then uses the host aggregator)
+    bad, _, _ = _rows_from_calls([lines[0].replace("\t+\t", "\t*\t").replace("\t-\t", "\t*\t")])
+    with pytest.raises(ValueError, match="host aggregator"):
+        nat.check(int(L.dsp_freq_block_keys(agg._h, p(bad.text.ctypes.data), p(bad.row_off.ctypes.data), p(bad.info_len.ctypes.data),
+                                            p(bad.kmer.ctypes.data), 5, 1, p(key.ctypes.data), p(pis.ctypes.data), p(meta.ctypes.data))))

@@ -151,6 +151,36 @@ def test_cli_fused_freq_file_equals_call_freq_on_the_result(tmp_path):
         r2 = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
         assert r2.returncode == 0, r2.stderr[-2000:]
         assert open(fq, "rb").read() == open(fq2, "rb").read() and os.path.getsize(fq) > 0
+        # the same through the host table (--freq_on host), and sharded over two ranks: records dealt to the ranks by
+        # site, reduced on the device, gathered to rank 0 (DeviceSiteFrequency.finish) -- the same bytes every time
+        fq3 = os.path.join(str(tmp_path), "host.freq")
+        r = _run_cli(["-i", inp2, "-m", ck, "-o", out, "--freq_file", fq3, "--prob_cf", "0.02", "--freq_on", "host"] + flags)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert open(fq3, "rb").read() == open(fq2, "rb").read()
+        for freq_on in ("device", "host"):
+            import socket
+            s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+            fq4 = os.path.join(str(tmp_path), "two_ranks_%s.freq" % freq_on)
+            out2 = os.path.join(str(tmp_path), "calls2.tsv")
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                   "127.0.0.1", "--master-port", str(port), "-m", "deepsignal_plant_amd.deepsignal_plant", "call_mods",
+                   "-i", inp2, "-m", ck, "-o", out2, "--freq_file", fq4, "--prob_cf", "0.02", "--freq_on", freq_on] + flags
+            r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0, r.stderr[-3000:]
+            assert open(out2, "rb").read() == open(out, "rb").read()
+            assert open(fq4, "rb").read() == open(fq2, "rb").read(), freq_on
+
+
+def test_cli_accepts_and_ignores_methy_label(tmp_path):
+    """--methy_label is an `extract` flag (deepsignal_plant.py:150) that the reference's call_mods parsers carry
+    commented out (:280-283); a command line that still has it must run, and change nothing"""
+    ck = _ckpt(tmp_path)
+    inp = os.path.join(GOLDEN, "f2_rows.tsv")
+    a, b = os.path.join(str(tmp_path), "a.tsv"), os.path.join(str(tmp_path), "b.tsv")
+    assert _run_cli(["-i", inp, "-m", ck, "-o", a, "--seed", "3"]).returncode == 0
+    r = _run_cli(["-i", inp, "-m", ck, "-o", b, "--seed", "3", "--methy_label", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert open(a, "rb").read() == open(b, "rb").read()
 
 
 def test_cli_binary_feature_container_gives_the_same_calls_as_the_tsv(tmp_path):
