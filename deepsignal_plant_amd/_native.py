@@ -120,6 +120,21 @@ def lib():
     L.dsp_freq_chrom_name.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_size_t]
     L.dsp_freq_intern_chrom.restype = ctypes.c_int32
     L.dsp_freq_intern_chrom.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    L.dsp_gz_index.restype = ctypes.c_int64
+    L.dsp_gz_index.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+    L.dsp_gz_inflate_members.restype = ctypes.c_int64
+    L.dsp_gz_inflate_members.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                         ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32]
+    L.dsp_bgzf_compress.restype = ctypes.c_int64
+    L.dsp_bgzf_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_int32]
+    L.dsp_bgzf_eof.restype = ctypes.c_int64
+    L.dsp_bgzf_eof.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    L.dsp_gz_open.restype = ctypes.c_void_p
+    L.dsp_gz_open.argtypes = [ctypes.c_char_p]
+    L.dsp_gz_read.restype = ctypes.c_int64
+    L.dsp_gz_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    L.dsp_gz_close.restype = None
+    L.dsp_gz_close.argtypes = [ctypes.c_void_p]
     L.dsp_feat_writer_create.restype = ctypes.c_int32
     L.dsp_feat_writer_create.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
                                          ctypes.POINTER(ctypes.c_void_p)]

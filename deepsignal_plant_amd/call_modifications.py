@@ -33,7 +33,7 @@ import time
 import numpy as np
 
 from . import dist as dsp_dist
-from . import featfile, feed, textio
+from . import featfile, feed, gzio, textio
 from .models import ModelBiLSTM
 from .utils.process_utils import display_args, str2bool
 
@@ -78,7 +78,7 @@ class _Writer(threading.Thread):
 
     def run(self):
         try:
-            wf = gzip.open(self.path, "wb", compresslevel=4) if self.is_gzip else open(self.path, "wb")
+            wf = gzio.open_write(self.path, self.is_gzip, nthreads=self.nthreads)  # --gzip: BGZF, deflated on nthreads threads
             with wf:
                 while True:
                     item = self.q.get()
@@ -115,8 +115,14 @@ def _call_mods_file(args, rank, local_rank, world):
     nthreads = max(1, (args.nproc if args.nproc > 0 else 1))
     nthreads = min(nthreads, os.cpu_count() or 1)
 
-    # my byte range and the global index of my first row (plain text only; .gz ranks inflate everything)
+    # my byte range and the global index of my first row (plain text: a byte range of the file; BGZF .gz: a member range,
+    # feed.FeatureReader._run_bgzf; a foreign single-stream .gz is inflated by every rank, which then knows all indices)
     first_row, byte_range = 0, None
+    if input_path.endswith(".gz") and world > 1:
+        mine = feed.count_rows_bgzf(input_path, world, rank, nthreads)
+        if mine is not None:
+            counts = dsp_dist.all_gather_ints(mine, world, coll_dev)
+            first_row = dsp_dist.exclusive_prefix(counts, rank)
     if not input_path.endswith(".gz") and world > 1 and not featfile.is_feature_file(input_path):
         import mmap
         size = os.path.getsize(input_path)
@@ -327,12 +333,30 @@ def _call_mods_reads(args, rank, local_rank, world):
     return n_rows, part_path, out_path
 
 
+_BGZF_EOF = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+
+
 def _merge_parts(out_path, world):
+    """concatenate the ranks' part files in rank order (gzip / BGZF members concatenate into a valid .gz; the empty
+    end-of-file member of every part but the last is dropped so that the result is one well-formed BGZF file)"""
     with open(out_path, "wb") as wf:
         for r in range(world):
             part = "%s.part%05d" % (out_path, r)
+            size = os.path.getsize(part)
             with open(part, "rb") as rf:
-                shutil.copyfileobj(rf, wf, 16 << 20)  # gzip members concatenate into a valid .gz
+                keep = size
+                if out_path.endswith(".gz") and r < world - 1 and size >= 28:
+                    rf.seek(size - 28)
+                    if rf.read(28) == _BGZF_EOF:
+                        keep = size - 28
+                    rf.seek(0)
+                left = keep
+                while left > 0:
+                    chunk = rf.read(min(left, 16 << 20))
+                    if not chunk:
+                        break
+                    wf.write(chunk)
+                    left -= len(chunk)
             os.remove(part)
 
 

@@ -94,7 +94,8 @@ class SiteFrequency(object):
         if is_gzip and not result_file.endswith(".gz"):
             result_file += ".gz"
         data = self.format(is_sort, is_bed)
-        with (gzip.open(result_file, "wb") if is_gzip else open(result_file, "wb")) as wf:
+        from . import gzio
+        with gzio.open_write(result_file, is_gzip) as wf:
             wf.write(data)
         return result_file
 

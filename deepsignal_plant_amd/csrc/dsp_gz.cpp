@@ -1,0 +1,229 @@
+// dsp_gz.cpp -- gzip I/O of the call_mods host pipeline (replaces the reference's `gzip.open(...)` reader / writers,
+// deepsignal_plant/call_modifications.py:66-69, :264-270; extract_features.py writers).
+//
+// A deflate stream cannot be entered in the middle, so ONE gzip member can only be inflated by one thread (about
+// 0.3-0.4 GB/s of text with zlib: a sixth of what the parser and the GPU take).  Everything this build WRITES with
+// --gzip is therefore a chain of BGZF members (the blocked gzip of htslib / bgzip: ordinary gzip members of at most
+// 64 KiB of text, each carrying its compressed size in a "BC" extra field, closed by an empty EOF member): any gzip
+// reader -- the reference's included -- reads it as one stream, while this reader walks the member headers, deals
+// contiguous member ranges to ranks and inflates a batch of members on N threads.  Foreign .gz files (one member, no
+// "BC" fields) fall back to a native streaming inflate (dsp_gz_open / dsp_gz_read), single-threaded by nature.
+#include "dsp_amd.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+extern "C" void dsp_set_error_(const char* msg);
+
+namespace {
+
+int gz_fail(int code, const char* fmt, long long a = 0, long long b = 0) {
+    char buf[256];
+    snprintf(buf, sizeof(buf), fmt, a, b);
+    dsp_set_error_(buf);
+    return code;
+}
+
+constexpr size_t kBgzfBlock = 0xff00;  // text bytes per member (htslib's BGZF_BLOCK_SIZE)
+
+// total size of the BGZF member starting at p (0 = not a BGZF member)
+size_t bgzf_member_size(const uint8_t* p, size_t left) {
+    if (left < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return 0;
+    const size_t xlen = p[10] | (size_t)p[11] << 8;
+    if (left < 12 + xlen) return 0;
+    for (size_t o = 12; o + 4 <= 12 + xlen;) {
+        const size_t slen = p[o + 2] | (size_t)p[o + 3] << 8;
+        if (p[o] == 'B' && p[o + 1] == 'C' && slen == 2 && o + 6 <= 12 + xlen) {
+            const size_t bs = (p[o + 4] | (size_t)p[o + 5] << 8) + 1;
+            return bs >= 12 + xlen + 8 && bs <= left ? bs : 0;
+        }
+        o += 4 + slen;
+    }
+    return 0;
+}
+
+int inflate_member(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* produced) {
+    z_stream z;
+    memset(&z, 0, sizeof(z));
+    if (inflateInit2(&z, 15 + 16) != Z_OK) return -1;  // gzip wrapper: header + CRC32 + ISIZE are checked by zlib
+    z.next_in = const_cast<Bytef*>(src); z.avail_in = (uInt)n;
+    z.next_out = dst; z.avail_out = (uInt)cap;
+    const int rc = inflate(&z, Z_FINISH);
+    *produced = (size_t)z.total_out;
+    inflateEnd(&z);
+    return rc == Z_STREAM_END ? 0 : -1;
+}
+
+}  // namespace
+
+struct dsp_gz_stream {
+    gzFile f = nullptr;
+};
+
+extern "C" {
+
+int64_t dsp_gz_index(const uint8_t* src, size_t len, int64_t max_members, uint64_t* member_off, uint32_t* member_isize) {
+    if (!src) return gz_fail(DSP_EINVAL, "dsp_gz_index: NULL argument");
+    int64_t m = 0;
+    size_t pos = 0;
+    while (pos < len) {
+        const size_t bs = bgzf_member_size(src + pos, len - pos);
+        if (!bs) return -1;  // not (entirely) BGZF: the caller streams it instead
+        if (member_off) {
+            if (m >= max_members) return gz_fail(DSP_ENOMEM, "dsp_gz_index: more than %lld members", (long long)max_members);
+            member_off[m] = pos;
+            const uint8_t* t = src + pos + bs - 4;
+            member_isize[m] = t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
+        }
+        ++m;
+        pos += bs;
+    }
+    if (member_off && m <= max_members) member_off[m] = pos;
+    return m;
+}
+
+int64_t dsp_gz_inflate_members(const uint8_t* src, const uint64_t* member_off, const uint32_t* member_isize, int64_t m0,
+                               int64_t m1, uint8_t* out, size_t out_cap, int32_t nthreads) {
+    if (!src || !member_off || !member_isize || !out || m0 < 0 || m1 < m0) return gz_fail(DSP_EINVAL, "dsp_gz_inflate_members: bad argument");
+    const int64_t m = m1 - m0;
+    std::vector<size_t> off((size_t)m + 1, 0);
+    for (int64_t i = 0; i < m; ++i) off[(size_t)i + 1] = off[(size_t)i] + member_isize[m0 + i];
+    if (off[(size_t)m] > out_cap) return gz_fail(DSP_ENOMEM, "dsp_gz_inflate_members: %lld bytes do not fit %lld", (long long)off[(size_t)m], (long long)out_cap);
+    int nt = nthreads < 1 ? 1 : nthreads;
+    if ((int64_t)nt > m) nt = (int)std::max<int64_t>(1, m);
+    std::atomic<int64_t> next(0), bad(-1);
+    auto work = [&]() {
+        for (;;) {
+            const int64_t i = next.fetch_add(16);
+            if (i >= m || bad.load() >= 0) return;
+            for (int64_t j = i; j < std::min(m, i + 16); ++j) {
+                size_t got = 0;
+                const uint64_t a = member_off[m0 + j], b = member_off[m0 + j + 1];
+                if (inflate_member(src + a, (size_t)(b - a), out + off[(size_t)j], member_isize[m0 + j], &got) != 0 ||
+                    got != member_isize[m0 + j]) {
+                    bad.store(m0 + j);
+                    return;
+                }
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+    if (bad.load() >= 0) return gz_fail(DSP_EPARSE, "corrupt gzip member %lld (inflate / CRC / size check failed)", (long long)bad.load());
+    return (int64_t)off[(size_t)m];
+}
+
+// text -> BGZF members (no EOF member: dsp_bgzf_eof), `nthreads` deflate threads.  Returns the bytes written.
+int64_t dsp_bgzf_compress(const uint8_t* in, size_t len, uint8_t* out, size_t out_cap, int32_t level, int32_t nthreads) {
+    if ((!in && len) || !out) return gz_fail(DSP_EINVAL, "dsp_bgzf_compress: NULL argument");
+    const size_t nb = (len + kBgzfBlock - 1) / kBgzfBlock;
+    if (nb == 0) return 0;
+    const size_t kMax = 65536;  // a member never exceeds 64 KiB (BSIZE is 16 bits)
+    std::vector<uint8_t> tmp(nb * kMax);
+    std::vector<uint32_t> sz(nb, 0);
+    int nt = nthreads < 1 ? 1 : nthreads;
+    if ((size_t)nt > nb) nt = (int)nb;
+    std::atomic<size_t> next(0);
+    std::atomic<int> err(0);
+    auto work = [&]() {
+        for (;;) {
+            const size_t b = next.fetch_add(1);
+            if (b >= nb || err.load()) return;
+            const uint8_t* p = in + b * kBgzfBlock;
+            const size_t n = std::min(kBgzfBlock, len - b * kBgzfBlock);
+            uint8_t* o = tmp.data() + b * kMax;
+            static const uint8_t hdr[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0, 0};
+            memcpy(o, hdr, 18);
+            z_stream z;
+            memset(&z, 0, sizeof(z));
+            int lv = level;
+            for (;;) {  // raw deflate; incompressible input that would overflow 64 KiB is stored (level 0)
+                if (deflateInit2(&z, lv, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { err.store(1); return; }
+                z.next_in = const_cast<Bytef*>(p); z.avail_in = (uInt)n;
+                z.next_out = o + 18; z.avail_out = (uInt)(kMax - 18 - 8);
+                const int rc = deflate(&z, Z_FINISH);
+                const size_t produced = (size_t)z.total_out;
+                deflateEnd(&z);
+                if (rc == Z_STREAM_END) {
+                    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), p, (uInt)n);
+                    uint8_t* t = o + 18 + produced;
+                    for (int i = 0; i < 4; ++i) t[i] = (uint8_t)(crc >> (8 * i));
+                    for (int i = 0; i < 4; ++i) t[4 + i] = (uint8_t)((uint32_t)n >> (8 * i));
+                    const size_t total = 18 + produced + 8;
+                    o[16] = (uint8_t)((total - 1) & 0xff); o[17] = (uint8_t)((total - 1) >> 8);
+                    sz[b] = (uint32_t)total;
+                    break;
+                }
+                if (lv == 0) { err.store(1); return; }
+                lv = 0;
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+    if (err.load()) return gz_fail(DSP_EHIP, "dsp_bgzf_compress: deflate failed");
+    size_t total = 0;
+    for (size_t b = 0; b < nb; ++b) total += sz[b];
+    if (total > out_cap) return gz_fail(DSP_ENOMEM, "dsp_bgzf_compress: %lld bytes do not fit %lld", (long long)total, (long long)out_cap);
+    size_t pos = 0;
+    for (size_t b = 0; b < nb; ++b) { memcpy(out + pos, tmp.data() + b * kMax, sz[b]); pos += sz[b]; }
+    return (int64_t)total;
+}
+
+// the 28-byte empty member that ends a BGZF file
+int64_t dsp_bgzf_eof(uint8_t* out, size_t cap) {
+    static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (!out || cap < 28) return gz_fail(DSP_ENOMEM, "dsp_bgzf_eof: 28 bytes needed");
+    memcpy(out, eof, 28);
+    return 28;
+}
+
+dsp_gz_stream* dsp_gz_open(const char* path) {
+    if (!path) return nullptr;
+    gzFile f = gzopen(path, "rb");
+    if (!f) { gz_fail(DSP_EINVAL, "dsp_gz_open: cannot open the file"); return nullptr; }
+    gzbuffer(f, 1u << 20);
+    dsp_gz_stream* s = new (std::nothrow) dsp_gz_stream();
+    if (!s) { gzclose(f); return nullptr; }
+    s->f = f;
+    return s;
+}
+
+// up to cap bytes of text (all members of the file, like gzip.open); 0 at the end, < 0 on a corrupt stream
+int64_t dsp_gz_read(dsp_gz_stream* s, uint8_t* out, size_t cap) {
+    if (!s || !s->f || !out) return gz_fail(DSP_EINVAL, "dsp_gz_read: NULL argument");
+    size_t got = 0;
+    while (got < cap) {
+        const unsigned want = (unsigned)std::min<size_t>(cap - got, 1u << 30);
+        const int k = gzread(s->f, out + got, want);
+        if (k < 0) {
+            int e = 0;
+            const char* msg = gzerror(s->f, &e);
+            char buf[200];
+            snprintf(buf, sizeof(buf), "corrupt gzip stream: %s", msg ? msg : "?");
+            dsp_set_error_(buf);
+            return DSP_EPARSE;
+        }
+        if (k == 0) break;
+        got += (size_t)k;
+    }
+    return (int64_t)got;
+}
+
+void dsp_gz_close(dsp_gz_stream* s) {
+    if (!s) return;
+    if (s->f) gzclose(s->f);
+    delete s;
+}
+
+}  // extern "C"

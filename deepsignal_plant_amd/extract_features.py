@@ -271,7 +271,8 @@ def extract_features(args):
     if to_dspf:
         writer = featfile.FeatureFileWriter(args.write_path, args.seq_len, args.signal_len)
     else:
-        op = (lambda p: gzip.open(p, "wb", compresslevel=4)) if is_gzip else (lambda p: open(p, "wb"))
+        from . import gzio
+        op = lambda p: gzio.open_write(p, is_gzip, nthreads=nthreads)  # --gzip: BGZF members (seekable by call_mods ranks)
         if is_dir:  # :474-510
             if os.path.isfile(args.write_path):
                 raise FileExistsError("{} already exists as a file, please use another write_dir".format(args.write_path))

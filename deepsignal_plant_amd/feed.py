@@ -52,6 +52,24 @@ def count_rows_in_range(path, a, b):
     return newlines + (1 if tail_open else 0)
 
 
+def count_rows_bgzf(path, world, rank, nthreads=8, block_bytes=BLOCK_BYTES):
+    """Rows owned by `rank` of a BGZF feature file (= newlines inside its member range, see FeatureReader._run_bgzf), or
+    None when the file is not BGZF.  One inflate pass on `nthreads` threads; the ranks then all_gather these counts to
+    learn the global index of their first row."""
+    from . import gzio
+    bz = gzio.BgzfFile(path)
+    if not bz.ok:
+        return None
+    m0, m1 = bz.members_for_rank(world, rank)
+    mine, m = 0, m0
+    while m < m1:
+        e = min(m1, max(m + 1, int(np.searchsorted(bz.text_off, bz.text_off[m] + block_bytes, side="left"))))
+        buf, n = bz.inflate(m, e, nthreads=nthreads)
+        mine += textio.count_newlines(buf[:n])
+        m = e
+    return mine
+
+
 class FeatureReader(threading.Thread):
     """Producer thread: yields parsed blocks of this rank's rows, in file order, through a bounded queue."""
 
@@ -161,28 +179,94 @@ class FeatureReader(threading.Thread):
         return row
 
     def _run_gz(self, row):
-        # .gz cannot be range-split: every rank inflates the stream and keeps the blocks it owns
-        # (block i -> rank i % world), counting the rows of foreign blocks to keep global row indices.
-        carry = b""
-        i = 0
-        with gzip.open(self.path, "rb") as f:
-            while True:
-                chunk = f.read(self.block_bytes)
-                if not chunk:
+        from . import gzio
+        bz = gzio.BgzfFile(self.path)
+        if bz.ok:
+            return self._run_bgzf(bz, row)
+        return self._run_gz_stream(row)
+
+    def _run_bgzf(self, bz, row):
+        """BGZF (what this build writes with --gzip, and what bgzip writes): this rank's contiguous member range, inflated
+        in batches on all parser threads.  A rank owns the rows that END inside its members; the start of its first row
+        is the tail of the previous rank's last members."""
+        m0, m1 = bz.members_for_rank(self.world, self.rank)
+        carry = np.zeros(0, np.uint8)
+        if m0 > 0:  # bytes after the last newline before member m0
+            k = m0
+            while k > 0:
+                k -= 1
+                tail, n = bz.inflate(k, k + 1, nthreads=1)
+                nl = np.flatnonzero(tail[:n] == 10)
+                if len(nl):
+                    carry = np.concatenate((tail[nl[-1] + 1:n], carry))
                     break
-                data = carry + chunk
-                nl = data.rfind(b"\n")
+                carry = np.concatenate((tail[:n], carry))
+        m = m0
+        last_rank = self.rank == self.world - 1
+        while m < m1:
+            e = self._batch_end(bz, m, m1)
+            need = int(bz.text_off[e] - bz.text_off[m])
+            buf = np.empty(len(carry) + need, np.uint8)
+            buf[:len(carry)] = carry
+            bz.inflate(m, e, out=buf, out_offset=len(carry), nthreads=self.nthreads)
+            m = e
+            nl = -1
+            if len(buf):
+                tailpos = np.flatnonzero(buf[max(0, len(buf) - (1 << 16)):] == 10)
+                if len(tailpos):
+                    nl = max(0, len(buf) - (1 << 16)) + int(tailpos[-1])
+                else:
+                    allpos = np.flatnonzero(buf == 10)
+                    nl = int(allpos[-1]) if len(allpos) else -1
+            if nl < 0:
+                carry = buf
+                continue
+            carry = buf[nl + 1:].copy()
+            n = self._emit(buf[:nl + 1], row)
+            row += n
+        if last_rank and len(carry) and carry.tobytes().strip():
+            row += self._emit(carry, row)  # an unterminated last row
+        return row
+
+    def _batch_end(self, bz, m, m1):
+        e = int(np.searchsorted(bz.text_off, bz.text_off[m] + self.block_bytes, side="left"))
+        return min(m1, max(m + 1, e))
+
+    def _run_gz_stream(self, row):
+        """A foreign .gz (one deflate stream): it cannot be range-split, so every rank inflates it -- natively, the GIL
+        released -- and keeps the blocks it owns (block i -> rank i % world), counting the rows of foreign blocks to
+        keep global row indices."""
+        from . import gzio
+        st = gzio.GzStream(self.path)
+        carry = np.zeros(0, np.uint8)
+        i = 0
+        try:
+            while True:
+                buf = np.empty(len(carry) + self.block_bytes, np.uint8)
+                buf[:len(carry)] = carry
+                got = st.readinto(buf, len(carry))
+                if got == 0:
+                    break
+                data = buf[:len(carry) + got]
+                pos = np.flatnonzero(data[max(0, len(data) - (1 << 16)):] == 10)
+                if len(pos):
+                    nl = max(0, len(data) - (1 << 16)) + int(pos[-1])
+                else:
+                    allpos = np.flatnonzero(data == 10)
+                    nl = int(allpos[-1]) if len(allpos) else -1
                 if nl < 0:
-                    carry = data
+                    carry = data.copy()
                     continue
-                carry = data[nl + 1:]
+                carry = data[nl + 1:].copy()
                 data = data[:nl + 1]
                 if i % self.world == self.rank:
                     row += self._emit(data, row)
                 else:
                     row += textio.count_rows(data)
                 i += 1
-        if carry.strip():
+        finally:
+            st.close()
+        if len(carry) and carry.tobytes().strip():
             if i % self.world == self.rank:
                 row += self._emit(carry, row)
             else:

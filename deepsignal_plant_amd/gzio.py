@@ -1,0 +1,130 @@
+"""gzip I/O of the host pipeline over the native layer in libdsp_amd.so (csrc/dsp_gz.cpp).
+
+Writers emit BGZF -- a chain of ordinary gzip members of <= 64 KiB of text, each carrying its compressed size, ended
+by an empty member -- which `gzip.open` / zcat / the reference read like any .gz (call_modifications.py:66-69 reads the
+feature file with gzip.open when it ends in .gz), and which this build's reader can index, deal to ranks by member
+ranges and inflate on many threads.  Other .gz files are streamed through one native inflate thread."""
+from __future__ import annotations
+
+import ctypes
+import mmap
+import os
+
+import numpy as np
+
+from . import _native as nat
+
+
+class BgzfWriter(object):
+    """file-like, write-only: bytes in -> BGZF members out (deflate on `nthreads` threads)"""
+
+    def __init__(self, path, level=4, nthreads=8, chunk=8 << 20):
+        self.f = open(path, "wb")
+        self.level, self.nthreads, self.chunk = int(level), max(1, int(nthreads)), int(chunk)
+        self.buf = bytearray()
+        self.out = np.empty(self.chunk + (self.chunk // 0xff00 + 2) * 64 + 65536, np.uint8)
+
+    def _flush(self, final=False):
+        L = nat.lib()
+        while len(self.buf) >= self.chunk or (final and self.buf):
+            n = min(len(self.buf), self.chunk)
+            if not final:
+                n -= n % 0xff00 or 0  # whole members only, so that the chain stays maximally packed
+                n = n or min(len(self.buf), self.chunk)
+            src = np.frombuffer(self.buf, np.uint8, n)
+            k = nat.check(int(L.dsp_bgzf_compress(ctypes.c_void_p(src.ctypes.data), n, ctypes.c_void_p(self.out.ctypes.data),
+                                                  self.out.nbytes, self.level, self.nthreads)))
+            self.f.write(memoryview(self.out)[:k])
+            del src
+            del self.buf[:n]
+
+    def write(self, data):
+        self.buf += data
+        if len(self.buf) >= self.chunk:
+            self._flush()
+        return len(data)
+
+    def close(self):
+        if self.f is None:
+            return
+        self._flush(final=True)
+        eof = np.empty(28, np.uint8)
+        nat.check(int(nat.lib().dsp_bgzf_eof(ctypes.c_void_p(eof.ctypes.data), 28)))
+        self.f.write(eof.tobytes())
+        self.f.close()
+        self.f = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+class BgzfFile(object):
+    """A .gz that is entirely BGZF: member table from a header walk over the mmap; members inflate independently."""
+
+    def __init__(self, path):
+        self.path = path
+        self.size = os.path.getsize(path)
+        self.f = open(path, "rb")
+        self.mm = mmap.mmap(self.f.fileno(), 0, access=mmap.ACCESS_READ) if self.size else None
+        self.src = np.frombuffer(self.mm, np.uint8) if self.mm is not None else np.zeros(0, np.uint8)
+        L = nat.lib()
+        m = int(L.dsp_gz_index(ctypes.c_void_p(self.src.ctypes.data), self.size, 0, None, None)) if self.size else 0
+        self.ok = m >= 0
+        self.n_members = max(m, 0)
+        if self.ok:
+            self.off = np.zeros(self.n_members + 1, np.uint64)
+            self.isize = np.zeros(max(self.n_members, 1), np.uint32)
+            if self.n_members:
+                nat.check(int(L.dsp_gz_index(ctypes.c_void_p(self.src.ctypes.data), self.size, self.n_members,
+                                             ctypes.c_void_p(self.off.ctypes.data), ctypes.c_void_p(self.isize.ctypes.data))))
+            self.text_off = np.r_[0, np.cumsum(self.isize[:self.n_members].astype(np.int64))]
+
+    def inflate(self, m0, m1, out=None, out_offset=0, nthreads=8):
+        """members [m0, m1) -> out[out_offset:...]; returns (array, bytes written)"""
+        need = int(self.text_off[m1] - self.text_off[m0])
+        if out is None:
+            out = np.empty(out_offset + need, np.uint8)
+        if need:
+            k = nat.check(int(nat.lib().dsp_gz_inflate_members(
+                ctypes.c_void_p(self.src.ctypes.data), ctypes.c_void_p(self.off.ctypes.data), ctypes.c_void_p(self.isize.ctypes.data),
+                int(m0), int(m1), ctypes.c_void_p(out.ctypes.data + out_offset), out.nbytes - out_offset, int(nthreads))))
+            assert k == need
+        return out, need
+
+    def members_for_rank(self, world, rank):
+        """contiguous member range of `rank`: equal shares of the compressed bytes"""
+        if self.n_members == 0:
+            return 0, 0
+        cuts = [int(np.searchsorted(self.off[:self.n_members], self.size * r // world, side="left")) for r in range(world)] + [self.n_members]
+        return cuts[rank], cuts[rank + 1]
+
+
+class GzStream(object):
+    """any .gz, sequentially (all members), through zlib in C with the GIL released"""
+
+    def __init__(self, path):
+        self.h = ctypes.c_void_p(nat.lib().dsp_gz_open(os.fsencode(path)))
+        if not self.h:
+            raise ValueError("cannot open %s" % path)
+
+    def readinto(self, arr, offset=0):
+        return nat.check(int(nat.lib().dsp_gz_read(self.h, ctypes.c_void_p(arr.ctypes.data + offset), arr.nbytes - offset)))
+
+    def close(self):
+        if self.h:
+            nat.lib().dsp_gz_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def open_write(path, is_gzip, nthreads=8, level=4):
+    """binary writer: plain file or BGZF"""
+    return BgzfWriter(path, level=level, nthreads=nthreads) if is_gzip else open(path, "wb")

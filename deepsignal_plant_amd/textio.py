@@ -42,6 +42,14 @@ def count_rows(text):
     return int(nat.lib().dsp_count_rows(p, n))
 
 
+def count_newlines(arr):
+    """newline bytes in a uint8 array (dsp_count_rows counts an unterminated tail as a row)"""
+    n = len(arr)
+    if n == 0:
+        return 0
+    return count_rows(arr) - (1 if arr[n - 1] != 10 else 0)
+
+
 def parse_rows(text, seq_len=13, signal_len=16, nthreads=4, out=None):
     """text: bytes-like holding complete lines.  out: optional dict of preallocated (e.g. pinned) numpy arrays
     with capacity >= the row count (keys as ParsedRows slots).  Raises ValueError on malformed rows (the

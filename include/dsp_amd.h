@@ -334,6 +334,24 @@ int32_t dsp_freq_chrom_count(const dsp_freq* f);
 int64_t dsp_freq_chrom_name(const dsp_freq* f, int32_t id, char* out, size_t cap);
 int32_t dsp_freq_intern_chrom(dsp_freq* f, const char* name, size_t len);
 
+/* ---- gzip I/O of the host pipeline (csrc/dsp_gz.cpp; replaces gzip.open at call_modifications.py:66-69, :264-270) ----
+ * Everything this build writes with --gzip is a chain of BGZF members (ordinary gzip members of <= 64 KiB of text that
+ * carry their compressed size, as written by htslib / bgzip; any gzip reader reads the chain as one stream) closed by
+ * the empty EOF member: such files are indexed by a header walk, dealt to ranks by member ranges and inflated on N
+ * threads.  Other .gz files are streamed through dsp_gz_open / dsp_gz_read (one thread: a deflate stream cannot be
+ * entered in the middle).
+ * dsp_gz_index: number of members if [src, src+len) is entirely BGZF (member_off[m+1] / member_isize[m] filled when
+ *   given), -1 if it is not.  dsp_gz_inflate_members: members [m0, m1) -> out back to back; zlib checks every CRC. */
+typedef struct dsp_gz_stream dsp_gz_stream;
+int64_t dsp_gz_index(const uint8_t* src, size_t len, int64_t max_members, uint64_t* member_off, uint32_t* member_isize);
+int64_t dsp_gz_inflate_members(const uint8_t* src, const uint64_t* member_off, const uint32_t* member_isize, int64_t m0,
+                               int64_t m1, uint8_t* out, size_t out_cap, int32_t nthreads);
+int64_t dsp_bgzf_compress(const uint8_t* in, size_t len, uint8_t* out, size_t out_cap, int32_t level, int32_t nthreads);
+int64_t dsp_bgzf_eof(uint8_t* out, size_t cap);
+dsp_gz_stream* dsp_gz_open(const char* path);
+int64_t dsp_gz_read(dsp_gz_stream* s, uint8_t* out, size_t cap);
+void dsp_gz_close(dsp_gz_stream* s);
+
 const char* dsp_last_error(void);
 int32_t dsp_abi_version(void);
 

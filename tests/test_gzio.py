@@ -1,0 +1,112 @@
+"""CPU: the native gzip layer (csrc/dsp_gz.cpp, gzio.py): what --gzip writes is a BGZF chain that Python's gzip (the
+reference's reader, call_modifications.py:66-69) reads back byte for byte; BGZF files are read by member ranges on N
+threads, foreign .gz files through the streaming inflater; rank splits cover every row exactly once."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from deepsignal_plant_amd import feed, gzio, textio
+from tests.helpers import GOLDEN
+
+
+def _text(n_rep=40):
+    return open(os.path.join(GOLDEN, "f2_rows.tsv"), "rb").read() * n_rep   # 8,000 rows, 16.7 MB
+
+
+def test_bgzf_writer_output_is_plain_gzip_and_indexable(tmp_path):
+    data = _text(8)
+    p = str(tmp_path / "x.tsv.gz")
+    with gzio.BgzfWriter(p, nthreads=4, chunk=1 << 20) as w:
+        for a in range(0, len(data), 300_001):   # ragged writes
+            w.write(data[a:a + 300_001])
+    assert gzip.open(p, "rb").read() == data                      # the reference's reader
+    bz = gzio.BgzfFile(p)
+    assert bz.ok and bz.n_members >= len(data) // 0xff00 and int(bz.text_off[-1]) == len(data)
+    assert int(bz.isize[bz.n_members - 1]) == 0                   # the empty end-of-file member
+    out, n = bz.inflate(0, bz.n_members, nthreads=5)
+    assert n == len(data) and out[:n].tobytes() == data
+    out, n = bz.inflate(3, 9, nthreads=2)
+    assert out[:n].tobytes() == data[int(bz.text_off[3]):int(bz.text_off[9])]
+    # empty input: just the EOF member
+    p2 = str(tmp_path / "empty.gz")
+    gzio.BgzfWriter(p2).close()
+    assert gzip.open(p2, "rb").read() == b"" and os.path.getsize(p2) == 28
+    # a corrupted member is refused (zlib checks the CRC of every member)
+    raw = bytearray(open(p, "rb").read())
+    raw[int(bz.off[2]) + 40] ^= 0x55
+    p3 = str(tmp_path / "bad.gz")
+    open(p3, "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="corrupt gzip member"):
+        gzio.BgzfFile(p3).inflate(0, 5)
+
+
+def _read_all(path, world, rank, first_row=0, block_bytes=700_000):
+    r = feed.FeatureReader(path, 13, 16, rank=rank, world=world, nthreads=3, nbuf=2, block_bytes=block_bytes,
+                           first_row=first_row, pinned=False)
+    r.start()
+    rows, firsts = [], []
+    for blk in r:
+        firsts.append(blk.first_row)
+        rows += [blk.rows.sampleinfo(i) for i in range(blk.rows.n)]
+        r.release(blk)
+    return rows, firsts
+
+
+@pytest.mark.parametrize("kind", ["bgzf", "single_member", "no_trailing_newline"])
+def test_gz_feature_files_are_read_completely_by_any_number_of_ranks(tmp_path, kind):
+    data = _text(6)
+    if kind == "no_trailing_newline":
+        data = data[:-1]
+    want = ["\t".join(l.split("\t")[:6]) for l in data.decode().splitlines()]
+    p = str(tmp_path / "f.tsv.gz")
+    if kind == "single_member":
+        with gzip.open(p, "wb", compresslevel=1) as f:
+            f.write(data)
+    else:
+        with gzio.BgzfWriter(p, nthreads=3) as w:
+            w.write(data)
+    for world in (1, 2, 3):
+        got, prefix = [], 0
+        for rank in range(world):
+            if kind == "single_member":
+                assert feed.count_rows_bgzf(p, world, rank) is None
+                rows, firsts = _read_all(p, world, rank)        # every rank inflates everything, keeps its blocks
+                got.append((firsts, rows))
+            else:
+                mine = feed.count_rows_bgzf(p, world, rank, nthreads=2, block_bytes=500_000)
+                rows, firsts = _read_all(p, world, rank, first_row=prefix)
+                assert len(rows) == mine + (1 if kind == "no_trailing_newline" and rank == world - 1 else 0)
+                assert not firsts or firsts[0] == prefix
+                prefix += mine
+                got.append((firsts, rows))
+        if kind == "single_member":  # blocks interleave over ranks: order them by their first row
+            allfirst = sorted(f for firsts, _ in got for f in firsts)
+            merged = {}
+            for firsts, rows in got:
+                pos = 0
+                for f in firsts:
+                    nxt = [x for x in allfirst if x > f]
+                    size = (nxt[0] if nxt else len(want)) - f
+                    merged[f] = rows[pos:pos + size]
+                    pos += size
+            flat = [r for f in sorted(merged) for r in merged[f]]
+            assert flat == want
+        else:
+            assert [r for _, rows in got for r in rows] == want
+
+
+def test_streaming_inflater_reads_concatenated_members(tmp_path):
+    a, b = _text(1), _text(2)
+    p = str(tmp_path / "cat.gz")
+    with open(p, "wb") as f:
+        f.write(gzip.compress(a))
+        f.write(gzip.compress(b))
+    st = gzio.GzStream(p)
+    buf = np.empty(len(a) + len(b) + 10, np.uint8)
+    n = st.readinto(buf)
+    assert buf[:n].tobytes() == a + b and st.readinto(buf) == 0
+    st.close()
+    assert textio.count_newlines(np.frombuffer(a, np.uint8)) == a.count(b"\n")
+    assert textio.count_newlines(np.frombuffer(a[:-1], np.uint8)) == a.count(b"\n") - 1
