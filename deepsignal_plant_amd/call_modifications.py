@@ -272,8 +272,8 @@ def _call_mods_reads(args, rank, local_rank, world):
 
     def load():
         try:
-            for item in batches:
-                rq.put(item)
+            for item in batches:  # the host half of the extraction (concatenation into pinned staging, site strings)
+                rq.put(fx.stage(item[0], read_uids=item[1]))   # runs here, under the previous batch's GPU work
         finally:
             rq.put(None)
     loader = threading.Thread(target=load, daemon=True)
@@ -290,8 +290,9 @@ def _call_mods_reads(args, rank, local_rank, world):
         if batch is None:
             break
         if writer.error is not None:
+            fx.discard(batch)
             continue
-        ext = fx.extract(batch[0], read_uids=batch[1], stream=stream)
+        ext = fx.launch(batch, stream=stream)
         n = ext.n
         if n == 0:
             continue

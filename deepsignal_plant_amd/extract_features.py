@@ -30,6 +30,11 @@ class ReadBatchC(ctypes.Structure):
                 ("ev_base", ctypes.c_void_p), ("ev_off", ctypes.c_void_p)]
 
 
+class _Staged(object):
+    """host half of one batch: pinned, concatenated read arrays + the sites (FeatureExtractor.stage)"""
+    __slots__ = ("set", "host", "rows", "n", "R", "n_samples", "E")
+
+
 class ExtractedBatch(object):
     """rows: textio.ParsedRows whose text/row_off/... address the sites' sampleinfo strings (host; its feature
     arrays are filled only by to_host()); kmer/means/stds/lens/signals: device tensors [n, L(, S)]."""
@@ -77,7 +82,9 @@ class FeatureExtractor(object):
         self.methy_label, self.seed, self.round_stats = int(methy_label), int(seed), bool(round_stats)
         self._motif_blob = "".join(self.motif_seqs).encode()
         self.nthreads = max(1, int(nthreads))
-        self._stage = {}  # pinned staging buffers, grown on demand
+        import threading
+        self.n_stage_sets = 4      # sets of pinned staging buffers (grown on demand), rotated between stage() calls
+        self._free_sets, self._set_lock = None, threading.Lock()
         nat.lib()
 
     # -- host: which reads / region bounds (extract_features.py:311-314, :337-341)
@@ -129,23 +136,53 @@ class FeatureExtractor(object):
             info_len, read_off, read_len = info_len[keep], read_off[keep], read_len[keep]
         return site_read, site_loc, info, row_off, info_len, read_off, read_len
 
-    def extract(self, reads, first_read_uid=0, stream=None, read_uids=None, f64=False):
-        """reads: sequence of reads.ReadRecord -> ExtractedBatch (sites in read order, then position order).
-        read_uids (default first_read_uid + index): 64-bit keys of the subsampler, one per read.
-        f64=True: means / stds / signals as float64 (what the feature TSV prints) instead of the float32 the model eats."""
+    # -- host half: everything that does not need the GPU.  Thread-safe: several threads may stage batches at once,
+    #    each into its own set of pinned buffers (K sets rotate; a set is reused once the uploads of the batch that
+    #    last used it have completed)
+    def _take_set(self):
+        with self._set_lock:
+            if self._free_sets is None:
+                import queue
+                self._free_sets = queue.Queue()
+                for _ in range(self.n_stage_sets):
+                    self._free_sets.put({})
+        st = self._free_sets.get()
+        if st.get("_event") is not None:
+            st["_event"].synchronize()  # the uploads of the batch that used this set have left its buffers
+            st["_event"] = None
+        return st
+
+    def stage(self, reads, first_read_uid=0, read_uids=None):
+        """reads: sequence of reads.ReadRecord -> _Staged: region-selected reads concatenated into pinned staging
+        buffers, the motif sites and their sampleinfo strings (csrc/dsp_sites.cpp).  No GPU call."""
         torch = self.torch
         uid_of = {id(r): (read_uids[i] if read_uids is not None else first_read_uid + i) for i, r in enumerate(reads)}
         reads, rg_lo, rg_hi = self._select_reads(reads)
         R = len(reads)
-        out = ExtractedBatch()
+        sg = _Staged()
         rows = textio.ParsedRows()
         rows.seq_len, rows.signal_len = self.L, self.S
-        out.rows = rows
         i64 = lambda xs: np.concatenate([[0], np.cumsum(xs)]).astype(np.int64)
         raw_off = i64([r.raw.shape[0] for r in reads])
         ev_off = i64([r.ev_base.shape[0] for r in reads])
-        cat = lambda xs, dt: (np.concatenate(xs).astype(dt, copy=False) if xs else np.zeros(0, dt))
-        ev_base = cat([r.ev_base for r in reads], np.uint8)
+        st = self._take_set()
+
+        def pin(name, parts, dt):
+            """concatenate host arrays into a pinned staging buffer of this set"""
+            if isinstance(parts, np.ndarray):
+                parts = [parts]
+            total = int(sum(p.shape[0] for p in parts))
+            buf = st.get(name)
+            if buf is None or buf.shape[0] < total or buf.dtype != dt:
+                buf = torch.empty(max(total + total // 2, 1024), dtype=dt, pin_memory=True)
+                st[name] = buf
+            view = buf[:total]
+            if total:
+                np.concatenate(parts, out=view.numpy(), casting="same_kind")
+            return view
+        h = {}
+        h["ev_base"] = pin("ev_base", [r.ev_base for r in reads], torch.uint8)
+        ev_base = h["ev_base"].numpy()
         site_read, site_loc, info, row_off, info_len, read_off, read_len = (
             self._sites(reads, ev_base, ev_off, rg_lo, rg_hi) if R else
             (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(1, np.uint8), np.zeros(0, np.uint64),
@@ -154,36 +191,33 @@ class FeatureExtractor(object):
         rows.text, rows.n = info, n
         rows.row_off, rows.info_len, rows.read_off, rows.read_len = row_off, info_len, read_off, read_len
         rows.labels = np.full(n, self.methy_label, np.int32)
-        out.n = n
+        h["raw"] = pin("raw", [r.raw for r in reads], torch.int16)
+        h["raw_off"], h["ev_off"] = pin("raw_off", raw_off, torch.int64), pin("ev_off", ev_off, torch.int64)
+        h["scaling"] = pin("scaling", np.array([r.scaling for r in reads], np.float64), torch.float64)
+        h["offset"] = pin("offset", np.array([r.offset for r in reads], np.float64), torch.float64)
+        h["ev_start"] = pin("ev_start", [r.ev_start for r in reads], torch.int64)
+        h["ev_len"] = pin("ev_len", [r.ev_len for r in reads], torch.int64)
+        h["site_read"], h["site_loc"] = pin("site_read", site_read, torch.int32), pin("site_loc", site_loc, torch.int32)
+        h["uid"] = pin("uid", np.array([uid_of[id(r)] for r in reads], np.uint64).view(np.int64), torch.int64)
+        sg.set, sg.host, sg.rows, sg.n, sg.R = st, h, rows, n, R
+        sg.n_samples, sg.E = int(raw_off[-1]), int(ev_off[-1])
+        return sg
+
+    # -- device half: uploads + the three kernels, asynchronous on `stream`
+    def launch(self, sg, stream=None, f64=False):
+        """_Staged -> ExtractedBatch (device tensors in dsp_forward's layout).  f64=True: means / stds / signals as float64
+        (what the feature TSV prints) instead of the float32 the model eats."""
+        torch = self.torch
         dev = self.dev
+        out = ExtractedBatch()
+        out.rows, out.n = sg.rows, sg.n
+        n, R, E = sg.n, sg.R, sg.E
         st = stream if stream is not None else torch.cuda.current_stream(dev)
-        if self._stage.get("_event") is not None:
-            self._stage["_event"].synchronize()  # the previous batch's uploads have left the staging buffers
         with torch.cuda.device(dev), torch.cuda.stream(st):
-            def up(name, parts, dt):
-                """concatenate host arrays into a pinned staging buffer and start the H2D copy"""
-                if isinstance(parts, np.ndarray):
-                    parts = [parts]
-                total = int(sum(p.shape[0] for p in parts))
-                buf = self._stage.get(name)
-                if buf is None or buf.shape[0] < total or buf.dtype != dt:
-                    buf = torch.empty(max(total + total // 2, 1024), dtype=dt, pin_memory=True)
-                    self._stage[name] = buf
-                view = buf[:total]
-                if total:
-                    np.concatenate(parts, out=view.numpy(), casting="same_kind")
-                return view.to(dev, non_blocking=True)
-            d_raw = up("raw", [r.raw for r in reads], torch.int16)
-            d_raw_off, d_ev_off = up("raw_off", raw_off, torch.int64), up("ev_off", ev_off, torch.int64)
-            d_scaling = up("scaling", np.array([r.scaling for r in reads], np.float64), torch.float64)
-            d_offset = up("offset", np.array([r.offset for r in reads], np.float64), torch.float64)
-            d_ev_start = up("ev_start", [r.ev_start for r in reads], torch.int64)
-            d_ev_len = up("ev_len", [r.ev_len for r in reads], torch.int64)
-            d_ev_base = up("ev_base", ev_base, torch.uint8)
-            E = int(ev_off[-1])
-            batch = ReadBatchC(R, int(raw_off[-1]), E, d_raw.data_ptr(), d_raw_off.data_ptr(), d_scaling.data_ptr(),
-                               d_offset.data_ptr(), d_ev_start.data_ptr(), d_ev_len.data_ptr(), d_ev_base.data_ptr(),
-                               d_ev_off.data_ptr())
+            d = {k: v.to(dev, non_blocking=True) for k, v in sg.host.items()}
+            batch = ReadBatchC(R, sg.n_samples, E, d["raw"].data_ptr(), d["raw_off"].data_ptr(), d["scaling"].data_ptr(),
+                               d["offset"].data_ptr(), d["ev_start"].data_ptr(), d["ev_len"].data_ptr(), d["ev_base"].data_ptr(),
+                               d["ev_off"].data_ptr())
             dbl = dict(dtype=torch.float64, device=dev)
             shift, scale = torch.empty(R, **dbl), torch.empty(R, **dbl)
             base_mean, base_std = torch.empty(E, **dbl), torch.empty(E, **dbl)
@@ -205,22 +239,47 @@ class FeatureExtractor(object):
                 nat.check(L.dsp_extract_base_stats(sp, ctypes.byref(batch), ptr(shift), ptr(scale), ptr(blk_off), ptr(base_mean),
                                                    ptr(base_std), ptr(base_len), ptr(base_lo)))
                 if n:
-                    d_site_read, d_site_loc = up("site_read", site_read, torch.int32), up("site_loc", site_loc, torch.int32)
-                    d_uid = up("uid", np.array([uid_of[id(r)] for r in reads], np.uint64).view(np.int64), torch.int64)
                     gather = L.dsp_extract_gather_f64 if f64 else L.dsp_extract_gather
                     nat.check(gather(sp, ctypes.byref(batch), ptr(shift), ptr(scale), ptr(base_mean),
-                                     ptr(base_std), ptr(base_len), ptr(base_lo), n, ptr(d_site_read),
-                                     ptr(d_site_loc), self.L, self.S, int(self.round_stats),
-                                     ctypes.c_uint64(self.seed & ((1 << 64) - 1)), ptr(d_uid),
+                                     ptr(base_std), ptr(base_len), ptr(base_lo), n, ptr(d["site_read"]),
+                                     ptr(d["site_loc"]), self.L, self.S, int(self.round_stats),
+                                     ctypes.c_uint64(self.seed & ((1 << 64) - 1)), ptr(d["uid"]),
                                      ptr(out.kmer), ptr(out.means), ptr(out.stds), ptr(out.lens), ptr(out.signals)))
-                    # the inputs must outlive the asynchronous kernels
-                    for t in (d_raw, d_raw_off, d_ev_off, d_scaling, d_offset, d_ev_start, d_ev_len, d_ev_base,
-                              base_mean, base_std, base_len, base_lo, blk_off, d_site_read, d_site_loc, d_uid):
-                        t.record_stream(st)
+                # the inputs must outlive the asynchronous kernels
+                for t in list(d.values()) + [base_mean, base_std, base_len, base_lo, blk_off]:
+                    t.record_stream(st)
             ev = torch.cuda.Event()
             ev.record(st)
-            self._stage["_event"] = ev
+            sg.set["_event"] = ev
+        self._free_sets.put(sg.set)  # reusable once `ev` has passed (checked by the next taker)
+        sg.set = sg.host = None
         return out
+
+    def discard(self, sg):
+        """give a staged batch's buffers back without launching it"""
+        if sg is not None and sg.set is not None:
+            self._free_sets.put(sg.set)
+            sg.set = sg.host = None
+
+    def extract(self, reads, first_read_uid=0, stream=None, read_uids=None, f64=False):
+        """reads: sequence of reads.ReadRecord -> ExtractedBatch (sites in read order, then position order).
+        read_uids (default first_read_uid + index): 64-bit keys of the subsampler, one per read."""
+        return self.launch(self.stage(reads, first_read_uid, read_uids), stream=stream, f64=f64)
+
+    def extract_stream(self, batches, workers=4, stream=None, f64=False):
+        """batches: iterable of (reads, read_uids or None) -> ExtractedBatch per batch, in order.  The host half of up to
+        `n_stage_sets` batches is staged ahead by `workers` threads while the device half of earlier batches runs."""
+        from concurrent.futures import ThreadPoolExecutor
+        import collections
+        pending = collections.deque()
+        with ThreadPoolExecutor(max(1, workers)) as pool:
+            for reads, uids in batches:
+                pending.append(pool.submit(self.stage, reads, 0, uids))
+                # never hold more staged batches than there are buffer sets: the next stage() would wait for a launch
+                while len(pending) >= max(1, self.n_stage_sets):
+                    yield self.launch(pending.popleft().result(), stream=stream, f64=f64)
+            while pending:
+                yield self.launch(pending.popleft().result(), stream=stream, f64=f64)
 
 
 # ---- `deepsignal_plant extract` (extract_features.py:589-651, :654-767) ---------------------------------------------
@@ -260,7 +319,7 @@ def extract_features(args):
     def load():
         try:
             for item in batches:
-                rq.put(item)
+                rq.put(fx.stage(item[0], read_uids=item[1]))  # host half here, GPU half in the main thread
         finally:
             rq.put(None)
     threading.Thread(target=load, daemon=True).start()
@@ -286,7 +345,7 @@ def extract_features(args):
             item = rq.get()
             if item is None:
                 break
-            out = fx.extract(item[0], read_uids=item[1], f64=not to_dspf)
+            out = fx.launch(item, f64=not to_dspf)
             if out.n == 0:
                 continue
             rows = out.to_host()
