@@ -41,12 +41,12 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 inline int rup(int x, int m) { return (x + m - 1) / m * m; }
-// hidden sizes are zero-padded to whole unit tiles: 32 units, or pairs of them (64) above 32 so that a wave of the
-// <2,1> tiling (dsp_kernels.hip) can own two unit tiles
-inline int pad_hidden(int h) { return h <= 32 ? 32 : rup(h, 64); }
-// one workgroup (at most 8 waves: two per SIMD, 256 registers each, one unit tile of 32 hidden units per wave) holds a
-// direction's whole hidden state, which its waves exchange every step through a workgroup barrier
-constexpr int kMaxHidden = 256;
+// hidden sizes are zero-padded to whole unit tiles: 32 units, pairs of them (64) above 32, and 16 tiles (512) above
+// 256, where every wave of the LSTM kernel computes two unit tiles per step (dsp_kernels.hip, NP = 2)
+inline int pad_hidden(int h) { return h <= 32 ? 32 : (h <= 256 ? rup(h, 64) : 512); }
+// one workgroup (at most 8 waves: two per SIMD, 256 registers each) holds a direction's whole hidden state, which its
+// waves exchange every step through a workgroup barrier: 8 waves x 2 passes x 32 units
+constexpr int kMaxHidden = 512;
 
 struct Dims {
     int T, S, H, C, V, E, l1, l2;
@@ -61,8 +61,8 @@ int derive(const dsp_model_cfg* c, Dims* d) {
         c->hidden_size < 2 || c->vocab_size < 1 || c->embedding_size < 1)
         return fail(DSP_EINVAL, "non-positive model dimension");
     if (c->hidden_size > kMaxHidden)
-        return fail(DSP_EINVAL, "hidden_size %d > %d is not supported by this build (one workgroup of 8 waves x 32 units holds a "
-                                "direction's whole hidden state)", c->hidden_size, kMaxHidden);
+        return fail(DSP_EINVAL, "hidden_size %d > %d is not supported by this build (one workgroup of 8 waves x 2 passes x 32 "
+                                "units holds a direction's whole hidden state)", c->hidden_size, kMaxHidden);
     if (c->num_classes > 64) return fail(DSP_EINVAL, "num_classes %d > 64 is not supported", c->num_classes);
     if (c->num_layers1 > 15 || c->num_layers2 > 15) return fail(DSP_EINVAL, "too many LSTM layers");
     d->T = c->seq_len; d->S = c->signal_len; d->H = c->hidden_size; d->C = c->num_classes;
@@ -442,7 +442,8 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
         a.nqx_used = (ly.Iused + 7) / 8;
         a.h0buf = m->h0buf;
         a.UT = ly.Hp / 32;
-        a.SG = pick_site_groups(m, a.UT);
+        a.NP = a.UT > 8 ? 2 : 1;
+        a.SG = a.NP == 2 ? 1 : pick_site_groups(m, a.UT);
         a.init_mode = init ? init->mode : DSP_INIT_ZEROS;
         a.seed = init ? init->seed : 0; a.site_offset = init ? init->site_offset : 0;
         a.stream_base = lstm_id * 64 + (int)k * 4;
@@ -457,7 +458,7 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
         // the front ends eat raw features (a signal mean of 1e6 is a legal row), so they take the bf16 variant, whose
         // pieces have fp32's range
         const int prec = (lstm_id != 2 && m->precision == DSP_PREC_FP16X3) ? DSP_PREC_BF16X6 : m->precision;
-        const bool split = prec != DSP_PREC_FP32 && ly.wsplit[0] && ly.wsplit[1];
+        const bool split = prec != DSP_PREC_FP32 && ly.wsplit[0] && ly.wsplit[1] && a.UT <= 8;
         if (split) {  // the split kernels run 8-wave workgroups; their own weights and k-stage count
             const bool f16 = prec == DSP_PREC_FP16X3;
             a.wpk0 = f16 ? ly.wsplit16[0] : ly.wsplit[0]; a.wpk1 = f16 ? ly.wsplit16[1] : ly.wsplit[1];

@@ -39,7 +39,8 @@ struct LstmArgs {
     int Ipad, H, Hp, T, Fout;
     int nqx_used;          // x-part k-groups that carry real features (the rest of Ipad/8 is zero padding)
     int NQ;                // k-groups per unit tile in wpk: (Ipad+Hp)/8 padded to a multiple of 4 (zero weights)
-    int UT, SG;            // unit tiles (Hp/32), site groups (of two 32-site tiles) per workgroup; block = 64*UT*SG threads
+    int UT, SG;            // unit tiles (Hp/32), site groups (of two 32-site tiles) per workgroup
+    int NP;                // passes over the unit tiles per time step (1, or 2 for UT = 16); block = 64*(UT/NP)*SG threads
     int init_mode;         // DSP_INIT_*
     int stream_base;       // philox stream of (lstm, layer, dir=0, h): lstm*64 + layer*4
     int flags;             // bit 8: stamp this launch (DSP_TRACE builds only)

@@ -173,8 +173,7 @@ __device__ __forceinline__ f32x4 init_state4(const float* src, int mode, long lo
 }
 
 // ------------------------------------------------------------------------------------------------
-// dsp_lstm_kernel<SPARSE, UPW, SPW>: one direction of one LSTM layer, all T steps, for 32*SPW*SG sites per
-// workgroup.  blockIdx.x & 1 = direction: with the observed block -> XCD (b % 8) placement even XCDs run the
+// dsp_lstm_kernel<SPARSE, NP>: one direction of one LSTM layer, all T steps, for 64*SG sites per workgroup.  blockIdx.x & 1 = direction: with the observed block -> XCD (b % 8) placement even XCDs run the
 // forward and odd XCDs the backward direction, so each XCD's 4 MiB L2 holds one direction's weights.
 // (History, all measured on MI355X: first kernel -- 8 waves, h in LDS, one-deep prefetch -- 76 % of the fp32 MFMA
 // peak; ablation showed operand loads, not MFMA issue, cost ~25 %.  One wave per SIMD with register rings 90.4 %;
@@ -248,23 +247,21 @@ extern "C" int dsp_k_trace_read(unsigned long long* t, unsigned int* hw) {
 #define TSTAMP(k) do { } while (0)
 #endif
 
-template <bool SPARSE, int UPW, int SPW>
+template <bool SPARSE, int NP>
 __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
-    static_assert(UPW * SPW == 2, "a wave owns 8 accumulator tiles");
-    // (a <1,1> variant -- 4 accumulator tiles, four waves per SIMD, 128 registers -- was measured on the front ends:
-    // +3 % on those two launches, i.e. 0.1 % of the forward; not kept)
-    constexpr int NF = UPW * 4;            // A fragments per k-group
-    constexpr int DA = UPW == 1 ? 4 : 2;   // A ring depth in k-groups (64 registers either way)
-    constexpr int DB = 4;                  // B ring depth
+    // NP = passes over the unit tiles per time step: 1 for hidden sizes up to 256 (8 unit tiles, one per wave); 2 for
+    // 257..512 (16 unit tiles: a wave computes unit tile w in pass 0 and w + 8 in pass 1, one barrier per step)
+    constexpr int NF = 4;                  // A fragments (gates) per k-group
+    constexpr int DA = 4, DB = 4;          // ring depths in k-groups
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nthr = blockDim.x;
-    f32x4* c_lds = (f32x4*)smem;           // [UPW*SPW*4 groups][nthr] float4
-    f32x4* b_lds = c_lds + UPW * SPW * 4 * nthr;  // [unit tile][aa][gate][half] float4
+    f32x4* c_lds = (f32x4*)smem;           // [NP][2 site tiles][4 groups][nthr] float4
+    f32x4* b_lds = c_lds + NP * 8 * nthr;  // [unit tile][aa][gate][half] float4
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const uint32_t voff = (uint32_t)lane * 16u;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int UTW = a.UT / UPW;            // waves per site group
+    const int UTW = a.UT / NP;             // waves per site group = unit tiles per pass
     const int ug = w % UTW, sg = w / UTW;
     const int dir = blockIdx.x & 1;
     const int grp = blockIdx.x >> 1;
@@ -275,11 +272,11 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
     const int F4 = a.Fout >> 2;
     const uint32_t xrow = (uint32_t)(a.Ipad >> 2) * 512u;  // bytes of one (tile, t) block of the input
     const uint32_t orow = (uint32_t)F4 * 512u;             // bytes of one (tile, t) block of the output
-    const uint32_t wstride = (uint32_t)NQ * 4096u;         // bytes between the unit tiles of a wave
+    const uint32_t pstride = (uint32_t)UTW * (uint32_t)NQ * 4096u;  // bytes between a wave's unit tiles of two passes
 
-    // first site tile of this wave; its SPW tiles are adjacent, so one descriptor per buffer serves them
-    const long long gt0 = ((long long)grp * a.SG + sg) * SPW;
-    const __amdgpu_buffer_rsrc_t rw = make_rsrc((const char*)(dir ? a.wpk1 : a.wpk0) + (size_t)(ug * UPW) * NQ * 4096);
+    // first site tile of this wave; its two tiles are adjacent, so one descriptor per buffer serves both
+    const long long gt0 = ((long long)grp * a.SG + sg) * 2;
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc((const char*)(dir ? a.wpk1 : a.wpk0) + (size_t)ug * NQ * 4096);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)a.x + (size_t)gt0 * T * xrow);
     const __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)a.out + (size_t)gt0 * T * orow + (size_t)dir * HQ * 512);
     const __amdgpu_buffer_rsrc_t rh0 = make_rsrc((const char*)a.h0buf + (size_t)gt0 * orow + (size_t)dir * HQ * 512);
@@ -291,10 +288,10 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
         b_lds[i] = bias4[g * HQ + ut * 8 + 2 * aa + h];
     }
 #pragma unroll
-    for (int uu = 0; uu < UPW; ++uu) {
-        const int u = ug * UPW + uu;
+    for (int p = 0; p < NP; ++p) {
+        const int u = ug + p * UTW;
 #pragma unroll
-        for (int m = 0; m < SPW; ++m) {
+        for (int m = 0; m < 2; ++m) {
             const long long site = (gt0 + m) * 32 + ls;
 #pragma unroll
             for (int aa = 0; aa < 4; ++aa) {
@@ -307,7 +304,7 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
                                      (uint32_t)(a.stream_base + dir * 2 + 1));
                 }
                 bst16(rh0, voff + aa * 1024u, (uint32_t)m * orow + (uint32_t)u * 4096u, hv);
-                c_lds[((uu * SPW + m) * 4 + aa) * nthr + tid] = cv;
+                c_lds[((p * 2 + m) * 4 + aa) * nthr + tid] = cv;
             }
         }
     }
@@ -316,85 +313,76 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
     // B-operand source of a step (all uniform): x_t from rx, h_{t-1} from the K4 output of the previous step
     // (ro) or, at step 0, from the h0 scratch (rh0).  Offsets are biased so that both parts are "base + q*1024".
     __amdgpu_buffer_rsrc_t rhp = rh0;
-    uint32_t xo[SPW], ho[SPW];
+    uint32_t xo[2], ho[2];
     auto set_bases = [&](int step) __attribute__((always_inline)) {
         const int t = dir ? (T - 1 - step) : step;
         const int tp = dir ? (t + 1) : (t - 1);
         rhp = step == 0 ? rh0 : ro;
 #pragma unroll
-        for (int m = 0; m < SPW; ++m) {
+        for (int m = 0; m < 2; ++m) {
             xo[m] = (uint32_t)(m * T + t) * xrow;
             ho[m] = (step == 0 ? (uint32_t)m * orow : (uint32_t)(m * T + tp) * orow) - (uint32_t)nqx * 1024u;
         }
     };
 
-    f32x4 A[DA][NF], B[DB][SPW];
-    f32x16 acc[UPW][4][SPW];
-    auto loadB = [&](f32x4 (&Bs)[SPW], int q) __attribute__((always_inline)) {
+    f32x4 A[DA][NF], B[DB][2];
+    f32x16 acc[4][2];
+    auto loadB = [&](f32x4 (&Bs)[2], int q) __attribute__((always_inline)) {
         const int qc = q < nq ? q : nq - 1;  // padded k-groups have zero weights: any finite B will do
         const bool isx = qc < nqx;
         const __amdgpu_buffer_rsrc_t r = isx ? rx : rhp;
 #pragma unroll
-        for (int m = 0; m < SPW; ++m) Bs[m] = bld16(r, voff, (isx ? xo[m] : ho[m]) + (uint32_t)qc * 1024u);
+        for (int m = 0; m < 2; ++m) Bs[m] = bld16(r, voff, (isx ? xo[m] : ho[m]) + (uint32_t)qc * 1024u);
     };
-    auto ldA = [&](int j, int q) __attribute__((always_inline)) {  // fragment j = (unit tile j/4, gate j%4) of k-group q
-        return bld16(rw, voff + (uint32_t)(j & 3) * 1024u, (uint32_t)(j >> 2) * wstride + (uint32_t)q * 4096u);
+    // weights of (this pass's unit tile, gate g, k-group q); k-groups >= NQ belong to the NEXT pass (or the next step's
+    // first pass): po_cur / po_next are the byte offsets of the two unit tiles
+    uint32_t po_cur = 0, po_next = NP > 1 ? pstride : 0;
+    auto ldA = [&](int g, int q) __attribute__((always_inline)) {
+        const uint32_t so = q < NQ ? po_cur + (uint32_t)q * 4096u : po_next + (uint32_t)(q - NQ) * 4096u;
+        return bld16(rw, voff + (uint32_t)g * 1024u, so);
     };
 #define QW(x) ((x) < NQ ? (x) : (x) - NQ)
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int nqx_used = a.nqx_used;
-    // one k-group (ring slots are compile-time: QS = q mod 4): the MFMAs of fragment j, then the refill of fragment
-    // j-1 for k-group q+DA; the last fragment of the PREVIOUS stage's slot is refilled after fragment 0.
+    // one k-group (ring slots are compile-time: QS = q mod 4): the 8 MFMAs of gate fragment g, then the refill of
+    // fragment g-1 for k-group q+4; fragment 3 of the PREVIOUS stage's slot is refilled after fragment 0.
     // first = true: the very first k-step of a time step accumulates onto literal zero.
     auto stage = [&](auto qs, int q, auto first) __attribute__((always_inline)) {
         constexpr int QS = decltype(qs)::value;
         constexpr int sa = QS % DA, sp = (QS + DA - 1) % DA, sb = QS % DB;
-        const int qa = QW(q + DA), qp = QW(q + DA - 1);
         const bool live = !SPARSE || q < nqx_used || (q >= nqx && q < nq);  // wave-uniform
-        // fragments are processed in groups of FG with the k-steps outermost, so that consecutive MFMAs never share an
-        // accumulator: FG = 1 for SPW = 2 (the two site tiles alternate), FG = 2 for SPW = 1 (two gates alternate)
-        constexpr int FG = SPW == 1 ? 2 : 1;
 #pragma unroll
-        for (int j0 = 0; j0 < NF; j0 += FG) {
+        for (int g = 0; g < NF; ++g) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (SPARSE && !live) break;
 #pragma unroll
-                for (int f = 0; f < FG; ++f) {
-                    const int j = j0 + f;
-#pragma unroll
-                    for (int m = 0; m < SPW; ++m) {
-                        if (decltype(first)::value && i == 0)
-                            acc[j >> 2][j & 3][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[sa][j][i], B[sb][m][i], zero16, 0, 0, 0);
-                        else
-                            acc[j >> 2][j & 3][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[sa][j][i], B[sb][m][i], acc[j >> 2][j & 3][m], 0, 0, 0);
-                    }
+                for (int m = 0; m < 2; ++m) {
+                    if (decltype(first)::value && i == 0)
+                        acc[g][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[sa][g][i], B[sb][m][i], zero16, 0, 0, 0);
+                    else
+                        acc[g][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[sa][g][i], B[sb][m][i], acc[g][m], 0, 0, 0);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);  // keep "MFMAs of a fragment group, then its refills" in program order
-#pragma unroll
-            for (int f = 0; f < FG; ++f) {
-                if (j0 == 0) A[sp][NF - FG + f] = ldA(NF - FG + f, qp);
-                else A[sa][j0 - FG + f] = ldA(j0 - FG + f, qa);
-            }
+            __builtin_amdgcn_sched_barrier(0);  // keep "MFMAs of a fragment, then one refill" in program order
+            if (g == 0) A[sp][NF - 1] = ldA(NF - 1, q + DA - 1);
+            else A[sa][g - 1] = ldA(g - 1, q + DA);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
     auto stage4 = [&](int q, auto first) __attribute__((always_inline)) {
-        stage(ic<0>{}, q + 0, first); loadB(B[0 % DB], QW(q + 0 + DB)); __builtin_amdgcn_sched_barrier(0);
-        stage(ic<1>{}, q + 1, std::false_type{}); loadB(B[1 % DB], QW(q + 1 + DB)); __builtin_amdgcn_sched_barrier(0);
-        stage(ic<2>{}, q + 2, std::false_type{}); loadB(B[2 % DB], QW(q + 2 + DB)); __builtin_amdgcn_sched_barrier(0);
-        stage(ic<3>{}, q + 3, std::false_type{}); loadB(B[3 % DB], QW(q + 3 + DB)); __builtin_amdgcn_sched_barrier(0);
+        stage(ic<0>{}, q + 0, first); loadB(B[0], QW(q + 0 + DB)); __builtin_amdgcn_sched_barrier(0);
+        stage(ic<1>{}, q + 1, std::false_type{}); loadB(B[1], QW(q + 1 + DB)); __builtin_amdgcn_sched_barrier(0);
+        stage(ic<2>{}, q + 2, std::false_type{}); loadB(B[2], QW(q + 2 + DB)); __builtin_amdgcn_sched_barrier(0);
+        stage(ic<3>{}, q + 3, std::false_type{}); loadB(B[3], QW(q + 3 + DB)); __builtin_amdgcn_sched_barrier(0);
     };
 
     set_bases(0);
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-        if (d < DA) {
 #pragma unroll
-            for (int j = 0; j < NF; ++j) A[d][j] = ldA(j, d);
-        }
-        if (d < DB) loadB(B[d], d);
+        for (int g = 0; g < NF; ++g) A[d][g] = ldA(g, d);
+        loadB(B[d], d);
     }
 
 #ifdef DSP_TRACE
@@ -408,41 +396,42 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
         TSTAMP(0);
         if (step > 0) barrier_after_global_stores();  // h_{t-1} of every wave stored before anyone reads it back
         TSTAMP(1);
-        stage4(0, std::true_type{});
-        for (int q = 4; q < NQ - 4; q += 4) stage4(q, std::false_type{});
-        set_bases(step + 1 < T ? step + 1 : step);  // B requests from here on belong to the next step
-        stage4(NQ - 4, std::false_type{});
-        // (stage NQ-1 leaves the last fragment of its ring slot, for the next step's k-group DA-1, to "the next
-        // stage": request it here, ahead of the cell phase)
 #pragma unroll
-        for (int f = SPW == 1 ? NF - 2 : NF - 1; f < NF; ++f) A[DA - 1][f] = ldA(f, DA - 1);
-        TSTAMP(2);
+        for (int p = 0; p < NP; ++p) {
+            const int u = ug + p * UTW;
+            if (NP > 1) { po_cur = (uint32_t)p * pstride; po_next = p + 1 < NP ? (uint32_t)(p + 1) * pstride : 0u; }
+            stage4(0, std::true_type{});
+            for (int q = 4; q < NQ - 4; q += 4) stage4(q, std::false_type{});
+            // B requests from here on belong to the next pass of this step (same rows) or to the next step
+            if (p == NP - 1) set_bases(step + 1 < T ? step + 1 : step);
+            stage4(NQ - 4, std::false_type{});
+            // (stage NQ-1 leaves the last fragment of its ring slot, for the next k-loop's k-group 3, to "the next
+            // stage": request it here, ahead of the cell phase)
+            A[DA - 1][NF - 1] = ldA(NF - 1, NQ + DA - 1);
+            if (p == NP - 1) TSTAMP(2);
 
-        // LSTM cell.  b_lds holds the PRE-SCALED biases (-log2e*b for i,f,o; -2*log2e*b for g), so
-        // sigmoid(x+b) = rcp(1 + exp2(fma(x, -log2e, b'))) costs no extra instruction for the bias.
-#pragma unroll
-        for (int uu = 0; uu < UPW; ++uu) {
-            const int u = ug * UPW + uu;
+            // LSTM cell.  b_lds holds the PRE-SCALED biases (-log2e*b for i,f,o; -2*log2e*b for g), so
+            // sigmoid(x+b) = rcp(1 + exp2(fma(x, -log2e, b'))) costs no extra instruction for the bias.
             const f32x4* b_my = b_lds + (size_t)u * 32 + half;  // + aa*8 + gate*2
 #pragma unroll
             for (int aa = 0; aa < 4; ++aa) {
                 const f32x4 bi = b_my[aa * 8 + 0], bf = b_my[aa * 8 + 2], bg = b_my[aa * 8 + 4], bo = b_my[aa * 8 + 6];
 #pragma unroll
-                for (int m = 0; m < SPW; ++m) {
-                    f32x4 cv = c_lds[((uu * SPW + m) * 4 + aa) * nthr + tid];
+                for (int m = 0; m < 2; ++m) {
+                    f32x4 cv = c_lds[((p * 2 + m) * 4 + aa) * nthr + tid];
                     f32x4 hv;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int r = 4 * aa + i;
-                        const float ig = sigmoid_pre(acc[uu][0][m][r], bi[i]);
-                        const float fg = sigmoid_pre(acc[uu][1][m][r], bf[i]);
-                        const float gg = tanh_pre(acc[uu][2][m][r], bg[i]);
-                        const float og = sigmoid_pre(acc[uu][3][m][r], bo[i]);
+                        const float ig = sigmoid_pre(acc[0][m][r], bi[i]);
+                        const float fg = sigmoid_pre(acc[1][m][r], bf[i]);
+                        const float gg = tanh_pre(acc[2][m][r], bg[i]);
+                        const float og = sigmoid_pre(acc[3][m][r], bo[i]);
                         const float cn = __builtin_fmaf(fg, cv[i], ig * gg);
                         cv[i] = cn;
                         hv[i] = og * fast_tanh(cn);
                     }
-                    c_lds[((uu * SPW + m) * 4 + aa) * nthr + tid] = cv;
+                    c_lds[((p * 2 + m) * 4 + aa) * nthr + tid] = cv;
                     bst16(ro, voff + aa * 1024u, (uint32_t)(m * T + t) * orow + (uint32_t)u * 4096u, hv);
                 }
             }
@@ -836,7 +825,8 @@ __global__ __launch_bounds__(256) void dsp_head_kernel(HeadArgs a) {
 // launch wrappers (called from dsp_capi.cpp; keep all <<<>>> syntax in this translation unit)
 // ------------------------------------------------------------------------------------------------
 extern "C" int dsp_k_init(void) {
-    const void* fns[] = {(const void*)dsp_lstm_kernel<false, 1, 2>, (const void*)dsp_lstm_kernel<true, 1, 2>,
+    const void* fns[] = {(const void*)dsp_lstm_kernel<false, 1>, (const void*)dsp_lstm_kernel<true, 1>,
+                         (const void*)dsp_lstm_kernel<false, 2>, (const void*)dsp_lstm_kernel<true, 2>,
                          (const void*)dsp_lstm6_kernel<6>, (const void*)dsp_lstm6_kernel<9>, (const void*)dsp_lstm6_kernel<3>};
     for (const void* f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -852,16 +842,22 @@ extern "C" int dsp_k_pack(const PackArgs* a, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-// a wave owns one unit tile x two site tiles; a->SG site groups (of two tiles) per workgroup
+// a wave owns one unit tile (per pass) x two site tiles; a->SG site groups (of two tiles) per workgroup; a->NP passes
 extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
-    const int threads = a->UT * a->SG * 64;
+    const int np = a->NP == 2 ? 2 : 1;
+    const int threads = (a->UT / np) * a->SG * 64;
     const unsigned groups = (unsigned)(a->NTp / (a->SG * 2));
-    const size_t lds = (size_t)8 * threads * 16 + (size_t)a->Hp * 16;
-    if ((a->Ipad >> 3) < 4 || threads > 512) return (int)hipErrorInvalidValue;  // see the SPARSE note: four x-part k-groups are required
+    const size_t lds = (size_t)np * 8 * threads * 16 + (size_t)a->Hp * 16;
+    if ((a->Ipad >> 3) < 4 || threads > 512 || a->UT % np) return (int)hipErrorInvalidValue;  // see the SPARSE note: four x-part k-groups are required
     const bool sparse = a->nqx_used < (a->Ipad >> 3) || a->NQ > ((a->Ipad + a->Hp) >> 3);
     const dim3 g(groups * 2), b(threads);
-    if (sparse) hipLaunchKernelGGL((dsp_lstm_kernel<true, 1, 2>), g, b, lds, s, *a);
-    else hipLaunchKernelGGL((dsp_lstm_kernel<false, 1, 2>), g, b, lds, s, *a);
+    if (np == 2) {
+        if (sparse) hipLaunchKernelGGL((dsp_lstm_kernel<true, 2>), g, b, lds, s, *a);
+        else hipLaunchKernelGGL((dsp_lstm_kernel<false, 2>), g, b, lds, s, *a);
+    } else {
+        if (sparse) hipLaunchKernelGGL((dsp_lstm_kernel<true, 1>), g, b, lds, s, *a);
+        else hipLaunchKernelGGL((dsp_lstm_kernel<false, 1>), g, b, lds, s, *a);
+    }
     return (int)hipGetLastError();
 }
 

@@ -125,7 +125,7 @@ def test_errors_are_loud():
     with pytest.raises(ValueError):
         ModelBiLSTM(module="bogus")
     with pytest.raises(ValueError):
-        ModelBiLSTM(hidden_size=258).cuda(0)  # the one documented limit: hid_rnn <= 256 (include/dsp_amd.h)
+        ModelBiLSTM(hidden_size=514).cuda(0)  # the one documented limit: hid_rnn <= 512 (include/dsp_amd.h)
     cfg = onp.OracleConfig()
     m = build_model(cfg, onp.make_weights(cfg, 1))
     cpu_ins = [torch.from_numpy(a) for a in onp.make_inputs(cfg, 4, 2)]
@@ -334,3 +334,29 @@ def test_philox_states_at_several_batches_are_deterministic_and_match_the_oracle
         worst = max(worst, float(np.abs(p[i].cpu().numpy() - po[0]).max()))
     print("philox full-batch: max|dprob| vs oracle on %d strided sites = %.3e" % (len(idx.tolist()[::8]), worst))
     assert worst <= TOL_TIGHT
+
+
+@pytest.mark.parametrize("hidden,module,n", [(320, "both_bilstm", 70), (384, "seq_bilstm", 130), (512, "both_bilstm", 70),
+                                             (512, "signal_bilstm", 33), (258, "both_bilstm", 200)])
+def test_hidden_sizes_above_256(hidden, module, n):
+    """hid_rnn > 256 (models.py:103-128 accepts any hidden_size): the hidden state is padded to 16 unit tiles and every
+    wave of the LSTM kernel computes two of them per step (dsp_lstm_kernel<.., NP = 2>); against the oracle with explicit
+    N(0,1) states, and with in-kernel Philox states (non-zero initial states through the h0 scratch)"""
+    torch = _torch()
+    from oracle import c_oracle as oc
+    from oracle import forward_np as onp
+    cfg = onp.OracleConfig(hidden_size=hidden, num_layers1=2, module=module)
+    w = onp.make_weights(cfg, 77, 2.0)
+    ins = onp.make_inputs(cfg, n, 78)
+    st = onp.make_init_states(cfg, n, 79)
+    m = build_model(cfg, w)
+    logits, probs = m.forward(*to_dev(ins), init_states={k: torch.from_numpy(v).cuda(0) for k, v in st.items()})
+    _, po = oc.forward(cfg, w, *ins, states=st, init_mode="explicit")
+    d = np.abs(probs.cpu().numpy() - po).max()
+    m.init_state, m.seed = "randn", 21
+    _, pp = m.forward(*to_dev(ins))
+    _, pq = oc.forward(cfg, w, *ins, init_mode="philox", seed=21)
+    d2 = np.abs(pp.cpu().numpy() - pq).max()
+    print("hidden %d %s: max|dprob| = %.3e (explicit states), %.3e (Philox states)" % (hidden, module, d, d2))
+    assert d <= TOL_TIGHT and d2 <= TOL_TIGHT
+    assert torch.equal(m.forward(*to_dev(ins))[1], pp)
