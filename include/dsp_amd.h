@@ -107,7 +107,13 @@ size_t dsp_workspace_bytes(const dsp_model* m, int64_t max_sites);
  *   signals [n, seq_len, signal_len]  fp32
  *   logits, probs [n, num_classes]    fp32 (either may be NULL);  labels [n] uint8 argmax (may be NULL)
  * All pointers are DEVICE pointers on the handle's device.  Asynchronous on `stream` (hipStream_t);
- * unused inputs of a branch that the module does not have may be NULL. */
+ * unused inputs of a branch that the module does not have may be NULL.
+ * Threading / ownership: a handle owns ONE scratch workspace (activations of the forward in flight), so forwards on
+ * the same handle must be issued by one host thread at a time and are ordered by the streams they are given; use one
+ * handle per stream for concurrent forwards (the repacked weights are 19 MB).  Launch geometry is derived per call and
+ * never stored in the handle.  hidden_size <= 512 is the one model-shape limit of this build (one workgroup holds a
+ * direction's whole hidden state: 8 waves x 2 passes x 32 units); the split-precision modes cover hidden_size <= 256
+ * and fall back to the fp32 kernels above it. */
 int32_t dsp_forward(dsp_model* m, void* stream, int64_t n_sites, const void* kmer, int32_t kmer_dtype,
                     const float* means, const float* stds, const void* lens, int32_t lens_dtype,
                     const float* signals, const dsp_init_state* init, float* logits, float* probs,

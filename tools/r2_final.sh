@@ -1,0 +1,15 @@
+#!/bin/bash
+# round-2 measurement set (GPU box): profiles of both bench configurations, the bench lines themselves, the CLI pipelines
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+mkdir -p gpurun_out/r2
+bash tools/profile.sh r2 5 > gpurun_out/prof_r2.log 2>&1
+bash tools/profile.sh r2_cfg3 5 --model_type seq_bilstm --layernum1 2 > gpurun_out/prof_r2_cfg3.log 2>&1
+python3 bench.py > gpurun_out/r2/bench_default.json 2> gpurun_out/r2/bench_default.err
+python3 bench.py --model_type seq_bilstm --layernum1 2 > gpurun_out/r2/bench_cfg3.json 2> gpurun_out/r2/bench_cfg3.err
+python3 bench.py --gpus 2 --steps 20 --no_cpu_baseline > gpurun_out/r2/bench_2ranks_shared_gpu.json 2> gpurun_out/r2/bench_2ranks.err
+python3 tools/per_launch.py --reps 10 > gpurun_out/r2/per_launch_hip_events.txt 2>&1
+python3 tools/per_launch.py --reps 10 --model_type seq_bilstm --layernum1 2 > gpurun_out/r2/per_launch_hip_events_cfg3.txt 2>&1
+python3 tools/bench_pipeline.py 100000 4000000 > gpurun_out/r2/pipeline_cli.jsonl 2> gpurun_out/r2/pipeline_cli.err
+python3 tools/bench_reads_pipeline.py > gpurun_out/r2/pipeline_reads.jsonl 2> gpurun_out/r2/pipeline_reads.err
+python3 tools/bench_freq.py > gpurun_out/r2/freq_host.txt 2>&1
+tail -n 2 gpurun_out/r2/*.json gpurun_out/r2/*.jsonl | cut -c1-400
