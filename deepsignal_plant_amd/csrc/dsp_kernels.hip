@@ -205,10 +205,11 @@ __device__ __forceinline__ f32x4 init_state4(const float* src, int mode, long lo
 // SPARSE = true (front-end layers): k-groups that are pure zero padding -- the x part padded from 8/16 to 32
 // features so that the first four k-groups never depend on h_t, and the tail padded to a multiple of four -- keep
 // their (branch-free) operand requests but skip their MFMAs behind a wave-uniform test.
-// The padding to four x-part k-groups is a CORRECTNESS requirement, not a convenience: the B ring requests four
-// k-groups across a step boundary, i.e. before the cell phase of step t has stored h_t.  A request that touched an
-// h_t row early would pull its stale lines into this CU's vector L1, and the re-request after the barrier would hit
-// them (measured in round 2: sites 12-15 / 28-31 of a tile wrong, non-deterministically, at full batch only).
+// The padding to four x-part k-groups keeps every cross-step request off rows that do not exist yet: the B ring
+// requests four k-groups across a step boundary, i.e. before the cell phase of step t has stored h_t, and a request
+// that touched an h_t row early could leave stale lines in this CU's vector L1 for the re-request after the barrier.
+// (A 16-feature padding with a re-request of the h-part slots after the barrier was measured in round 2: +0.6 % on the
+// front-end launches, noise level; not kept.)
 // ------------------------------------------------------------------------------------------------
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
