@@ -10,7 +10,7 @@ import pytest
 
 from deepsignal_plant_amd import reads as dsp_reads
 from oracle import extract_np as ox
-from tests.helpers import GOLDEN
+from tests.helpers import GOLDEN, ROOT
 
 F6 = np.load(os.path.join(GOLDEN, "f6_extract.npz"))
 CASES = ast.literal_eval(str(F6["cases"]))
@@ -77,3 +77,18 @@ def test_rows_feed_the_tsv_parser_identically():
     for k in ("kmer", "means", "stds", "lens", "signals", "labels"):
         assert np.array_equal(getattr(rows, k), arr[k]), k
     assert [rows.sampleinfo(i) for i in range(rows.n)] == arr["sampleinfo"]
+
+
+def test_mad_scale_constant_is_the_call_statsmodels_makes():
+    """statsmodels is not in the image; its robust.mad divides by c = Gaussian.ppf(3/4.) with Gaussian = scipy.stats.norm
+    (statsmodels/robust/scale.py).  scipy IS here: the constant restated in the oracle, in the fixture generator and in
+    csrc/dsp_extract.hip (kMadC) is that very call's result, bit for bit."""
+    import re
+    from scipy.stats import norm
+    from oracle import extract_np as ox
+    c = float(norm.ppf(3 / 4.))
+    assert c == ox.MAD_C == 0.6744897501960817
+    hip = open(os.path.join(ROOT, "deepsignal_plant_amd", "csrc", "dsp_extract.hip")).read()
+    assert float(re.search(r"kMadC = ([0-9.]+);", hip).group(1)) == c
+    gen = open(os.path.join(ROOT, "tests", "golden", "make_golden_extract.py")).read()
+    assert float(re.search(r"def _mad\(a, c=([0-9.]+)\)", gen).group(1)) == c
