@@ -44,6 +44,27 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // Philox4x32-10 (Salmon et al., SC'11) + Box-Muller: the in-kernel stand-in for torch.randn in
 // init_hidden (models.py:169-176).  Key = seed; counter = (site_lo, site_hi, stream, unit/4).
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sincos2pi(float u, float& sn, float& cs) {  // u in [0, 1)
+    const float k = __builtin_rintf(u * 4.0f);              // quadrant 0..4
+    const float t = 6.283185307179586f * (u - 0.25f * k);   // the subtraction is exact; |t| <= pi/4
+    const float t2 = t * t;
+    const float ps = t * __builtin_fmaf(t2, __builtin_fmaf(t2, __builtin_fmaf(t2, __builtin_fmaf(t2, 2.7557319e-6f, -1.9841270e-4f),
+                                                                            8.3333333e-3f), -1.6666667e-1f), 1.0f);
+    const float pc = __builtin_fmaf(t2, __builtin_fmaf(t2, __builtin_fmaf(t2, __builtin_fmaf(t2, __builtin_fmaf(t2, -2.7557319e-7f, 2.4801587e-5f),
+                                                                                          -1.3888889e-3f), 4.1666667e-2f), -0.5f), 1.0f);
+    const int q = (int)k & 3;   // angle = t + q * pi/2
+    sn = q == 0 ? ps : (q == 1 ? pc : (q == 2 ? -ps : -pc));
+    cs = q == 0 ? pc : (q == 1 ? -ps : (q == 2 ? -pc : ps));
+}
+__device__ __forceinline__ void bm_pair(uint32_t a, uint32_t b, float& z0, float& z1) {
+    const float u1 = ((float)(a >> 9) + 0.5f) * (1.0f / 8388608.0f);
+    const float u2 = ((float)(b >> 9) + 0.5f) * (1.0f / 8388608.0f);
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // sqrt(-2 ln u1), v_log_f32 = log2
+    float sn, cs;
+    sincos2pi(u2, sn, cs);
+    z0 = r * cs; z1 = r * sn;
+}
+
 __device__ __forceinline__ f32x4 philox_normal4(uint64_t seed, uint64_t site, uint32_t stream, uint32_t group) {
     uint32_t c0 = (uint32_t)site, c1 = (uint32_t)(site >> 32), c2 = stream, c3 = group;
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
@@ -55,24 +76,14 @@ __device__ __forceinline__ f32x4 philox_normal4(uint64_t seed, uint64_t site, ui
         c0 = n0; c1 = l1; c2 = n2; c3 = l0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
-    f32x4 o;
-    {
-        const float u1 = ((float)(c0 >> 9) + 0.5f) * (1.0f / 8388608.0f);
-        const float u2 = ((float)(c1 >> 9) + 0.5f) * (1.0f / 8388608.0f);
-        const float r = sqrtf(-2.0f * logf(u1));
-        float s, c;
-        sincosf(6.283185307179586f * u2, &s, &c);
-        o[0] = r * c; o[1] = r * s;
-    }
-    {
-        const float u1 = ((float)(c2 >> 9) + 0.5f) * (1.0f / 8388608.0f);
-        const float u2 = ((float)(c3 >> 9) + 0.5f) * (1.0f / 8388608.0f);
-        const float r = sqrtf(-2.0f * logf(u1));
-        float s, c;
-        sincosf(6.283185307179586f * u2, &s, &c);
-        o[2] = r * c; o[3] = r * s;
-    }
-    return o;
+    // Box-Muller on (c0, c1) and (c2, c3).  The transcendental work runs once per workgroup and time step 0, but for
+    // 16 such calls per lane it was 0.9 % of the forward with the OCML logf / sincosf (generic range reduction): here
+    // ln(u) = ln2 * v_log_f32(u), v_sqrt_f32, and sin / cos of 2*pi*u by quadrant reduction + two short polynomials on
+    // [-pi/4, pi/4] (errors < 1 ulp of the result: within 3e-7 of the oracle's libm evaluation of the same formula).
+    float z0, z1, z2, z3;
+    bm_pair(c0, c1, z0, z1);
+    bm_pair(c2, c3, z2, z3);
+    return f32x4{z0, z1, z2, z3};
 }
 
 // activations with the bias folded into the exp2 argument: bp = -log2e*b (sigmoid) / -2*log2e*b (tanh)
