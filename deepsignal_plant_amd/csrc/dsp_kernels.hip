@@ -782,25 +782,38 @@ __global__ __launch_bounds__(256) void dsp_head_kernel(HeadArgs a) {
     const f32x4* xf = x4 + ((tile * a.T + (a.T - 1)) * F4 + half) * 32 + ls;
     const f32x4* xr = x4 + ((tile * a.T + 0) * F4 + half) * 32 + ls;
     const f32x4* bias4 = (const f32x4*)a.b1;
-    for (int rt = w; rt < (a.Hp >> 5); rt += 4) {
-        const f32x4* wq = (const f32x4*)a.w1pk + (size_t)rt * nq * 64 + lane;
-        f32x16 acc;
+    // a wave takes its row tiles two at a time (they share the B fragment: 8 MFMAs per 3 fragment loads) and requests
+    // the fragments of k-group q+1 before the MFMAs of group q (round 1: one tile, one k-group at a time, 47 % of peak)
+    const int NRT = a.Hp >> 5;
+    for (int rt = w; rt < NRT; rt += 8) {
+        const bool two = rt + 4 < NRT;
+        const f32x4* wq0 = (const f32x4*)a.w1pk + (size_t)rt * nq * 64 + lane;
+        const f32x4* wq1 = two ? wq0 + (size_t)4 * nq * 64 : wq0;
+        f32x16 acc0, acc1;
 #pragma unroll
         for (int aa = 0; aa < 4; ++aa) {
-            const f32x4 b = bias4[rt * 8 + 2 * aa + half];
+            const f32x4 b0 = bias4[rt * 8 + 2 * aa + half];
+            const f32x4 b1 = two ? bias4[(rt + 4) * 8 + 2 * aa + half] : b0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[4 * aa + i] = b[i];
+            for (int i = 0; i < 4; ++i) { acc0[4 * aa + i] = b0[i]; acc1[4 * aa + i] = b1[i]; }
         }
+        f32x4 A0n = wq0[0], A1n = wq1[0], Bn = xf[0];
         for (int q = 0; q < nq; ++q) {
-            const f32x4 A = wq[(size_t)q * 64];
-            const f32x4 B = (q < nqf) ? xf[(size_t)q * 64] : xr[(size_t)q * 64];
+            const f32x4 A0 = A0n, A1 = A1n, B = Bn;
+            const int qn = q + 1 < nq ? q + 1 : q;
+            A0n = wq0[(size_t)qn * 64]; A1n = wq1[(size_t)qn * 64];
+            Bn = (qn < nqf) ? xf[(size_t)qn * 64] : xr[(size_t)qn * 64];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[i], B[i], acc, 0, 0, 0);
+            for (int i = 0; i < 4; ++i) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[i], B[i], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[i], B[i], acc1, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = rt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-            hid[row * 32 + ls] = fmaxf(acc[r], 0.f);
+            hid[row * 32 + ls] = fmaxf(acc0[r], 0.f);
+            if (two) hid[(row + 128) * 32 + ls] = fmaxf(acc1[r], 0.f);
         }
     }
     __syncthreads();
