@@ -40,12 +40,18 @@ KERNEL_SOURCES = ("deepsignal_plant_amd/csrc/dsp_kernels.hip", "deepsignal_plant
 
 
 def kernel_source_hash():
-    """sha256 over the sources that determine the forward's kernels and launch geometry: a committed PMC traffic
-    figure is only quoted while it was measured on exactly these sources."""
+    """sha256 over the CODE of the sources that determine the forward's kernels and launch geometry (// comments and
+    blank lines are dropped first, so that editing a comment does not orphan a measurement): a committed PMC traffic
+    figure is only quoted while it was measured on exactly this code."""
+    import re
     h = hashlib.sha256()
     for rel in KERNEL_SOURCES:
-        with open(os.path.join(ROOT, rel), "rb") as f:
-            h.update(f.read())
+        with open(os.path.join(ROOT, rel), "r") as f:
+            for line in f:
+                line = re.sub(r"//.*$", "", line).strip()
+                if line:
+                    h.update(line.encode())
+                    h.update(b"\n")
     return h.hexdigest()[:16]
 
 

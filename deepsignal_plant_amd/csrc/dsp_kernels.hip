@@ -184,26 +184,26 @@ __device__ __forceinline__ f32x4 init_state4(const float* src, int mode, long lo
 }
 
 // ------------------------------------------------------------------------------------------------
-// dsp_lstm_kernel<SPARSE, NP>: one direction of one LSTM layer, all T steps, for 64*SG sites per workgroup.  blockIdx.x & 1 = direction: with the observed block -> XCD (b % 8) placement even XCDs run the
-// forward and odd XCDs the backward direction, so each XCD's 4 MiB L2 holds one direction's weights.
+// dsp_lstm_kernel<SPARSE, NP>: one direction of one LSTM layer, all T steps, for 64*SG sites per workgroup.
+// blockIdx.x & 1 = direction: with the observed block -> XCD (b % 8) placement even XCDs run the forward and odd XCDs
+// the backward direction, so each XCD's 4 MiB L2 holds one direction's weights.
 // (History, all measured on MI355X: first kernel -- 8 waves, h in LDS, one-deep prefetch -- 76 % of the fp32 MFMA
 // peak; ablation showed operand loads, not MFMA issue, cost ~25 %.  One wave per SIMD with register rings 90.4 %;
-// two waves per SIMD 93.6 %; profiles/README.md.)
-//   * TWO waves per SIMD, 256 registers each.  A wave owns UPW unit tiles (32 hidden units x 4 gates each) x SPW
-//     site tiles (32 sites each), UPW*SPW = 2: 8 accumulator tiles (128 registers), 32 MFMAs per k-group (8 k).
-//       <1,2>: a weight fragment feeds 8 MFMAs; a workgroup needs UT waves per 64 sites (UT = Hp/32 unit tiles).
-//       <2,1>: a weight fragment feeds 4 MFMAs (twice the weight stream out of L2), but a workgroup needs only
-//              UT/2 waves per 32 sites: for UT = 8 that is FOUR waves, so TWO INDEPENDENT workgroups share a CU
-//              (one wave of each per SIMD).  Measured in round 2: +0.6 % on the combined-stack launches, but with
-//              non-zero initial states the h0 read-back of the second wave of a SIMD came out wrong for sites 12-15 /
-//              28-31 of a tile, non-deterministically (not root-caused: an explicit vmcnt(0) before the barriers, L1
-//              invalidation, sc0 loads and a different MFMA order all left it unchanged) -- NOT INSTANTIATED.
+// two waves per SIMD 93.6 %; round 2 94.7 %; profiles/README.md.)
+//   * TWO waves per SIMD, 256 registers each.  A wave owns one unit tile (32 hidden units x 4 gates) x two site tiles
+//     (32 sites each): 8 accumulator tiles (128 registers), 32 MFMAs per k-group (8 k); a weight fragment feeds 8
+//     MFMAs; a workgroup has UT waves per 64 sites (UT = Hp/32 unit tiles) and SG such site groups.
+//     A <2 unit tiles, 1 site tile> tiling (a fragment feeds 4 MFMAs, twice the weight stream out of L2, but only UT/2
+//     waves per 32 sites: two INDEPENDENT 4-wave workgroups per CU at hidden 256) was measured in round 2: +0.6 % on the
+//     combined-stack launches, but with non-zero initial states the h0 read-back of the second wave of a SIMD came out
+//     wrong for sites 12-15 / 28-31 of a tile, non-deterministically (not root-caused: an explicit vmcnt(0) before the
+//     barriers, L1 invalidation, sc0 loads and a different MFMA order all left it unchanged) -- not in the tree.
 //   * EVERY operand is a coalesced BUFFER load: a wave-uniform 128-bit descriptor (SGPRs) + a wave-uniform byte
 //     offset (SGPR soffset) + lane*16 (the only address VGPR of the kernel): weights (A), x_t (B) and also h_{t-1}
 //     (B), which is read back from the K4 output the workgroup itself stored one step earlier (same CU, visible
 //     after the per-step workgroup barrier; L2-resident).  Compared with flat/global addressing this removes all
 //     64-bit VALU address arithmetic from the MFMA stream (measured: ~5 % of the MFMA issue rate).
-//   * Register rings: an A fragment (weights of one unit tile x gate, 4 VGPRs) is re-requested for k-group q+DA
+//   * Register rings: an A fragment (weights of one unit tile x gate, 4 VGPRs) is re-requested for k-group q+4
 //     after the MFMAs of the NEXT fragment of group q (one fragment late, so the load never writes registers
 //     that the MFMA issued just before it is still reading: a WAR interlock that otherwise stalls the in-order
 //     issue); B fragments four k-groups deep.  The k-group count is padded to a multiple of 4 with zero weights
@@ -454,14 +454,14 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// dsp_lstm6_kernel<NPROD> (opt-in, DSP_PRECISION=bf16x6 | bf16x9): dsp_lstm4_kernel with every fp32 product
+// dsp_lstm6_kernel<NPROD> (opt-in, DSP_PRECISION=bf16x6 | bf16x9 | fp16x3): dsp_lstm_kernel<false, 1> with every fp32 product
 // emulated on the bf16 matrix cores.  Both operands are split into three bf16 pieces (hi + mid + lo == x exactly
 // for an fp32 x); a product keeps the NPROD largest piece products (9 = all of them, exact; 6 = without ml, lm,
 // ll, i.e. about 2^-24 relative -- below the rounding of an fp32 accumulation), smallest first, accumulated in
 // fp32 by v_mfma_f32_32x32x16_bf16 (8x the fp32 MFMA rate per piece product).  Weights come pre-split from the
 // host ([unit tile][k-stage of 16][gate][piece][lane] 16 B); activations stay fp32 in the K4 layout -- nothing
 // changes for the other kernels -- and are split in registers after the load.  Same wave/tile mapping, cell phase,
-// h exchange and initial-state handling as dsp_lstm4_kernel; one k-stage = 16 k = 4 K4 groups.
+// h exchange and initial-state handling as dsp_lstm_kernel; one k-stage = 16 k = 4 K4 groups.
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm6_kernel(LstmArgs a) {
         set_bases(step + 1 < T ? step + 1 : step);  // the activation request of the last stage belongs to the next step
         stage(NQ - 1, 0, std::false_type{});
 
-        // LSTM cell (see lstm3): pre-scaled biases folded into the exp2 arguments
+        // LSTM cell (see dsp_lstm_kernel): pre-scaled biases folded into the exp2 arguments
 #pragma unroll
         for (int aa = 0; aa < 4; ++aa) {
             const f32x4 bi = b_my[aa * 8 + 0], bf = b_my[aa * 8 + 2], bg = b_my[aa * 8 + 4], bo = b_my[aa * 8 + 6];

@@ -49,5 +49,5 @@ for i in range(n):
     tot += ms
     print("%d %-12s %8.3f ms%s" % (i, name, ms, tf))
 fl = m.flops_per_site()
-print("sum %.3f ms  -> %.4f M sites/s, %.1f TFLOP/s = %.1f %% of the fp32 MFMA peak  [DSP_LSTM_TILING=%s]" % (
-    tot, B / tot / 1e3, fl * B / tot / 1e9, fl * B / tot / 1e9 / 1.573, os.environ.get("DSP_LSTM_TILING", "")))
+print("sum %.3f ms  -> %.4f M sites/s, %.1f TFLOP/s = %.1f %% of the fp32 MFMA peak  [DSP_LSTM_SG=%s]" % (
+    tot, B / tot / 1e3, fl * B / tot / 1e9, fl * B / tot / 1e9 / 1.573, os.environ.get("DSP_LSTM_SG", "")))
