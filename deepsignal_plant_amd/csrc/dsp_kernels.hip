@@ -79,7 +79,7 @@ __device__ __forceinline__ f32x4 philox_normal4(uint64_t seed, uint64_t site, ui
     // Box-Muller on (c0, c1) and (c2, c3).  The transcendental work runs once per workgroup and time step 0, but for
     // 16 such calls per lane it was 0.9 % of the forward with the OCML logf / sincosf (generic range reduction): here
     // ln(u) = ln2 * v_log_f32(u), v_sqrt_f32, and sin / cos of 2*pi*u by quadrant reduction + two short polynomials on
-    // [-pi/4, pi/4] (errors < 1 ulp of the result: within 3e-7 of the oracle's libm evaluation of the same formula).
+    // [-pi/4, pi/4] (errors < 1 ulp of the result: within 3e-7 of a double-precision libm evaluation of the same formula).
     float z0, z1, z2, z3;
     bm_pair(c0, c1, z0, z1);
     bm_pair(c2, c3, z2, z3);
