@@ -143,7 +143,8 @@ class DeviceSiteFrequency(object):
                                             p(rows.info_len[start:stop].ctypes.data), p(rows.kmer[start:stop].ctypes.data),
                                             rows.seq_len, n, p(key.ctypes.data), p(pis.ctypes.data), p(meta.ctypes.data))))
         s = stream if stream is not None else torch.cuda.current_stream(self.dev)
-        with torch.cuda.stream(s):
+        # (this may run in a writer thread, whose current device is 0 whatever the rank: select ours for the launches)
+        with torch.cuda.device(self.dev), torch.cuda.stream(s):
             if not torch.is_tensor(probs_dev):   # host copies (the reads branch feeds from its writer thread): 9 B per row up
                 probs_dev = torch.from_numpy(np.ascontiguousarray(probs_dev[start:stop], np.float32)).to(self.dev)
                 labels_dev = torch.from_numpy(np.ascontiguousarray(labels_dev[start:stop], np.uint8)).to(self.dev)
@@ -241,6 +242,7 @@ class DeviceSiteFrequency(object):
             total = int(t.item())
             names = glob
         n = int(key.numel())
+        torch.cuda.set_device(dev)
         s = torch.cuda.current_stream(dev)
         key, perm = torch.sort(key, stable=True)   # file order inside a site survives
         packed, pis, row = packed[perm], pis[perm], row[perm]

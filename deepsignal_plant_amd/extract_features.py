@@ -156,6 +156,7 @@ class FeatureExtractor(object):
         """reads: sequence of reads.ReadRecord -> _Staged: region-selected reads concatenated into pinned staging
         buffers, the motif sites and their sampleinfo strings (csrc/dsp_sites.cpp).  No GPU call."""
         torch = self.torch
+        torch.cuda.set_device(self.dev)  # staging threads start on device 0: pinned allocations belong with this rank's GPU
         uid_of = {id(r): (read_uids[i] if read_uids is not None else first_read_uid + i) for i, r in enumerate(reads)}
         reads, rg_lo, rg_hi = self._select_reads(reads)
         R = len(reads)
