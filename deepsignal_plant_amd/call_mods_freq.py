@@ -264,9 +264,8 @@ class DeviceSiteFrequency(object):
             if rank != 0:
                 return None
             cols = gathered
-        host = [c.cpu().numpy() for c in cols]
-        order = np.argsort(host[1], kind="stable")   # by first row: deterministic whatever order the slots were taken in
-        host = [np.ascontiguousarray(h[order]) for h in host]
+        order = torch.sort(cols[1], stable=True)[1]   # by first row: deterministic whatever order the slots were taken in
+        host = [np.ascontiguousarray(c[order].cpu().numpy()) for c in cols]
         table = SiteFrequency(self.prob_cf)
         for nm in names:
             L.dsp_freq_intern_chrom(table._h, nm, len(nm))

@@ -272,6 +272,9 @@ struct dsp_freq {
     Partition parts[kParts];
     long long count = 0;
     uint64_t seq = 0;  // records seen so far (sequence numbers of first_use)
+    mutable std::string format_cache;          // text of the last dsp_freq_format call ...
+    mutable long long format_cache_key = -1;   // ... for this (records seen, sort, bed) ...
+    mutable size_t format_cache_sites = 0;     // ... and this many sites
 
     uint32_t intern(const char* chrom, size_t n) {
         if (!chroms.empty() && chroms[last_chrom].size() == n && memcmp(chroms[last_chrom].data(), chrom, n) == 0)
@@ -550,27 +553,78 @@ int64_t dsp_freq_add_sites(dsp_freq* f, int64_t n, const int64_t* key, const int
                            const int64_t* pis, const double* sum0, const double* sum1, const int64_t* met, const int64_t* cov) {
     if (!f || (n && (!key || !first_row || !packed_first || !pis || !sum0 || !sum1 || !met || !cov)))
         return freq_fail(DSP_EINVAL, "NULL argument");
-    for (int64_t i = 0; i < n; ++i) {
-        const uint32_t cid = (uint32_t)((uint64_t)key[i] >> 40);
-        const long long pos = (long long)((uint64_t)key[i] & ((1ull << 40) - 1));
-        if (cid >= f->chroms.size()) return freq_fail(DSP_EINVAL, "site %lld: unknown chromosome id %u", (long long)i, cid);
-        const uint32_t meta = (uint32_t)((uint64_t)packed_first[i] >> 41);
-        Partition& part = f->parts[part_of(cid, pos)];
-        bool found;
-        SiteIndex::Slot* slot = part.index.find_or_slot(cid, pos, &found);
-        if (found) return freq_fail(DSP_EINVAL, "site %lld: (chromosome, pos) added twice", (long long)i);
-        Site s;
-        s.chrom = cid; s.pos = pos; s.pos_in_strand = pis[i]; s.first_use = (uint64_t)first_row[i];
-        s.strand_len = 1; s.strand[0] = (meta & 1) ? '-' : '+';
-        s.kmer_len = 5;
-        for (int b = 0; b < 5; ++b) s.kmer[b] = kCode2Base[(meta >> (2 + 4 * b)) & 15];
-        s.prob0 = sum0[i]; s.prob1 = sum1[i];
-        s.met = met[i]; s.coverage = cov[i]; s.unmet = cov[i] - met[i];
-        slot->pos = pos; slot->chrom = cid; slot->idx = (uint32_t)part.sites.size();
-        part.sites.push_back(s);
-        ++part.index.used;
-        part.used += cov[i];
+    // partitions are independent: worker w inserts the sites of partitions w, w + workers, ... (every worker scans all
+    // sites, like the record feeder above)
+    const int workers = std::max(1, std::min(f->nthreads, kParts));
+    std::vector<long long> bad((size_t)workers, -1);
+    std::vector<int> why((size_t)workers, 0);
+    const size_t nchrom = f->chroms.size();
+    // pass 1 (parallel over sites): the partition of every site; pass 2 (parallel over partitions): the inserts
+    std::vector<uint8_t> pid((size_t)n);
+    auto hash_range = [&](int wk) {
+        for (int64_t i = n * wk / workers; i < n * (wk + 1) / workers; ++i) {
+            const uint32_t cid = (uint32_t)((uint64_t)key[i] >> 40);
+            if (cid >= nchrom) { bad[wk] = i; why[wk] = 1; return; }
+            pid[(size_t)i] = (uint8_t)part_of(cid, (long long)((uint64_t)key[i] & ((1ull << 40) - 1)));
+        }
+    };
+    if (workers == 1 || n < 65536) {
+        for (int wk = 0; wk < workers; ++wk) hash_range(wk);
+    } else {
+        std::vector<std::thread> th;
+        for (int wk = 1; wk < workers; ++wk) th.emplace_back(hash_range, wk);
+        hash_range(0);
+        for (auto& x : th) x.join();
     }
+    for (int wk = 0; wk < workers; ++wk)
+        if (bad[wk] >= 0) return freq_fail(DSP_EINVAL, "site %lld: unknown chromosome id", bad[wk]);
+    {   // size every partition once (no vector regrowth / rehash cascade during the inserts)
+        size_t cnt[kParts] = {0};
+        for (int64_t i = 0; i < n; ++i) ++cnt[pid[(size_t)i]];
+        for (int p = 0; p < kParts; ++p) {
+            Partition& part = f->parts[p];
+            part.sites.reserve(part.sites.size() + cnt[p]);
+            size_t cap = part.index.slots.empty() ? 1024 : part.index.slots.size();
+            while ((part.index.used + cnt[p] + 1) * 10 > cap * 6) cap *= 2;
+            if (cap != part.index.slots.size()) part.index.rehash(cap);
+        }
+    }
+    auto work = [&](int wk) {
+        for (int64_t i = 0; i < n; ++i) {
+            const int pidx = pid[(size_t)i];
+            if (pidx % workers != wk) continue;
+            const uint32_t cid = (uint32_t)((uint64_t)key[i] >> 40);
+            const long long pos = (long long)((uint64_t)key[i] & ((1ull << 40) - 1));
+            const uint32_t meta = (uint32_t)((uint64_t)packed_first[i] >> 41);
+            Partition& part = f->parts[pidx];
+            bool found;
+            SiteIndex::Slot* slot = part.index.find_or_slot(cid, pos, &found);
+            if (found) { bad[wk] = i; why[wk] = 2; return; }
+            Site s;
+            s.chrom = cid; s.pos = pos; s.pos_in_strand = pis[i]; s.first_use = (uint64_t)first_row[i];
+            s.strand_len = 1; s.strand[0] = (meta & 1) ? '-' : '+';
+            s.kmer_len = 5;
+            for (int b = 0; b < 5; ++b) s.kmer[b] = kCode2Base[(meta >> (2 + 4 * b)) & 15];
+            s.prob0 = sum0[i]; s.prob1 = sum1[i];
+            s.met = met[i]; s.coverage = cov[i]; s.unmet = cov[i] - met[i];
+            slot->pos = pos; slot->chrom = cid; slot->idx = (uint32_t)part.sites.size();
+            part.sites.push_back(s);
+            ++part.index.used;
+            part.used += cov[i];
+        }
+    };
+    if (workers == 1 || n < 65536) {
+        for (int wk = 0; wk < workers; ++wk) work(wk);
+    } else {
+        std::vector<std::thread> th;
+        for (int wk = 1; wk < workers; ++wk) th.emplace_back(work, wk);
+        work(0);
+        for (auto& x : th) x.join();
+    }
+    for (int wk = 0; wk < workers; ++wk)
+        if (bad[wk] >= 0)
+            return why[wk] == 1 ? freq_fail(DSP_EINVAL, "site %lld: unknown chromosome id", bad[wk])
+                                : freq_fail(DSP_EINVAL, "site %lld: (chromosome, pos) added twice", bad[wk]);
     return n;
 }
 
@@ -584,6 +638,12 @@ void dsp_freq_counts(const dsp_freq* f, int64_t* count, int64_t* used, int64_t* 
 // write_sitekey2stats (call_mods_freq.py:77-122).  Returns bytes needed; writes at most cap bytes.
 int64_t dsp_freq_format(const dsp_freq* f, int32_t is_sort, int32_t is_bed, char* out, size_t cap) {
     if (!f) return freq_fail(DSP_EINVAL, "NULL argument");
+    // callers ask twice -- once for the size, once with a buffer: the second call copies the cached text
+    const long long key = ((long long)f->seq << 2) | (is_sort ? 2 : 0) | (is_bed ? 1 : 0);
+    if (f->format_cache_key == key && f->format_cache_sites == f->n_sites()) {
+        if (out && cap) memcpy(out, f->format_cache.data(), std::min(cap, f->format_cache.size()));
+        return (int64_t)f->format_cache.size();
+    }
     // global insertion order: merge the partitions by the sequence number of each site's first record
     struct Ref { uint64_t first_use; uint32_t part; uint32_t idx; };
     std::vector<Ref> order;
@@ -599,38 +659,74 @@ int64_t dsp_freq_format(const dsp_freq* f, int32_t is_sort, int32_t is_bed, char
             const int c = x.chrom == y.chrom ? 0 : f->chroms[x.chrom].compare(f->chroms[y.chrom]);
             return c != 0 ? c < 0 : x.pos < y.pos;
         });
-    std::string s;
-    s.reserve(order.size() * 72);
-    char buf[512];
-    for (const Ref& ref : order) {
-        const Partition& part = f->parts[ref.part];
-        const Site& t = part.sites[ref.idx];
-        if (t.coverage <= 0) continue;
-        const std::string strand = part.strand_of(ref.idx), kmer = part.kmer_of(ref.idx);
-        const double rmet = (double)t.met / (double)t.coverage;
-        int k;
-        if (is_bed) {
-            const long long pct = (long long)std::nearbyint(rmet * 100 + 0.001);  // int(round(rmet*100+0.001, 0)), :110
-            k = snprintf(buf, sizeof(buf), "%s\t%lld\t%lld\t.\t%lld\t%s\t%lld\t%lld\t0,0,0\t%lld\t%lld\n", f->chroms[t.chrom].c_str(),
-                         t.pos, t.pos + 1, t.coverage, strand.c_str(), t.pos, t.pos + 1, t.coverage, pct);
-        } else {
-            k = snprintf(buf, sizeof(buf), "%s\t%lld\t%s\t%lld\t%.3f\t%.3f\t%lld\t%lld\t%lld\t%.4f\t%s\n", f->chroms[t.chrom].c_str(), t.pos,
-                         strand.c_str(), t.pos_in_strand, t.prob0, t.prob1, t.met, t.unmet, t.coverage, rmet,
-                         kmer.c_str());
+    // the lines are independent: f->nthreads threads format contiguous chunks of `order`, concatenated in order
+    auto format_range = [&](size_t lo, size_t hi, std::string& s) {
+        s.reserve((hi - lo) * 72);
+        char num[64];
+        auto put_ll = [&](long long v) {  // "%lld"
+            char* e = num + sizeof(num);
+            char* q = e;
+            unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+            do { *--q = (char)('0' + u % 10); u /= 10; } while (u);
+            if (v < 0) *--q = '-';
+            s.append(q, (size_t)(e - q));
+        };
+        auto put_f = [&](const char* fmt, double v) {  // the three "%.3f" / "%.4f" fields: glibc's exact decimal rounding
+            const int k = snprintf(num, sizeof(num), fmt, v);
+            if (k >= 0 && (size_t)k < sizeof(num)) { s.append(num, (size_t)k); return; }
+            std::string big((size_t)(k > 0 ? k : 0) + 1, '\0');  // sums of malformed inputs can have hundreds of digits
+            const int k2 = snprintf(&big[0], big.size(), fmt, v);
+            if (k2 > 0) s.append(big.data(), (size_t)k2);
+        };
+        for (size_t oi = lo; oi < hi; ++oi) {
+            const Ref& ref = order[oi];
+            const Partition& part = f->parts[ref.part];
+            const Site& t = part.sites[ref.idx];
+            if (t.coverage <= 0) continue;
+            const bool spilled = t.strand_len == 255;
+            const std::string* lt = spilled ? &part.long_text.at(ref.idx).first : nullptr;
+            const std::string* lk = spilled ? &part.long_text.at(ref.idx).second : nullptr;
+            const char* strand = spilled ? lt->data() : t.strand;
+            const size_t strand_len = spilled ? lt->size() : t.strand_len;
+            const char* kmer = spilled ? lk->data() : t.kmer;
+            const size_t kmer_len = spilled ? lk->size() : t.kmer_len;
+            const std::string& chrom = f->chroms[t.chrom];
+            const double rmet = (double)t.met / (double)t.coverage;
+            s.append(chrom);
+            s.push_back('\t');
+            if (is_bed) {  // chrom pos pos+1 . cov strand pos pos+1 0,0,0 cov pct
+                const long long pct = (long long)std::nearbyint(rmet * 100 + 0.001);  // int(round(rmet*100+0.001, 0)), :110
+                put_ll(t.pos); s.push_back('\t'); put_ll(t.pos + 1); s.append("\t.\t", 3); put_ll(t.coverage); s.push_back('\t');
+                s.append(strand, strand_len); s.push_back('\t'); put_ll(t.pos); s.push_back('\t'); put_ll(t.pos + 1);
+                s.append("\t0,0,0\t", 7); put_ll(t.coverage); s.push_back('\t'); put_ll(pct); s.push_back('\n');
+            } else {       // chrom pos strand pos_in_strand prob0 prob1 met unmet cov rmet kmer
+                put_ll(t.pos); s.push_back('\t'); s.append(strand, strand_len); s.push_back('\t'); put_ll(t.pos_in_strand); s.push_back('\t');
+                put_f("%.3f", t.prob0); s.push_back('\t'); put_f("%.3f", t.prob1); s.push_back('\t');
+                put_ll(t.met); s.push_back('\t'); put_ll(t.unmet); s.push_back('\t'); put_ll(t.coverage); s.push_back('\t');
+                put_f("%.4f", rmet); s.push_back('\t'); s.append(kmer, kmer_len); s.push_back('\n');
+            }
         }
-        if (k < 0 || (size_t)k >= sizeof(buf)) {  // very long contig names: format into a growing string
-            std::string big(1024 + f->chroms[t.chrom].size() * 2 + kmer.size(), '\0');
-            k = is_bed ? snprintf(&big[0], big.size(), "%s\t%lld\t%lld\t.\t%lld\t%s\t%lld\t%lld\t0,0,0\t%lld\t%lld\n", f->chroms[t.chrom].c_str(),
-                                  t.pos, t.pos + 1, t.coverage, strand.c_str(), t.pos, t.pos + 1, t.coverage,
-                                  (long long)std::nearbyint(rmet * 100 + 0.001))
-                       : snprintf(&big[0], big.size(), "%s\t%lld\t%s\t%lld\t%.3f\t%.3f\t%lld\t%lld\t%lld\t%.4f\t%s\n", f->chroms[t.chrom].c_str(),
-                                  t.pos, strand.c_str(), t.pos_in_strand, t.prob0, t.prob1, t.met, t.unmet, t.coverage, rmet,
-                                  kmer.c_str());
-            s.append(big.data(), (size_t)k);
-        } else {
-            s.append(buf, (size_t)k);
-        }
+    };
+    int nt = f->nthreads < 1 ? 1 : f->nthreads;
+    if ((size_t)nt > order.size() / 4096 + 1) nt = (int)(order.size() / 4096 + 1);
+    std::vector<std::string> chunks((size_t)nt);
+    if (nt == 1) {
+        format_range(0, order.size(), chunks[0]);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t)
+            th.emplace_back([&, t] { format_range(order.size() * t / nt, order.size() * (t + 1) / nt, chunks[t]); });
+        format_range(0, order.size() / nt, chunks[0]);
+        for (auto& x : th) x.join();
     }
+    size_t total = 0;
+    for (const std::string& c : chunks) total += c.size();
+    std::string& s = f->format_cache;
+    s.clear();
+    s.reserve(total);
+    for (const std::string& c : chunks) s.append(c);
+    f->format_cache_key = key;
+    f->format_cache_sites = f->n_sites();
     if (out && cap) memcpy(out, s.data(), std::min(cap, s.size()));
     return (int64_t)s.size();
 }
