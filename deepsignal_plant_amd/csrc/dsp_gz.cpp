@@ -10,12 +10,14 @@
 // "BC" fields) fall back to a native streaming inflate (dsp_gz_open / dsp_gz_read), single-threaded by nature.
 #include "dsp_amd.h"
 
+#include <dlfcn.h>
 #include <zlib.h>
 
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -31,6 +33,39 @@ int gz_fail(int code, const char* fmt, long long a = 0, long long b = 0) {
 }
 
 constexpr size_t kBgzfBlock = 0xff00;  // text bytes per member (htslib's BGZF_BLOCK_SIZE)
+
+// libdeflate (whole-buffer deflate / inflate, 2-3x zlib's speed) is used for the BGZF members when the shared library
+// is present on the box (the image ships libdeflate.so.0 without headers: bound at run time, its C ABI is stable);
+// zlib otherwise, and always for the streaming reader.  DSP_GZ_ZLIB=1 forces zlib (A/B, tests).
+struct LibDeflate {
+    void* (*alloc_c)(int) = nullptr;
+    size_t (*compress)(void*, const void*, size_t, void*, size_t) = nullptr;
+    void (*free_c)(void*) = nullptr;
+    void* (*alloc_d)() = nullptr;
+    int (*decompress)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
+    void (*free_d)(void*) = nullptr;
+    uint32_t (*crc32)(uint32_t, const void*, size_t) = nullptr;
+    bool ok = false;
+};
+const LibDeflate& libdeflate() {
+    static LibDeflate ld;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        if (getenv("DSP_GZ_ZLIB")) return;
+        void* h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        ld.alloc_c = (void* (*)(int))dlsym(h, "libdeflate_alloc_compressor");
+        ld.compress = (size_t (*)(void*, const void*, size_t, void*, size_t))dlsym(h, "libdeflate_deflate_compress");
+        ld.free_c = (void (*)(void*))dlsym(h, "libdeflate_free_compressor");
+        ld.alloc_d = (void* (*)())dlsym(h, "libdeflate_alloc_decompressor");
+        ld.decompress = (int (*)(void*, const void*, size_t, void*, size_t, size_t*))dlsym(h, "libdeflate_deflate_decompress");
+        ld.free_d = (void (*)(void*))dlsym(h, "libdeflate_free_decompressor");
+        ld.crc32 = (uint32_t (*)(uint32_t, const void*, size_t))dlsym(h, "libdeflate_crc32");
+        ld.ok = ld.alloc_c && ld.compress && ld.free_c && ld.alloc_d && ld.decompress && ld.free_d && ld.crc32;
+    });
+    return ld;
+}
 
 // total size of the BGZF member starting at p (0 = not a BGZF member)
 size_t bgzf_member_size(const uint8_t* p, size_t left) {
@@ -98,20 +133,36 @@ int64_t dsp_gz_inflate_members(const uint8_t* src, const uint64_t* member_off, c
     int nt = nthreads < 1 ? 1 : nthreads;
     if ((int64_t)nt > m) nt = (int)std::max<int64_t>(1, m);
     std::atomic<int64_t> next(0), bad(-1);
+    const LibDeflate& ld = libdeflate();
     auto work = [&]() {
+        void* dec = ld.ok ? ld.alloc_d() : nullptr;
         for (;;) {
             const int64_t i = next.fetch_add(16);
-            if (i >= m || bad.load() >= 0) return;
+            if (i >= m || bad.load() >= 0) break;
             for (int64_t j = i; j < std::min(m, i + 16); ++j) {
                 size_t got = 0;
                 const uint64_t a = member_off[m0 + j], b = member_off[m0 + j + 1];
-                if (inflate_member(src + a, (size_t)(b - a), out + off[(size_t)j], member_isize[m0 + j], &got) != 0 ||
-                    got != member_isize[m0 + j]) {
+                const uint32_t isz = member_isize[m0 + j];
+                bool good;
+                if (dec) {  // BGZF member: 18-byte header (12 + the 6-byte BC field), raw deflate, CRC32, ISIZE
+                    const uint8_t* p = src + a;
+                    const size_t xlen = p[10] | (size_t)p[11] << 8, hdr = 12 + xlen, n = (size_t)(b - a);
+                    good = n >= hdr + 8 && ld.decompress(dec, p + hdr, n - hdr - 8, out + off[(size_t)j], isz, &got) == 0 && got == isz;
+                    if (good) {
+                        const uint8_t* t = p + n - 8;
+                        const uint32_t crc = t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
+                        good = ld.crc32(0, out + off[(size_t)j], isz) == crc;
+                    }
+                } else {
+                    good = inflate_member(src + a, (size_t)(b - a), out + off[(size_t)j], isz, &got) == 0 && got == isz;
+                }
+                if (!good) {
                     bad.store(m0 + j);
-                    return;
+                    break;
                 }
             }
         }
+        if (dec) ld.free_d(dec);
     };
     std::vector<std::thread> th;
     for (int t = 1; t < nt; ++t) th.emplace_back(work);
@@ -133,39 +184,56 @@ int64_t dsp_bgzf_compress(const uint8_t* in, size_t len, uint8_t* out, size_t ou
     if ((size_t)nt > nb) nt = (int)nb;
     std::atomic<size_t> next(0);
     std::atomic<int> err(0);
+    const LibDeflate& ld = libdeflate();
     auto work = [&]() {
+        void* comp = ld.ok ? ld.alloc_c(level < 1 ? 1 : (level > 12 ? 12 : level)) : nullptr;
+        void* comp0 = nullptr;  // level 0 (stored) for incompressible blocks
         for (;;) {
             const size_t b = next.fetch_add(1);
-            if (b >= nb || err.load()) return;
+            if (b >= nb || err.load()) break;
             const uint8_t* p = in + b * kBgzfBlock;
             const size_t n = std::min(kBgzfBlock, len - b * kBgzfBlock);
             uint8_t* o = tmp.data() + b * kMax;
             static const uint8_t hdr[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0, 0};
             memcpy(o, hdr, 18);
-            z_stream z;
-            memset(&z, 0, sizeof(z));
-            int lv = level;
-            for (;;) {  // raw deflate; incompressible input that would overflow 64 KiB is stored (level 0)
-                if (deflateInit2(&z, lv, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { err.store(1); return; }
-                z.next_in = const_cast<Bytef*>(p); z.avail_in = (uInt)n;
-                z.next_out = o + 18; z.avail_out = (uInt)(kMax - 18 - 8);
-                const int rc = deflate(&z, Z_FINISH);
-                const size_t produced = (size_t)z.total_out;
-                deflateEnd(&z);
-                if (rc == Z_STREAM_END) {
-                    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), p, (uInt)n);
-                    uint8_t* t = o + 18 + produced;
-                    for (int i = 0; i < 4; ++i) t[i] = (uint8_t)(crc >> (8 * i));
-                    for (int i = 0; i < 4; ++i) t[4 + i] = (uint8_t)((uint32_t)n >> (8 * i));
-                    const size_t total = 18 + produced + 8;
-                    o[16] = (uint8_t)((total - 1) & 0xff); o[17] = (uint8_t)((total - 1) >> 8);
-                    sz[b] = (uint32_t)total;
-                    break;
+            size_t produced = 0;
+            uint32_t crc = 0;
+            if (comp) {
+                produced = ld.compress(comp, p, n, o + 18, kMax - 18 - 8);
+                if (!produced) {  // did not fit 64 KiB: store it
+                    if (!comp0) comp0 = ld.alloc_c(0);
+                    produced = comp0 ? ld.compress(comp0, p, n, o + 18, kMax - 18 - 8) : 0;
                 }
-                if (lv == 0) { err.store(1); return; }
-                lv = 0;
+                if (!produced) { err.store(1); break; }
+                crc = ld.crc32(0, p, n);
+            } else {
+                z_stream z;
+                int lv = level;
+                for (;;) {  // raw deflate; incompressible input that would overflow 64 KiB is stored (level 0)
+                    memset(&z, 0, sizeof(z));
+                    if (deflateInit2(&z, lv, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { err.store(1); break; }
+                    z.next_in = const_cast<Bytef*>(p); z.avail_in = (uInt)n;
+                    z.next_out = o + 18; z.avail_out = (uInt)(kMax - 18 - 8);
+                    const int rc = deflate(&z, Z_FINISH);
+                    produced = (size_t)z.total_out;
+                    deflateEnd(&z);
+                    if (rc == Z_STREAM_END) break;
+                    produced = 0;
+                    if (lv == 0) { err.store(1); break; }
+                    lv = 0;
+                }
+                if (err.load()) break;
+                crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), p, (uInt)n);
             }
+            uint8_t* t = o + 18 + produced;
+            for (int i = 0; i < 4; ++i) t[i] = (uint8_t)(crc >> (8 * i));
+            for (int i = 0; i < 4; ++i) t[4 + i] = (uint8_t)((uint32_t)n >> (8 * i));
+            const size_t total = 18 + produced + 8;
+            o[16] = (uint8_t)((total - 1) & 0xff); o[17] = (uint8_t)((total - 1) >> 8);
+            sz[b] = (uint32_t)total;
         }
+        if (comp) ld.free_c(comp);
+        if (comp0) ld.free_c(comp0);
     };
     std::vector<std::thread> th;
     for (int t = 1; t < nt; ++t) th.emplace_back(work);

@@ -266,7 +266,35 @@ int format_float_numpy(T x, char* out) {
 
 inline int format_f32_numpy(float x, char* out) { return format_float_numpy<float>(x, out); }
 // str(numpy.float64) == Python's repr(float): same layout rules, 17 significant digits at most
-inline int format_f64_numpy(double x, char* out) { return format_float_numpy<double>(x, out); }
+inline int format_f64_numpy(double x, char* out) {
+    // Fast path for what the feature rows mostly hold: values rounded to 6 decimals (np.around(x, 6),
+    // extract_features.py:188, :389-390).  If x == k / 1e6 for an integer k and 1e-4 <= |x| < 1e9, the shortest
+    // round-trip decimal is k's digits with the trailing zeros of the fraction stripped: below 2^30 a double's ulp is
+    // under 2.4e-7, so no other decimal with <= 6 fractional digits rounds to x, and one with more fractional digits has
+    // more significant digits.  Everything else takes the general shortest-digits path.
+    const double ax = std::fabs(x);
+    if (ax >= 1e-4 && ax < 1e9) {
+        const long long k = std::llrint(ax * 1e6);
+        if ((double)k / 1e6 == ax) {
+            char* o = out;
+            if (x < 0) *o++ = '-';
+            char tmp[24];
+            int n = 0;
+            unsigned long long ip = (unsigned long long)(k / 1000000);
+            do { tmp[n++] = (char)('0' + ip % 10); ip /= 10; } while (ip);
+            while (n) *o++ = tmp[--n];
+            *o++ = '.';
+            unsigned fr = (unsigned)(k % 1000000);
+            char f6[6];
+            for (int i = 5; i >= 0; --i) { f6[i] = (char)('0' + fr % 10); fr /= 10; }
+            int last = 5;
+            while (last > 0 && f6[last] == '0') --last;
+            for (int i = 0; i <= last; ++i) *o++ = f6[i];
+            return (int)(o - out);
+        }
+    }
+    return format_float_numpy<double>(x, out);
+}
 
 // round(np.float32, 6): numpy multiplies by 1e6, rints (half-even), divides by 1e6 -- all in float32
 inline float np_round6_f32(float x) {

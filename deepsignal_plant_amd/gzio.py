@@ -16,38 +16,74 @@ from . import _native as nat
 
 
 class BgzfWriter(object):
-    """file-like, write-only: bytes in -> BGZF members out (deflate on `nthreads` threads)"""
+    """file-like, write-only: bytes in -> BGZF members out.  write() only queues the data: a background thread deflates
+    it (on `nthreads` threads, inside the library, GIL released) and appends to the file, so that the caller formats its
+    next block meanwhile; errors surface at the next write() / close()."""
 
     def __init__(self, path, level=4, nthreads=8, chunk=8 << 20):
+        import queue
+        import threading
         self.f = open(path, "wb")
         self.level, self.nthreads, self.chunk = int(level), max(1, int(nthreads)), int(chunk)
         self.buf = bytearray()
-        self.out = np.empty(self.chunk + (self.chunk // 0xff00 + 2) * 64 + 65536, np.uint8)
+        self.q = queue.Queue(maxsize=3)
+        self.error = None
+        self.worker = threading.Thread(target=self._run, daemon=True)
+        self.worker.start()
 
-    def _flush(self, final=False):
+    def _run(self):
         L = nat.lib()
+        out = None
+        while True:
+            data = self.q.get()
+            if data is None:
+                return
+            if self.error is not None:
+                continue  # drain
+            try:
+                n = len(data)
+                need = n + (n // 0xff00 + 2) * 64 + 65536
+                if out is None or out.nbytes < need:
+                    out = np.empty(need, np.uint8)
+                src = np.frombuffer(data, np.uint8)
+                k = nat.check(int(L.dsp_bgzf_compress(ctypes.c_void_p(src.ctypes.data), n, ctypes.c_void_p(out.ctypes.data),
+                                                      out.nbytes, self.level, self.nthreads)))
+                self.f.write(memoryview(out)[:k])
+            except BaseException as e:  # surfaced by the producer
+                self.error = e
+
+    def _submit(self, final=False):
         while len(self.buf) >= self.chunk or (final and self.buf):
-            n = min(len(self.buf), self.chunk)
-            if not final:
-                n -= n % 0xff00 or 0  # whole members only, so that the chain stays maximally packed
-                n = n or min(len(self.buf), self.chunk)
-            src = np.frombuffer(self.buf, np.uint8, n)
-            k = nat.check(int(L.dsp_bgzf_compress(ctypes.c_void_p(src.ctypes.data), n, ctypes.c_void_p(self.out.ctypes.data),
-                                                  self.out.nbytes, self.level, self.nthreads)))
-            self.f.write(memoryview(self.out)[:k])
-            del src
+            n = min(len(self.buf), max(self.chunk, 0xff00))
+            if not final or n < len(self.buf):
+                n -= n % 0xff00   # whole members only, so that the chain stays maximally packed
+            self.q.put(bytes(self.buf[:n]))
             del self.buf[:n]
+            if self.error is not None:
+                raise self.error
 
     def write(self, data):
-        self.buf += data
-        if len(self.buf) >= self.chunk:
-            self._flush()
+        if self.error is not None:
+            raise self.error
+        if not self.buf and len(data) >= self.chunk and len(data) % 0xff00 == 0:
+            self.q.put(bytes(data))  # already member-aligned: no copy through the carry buffer
+        else:
+            self.buf += data
+            self._submit()
         return len(data)
 
     def close(self):
         if self.f is None:
             return
-        self._flush(final=True)
+        try:
+            self._submit(final=True)
+        finally:
+            self.q.put(None)
+            self.worker.join()
+        if self.error is not None:
+            self.f.close()
+            self.f = None
+            raise self.error
         eof = np.empty(28, np.uint8)
         nat.check(int(nat.lib().dsp_bgzf_eof(ctypes.c_void_p(eof.ctypes.data), 28)))
         self.f.write(eof.tobytes())

@@ -90,6 +90,11 @@ def test_feature_row_formatter_reproduces_the_reference_rows():
             0.1, 0.30000000000000004, 2.5e-05, float("nan"), float("inf"), -float("inf"), 1e22, 123456789012345680.0]
     vals += list(np.around(rng.normal(size=3000) * rng.choice([1e-3, 1, 30], size=3000), 6))
     vals += list(rng.normal(size=2000) * 10.0 ** rng.integers(-12, 20, size=2000))
+    # the 6-decimal fast path (x == k / 1e6, 1e-4 <= |x| < 1e9) and its borders
+    vals += list(np.around(rng.uniform(-1e9, 1e9, size=20000) * 10.0 ** -rng.integers(0, 10, size=20000), 6))
+    vals += list(rng.integers(0, 10 ** 15, size=20000) / 1e6) + list(-(rng.integers(0, 10 ** 9, size=5000) / 1e6))
+    vals += [1e-4, 0.0001, 0.000101, 0.000099, 999999999.999999, 1e9, 1000000000.000001, 1073741823.999999, 1073741824.000001,
+             0.1 + 0.2, 0.5, 0.25, 123.456789, 123.4567891, 1.0000005, 2.0000015, 4503599627.370496, 0.000123, 33554432.000001]
     for v in vals:
         k = L.dsp_format_f64_(float(v), buf)
         assert buf.raw[:k].decode() == str(np.float64(v)), (v, buf.raw[:k], str(np.float64(v)))
