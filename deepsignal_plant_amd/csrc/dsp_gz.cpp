@@ -144,7 +144,7 @@ int64_t dsp_gz_inflate_members(const uint8_t* src, const uint64_t* member_off, c
                 const uint64_t a = member_off[m0 + j], b = member_off[m0 + j + 1];
                 const uint32_t isz = member_isize[m0 + j];
                 bool good;
-                if (dec) {  // BGZF member: 18-byte header (12 + the 6-byte BC field), raw deflate, CRC32, ISIZE
+                if (dec && src[a + 3] == 4) {  // BGZF member (FLG = FEXTRA only): header, raw deflate, CRC32, ISIZE
                     const uint8_t* p = src + a;
                     const size_t xlen = p[10] | (size_t)p[11] << 8, hdr = 12 + xlen, n = (size_t)(b - a);
                     good = n >= hdr + 8 && ld.decompress(dec, p + hdr, n - hdr - 8, out + off[(size_t)j], isz, &got) == 0 && got == isz;
