@@ -152,3 +152,31 @@ def test_plain_start_on_a_multi_gpu_node_launches_one_rank_per_gpu(monkeypatch):
     monkeypatch.setenv("RANK", "0")
     assert cm._self_launch(args, []) is None  # already under a launcher
     assert len(calls) == n
+
+
+def _gather_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+
+    from deepsignal_plant_amd import dist as dd
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = [5, 0, 3][rank]                                   # ragged, one rank empty
+    cols = [torch.arange(n, dtype=torch.int64) + 100 * rank, torch.full((n,), rank, dtype=torch.int64)]
+    got = dd.gather_columns(cols, world)
+    if rank == 0:
+        np.savez(os.path.join(outdir, "g.npz"), a=got[0].numpy(), b=got[1].numpy())
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ragged_gather_of_site_columns_to_rank_0(tmp_path):
+    """dist.gather_columns (the last step of the sharded call_freq): ragged per-rank columns, rank order preserved"""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.start_processes(_gather_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True, start_method="spawn")
+    d = np.load(os.path.join(str(tmp_path), "g.npz"))
+    assert d["a"].tolist() == [0, 1, 2, 3, 4, 200, 201, 202] and d["b"].tolist() == [0] * 5 + [2] * 3
