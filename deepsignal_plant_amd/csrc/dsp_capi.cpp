@@ -279,6 +279,7 @@ struct dsp_model {
     std::vector<int> comb_in_map;  // padded comb-input feature -> reference feature
     int trace_launch = -1, lstm_launch_no = 0;  // DSP_TRACE_LAUNCH: index of the LSTM launch (within a forward) to stamp
     int sg_override = 0;  // DSP_LSTM_SG: site groups per LSTM workgroup (0 = default policy)
+    bool phase_prio = true;  // s_setprio by phase in the LSTM kernel (DSP_LSTM_PRIO=0 turns it off: A/B switch)
     bool fp16_safe = true;         // every operand of the combined stack provably inside the fp16 range (fp16x3 only then)
     int precision = DSP_PREC_FP32; // products of the combined stack: fp32 MFMA, or split-bf16 emulation (dsp_lstm6_kernel)
     // scratch
@@ -447,7 +448,7 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
         a.init_mode = init ? init->mode : DSP_INIT_ZEROS;
         a.seed = init ? init->seed : 0; a.site_offset = init ? init->site_offset : 0;
         a.stream_base = lstm_id * 64 + (int)k * 4;
-        a.flags = 0;
+        a.flags = m->phase_prio ? 1 : 0;
         if (m->trace_launch >= 0 && m->trace_launch == m->lstm_launch_no) a.flags |= 256;  // DSP_TRACE builds
         ++m->lstm_launch_no;
         if (a.init_mode == DSP_INIT_EXPLICIT) {
@@ -550,6 +551,7 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
     m->cfg = *cfg; m->d = d; m->device = device;
     if (const char* v = getenv("DSP_TRACE_LAUNCH")) m->trace_launch = atoi(v);
     if (const char* v = getenv("DSP_LSTM_SG")) m->sg_override = atoi(v);  // A/B switch
+    if (const char* v = getenv("DSP_LSTM_PRIO")) m->phase_prio = atoi(v) != 0;    // A/B switch
     if (const char* v = getenv("DSP_PRECISION"))
         m->precision = !strcmp(v, "bf16x6") ? DSP_PREC_BF16X6 : (!strcmp(v, "bf16x9") ? DSP_PREC_BF16X9 :
                        (!strcmp(v, "fp16x3") ? DSP_PREC_FP16X3 : DSP_PREC_FP32));

@@ -43,7 +43,7 @@ struct LstmArgs {
     int NP;                // passes over the unit tiles per time step (1, or 2 for UT = 16); block = 64*(UT/NP)*SG threads
     int init_mode;         // DSP_INIT_*
     int stream_base;       // philox stream of (lstm, layer, dir=0, h): lstm*64 + layer*4
-    int flags;             // bit 8: stamp this launch (DSP_TRACE builds only)
+    int flags;             // bit 0: issue priority by phase (k-loop 2, cell 0); bit 8: stamp this launch (DSP_TRACE builds only)
 };
 
 struct LinArgs {

@@ -285,6 +285,7 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
     const uint32_t xrow = (uint32_t)(a.Ipad >> 2) * 512u;  // bytes of one (tile, t) block of the input
     const uint32_t orow = (uint32_t)F4 * 512u;             // bytes of one (tile, t) block of the output
     const uint32_t pstride = (uint32_t)UTW * (uint32_t)NQ * 4096u;  // bytes between a wave's unit tiles of two passes
+    const bool prio = (a.flags & 1) != 0;
 
     // first site tile of this wave; its two tiles are adjacent, so one descriptor per buffer serves both
     const long long gt0 = ((long long)grp * a.SG + sg) * 2;
@@ -408,6 +409,10 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
         TSTAMP(0);
         if (step > 0) barrier_after_global_stores();  // h_{t-1} of every wave stored before anyone reads it back
         TSTAMP(1);
+        // issue priority by phase: a wave in its k-loop outranks its SIMD partner's cell phase, so that the partner's
+        // VALU / transcendental stream takes the issue slots the MFMA stream leaves and not the other way round
+        // (measured on the combined stack: +0.7 %; no effect on the front ends, whose waves change phase together)
+        if (prio) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int u = ug + p * UTW;
@@ -421,6 +426,7 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
             // stage": request it here, ahead of the cell phase)
             A[DA - 1][NF - 1] = ldA(NF - 1, NQ + DA - 1);
             if (p == NP - 1) TSTAMP(2);
+            if (prio) __builtin_amdgcn_s_setprio(0);
 
             // LSTM cell.  b_lds holds the PRE-SCALED biases (-log2e*b for i,f,o; -2*log2e*b for g), so
             // sigmoid(x+b) = rcp(1 + exp2(fma(x, -log2e, b'))) costs no extra instruction for the bias.
