@@ -117,18 +117,21 @@ std::vector<Spec> weight_spec(const Dims& d) {
 int64_t spec_numel(const Spec& s) { return s.ndim == 2 ? s.shape[0] * s.shape[1] : s.shape[0]; }
 
 // ---- feature maps: padded K4 feature index -> column of the reference weight matrix (or -1 = zero pad)
-std::vector<int> map_pad(int n, int padded) {
+std::vector<int> map_pad(int n, int padded, int off = 0) {
     std::vector<int> m(padded, -1);
-    for (int i = 0; i < n; ++i) m[i] = i;
+    for (int i = 0; i < n; ++i) m[off + i] = i;
     return m;
 }
+// A front-end input of I features in a 32-wide block: the LSTM kernel wants the k-groups that carry data to be the LAST
+// of the block (dsp_lstm_kernel<2, 1, XL>), so the features start at 32 - roundup(I, 8).  Other shapes: at the front.
+int front_end_offset(int I, int F, int Hp) { return (F == 32 && rup(I, 8) < 32 && Hp <= 256) ? 32 - rup(I, 8) : 0; }
 std::vector<int> map_bidir(int H, int Hp) {  // [fwd Hp | bwd Hp] -> [fwd H | bwd H]
     std::vector<int> m(2 * Hp, -1);
     for (int i = 0; i < H; ++i) { m[i] = i; m[Hp + i] = H + i; }
     return m;
 }
 
-struct DevLstmLayer { int Ipad, Iused, H, Hp; float* wpk[2]; float* sbias[2]; float* wsplit[2]; float* wsplit16[2]; };  // wsplit: see pack_lstm_dir_split
+struct DevLstmLayer { int Ipad, Ilo, Iused, H, Hp; float* wpk[2]; float* sbias[2]; float* wsplit[2]; float* wsplit16[2]; };  // wsplit: see pack_lstm_dir_split
 struct DevLinear { int Fin, ORT; float* wpk; float* bias; };
 
 // A fragments for gates^T = W * act^T :  [UT][NQ][4 gates][64 lanes][4]
@@ -276,7 +279,9 @@ struct dsp_model {
     DevLinear fc_seq{}, fc_sig{}, fc1{};
     float* w2 = nullptr; float* b2 = nullptr;
     int hseq_p = 0, hsig_p = 0, Hp = 0, Fseq = 0, Fsig = 0, Fcomb = 0, Fwide = 0;
+    int xoff_seq = 0, xoff_sig = 0;  // first feature of the padded front-end blocks that carries data (front_end_offset)
     std::vector<int> comb_in_map;  // padded comb-input feature -> reference feature
+    int trace_wave = 0;  // DSP_TRACE_WAVE: the wave of each workgroup that stamps
     int trace_launch = -1, lstm_launch_no = 0;  // DSP_TRACE_LAUNCH: index of the LSTM launch (within a forward) to stamp
     int sg_override = 0;  // DSP_LSTM_SG: site groups per LSTM workgroup (0 = default policy)
     bool phase_prio = true;  // s_setprio by phase in the LSTM kernel (DSP_LSTM_PRIO=0 turns it off: A/B switch)
@@ -314,9 +319,9 @@ int build_stack(dsp_model* m, const float* const* w, int in, int hid, int layers
         const std::vector<int> in_map = k == 0 ? in_map0 : map_bidir(hid, Hp);
         DevLstmLayer L{};
         L.Ipad = (int)in_map.size(); L.H = hid; L.Hp = Hp;
-        L.Iused = 0;  // features up to the last mapped one carry data; whole k-groups beyond it are padding
+        L.Iused = 0; L.Ilo = L.Ipad;  // features [Ilo, Iused) carry data; whole k-groups outside are padding
         for (int i = 0; i < L.Ipad; ++i)
-            if (in_map[i] >= 0) L.Iused = i + 1;
+            if (in_map[i] >= 0) { L.Iused = i + 1; L.Ilo = std::min(L.Ilo, i); }
         for (int d = 0; d < 2; ++d) {
             const float* const* p = w + (k * 2 + d) * 4;
             std::vector<float> wpk, bias;
@@ -440,7 +445,7 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
         a.n = n; a.NTp = L.NTp;
         a.Ipad = ly.Ipad; a.H = ly.H; a.Hp = ly.Hp; a.T = m->d.T; a.Fout = 2 * ly.Hp;
         a.NQ = rup((ly.Ipad + ly.Hp) / 8, 4);
-        a.nqx_used = (ly.Iused + 7) / 8;
+        a.nqx_used = (ly.Iused + 7) / 8; a.nqx_lo = ly.Ilo / 8;
         a.h0buf = m->h0buf;
         a.UT = ly.Hp / 32;
         a.NP = a.UT > 8 ? 2 : 1;
@@ -449,7 +454,7 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
         a.seed = init ? init->seed : 0; a.site_offset = init ? init->site_offset : 0;
         a.stream_base = lstm_id * 64 + (int)k * 4;
         a.flags = m->phase_prio ? 1 : 0;
-        if (m->trace_launch >= 0 && m->trace_launch == m->lstm_launch_no) a.flags |= 256;  // DSP_TRACE builds
+        if (m->trace_launch >= 0 && m->trace_launch == m->lstm_launch_no) a.flags |= 256 | (m->trace_wave << 9);  // DSP_TRACE builds
         ++m->lstm_launch_no;
         if (a.init_mode == DSP_INIT_EXPLICIT) {
             a.h0 = h0 + (size_t)(2 * k) * (size_t)n * ly.H;
@@ -550,6 +555,7 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
     if (!m) { hipSetDevice(prev); return fail(DSP_ENOMEM, "out of host memory"); }
     m->cfg = *cfg; m->d = d; m->device = device;
     if (const char* v = getenv("DSP_TRACE_LAUNCH")) m->trace_launch = atoi(v);
+    if (const char* v = getenv("DSP_TRACE_WAVE")) m->trace_wave = atoi(v) & 7;
     if (const char* v = getenv("DSP_LSTM_SG")) m->sg_override = atoi(v);  // A/B switch
     if (const char* v = getenv("DSP_LSTM_PRIO")) m->phase_prio = atoi(v) != 0;    // A/B switch
     if (const char* v = getenv("DSP_PRECISION"))
@@ -562,6 +568,8 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
     // x-part groups: the LSTM kernel requests them before h_t exists (dsp_kernels.hip, SPARSE note)
     m->Fseq = d.hseq ? std::max(32, rup(d.Iseq, 8)) : 0;
     m->Fsig = d.hsig ? std::max(32, rup(d.S, 8)) : 0;
+    m->xoff_seq = d.hseq ? front_end_offset(d.Iseq, m->Fseq, pad_hidden(d.hseq)) : 0;
+    m->xoff_sig = d.hsig ? front_end_offset(d.S, m->Fsig, pad_hidden(d.hsig)) : 0;
     m->Fcomb = m->hseq_p + m->hsig_p;
     m->Fwide = 2 * m->Hp;
     if (2 * m->hseq_p > m->Fwide) m->Fwide = 2 * m->hseq_p;
@@ -577,7 +585,7 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
         std::vector<float> emb(w[wi], w[wi] + (size_t)d.V * d.E);
         rc = upload(m, emb, &m->embed); if (rc) return done(rc);
         ++wi;
-        rc = build_stack(m, w + wi, d.Iseq, d.hseq, d.l2, map_pad(d.Iseq, m->Fseq), m->seq, 1); if (rc) return done(rc);
+        rc = build_stack(m, w + wi, d.Iseq, d.hseq, d.l2, map_pad(d.Iseq, m->Fseq, m->xoff_seq), m->seq, 1); if (rc) return done(rc);
         wi += 8 * d.l2;
         std::vector<float> wpk, bias;
         pack_linear(w[wi], w[wi + 1], d.hseq, m->hseq_p, 2 * d.hseq, map_bidir(d.hseq, m->hseq_p), wpk, bias);
@@ -588,7 +596,7 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
         wi += 2;
     }
     if (d.hsig) {
-        rc = build_stack(m, w + wi, d.S, d.hsig, d.l2, map_pad(d.S, m->Fsig), m->sig, 1); if (rc) return done(rc);
+        rc = build_stack(m, w + wi, d.S, d.hsig, d.l2, map_pad(d.S, m->Fsig, m->xoff_sig), m->sig, 1); if (rc) return done(rc);
         wi += 8 * d.l2;
         std::vector<float> wpk, bias;
         pack_linear(w[wi], w[wi + 1], d.hsig, m->hsig_p, 2 * d.hsig, map_bidir(d.hsig, m->hsig_p), wpk, bias);
@@ -679,7 +687,7 @@ int32_t dsp_forward(dsp_model* m, void* stream, int64_t n, const void* kmer, int
     p.xseq = d.hseq ? m->xseq : nullptr; p.xsig = d.hsig ? m->xsig : nullptr;
     p.n = n; p.NTp = NTp; p.kdt = kmer_dtype; p.ldt = lens_dtype;
     p.T = d.T; p.S = d.S; p.E = d.E; p.V = d.V; p.is_base = d.is_base; p.is_siglen = d.is_siglen;
-    p.Fseq = m->Fseq; p.Fsig = m->Fsig;
+    p.Fseq = m->Fseq; p.Fsig = m->Fsig; p.xoff_seq = m->xoff_seq; p.xoff_sig = m->xoff_sig;
     L.run("pack", [&] { return dsp_k_pack(&p, s); });
 
     auto linear = [&](const char* name, const DevLinear& fc, const float* x, int out_off) {

@@ -21,6 +21,7 @@ struct PackArgs {
     int T, S, E, V;
     int is_base, is_siglen;
     int Fseq, Fsig;
+    int xoff_seq, xoff_sig;  // first padded feature that carries data (the features sit at the end of a padded block)
 };
 
 struct LstmArgs {
@@ -37,13 +38,13 @@ struct LstmArgs {
     long long NTp;
     unsigned long long seed, site_offset;
     int Ipad, H, Hp, T, Fout;
-    int nqx_used;          // x-part k-groups that carry real features (the rest of Ipad/8 is zero padding)
+    int nqx_lo, nqx_used;  // x-part k-groups [nqx_lo, nqx_used) carry real features (the rest of Ipad/8 is zero padding)
     int NQ;                // k-groups per unit tile in wpk: (Ipad+Hp)/8 padded to a multiple of 4 (zero weights)
     int UT, SG;            // unit tiles (Hp/32), site groups (of two 32-site tiles) per workgroup
     int NP;                // passes over the unit tiles per time step (1, or 2 for UT = 16); block = 64*(UT/NP)*SG threads
     int init_mode;         // DSP_INIT_*
     int stream_base;       // philox stream of (lstm, layer, dir=0, h): lstm*64 + layer*4
-    int flags;             // bit 0: issue priority by phase (k-loop 2, cell 0); bit 8: stamp this launch (DSP_TRACE builds only)
+    int flags;             // bit 0: issue priority by phase (k-loop 2, cell 0); bit 8: stamp this launch, bits 9..11: its stamping wave (DSP_TRACE builds only)
 };
 
 struct LinArgs {

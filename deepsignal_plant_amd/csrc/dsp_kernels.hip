@@ -133,9 +133,9 @@ __global__ __launch_bounds__(256) void dsp_pack_kernel(PackArgs a) {
             f32x4 v;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int f = 4 * g + i;
+                const int f = 4 * g + i - a.xoff_seq;  // the features sit at the END of the padded block
                 float x = 0.f;
-                if (live) {
+                if (live && f >= 0) {
                     if (f < E) x = a.embed[(size_t)code * a.E + f];
                     else if (f == E) x = mean;
                     else if (f == E + 1) x = sd;
@@ -153,8 +153,8 @@ __global__ __launch_bounds__(256) void dsp_pack_kernel(PackArgs a) {
             f32x4 v;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int f = 4 * g + i;
-                v[i] = (live && f < a.S) ? src[f] : 0.f;
+                const int f = 4 * g + i - a.xoff_sig;
+                v[i] = (live && f >= 0 && f < a.S) ? src[f] : 0.f;
             }
             dst[(size_t)g * 32] = v;
         }
@@ -184,7 +184,7 @@ __device__ __forceinline__ f32x4 init_state4(const float* src, int mode, long lo
 }
 
 // ------------------------------------------------------------------------------------------------
-// dsp_lstm_kernel<SPARSE, NP>: one direction of one LSTM layer, all T steps, for 64*SG sites per workgroup.
+// dsp_lstm_kernel<SPARSE, NP, XL>: one direction of one LSTM layer, all T steps, for 64*SG sites per workgroup.
 // blockIdx.x & 1 = direction: with the observed block -> XCD (b % 8) placement even XCDs run the forward and odd XCDs
 // the backward direction, so each XCD's 4 MiB L2 holds one direction's weights.
 // (History, all measured on MI355X: first kernel -- 8 waves, h in LDS, one-deep prefetch -- 76 % of the fp32 MFMA
@@ -213,9 +213,16 @@ __device__ __forceinline__ f32x4 init_state4(const float* src, int mode, long lo
 //     accumulators start from literal zero (first MFMA of a step takes C = 0) and the biases are folded into
 //     the exp2 arguments of the activations; the per-step cost that does not scale with K is ~4.5 us
 //     (transcendental-bound: 10 v_exp/v_rcp per element, tools/micro/trans_rate.hip).
-// SPARSE = true (front-end layers): k-groups that are pure zero padding -- the x part padded from 8/16 to 32
-// features so that the first four k-groups never depend on h_t, and the tail padded to a multiple of four -- keep
-// their (branch-free) operand requests but skip their MFMAs behind a wave-uniform test.
+// SPARSE != 0 (front-end layers): the x part is padded from 8/16 to 32 features so that the first four k-groups never
+// depend on h_t; k-groups that are pure zero padding keep their operand requests but issue no MFMAs.
+//   SPARSE = 2, XL = 1..3 (the shipped front ends: hidden <= 256, features at the END of the 32-wide block): which of the
+//     first four k-groups are padding is a template parameter.  A step opens with 4 - XL refill-only stages (the requests
+//     for the first h-part k-groups go out right behind the barrier), runs the XL live x-part k-groups while those are
+//     in flight and continues with the same branch-free stages as the dense kernel.  No spills, exact s_waitcnt counts.
+//   SPARSE = 1 (any other padded shape, e.g. hidden > 256 or a signal window wider than 32): a wave-uniform test
+//     around the MFMAs of every k-group.  Measured on the front ends before SPARSE = 2 existed: 2,490 cycles per
+//     k-group instead of 2,110 (a branch around every fragment's MFMAs, s_waitcnt counts merged conservatively at every
+//     join, two ring fragments spilled to scratch at the end of every step).
 // The padding to four x-part k-groups keeps every cross-step request off rows that do not exist yet: the B ring
 // requests four k-groups across a step boundary, i.e. before the cell phase of step t has stored h_t, and a request
 // that touched an h_t row early could leave stale lines in this CU's vector L1 for the re-request after the barrier.
@@ -247,9 +254,9 @@ __device__ __forceinline__ void barrier_after_global_stores() { __syncthreads();
 // every workgroup of ONE chosen LSTM launch, at the start / after the k-loop / after the cell phase of every step
 #ifdef DSP_TRACE
 #define DSP_TRACE_WGS 8192
-__device__ unsigned long long g_trace[DSP_TRACE_WGS][16][4];
+__device__ unsigned long long g_trace[DSP_TRACE_WGS][16][8];
 __device__ unsigned int g_trace_hw[DSP_TRACE_WGS][4];
-#define TSTAMP(k) do { if ((a.flags & 256) && tid == 0 && blockIdx.x < DSP_TRACE_WGS && step < 16) g_trace[blockIdx.x][step][k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define TSTAMP(k) do { if ((a.flags & 256) && tid == ((a.flags >> 9) & 7) * 64 && blockIdx.x < DSP_TRACE_WGS && step < 16) g_trace[blockIdx.x][step][k] = __builtin_amdgcn_s_memtime(); } while (0)
 extern "C" int dsp_k_trace_read(unsigned long long* t, unsigned int* hw) {
     hipError_t e = hipMemcpyFromSymbol(t, HIP_SYMBOL(g_trace), sizeof(g_trace));
     if (e == hipSuccess) e = hipMemcpyFromSymbol(hw, HIP_SYMBOL(g_trace_hw), sizeof(g_trace_hw));
@@ -259,7 +266,7 @@ extern "C" int dsp_k_trace_read(unsigned long long* t, unsigned int* hw) {
 #define TSTAMP(k) do { } while (0)
 #endif
 
-template <bool SPARSE, int NP>
+template <int SPARSE, int NP, int XL = 0>
 __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
     // NP = passes over the unit tiles per time step: 1 for hidden sizes up to 256 (8 unit tiles, one per wave); 2 for
     // 257..512 (16 unit tiles: a wave computes unit tile w in pass 0 and w + 8 in pass 1, one barrier per step)
@@ -356,19 +363,21 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
     };
 #define QW(x) ((x) < NQ ? (x) : (x) - NQ)
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int nqx_used = a.nqx_used;
+    const int nqx_used = a.nqx_used, nqx_lo = a.nqx_lo;
     // one k-group (ring slots are compile-time: QS = q mod 4): the 8 MFMAs of gate fragment g, then the refill of
     // fragment g-1 for k-group q+4; fragment 3 of the PREVIOUS stage's slot is refilled after fragment 0.
     // first = true: the very first k-step of a time step accumulates onto literal zero.
-    auto stage = [&](auto qs, int q, auto first) __attribute__((always_inline)) {
+    // mode (compile time) 0: a live k-group; 1: may be pure padding (wave-uniform test); 2: is padding (refills only)
+    auto stage = [&](auto qs, int q, auto first, auto mode) __attribute__((always_inline)) {
         constexpr int QS = decltype(qs)::value;
         constexpr int sa = QS % DA, sp = (QS + DA - 1) % DA, sb = QS % DB;
-        const bool live = !SPARSE || q < nqx_used || (q >= nqx && q < nq);  // wave-uniform
+        constexpr int MODE = decltype(mode)::value;
+        const bool live = MODE != 1 || (q >= nqx_lo && q < nqx_used) || (q >= nqx && q < nq);  // wave-uniform
 #pragma unroll
         for (int g = 0; g < NF; ++g) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (SPARSE && !live) break;
+                if (MODE == 2 || (MODE == 1 && !live)) break;
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     if (decltype(first)::value && i == 0)
@@ -383,12 +392,30 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto stage4 = [&](int q, auto first) __attribute__((always_inline)) {
-        stage(ic<0>{}, q + 0, first); loadB(B[0], QW(q + 0 + DB)); __builtin_amdgcn_sched_barrier(0);
-        stage(ic<1>{}, q + 1, std::false_type{}); loadB(B[1], QW(q + 1 + DB)); __builtin_amdgcn_sched_barrier(0);
-        stage(ic<2>{}, q + 2, std::false_type{}); loadB(B[2], QW(q + 2 + DB)); __builtin_amdgcn_sched_barrier(0);
-        stage(ic<3>{}, q + 3, std::false_type{}); loadB(B[3], QW(q + 3 + DB)); __builtin_amdgcn_sched_barrier(0);
+    auto stage4 = [&](int q, auto first, auto mode) __attribute__((always_inline)) {
+        stage(ic<0>{}, q + 0, first, mode); loadB(B[0], QW(q + 0 + DB)); __builtin_amdgcn_sched_barrier(0);
+        stage(ic<1>{}, q + 1, std::false_type{}, mode); loadB(B[1], QW(q + 1 + DB)); __builtin_amdgcn_sched_barrier(0);
+        stage(ic<2>{}, q + 2, std::false_type{}, mode); loadB(B[2], QW(q + 2 + DB)); __builtin_amdgcn_sched_barrier(0);
+        stage(ic<3>{}, q + 3, std::false_type{}, mode); loadB(B[3], QW(q + 3 + DB)); __builtin_amdgcn_sched_barrier(0);
     };
+    // SPARSE = 2 (the front ends: 7 or 16 features in a 32-wide block, no tail padding): the XL live x-part k-groups are
+    // the LAST of the first four, everything known at compile time.  A step then opens with 4 - XL refill-only stages
+    // -- the requests for the first h-part k-groups go out right behind the barrier -- runs the live x-part MFMAs while
+    // those are in flight, and continues with the branch-free dense stages.  (With a wave-uniform test in every stage,
+    // SPARSE = 1, the k-loop ran at 2,490 cycles per k-group instead of 2,110: a branch around every fragment's MFMAs,
+    // s_waitcnt counts merged conservatively at every join, two ring fragments spilled.)
+    auto stage4_first = [&]() __attribute__((always_inline)) {
+        if constexpr (SPARSE == 2) {
+            constexpr int D = 4 - XL;  // dead stages
+            stage(ic<0>{}, 0, std::integral_constant<bool, D == 0>{}, ic<(0 < D ? 2 : 0)>{}); loadB(B[0], QW(0 + DB)); __builtin_amdgcn_sched_barrier(0);
+            stage(ic<1>{}, 1, std::integral_constant<bool, D == 1>{}, ic<(1 < D ? 2 : 0)>{}); loadB(B[1], QW(1 + DB)); __builtin_amdgcn_sched_barrier(0);
+            stage(ic<2>{}, 2, std::integral_constant<bool, D == 2>{}, ic<(2 < D ? 2 : 0)>{}); loadB(B[2], QW(2 + DB)); __builtin_amdgcn_sched_barrier(0);
+            stage(ic<3>{}, 3, std::integral_constant<bool, D == 3>{}, ic<0>{}); loadB(B[3], QW(3 + DB)); __builtin_amdgcn_sched_barrier(0);
+        } else {
+            stage4(0, std::true_type{}, ic<SPARSE>{});
+        }
+    };
+    using rest_mode = ic<(SPARSE == 1 ? 1 : 0)>;
 
     set_bases(0);
 #pragma unroll
@@ -399,7 +426,7 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
     }
 
 #ifdef DSP_TRACE
-    if ((a.flags & 256) && tid == 0 && blockIdx.x < DSP_TRACE_WGS) {
+    if ((a.flags & 256) && tid == ((a.flags >> 9) & 7) * 64 && blockIdx.x < DSP_TRACE_WGS) {
         g_trace_hw[blockIdx.x][0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
         g_trace_hw[blockIdx.x][1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
     }
@@ -411,17 +438,19 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
         TSTAMP(1);
         // issue priority by phase: a wave in its k-loop outranks its SIMD partner's cell phase, so that the partner's
         // VALU / transcendental stream takes the issue slots the MFMA stream leaves and not the other way round
-        // (measured on the combined stack: +0.7 %; no effect on the front ends, whose waves change phase together)
+        // (measured on the combined stack: +0.45 %; no setting of the two priorities changes the front ends)
         if (prio) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int u = ug + p * UTW;
             if (NP > 1) { po_cur = (uint32_t)p * pstride; po_next = p + 1 < NP ? (uint32_t)(p + 1) * pstride : 0u; }
-            stage4(0, std::true_type{});
-            for (int q = 4; q < NQ - 4; q += 4) stage4(q, std::false_type{});
+            stage4_first();
+            TSTAMP(4);
+            for (int q = 4; q < NQ - 4; q += 4) stage4(q, std::false_type{}, rest_mode{});
+            TSTAMP(5);
             // B requests from here on belong to the next pass of this step (same rows) or to the next step
             if (p == NP - 1) set_bases(step + 1 < T ? step + 1 : step);
-            stage4(NQ - 4, std::false_type{});
+            stage4(NQ - 4, std::false_type{}, rest_mode{});
             // (stage NQ-1 leaves the last fragment of its ring slot, for the next k-loop's k-group 3, to "the next
             // stage": request it here, ahead of the cell phase)
             A[DA - 1][NF - 1] = ldA(NF - 1, NQ + DA - 1);
@@ -452,6 +481,12 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
                     c_lds[((p * 2 + m) * 4 + aa) * nthr + tid] = cv;
                     bst16(ro, voff + aa * 1024u, (uint32_t)(m * T + t) * orow + (uint32_t)u * 4096u, hv);
                 }
+#ifdef DSP_TRACE
+                __builtin_amdgcn_sched_barrier(0);
+                if (aa == 0) TSTAMP(6);
+                if (aa == 2) TSTAMP(7);
+                __builtin_amdgcn_sched_barrier(0);
+#endif
             }
         }
         TSTAMP(3);
@@ -460,7 +495,7 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// dsp_lstm6_kernel<NPROD> (opt-in, DSP_PRECISION=bf16x6 | bf16x9 | fp16x3): dsp_lstm_kernel<false, 1> with every fp32 product
+// dsp_lstm6_kernel<NPROD> (opt-in, DSP_PRECISION=bf16x6 | bf16x9 | fp16x3): dsp_lstm_kernel<0, 1> with every fp32 product
 // emulated on the bf16 matrix cores.  Both operands are split into three bf16 pieces (hi + mid + lo == x exactly
 // for an fp32 x); a product keeps the NPROD largest piece products (9 = all of them, exact; 6 = without ml, lm,
 // ll, i.e. about 2^-24 relative -- below the rounding of an fp32 accumulation), smallest first, accumulated in
@@ -856,8 +891,9 @@ __global__ __launch_bounds__(256) void dsp_head_kernel(HeadArgs a) {
 // launch wrappers (called from dsp_capi.cpp; keep all <<<>>> syntax in this translation unit)
 // ------------------------------------------------------------------------------------------------
 extern "C" int dsp_k_init(void) {
-    const void* fns[] = {(const void*)dsp_lstm_kernel<false, 1>, (const void*)dsp_lstm_kernel<true, 1>,
-                         (const void*)dsp_lstm_kernel<false, 2>, (const void*)dsp_lstm_kernel<true, 2>,
+    const void* fns[] = {(const void*)dsp_lstm_kernel<0, 1>, (const void*)dsp_lstm_kernel<1, 1>,
+                         (const void*)dsp_lstm_kernel<2, 1, 1>, (const void*)dsp_lstm_kernel<2, 1, 2>, (const void*)dsp_lstm_kernel<2, 1, 3>,
+                         (const void*)dsp_lstm_kernel<0, 2>, (const void*)dsp_lstm_kernel<1, 2>,
                          (const void*)dsp_lstm6_kernel<6>, (const void*)dsp_lstm6_kernel<9>, (const void*)dsp_lstm6_kernel<3>};
     for (const void* f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -879,15 +915,23 @@ extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
     const int threads = (a->UT / np) * a->SG * 64;
     const unsigned groups = (unsigned)(a->NTp / (a->SG * 2));
     const size_t lds = (size_t)np * 8 * threads * 16 + (size_t)a->Hp * 16;
-    if ((a->Ipad >> 3) < 4 || threads > 512 || a->UT % np) return (int)hipErrorInvalidValue;  // see the SPARSE note: four x-part k-groups are required
-    const bool sparse = a->nqx_used < (a->Ipad >> 3) || a->NQ > ((a->Ipad + a->Hp) >> 3);
+    const int nqx = a->Ipad >> 3, nq = (a->Ipad + a->Hp) >> 3;
+    if (nqx < 4 || threads > 512 || a->UT % np) return (int)hipErrorInvalidValue;  // see the SPARSE note: four x-part k-groups are required
+    // 0: no padded k-groups; 2: the front-end shape (dead k-groups first, inside the first four); 1: padding anywhere else
+    const bool padded = a->nqx_lo > 0 || a->nqx_used < nqx || a->NQ > nq;
+    const int sparse = !padded ? 0 : (np == 1 && nqx == 4 && a->NQ == nq && a->nqx_used == 4 && a->nqx_lo > 0) ? 2 : 1;
+    if (sparse == 1 && a->nqx_lo != 0) return (int)hipErrorInvalidValue;  // the tested k-loop starts on a live k-group
     const dim3 g(groups * 2), b(threads);
-    if (np == 2) {
-        if (sparse) hipLaunchKernelGGL((dsp_lstm_kernel<true, 2>), g, b, lds, s, *a);
-        else hipLaunchKernelGGL((dsp_lstm_kernel<false, 2>), g, b, lds, s, *a);
+    if (sparse == 2) {
+        if (a->nqx_lo == 3) hipLaunchKernelGGL((dsp_lstm_kernel<2, 1, 1>), g, b, lds, s, *a);
+        else if (a->nqx_lo == 2) hipLaunchKernelGGL((dsp_lstm_kernel<2, 1, 2>), g, b, lds, s, *a);
+        else hipLaunchKernelGGL((dsp_lstm_kernel<2, 1, 3>), g, b, lds, s, *a);
+    } else if (np == 2) {
+        if (sparse) hipLaunchKernelGGL((dsp_lstm_kernel<1, 2>), g, b, lds, s, *a);
+        else hipLaunchKernelGGL((dsp_lstm_kernel<0, 2>), g, b, lds, s, *a);
     } else {
-        if (sparse) hipLaunchKernelGGL((dsp_lstm_kernel<true, 1>), g, b, lds, s, *a);
-        else hipLaunchKernelGGL((dsp_lstm_kernel<false, 1>), g, b, lds, s, *a);
+        if (sparse) hipLaunchKernelGGL((dsp_lstm_kernel<1, 1>), g, b, lds, s, *a);
+        else hipLaunchKernelGGL((dsp_lstm_kernel<0, 1>), g, b, lds, s, *a);
     }
     return (int)hipGetLastError();
 }

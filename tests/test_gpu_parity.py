@@ -360,3 +360,38 @@ def test_hidden_sizes_above_256(hidden, module, n):
     print("hidden %d %s: max|dprob| = %.3e (explicit states), %.3e (Philox states)" % (hidden, module, d, d2))
     assert d <= TOL_TIGHT and d2 <= TOL_TIGHT
     assert torch.equal(m.forward(*to_dev(ins))[1], pp)
+
+
+@pytest.mark.parametrize("signal_len,is_base,is_signallen,hidden,module,what", [
+    (8, True, True, 128, "both_bilstm", "one live x-part k-group in both front ends (dsp_lstm_kernel<2, 1, 1>)"),
+    (16, True, True, 128, "both_bilstm", "seq one, signal two live k-groups (<2, 1, 1> and <2, 1, 2>)"),
+    (24, True, True, 64, "both_bilstm", "signal three live k-groups (<2, 1, 3>)"),
+    (32, True, True, 64, "both_bilstm", "signal block full: the dense kernel (<0, 1>)"),
+    (40, True, True, 64, "both_bilstm", "signal block of 40: padding in the tail k-groups, the tested kernel (<1, 1>)"),
+    (16, False, False, 128, "both_bilstm", "seq branch of 2 features (mean, std)"),
+    (20, True, True, 320, "signal_bilstm", "hidden 320: two passes, features at the front (<1, 2>)"),
+])
+def test_front_end_shapes(signal_len, is_base, is_signallen, hidden, module, what):
+    """Every instantiation of the LSTM kernel that a front end can select: the features sit at the end of the 32-wide
+    padded block when hidden <= 256 (refill-only stages first, known at compile time), at the front otherwise; against
+    the oracle with explicit N(0,1) initial states and with Philox states (models.py:178-214 for any signal_len /
+    is_base / is_signallen)"""
+    torch = _torch()
+    from oracle import c_oracle as oc
+    from oracle import forward_np as onp
+    cfg = onp.OracleConfig(signal_len=signal_len, hidden_size=hidden, num_layers1=1, is_base=is_base,
+                           is_signallen=is_signallen, module=module)
+    n = 150
+    w = onp.make_weights(cfg, 91, 2.0)
+    ins = onp.make_inputs(cfg, n, 92)
+    st = onp.make_init_states(cfg, n, 93)
+    m = build_model(cfg, w)
+    _, probs = m.forward(*to_dev(ins), init_states={k: torch.from_numpy(v).cuda(0) for k, v in st.items()})
+    _, po = oc.forward(cfg, w, *ins, states=st, init_mode="explicit")
+    d = np.abs(probs.cpu().numpy() - po).max()
+    m.init_state, m.seed = "randn", 5
+    _, pp = m.forward(*to_dev(ins))
+    _, pq = oc.forward(cfg, w, *ins, init_mode="philox", seed=5)
+    d2 = np.abs(pp.cpu().numpy() - pq).max()
+    print("%s: max|dprob| = %.3e (explicit states), %.3e (Philox states)" % (what, d, d2))
+    assert d <= TOL_TIGHT and d2 <= TOL_TIGHT

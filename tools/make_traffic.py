@@ -22,12 +22,12 @@ def avg_of(path, kernel_re, counter):
 def main():
     d = sys.argv[1]
     args = bench.parse_args(sys.argv[2:])
-    kern = r"dsp_lstm_kernel<false"
+    kern = r"dsp_lstm_kernel<(false|0),"
     fetch_kb = avg_of(os.path.join(d, "pmc_FETCH_SIZE.txt"), kern, "FETCH_SIZE")
     write_kb = avg_of(os.path.join(d, "pmc_WRITE_SIZE.txt"), kern, "WRITE_SIZE")
     entry = {"model_type": args.model_type, "layernum1": args.layernum1, "hid_rnn": args.hid_rnn, "batch": args.batch,
              "precision": args.precision, "kernel_src_sha16": bench.kernel_source_hash(),
-             "kernel": "dsp_lstm_kernel<false, 1, 2> (combined stack)",
+             "kernel": "dsp_lstm_kernel<0, 1> (combined stack)",
              "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python3 bench.py --steps 2 --warmup 1 "
                        "--no_cpu_baseline --no_alt %s`, tools/profile.sh" % " ".join(sys.argv[2:]),
              "fetch_size_kb_per_launch": fetch_kb, "write_size_kb_per_launch": write_kb,

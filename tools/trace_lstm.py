@@ -25,7 +25,7 @@ ins = synth.feature_batch(a.batch, device="cuda:0", seed=1)
 for _ in range(3): m(*ins)
 torch.cuda.synchronize()
 W = 8192
-t = np.zeros((W, 16, 4), np.uint64); hw = np.zeros((W, 4), np.uint32)
+t = np.zeros((W, 16, 8), np.uint64); hw = np.zeros((W, 4), np.uint32)
 L = nat.lib()
 rc = L.dsp_k_trace_read(t.ctypes.data_as(ctypes.c_void_p), hw.ctypes.data_as(ctypes.c_void_p))
 assert rc == 0, rc
@@ -55,3 +55,9 @@ mid = t[used][:, 2:12, :]
 bar = np.median(mid[:, :, 1] - mid[:, :, 0]); kl = np.median(mid[:, :, 2] - mid[:, :, 1]); ce = np.median(mid[:, :, 3] - mid[:, :, 2])
 step = np.median(mid[:, 1:, 0] - mid[:, :-1, 0])
 print("median cycles per step %d = barrier wait %d + k-loop %d + cell %d (+ stamp overhead)" % (step, bar, kl, ce))
+if mid[:, :, 4].any():
+    print("k-loop split: first four k-groups %d, middle %d, last four %d" % (
+        np.median(mid[:, :, 4] - mid[:, :, 1]), np.median(mid[:, :, 5] - mid[:, :, 4]), np.median(mid[:, :, 2] - mid[:, :, 5])))
+if mid[:, :, 6].any():
+    print("cell split: first quarter %d, second+third %d, last %d" % (
+        np.median(mid[:, :, 6] - mid[:, :, 2]), np.median(mid[:, :, 7] - mid[:, :, 6]), np.median(mid[:, :, 3] - mid[:, :, 7])))
