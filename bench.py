@@ -293,7 +293,10 @@ def main(argv=None):
                          "hbm_gbps_algorithmic": round(value / world * 1048 / 1e9, 3),
                          "kernel_time_frac_of_wall": round(all_ms * 1e-3 / dt, 4) if dt > 0 else None,
                          "ms_per_step_by_launch": {k: round(sum(v) / max(K, 1), 4) for k, v in per_launch.items()},
-                         "kernel_src_sha16": kernel_source_hash()},
+                         "kernel_src_sha16": kernel_source_hash(),
+                         "note": ("fp32 MFMA and VALU work do not overlap on gfx950 (profiles/r2/micro_mfma_cell_overlap.txt): "
+                                 "with the LSTM cell phase counted the bound of this kernel is 0.974 of the MFMA peak "
+                                 "(DESIGN.md section 3)") if nprod == 1 else None},
         }
         if alt:
             line["alt_precision"] = alt
