@@ -30,6 +30,15 @@ class InitState(ctypes.Structure):
 _lib = None
 
 
+class Fast5Read(ctypes.Structure):  # dsp_fast5_read, include/dsp_amd.h
+    _fields_ = [("n_raw", ctypes.c_int64), ("raw", ctypes.POINTER(ctypes.c_int16)),
+                ("n_events", ctypes.c_int64), ("ev_start", ctypes.POINTER(ctypes.c_int64)),
+                ("ev_len", ctypes.POINTER(ctypes.c_int64)), ("ev_base", ctypes.POINTER(ctypes.c_uint8)),
+                ("digitisation", ctypes.c_double), ("range", ctypes.c_double), ("offset", ctypes.c_double),
+                ("mapped_start", ctypes.c_int64), ("has_alignment", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("read_id", ctypes.c_char * 256), ("mapped_chrom", ctypes.c_char * 256), ("mapped_strand", ctypes.c_char * 8)]
+
+
 def lib():
     """Load libdsp_amd.so or raise: the product path never falls back to a CPU implementation."""
     global _lib
@@ -129,6 +138,14 @@ def lib():
     L.dsp_bgzf_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_int32]
     L.dsp_bgzf_eof.restype = ctypes.c_int64
     L.dsp_bgzf_eof.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    L.dsp_fast5_available.restype = ctypes.c_int32
+    L.dsp_fast5_available.argtypes = []
+    L.dsp_fast5_library.restype = ctypes.c_char_p
+    L.dsp_fast5_library.argtypes = []
+    L.dsp_fast5_load.restype = ctypes.c_int32
+    L.dsp_fast5_load.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(Fast5Read)]
+    L.dsp_fast5_free.restype = None
+    L.dsp_fast5_free.argtypes = [ctypes.POINTER(Fast5Read)]
     L.dsp_gz_open.restype = ctypes.c_void_p
     L.dsp_gz_open.argtypes = [ctypes.c_char_p]
     L.dsp_gz_read.restype = ctypes.c_int64

@@ -234,7 +234,7 @@ class _NoRelease(object):
 def _call_mods_reads(args, rank, local_rank, world):
     """The fast5-directory branch (call_modifications.py:559-583, :285-470): read records -> features extracted on the
     GPU (extract_features.py of this build) -> forward -> per-read calls, the features never leaving HBM.
-    Input files: *.fast5 (needs h5py on the host) and *.reads.npz (reads.save_reads).  Files are dealt to ranks
+    Input files: *.fast5 (native reader over the HDF5 C library) and *.reads.npz (reads.save_reads).  Files are dealt to ranks
     in contiguous ranges; output order = file order."""
     import torch
     from . import reads as dsp_reads
@@ -482,7 +482,7 @@ def add_call_mods_args(p):
     g = p.add_argument_group("OUTPUT")
     g.add_argument("--result_file", "-o", type=str, required=True, help="per-read call file to write")
     g.add_argument("--gzip", action="store_true", default=False, help="gzip the output")
-    g = p.add_argument_group("EXTRACTION (used when --input_path is a directory of *.fast5 [needs h5py] / *.reads.npz files)")
+    g = p.add_argument_group("EXTRACTION (used when --input_path is a directory of *.fast5 / *.reads.npz files)")
     g.add_argument("--recursively", "-r", type=str, default="yes")
     g.add_argument("--corrected_group", type=str, default="RawGenomeCorrected_000")
     g.add_argument("--basecall_subgroup", type=str, default="BaseCalled_template")

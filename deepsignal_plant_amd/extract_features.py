@@ -285,7 +285,7 @@ class FeatureExtractor(object):
 
 # ---- `deepsignal_plant extract` (extract_features.py:589-651, :654-767) ---------------------------------------------
 def extract_features(args):
-    """Reads in (a directory of *.fast5 [needs h5py] / *.reads.npz), feature rows out: the reference's `extract`.
+    """Reads in (a directory of *.fast5 / *.reads.npz), feature rows out: the reference's `extract`.
     Output: the feature TSV (plain / --gzip / --w_is_dir batches, byte-compatible with _features_to_str), or the
     binary container when --write_path ends with .dspf (what call_mods reads fastest)."""
     import gzip
@@ -314,7 +314,7 @@ def extract_features(args):
                           region=args.region, methy_label=args.methy_label, is_dna=str2bool(args.is_dna), device=0,
                           seed=getattr(args, "seed", 0), round_stats=True, nthreads=nthreads)
     batches = dsp_reads.ReadBatches(files, max(1, int(args.f5_batch_size)) * 8, args.corrected_group,
-                                    args.basecall_subgroup, workers=min(8, nthreads))
+                                    args.basecall_subgroup, workers=min(8, nthreads), only_chrom=fx.regioninfo[0])
     rq = queue.Queue(maxsize=3)
 
     def load():
@@ -374,7 +374,7 @@ def extract_features(args):
 def add_extract_args(p):
     """The reference's `extract` flags (extract_features.py:654-745) + --seed of the subsampler."""
     g = p.add_argument_group("INPUT")
-    g.add_argument("--fast5_dir", "-i", type=str, required=True, help="directory of read files (*.fast5 [needs h5py] / *.reads.npz)")
+    g.add_argument("--fast5_dir", "-i", type=str, required=True, help="directory of read files (*.fast5 / *.reads.npz)")
     g.add_argument("--recursively", "-r", type=str, default="yes")
     g.add_argument("--corrected_group", type=str, default="RawGenomeCorrected_000")
     g.add_argument("--basecall_subgroup", type=str, default="BaseCalled_template")

@@ -1,9 +1,10 @@
 """Read records: what the reference pulls out of one resquiggled fast5 before any arithmetic
 (extract_features.py:44-91 `_get_label_raw`, :151-176 `_get_alignment_info_from_fast5`, :255-270
-`_get_scaling_of_a_read`), as plain arrays.  The HDF5 side itself is outside this build (h5py is not in the
-image); `from_fast5` is the gated loader for hosts that have it, `synth_reads` the seeded generator used by
-tests and benchmarks."""
+`_get_scaling_of_a_read`), as plain arrays.  `from_fast5` reads them from a fast5 through the native reader
+(csrc/dsp_fast5.cpp over the HDF5 C library); `synth_reads` is the seeded generator used by tests and benchmarks."""
 from __future__ import annotations
+
+import os
 
 import numpy as np
 
@@ -64,30 +65,47 @@ def synth_reads(n_reads, seed=0, mean_bases=400, max_len=40, long_every=97, n_ch
     return reads
 
 
-def from_fast5(path, corrected_group="RawGenomeCorrected_000", basecall_subgroup="BaseCalled_template"):
-    """Gated single-read fast5 loader for hosts with h5py (not in this image, untested here): the HDF5 paths are
-    those of extract_features.py:36-37, :57-89, :151-176, :255-266."""
-    try:
-        import h5py
-    except ImportError:
-        raise RuntimeError("reading fast5 files needs h5py, which this image does not have; feed ReadRecord "
-                           "arrays (deepsignal_plant_amd.reads) instead")
-    with h5py.File(path, "r") as h5:
-        raw = list(h5["/Raw/Reads"].values())[0]
-        readname = raw.attrs["read_id"]
-        readname = readname.decode() if isinstance(readname, bytes) else str(readname)
-        signal = raw["Signal"][()]
-        ch = dict(h5["UniqueGlobalKey/channel_id"].attrs.items())
-        ev = h5["Analyses/%s/%s/Events" % (corrected_group, basecall_subgroup)]
-        rel = dict(ev.attrs.items())["read_start_rel_to_raw"]
-        al = h5["Analyses/%s/%s/Alignment" % (corrected_group, basecall_subgroup)].attrs
+class NoAlignment(RuntimeError):
+    """The fast5 has no Analyses/<corrected group>/<subgroup>/Alignment group: the reference carries on with empty
+    alignment fields and fails the read at extract_features.py:327 (counted as an error)."""
 
-        def s(x):
-            return x.decode() if isinstance(x, bytes) else str(x)
-        return ReadRecord(readname, "t" if basecall_subgroup.endswith("template") else "c", s(al["mapped_strand"]),
-                          s(al["mapped_chrom"]), int(al["mapped_start"]), signal, ch["range"] / ch["digitisation"],
-                          ch["offset"], ev["start"].astype(np.int64) + int(rel), ev["length"].astype(np.int64),
-                          np.frombuffer(b"".join(ev["base"]), np.uint8))
+
+def fast5_available():
+    """True if the native reader found an HDF5 library (libdsp_amd.so dlopens it; DSP_HDF5_LIB overrides the search)."""
+    from . import _native as nat
+    return bool(nat.lib().dsp_fast5_available())
+
+
+def from_fast5(path, corrected_group="RawGenomeCorrected_000", basecall_subgroup="BaseCalled_template", only_chrom=None):
+    """One tombo-resquiggled single-read fast5 -> ReadRecord, through the native reader (csrc/dsp_fast5.cpp: the HDF5 C
+    library, no h5py): the HDF5 paths and the failure texts are those of extract_features.py:36-37, :44-91, :94-176,
+    :255-270.  only_chrom: the region filter's chromosome -- a read that maps elsewhere (or has no alignment, or cannot
+    be opened) returns None before anything else is read, as at :308-309.  Errors raise RuntimeError (the caller counts
+    the file as failed, :373-375)."""
+    import ctypes
+    from . import _native as nat
+    L = nat.lib()
+    rec = nat.Fast5Read()
+    rc = L.dsp_fast5_load(os.fsencode(path), corrected_group.encode(), basecall_subgroup.encode(),
+                          None if only_chrom is None else only_chrom.encode(), ctypes.byref(rec))
+    if rc == 1:  # DSP_FAST5_SKIPPED
+        return None
+    if rc != 0:
+        raise RuntimeError(nat.last_error())
+    try:
+        if not rec.has_alignment:
+            raise NoAlignment("no Alignment group in %s" % path)
+        n, m = int(rec.n_raw), int(rec.n_events)
+        raw = np.ctypeslib.as_array(rec.raw, shape=(max(n, 1),))[:n].copy()
+        ev_start = np.ctypeslib.as_array(rec.ev_start, shape=(max(m, 1),))[:m].copy()
+        ev_len = np.ctypeslib.as_array(rec.ev_len, shape=(max(m, 1),))[:m].copy()
+        ev_base = np.ctypeslib.as_array(rec.ev_base, shape=(max(m, 1),))[:m].copy()
+        # scaling = range / digitisation in float64, as the reference divides the two attributes (:262)
+        return ReadRecord(rec.read_id.decode("utf-8", "replace"), "t" if basecall_subgroup.endswith("template") else "c",
+                          rec.mapped_strand.decode("utf-8", "replace"), rec.mapped_chrom.decode("utf-8", "replace"),
+                          int(rec.mapped_start), raw, rec.range / rec.digitisation, rec.offset, ev_start, ev_len, ev_base)
+    finally:
+        L.dsp_fast5_free(ctypes.byref(rec))
 
 
 # ---- read-record container (.reads.npz): the HDF5-free interchange of this build ------------------------------------
@@ -120,7 +138,7 @@ def load_reads(path):
 
 
 def list_read_files(input_dir, recursive=True):
-    """*.fast5 (needs h5py) and *.reads.npz under a directory, sorted (the reference's get_fast5s walks the tree for
+    """*.fast5 and *.reads.npz under a directory, sorted (the reference's get_fast5s walks the tree for
     *.fast5, utils/process_utils.py:148-161)."""
     import os
     found = []
@@ -133,12 +151,13 @@ def list_read_files(input_dir, recursive=True):
     return sorted(found)
 
 
-def load_read_file(path, corrected_group="RawGenomeCorrected_000", basecall_subgroup="BaseCalled_template"):
+def load_read_file(path, corrected_group="RawGenomeCorrected_000", basecall_subgroup="BaseCalled_template", only_chrom=None):
     """-> list of ReadRecord.  A fast5 that cannot be parsed raises; the caller counts it as failed like the
-    reference (extract_features.py:373-375)."""
+    reference (extract_features.py:373-375).  only_chrom: see from_fast5."""
     if path.endswith(".reads.npz"):
         return load_reads(path)
-    return [from_fast5(path, corrected_group, basecall_subgroup)]
+    r = from_fast5(path, corrected_group, basecall_subgroup, only_chrom)
+    return [] if r is None else [r]
 
 
 class ReadBatches(object):
@@ -149,15 +168,16 @@ class ReadBatches(object):
     and of how files are dealt to ranks."""
 
     def __init__(self, files, batch_reads, corrected_group="RawGenomeCorrected_000",
-                 basecall_subgroup="BaseCalled_template", first_file_index=0, workers=4, lookahead=8):
+                 basecall_subgroup="BaseCalled_template", first_file_index=0, workers=4, lookahead=8, only_chrom=None):
         self.files, self.batch_reads = list(files), max(1, int(batch_reads))
         self.cg, self.sg, self.first = corrected_group, basecall_subgroup, int(first_file_index)
         self.workers, self.lookahead = max(1, int(workers)), max(1, int(lookahead))
         self.failed = 0
+        self.only_chrom = only_chrom  # chromosome of the region of interest: reads elsewhere are dropped unread
 
     def _load(self, path):
         try:
-            return load_read_file(path, self.cg, self.sg)
+            return load_read_file(path, self.cg, self.sg, self.only_chrom)
         except Exception:
             return None
 

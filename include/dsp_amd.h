@@ -358,6 +358,38 @@ dsp_gz_stream* dsp_gz_open(const char* path);
 int64_t dsp_gz_read(dsp_gz_stream* s, uint8_t* out, size_t cap);
 void dsp_gz_close(dsp_gz_stream* s);
 
+/* ---- fast5 ingestion (csrc/dsp_fast5.cpp): what extract_features.py:44-91 (_get_label_raw), :94-176
+ * (_get_alignment_info_from_fast5) and :255-270 (_get_scaling_of_a_read) read from one tombo-resquiggled single-read
+ * fast5 through h5py, read here through the HDF5 C library itself (found with dlopen at run time: DSP_HDF5_LIB, the usual
+ * sonames, conda / system library directories; HDF5 >= 1.10).
+ * dsp_fast5_load fills `out` (arrays are malloc'ed, release with dsp_fast5_free) and returns 0; DSP_FAST5_SKIPPED when
+ * `only_chrom` is given and the read maps elsewhere, has no Alignment group or cannot be opened (the reference's region
+ * filter at :308-309 runs before anything else is read); a negative dsp_status whose message is the reference's
+ * exception text otherwise (the caller counts the file as failed, :373-375).  A file without an Alignment group loads with
+ * has_alignment = 0 (the reference carries on with empty fields and fails later, at :327).
+ * ev_start already includes the Events attribute read_start_rel_to_raw (:81).  Thread-safe (one internal lock). */
+#define DSP_FAST5_SKIPPED 1
+typedef struct dsp_fast5_read {
+    int64_t n_raw;
+    int16_t* raw;              /* Raw/Reads/<first read>/Signal */
+    int64_t n_events;
+    int64_t* ev_start;         /* Events 'start' + read_start_rel_to_raw */
+    int64_t* ev_len;           /* Events 'length' */
+    uint8_t* ev_base;          /* Events 'base' (ASCII) */
+    double digitisation, range, offset; /* UniqueGlobalKey/channel_id */
+    int64_t mapped_start;
+    int32_t has_alignment;
+    int32_t reserved;
+    char read_id[256];
+    char mapped_chrom[256];
+    char mapped_strand[8];
+} dsp_fast5_read;
+int32_t dsp_fast5_available(void);       /* 1 if an HDF5 library was found (else dsp_last_error says what was tried) */
+const char* dsp_fast5_library(void);     /* path of the library in use, "" if none */
+int32_t dsp_fast5_load(const char* path, const char* corrected_group, const char* basecall_subgroup, const char* only_chrom,
+                       dsp_fast5_read* out);
+void dsp_fast5_free(dsp_fast5_read* r);
+
 const char* dsp_last_error(void);
 int32_t dsp_abi_version(void);
 

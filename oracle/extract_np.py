@@ -11,9 +11,10 @@ Follows deepsignal_plant/extract_features.py:
                                    k-mer window, per-base mean / std / length
   _features_to_str      :381-395   the feature-TSV row
 and utils/process_utils.py:97-112 (get_refloc_of_methysite_in_motif).  `robust.mad` is statsmodels'
-(robust/scale.py: median(|a - median(a)| / c), c = norm.ppf(3/4)); statsmodels is NOT in the image, so that one
-function is restated from its published definition and is unpinned by the reference's dependency itself
-(everything else is pinned by tests/golden/f6_extract.npz, captured from the imported reference).
+(robust/scale.py: median(|a - median(a)| / c), c = norm.ppf(3/4)), restated here.  Pinned twice: by
+tests/golden/f6_extract.npz (the imported reference with its three HDF5 accessors replaced and the same restated mad) and
+by tests/golden/fast5/ (F7: the reference UNMODIFIED, h5py + statsmodels' own robust.mad from the image's python3.9, on
+real fast5 files -- tests/test_fast5_reader.py compares this module's rows with those byte for byte).
 
 Sampling of long bases: the reference calls the process-global, unseeded `random.sample`, i.e. it is not
 reproducible against itself.  sampler="python" uses the same `random.sample` calls in the same order (pins the
@@ -31,7 +32,7 @@ M64 = (1 << 64) - 1
 
 
 def mad(a):
-    """statsmodels.robust.mad(a) with its defaults (restated; see the module docstring)."""
+    """statsmodels.robust.mad(a) with its defaults (restated; pinned by F7, see the module docstring)."""
     a = np.asarray(a)
     center = np.median(a)
     err = np.abs(a - center) / MAD_C

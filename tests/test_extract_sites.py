@@ -121,5 +121,5 @@ def test_read_container_roundtrip_and_ordered_batches(tmp_path):
     assert bt.failed == 1 and [len(x[0]) for x in out] == [4, 6]
     assert [r.readname for x in out for r in x[0]] == [r.readname for r in rs]
     assert [u for x in out for u in x[1]] == [(5 << 20) + i for i in range(3)] + [6 << 20] + [(8 << 20) + i for i in range(6)]
-    with pytest.raises(RuntimeError, match="h5py"):
+    with pytest.raises(RuntimeError, match="Error opening file"):
         R.from_fast5(d + "/c.fast5")

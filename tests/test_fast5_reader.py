@@ -1,0 +1,116 @@
+"""CPU: the native fast5 reader (csrc/dsp_fast5.cpp over the HDF5 C library) against fixture F7 -- real HDF5 files
+written with h5py and what the REFERENCE's own accessors (_get_label_raw, _get_alignment_info_from_fast5,
+_get_scaling_of_a_read, extract_features.py:44-176, :255-270) returned for each of them, recorded by
+tests/golden/make_golden_fast5.py under the image's python3.9 (h5py 3.3.0 / HDF5 1.10.6)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from deepsignal_plant_amd import reads as R
+from tests.helpers import ROOT
+
+F7 = os.path.join(ROOT, "tests", "golden", "fast5")
+EXPECT = json.load(open(os.path.join(F7, "expect.json")))
+# what the reference raised for the broken files -> the text this build reports for them
+REF_ERRORS = {"OSError": "Error opening file. Likely a corrupted file.", "KeyError": "no read_start_rel_to_raw in event attributes",
+              "RuntimeError": "Raw/Reads"}
+
+
+def _need_hdf5():
+    if not R.fast5_available():
+        from deepsignal_plant_amd import _native as nat
+        if os.path.exists("/opt/conda/lib/libhdf5.so"):
+            pytest.fail("the image's libhdf5 was not loaded: " + nat.last_error())
+        pytest.skip("no HDF5 library on this host: " + nat.last_error())
+
+
+def test_every_fixture_file_reads_like_h5py_did():
+    _need_hdf5()
+    n_ok = 0
+    for rel, info in sorted(EXPECT["files"].items()):
+        path = os.path.join(F7, "reads", rel)
+        if not info["ok"]:
+            with pytest.raises(RuntimeError) as e:
+                R.from_fast5(path)
+            assert REF_ERRORS[info["error"]] in str(e.value), (rel, info["error"], str(e.value))
+            continue
+        if info["chrom"] == "":  # no Alignment group: the reference goes on with empty fields and fails the read later
+            with pytest.raises(R.NoAlignment):
+                R.from_fast5(path)
+            continue
+        r = R.from_fast5(path)
+        assert (len(r.raw), int(r.raw.astype(np.int64).sum())) == (info["n_raw"], info["raw_sum"]), rel
+        assert (len(r.ev_base), int(r.ev_start.sum()), int(r.ev_len.sum())) == (info["n_events"], info["start_sum"], info["len_sum"]), rel
+        assert r.seq == info["seq"] and r.readname == info["readname"] and r.strand == info["strand"], rel
+        assert (r.chrom, r.alignstrand, r.chrom_start) == (info["chrom"], info["alignstrand"], info["chrom_start"]), rel
+        assert (r.scaling, r.offset) == (info["scaling"], info["offset"]), rel  # float64, bit for bit
+        n_ok += 1
+    assert n_ok >= 10 and {i["variant"] for i in EXPECT["files"].values()} >= {0, 1, 2, 3, 4, 5, 6}
+
+
+def test_region_chromosome_drops_reads_before_anything_else_is_read():
+    """extract_features.py:308-309: with a region of interest a read that maps elsewhere, has no alignment or cannot even be
+    opened is skipped, not failed"""
+    _need_hdf5()
+    for rel, info in sorted(EXPECT["files"].items()):
+        path = os.path.join(F7, "reads", rel)
+        if info["ok"] and info["chrom"] == "chr2":
+            assert R.from_fast5(path, only_chrom="chr2").chrom == "chr2"
+        elif info["ok"] or info["variant"] == 6:
+            assert R.from_fast5(path, only_chrom="chr2") is None, rel
+    batches = R.ReadBatches(R.list_read_files(os.path.join(F7, "reads")), 100, only_chrom="chr2")
+    got = [r for rs, _ in batches for r in rs]
+    assert {r.chrom for r in got} == {"chr2"} and batches.failed == EXPECT["cases"]["mad_region"]["errors"]
+
+
+def test_other_groups_and_missing_library_are_loud(tmp_path):
+    _need_hdf5()
+    good = next(os.path.join(F7, "reads", rel) for rel, i in sorted(EXPECT["files"].items()) if i["ok"] and i["chrom"])
+    with pytest.raises(RuntimeError, match="events not found"):
+        R.from_fast5(good, corrected_group="RawGenomeCorrected_001")
+    with pytest.raises(RuntimeError, match="events not found"):
+        R.from_fast5(good, basecall_subgroup="BaseCalled_complement")
+    with pytest.raises(RuntimeError, match="Error opening file"):
+        R.from_fast5(str(tmp_path / "absent.fast5"))
+    # a process that cannot find the library says what it tried (fresh interpreter: the search runs once per process)
+    import subprocess
+    import sys
+    code = ("from deepsignal_plant_amd import reads as R\n"
+            "try:\n    R.from_fast5(%r)\nexcept RuntimeError as e:\n    print('ERR', e)\n" % good)
+    env = dict(os.environ, DSP_HDF5_LIB="/nonexistent/libhdf5.so", DSP_HDF5_NO_SEARCH="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT).stdout
+    assert "ERR" in out and "HDF5" in out
+
+
+@pytest.mark.parametrize("name", sorted(EXPECT["cases"]))
+def test_oracle_extraction_of_the_fast5_reads_equals_the_reference_rows(name):
+    """Pins the oracle (oracle/extract_np.py, incl. its restated robust.mad) against the reference run with statsmodels'
+    own robust.mad on the same files: every deterministic column of every row, byte for byte"""
+    import gzip
+    from deepsignal_plant_amd.utils.process_utils import get_motif_seqs, parse_region_str
+    from oracle import extract_np as ox
+    _need_hdf5()
+    c = EXPECT["cases"][name]
+    rs = []
+    for p in R.list_read_files(os.path.join(F7, "reads")):
+        try:
+            rs.append(R.from_fast5(p))
+        except RuntimeError:
+            pass
+    feats = ox.extract_features(rs, c["method"], get_motif_seqs(c["motifs"], True), c["mod_loc"],
+                                EXPECT["chrom_len"] if c["c2l"] else None, c["k"], c["s"], c["label"], None,
+                                parse_region_str(c["region"]), sampler="hash", seed=0)
+    got = [ox.features_to_str(f) for f in feats]
+    want = gzip.open(os.path.join(F7, "expect_%s.tsv.gz" % name), "rt").read().splitlines()
+    assert len(got) == len(want) == c["rows"]
+    n_exact = 0
+    for g, w in zip(got, want):
+        fg, fw = g.split("\t"), w.split("\t")
+        assert fg[:10] == fw[:10] and fg[11] == fw[11]
+        for j, n in enumerate(int(x) for x in fw[9].split(",")):
+            if n <= c["s"]:
+                assert fg[10].split(";")[j] == fw[10].split(";")[j]
+                n_exact += 1
+    assert n_exact > 1000

@@ -1,0 +1,115 @@
+"""GPU: `deepsignal_plant extract` and `call_mods` on a directory of REAL fast5 files (fixture F7: HDF5 files written with
+h5py; expected rows = the reference's own _extract_features + _features_to_str run on them with h5py and statsmodels'
+robust.mad, tests/golden/make_golden_fast5.py).  Every column the reference computes deterministically must be
+byte-identical; the signal groups of bases longer than signal_len (which the reference subsamples with the unseeded global
+`random`, extract_features.py:247-249) must be an order-preserving selection of that base's own normalised samples."""
+import gzip
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from deepsignal_plant_amd import reads as R
+from oracle import extract_np as ox
+from tests.helpers import ROOT
+
+pytestmark = pytest.mark.gpu
+F7 = os.path.join(ROOT, "tests", "golden", "fast5")
+EXPECT = json.load(open(os.path.join(F7, "expect.json")))
+
+
+def _ref_fasta(tmp_path):
+    fa = tmp_path / "ref.fa"
+    with open(fa, "w") as f:
+        for c, n in EXPECT["chrom_len"].items():
+            f.write(">%s synthetic\n" % c)
+            for o in range(0, n, 60):
+                f.write("N" * min(60, n - o) + "\n")
+    return str(fa)
+
+
+@pytest.mark.parametrize("name", sorted(EXPECT["cases"]))
+def test_extract_cli_on_fast5_files_writes_the_reference_rows(name, tmp_path):
+    if not R.fast5_available():
+        pytest.fail("no HDF5 library on the GPU box")
+    c = EXPECT["cases"][name]
+    out = str(tmp_path / "feats.tsv")
+    cmd = [sys.executable, "-m", "deepsignal_plant_amd.deepsignal_plant", "extract", "-i", os.path.join(F7, "reads"), "-o", out,
+           "--normalize_method", c["method"], "--motifs", c["motifs"], "--mod_loc", str(c["mod_loc"]), "--seq_len", str(c["k"]),
+           "--signal_len", str(c["s"]), "--methy_label", str(c["label"]), "--f5_batch_size", "2"]
+    if c["c2l"]:
+        cmd += ["--reference_path", _ref_fasta(tmp_path)]
+    if c["region"]:
+        cmd += ["--region", c["region"]]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "%d of %d read files failed" % (c["errors"], len(EXPECT["files"])) in r.stdout
+    got = open(out).read().splitlines()
+    want = gzip.open(os.path.join(F7, "expect_%s.tsv.gz" % name), "rt").read().splitlines()
+    assert len(got) == len(want) == c["rows"]
+    reads = {}
+    for rel, info in EXPECT["files"].items():
+        if info["ok"] and info["chrom"]:
+            rd = R.from_fast5(os.path.join(F7, "reads", rel))
+            reads[rd.readname] = rd
+    n_long = n_short = 0
+    half = (c["k"] - 1) // 2
+    for g, w in zip(got, want):
+        fg, fw = g.split("\t"), w.split("\t")
+        assert fg[:10] == fw[:10] and fg[11] == fw[11], (fg[:7], fw[:7])
+        lens = [int(x) for x in fw[9].split(",")]
+        gg, gw = fg[10].split(";"), fw[10].split(";")
+        rd = norm = None
+        for j, n in enumerate(lens):
+            if n <= c["s"]:
+                assert gg[j] == gw[j]
+                n_short += 1
+                continue
+            if rd is None:  # the base's own samples, normalised as the reference does (oracle restatement, pinned by F6)
+                rd = reads[fw[4]]
+                norm = ox.normalize_signals(ox.rescale_signals(rd.raw, rd.scaling, rd.offset), c["method"])
+                pos = int(fw[1])
+                loc = (rd.chrom_start + len(rd.seq) - 1 - pos) if rd.alignstrand == "-" else pos - rd.chrom_start
+            b = loc - half + j
+            base = [str(x) for x in np.around(norm[int(rd.ev_start[b]):int(rd.ev_start[b] + rd.ev_len[b])], decimals=6)]
+            for vals in (gg[j].split(","), gw[j].split(",")):  # this build's selection and the reference's own
+                assert len(vals) == c["s"]
+                p = 0
+                for v in vals:
+                    while p < len(base) and base[p] != v:
+                        p += 1
+                    assert p < len(base), (fw[:7], j)
+                    p += 1
+            n_long += 1
+    assert n_short > 1000 and n_long > 10
+
+
+def test_call_mods_on_fast5_files_equals_call_mods_on_the_same_reads_as_records(tmp_path):
+    """call_mods -i <dir of fast5> (the reference's fast5 branch, call_modifications.py:559-583) == the same reads handed
+    over as read records (the path the extraction tests pin against the oracle)"""
+    import torch
+    from oracle import forward_np as onp
+    w = onp.make_weights(onp.OracleConfig(), 23, 2.0)
+    ck = str(tmp_path / "m.ckpt")
+    torch.save({k: torch.from_numpy(v) for k, v in w.items()}, ck)
+    files = R.list_read_files(os.path.join(F7, "reads"))
+    d = tmp_path / "records"
+    d.mkdir()
+    for i, p in enumerate(files):  # one record file per fast5, same order => same subsampler keys
+        try:
+            R.save_reads(str(d / ("%04d.reads.npz" % i)), [R.from_fast5(p)])
+        except RuntimeError:
+            (d / ("%04d.fast5" % i)).write_bytes(b"broken")
+    outs = []
+    for src in (os.path.join(F7, "reads"), str(d)):
+        out = str(tmp_path / ("calls_%d.tsv" % len(outs)))
+        cmd = [sys.executable, "-m", "deepsignal_plant_amd.deepsignal_plant", "call_mods", "-i", src, "-m", ck, "-o", out,
+               "--init_state", "zeros", "--seed", "9"]
+        r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert "4 of 15 read files failed" in r.stdout
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1] and outs[0].count(b"\n") == EXPECT["cases"]["mad_cg"]["rows"]
