@@ -39,6 +39,11 @@ class Fast5Read(ctypes.Structure):  # dsp_fast5_read, include/dsp_amd.h
                 ("read_id", ctypes.c_char * 256), ("mapped_chrom", ctypes.c_char * 256), ("mapped_strand", ctypes.c_char * 8)]
 
 
+# Set by the fast5 reader's worker processes (reads.ReadBatches(procs=...)) before their first lib() call: they only use
+# the host-side entry points, never the GPU, so they skip the 1.5 s torch import.  Never set it in a process that computes.
+NO_TORCH = False
+
+
 def lib():
     """Load libdsp_amd.so or raise: the product path never falls back to a CPU implementation."""
     global _lib
@@ -51,7 +56,8 @@ def lib():
     # PyTorch-ROCm bundles its own libamdhip64.so (SONAME libamdhip64.so.7).  Import torch FIRST so that
     # libdsp_amd.so's NEEDED libamdhip64.so.7 resolves to the already-loaded runtime; loading ours first
     # would leave two HIP runtimes in one process (the second one reports "no ROCm-capable device").
-    import torch  # noqa: F401
+    if not NO_TORCH:
+        import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     L.dsp_last_error.restype = ctypes.c_char_p
     L.dsp_abi_version.restype = ctypes.c_int32

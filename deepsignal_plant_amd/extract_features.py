@@ -314,7 +314,8 @@ def extract_features(args):
                           region=args.region, methy_label=args.methy_label, is_dna=str2bool(args.is_dna), device=0,
                           seed=getattr(args, "seed", 0), round_stats=True, nthreads=nthreads)
     batches = dsp_reads.ReadBatches(files, max(1, int(args.f5_batch_size)) * 8, args.corrected_group,
-                                    args.basecall_subgroup, workers=min(8, nthreads), only_chrom=fx.regioninfo[0])
+                                    args.basecall_subgroup, workers=min(8, nthreads), only_chrom=fx.regioninfo[0],
+                                    procs=min(16, nthreads))  # --nproc reader processes once there are >= 256 files
     rq = queue.Queue(maxsize=3)
 
     def load():

@@ -160,20 +160,41 @@ def load_read_file(path, corrected_group="RawGenomeCorrected_000", basecall_subg
     return [] if r is None else [r]
 
 
+def _reader_init():
+    from . import _native
+    _native.NO_TORCH = True  # reader processes never touch the GPU
+
+
+def _load_chunk(task):
+    paths, cg, sg, only_chrom = task
+    out = []
+    for p in paths:
+        try:
+            out.append(load_read_file(p, cg, sg, only_chrom))
+        except Exception:
+            out.append(None)
+    return out
+
+
 class ReadBatches(object):
-    """Iterate (reads, uids) batches over a list of read files: files are decoded by a small thread pool (HDF5 / zip
-    decoding releases the GIL) with bounded look-ahead and delivered in FILE ORDER; a file that cannot be parsed is
-    counted in .failed and skipped, like the reference (extract_features.py:373-375).  uid of a read =
-    ((first_file_index + file index) << 20) + index in the file: the key of the subsampler, independent of batching
-    and of how files are dealt to ranks."""
+    """Iterate (reads, uids) batches over a list of read files, delivered in FILE ORDER with bounded look-ahead; a file
+    that cannot be parsed is counted in .failed and skipped, like the reference (extract_features.py:373-375).
+    Decoding runs on `workers` threads, or -- procs > 1 and at least `procs_min_files` files -- on `procs` reader
+    PROCESSES (spawned, no GPU, no torch): libhdf5 decodes one file at a time per process (≈ 200 files/s of 100 k samples),
+    so fast5 directories scale with processes the way the reference's --nproc does (extract_features.py:589-651).
+    uid of a read = ((first_file_index + file index) << 20) + index in the file: the key of the subsampler, independent
+    of batching and of how files are dealt to ranks."""
 
     def __init__(self, files, batch_reads, corrected_group="RawGenomeCorrected_000",
-                 basecall_subgroup="BaseCalled_template", first_file_index=0, workers=4, lookahead=8, only_chrom=None):
+                 basecall_subgroup="BaseCalled_template", first_file_index=0, workers=4, lookahead=8, only_chrom=None,
+                 procs=0, procs_min_files=256, chunk_files=8):
         self.files, self.batch_reads = list(files), max(1, int(batch_reads))
         self.cg, self.sg, self.first = corrected_group, basecall_subgroup, int(first_file_index)
         self.workers, self.lookahead = max(1, int(workers)), max(1, int(lookahead))
         self.failed = 0
         self.only_chrom = only_chrom  # chromosome of the region of interest: reads elsewhere are dropped unread
+        self.procs = int(procs) if (int(procs) > 1 and len(self.files) >= int(procs_min_files)) else 0
+        self.chunk_files = max(1, int(chunk_files))
 
     def _load(self, path):
         try:
@@ -181,10 +202,31 @@ class ReadBatches(object):
         except Exception:
             return None
 
-    def __iter__(self):
+    def _decoded(self):
+        """-> (file index, list of ReadRecord or None) in file order"""
         from collections import deque
+        if self.procs:
+            import multiprocessing as mp
+            from concurrent.futures import ProcessPoolExecutor
+            chunks = [(i, self.files[i:i + self.chunk_files]) for i in range(0, len(self.files), self.chunk_files)]
+            with ProcessPoolExecutor(self.procs, mp_context=mp.get_context("spawn"), initializer=_reader_init) as pool:
+                pending, it = deque(), iter(chunks)
+
+                def refill():
+                    while len(pending) < 3 * self.procs:
+                        nxt = next(it, None)
+                        if nxt is None:
+                            return
+                        pending.append((nxt[0], pool.submit(_load_chunk, (nxt[1], self.cg, self.sg, self.only_chrom))))
+                refill()
+                while pending:
+                    i0, fut = pending.popleft()
+                    got = fut.result()
+                    refill()
+                    for k, g in enumerate(got):
+                        yield i0 + k, g
+            return
         from concurrent.futures import ThreadPoolExecutor
-        cur, uids = [], []
         with ThreadPoolExecutor(self.workers) as pool:
             pending = deque()
             it = iter(enumerate(self.files))
@@ -200,13 +242,18 @@ class ReadBatches(object):
                 fi, fut = pending.popleft()
                 got = fut.result()
                 refill()
-                if got is None:
-                    self.failed += 1
-                    continue
-                cur += got
-                uids += [((self.first + fi) << 20) + i for i in range(len(got))]
-                if len(cur) >= self.batch_reads:
-                    yield cur, uids
-                    cur, uids = [], []
+                yield fi, got
+
+    def __iter__(self):
+        cur, uids = [], []
+        for fi, got in self._decoded():
+            if got is None:
+                self.failed += 1
+                continue
+            cur += got
+            uids += [((self.first + fi) << 20) + i for i in range(len(got))]
+            if len(cur) >= self.batch_reads:
+                yield cur, uids
+                cur, uids = [], []
         if cur:
             yield cur, uids

@@ -114,3 +114,22 @@ def test_oracle_extraction_of_the_fast5_reads_equals_the_reference_rows(name):
                 assert fg[10].split(";")[j] == fw[10].split(";")[j]
                 n_exact += 1
     assert n_exact > 1000
+
+
+def test_reader_processes_deliver_what_the_threads_deliver():
+    """ReadBatches(procs=N): spawned reader processes (no GPU, no torch), same reads in the same order with the same uids
+    and the same failed-file count as the in-process thread pool"""
+    _need_hdf5()
+    files = R.list_read_files(os.path.join(F7, "reads")) * 3
+    a = R.ReadBatches(files, 5, first_file_index=7, workers=3)
+    b = R.ReadBatches(files, 5, first_file_index=7, procs=2, procs_min_files=1, chunk_files=4)
+    assert b.procs == 2 and R.ReadBatches(files, 5, procs=2).procs == 0  # below procs_min_files: threads
+    la, lb = list(a), list(b)
+    assert a.failed == b.failed == 3 * EXPECT["cases"]["mad_cg"]["errors"]
+    assert [u for _, us in la for u in us] == [u for _, us in lb for u in us]
+    ra, rb = [r for rs, _ in la for r in rs], [r for rs, _ in lb for r in rs]
+    assert len(ra) == len(rb) == 33
+    for x, y in zip(ra, rb):
+        assert (x.readname, x.chrom, x.chrom_start, x.alignstrand, x.scaling, x.offset) == \
+               (y.readname, y.chrom, y.chrom_start, y.alignstrand, y.scaling, y.offset)
+        assert np.array_equal(x.raw, y.raw) and np.array_equal(x.ev_start, y.ev_start) and np.array_equal(x.ev_base, y.ev_base)
