@@ -228,6 +228,76 @@ int main(int argc, char** argv) {
         }
         dsp_freq_destroy(fq);
     }
+    // ---- gzip layer: BGZF round trip on all thread counts, truncated / corrupted members fail cleanly
+    {
+        std::string text;
+        for (int i = 0; i < 40000; i++) text += "chr1\t" + std::to_string(rnd() % 1000000) + "\t+\t0.123456\n";
+        std::vector<uint8_t> comp(text.size() + text.size() / 2 + 4096);
+        const int64_t cb = dsp_bgzf_compress((const uint8_t*)text.data(), text.size(), comp.data(), comp.size(), 1, 3);
+        CHECK(cb > 0);
+        const int64_t eb = dsp_bgzf_eof(comp.data() + cb, comp.size() - (size_t)cb);
+        CHECK(eb == 28);
+        const size_t total = (size_t)(cb + eb);
+        std::vector<uint64_t> off(4096);
+        std::vector<uint32_t> isz(4096);
+        const int64_t nm = dsp_gz_index(comp.data(), total, 4095, off.data(), isz.data());
+        CHECK(nm > 2);
+        std::vector<uint8_t> back(text.size() + 16);
+        for (int nt : {1, 4}) {
+            CHECK(dsp_gz_inflate_members(comp.data(), off.data(), isz.data(), 0, nm, back.data(), back.size(), nt) == (int64_t)text.size());
+            CHECK(memcmp(back.data(), text.data(), text.size()) == 0);
+        }
+        CHECK(dsp_gz_inflate_members(comp.data(), off.data(), isz.data(), 0, nm, back.data(), 100, 2) == DSP_ENOMEM);
+        CHECK(dsp_gz_index(comp.data(), total - 5, 4095, off.data(), isz.data()) == -1);  // truncated: not a BGZF chain
+        for (int it = 0; it < 40; it++) {
+            std::vector<uint8_t> bad(comp.begin(), comp.begin() + (long)total);
+            bad[40 + rnd() % (total - 80)] ^= (uint8_t)(1 + rnd() % 255);
+            std::vector<uint64_t> o2(4096);
+            std::vector<uint32_t> i2(4096);
+            const int64_t n2 = dsp_gz_index(bad.data(), total, 4095, o2.data(), i2.data());
+            if (n2 > 0) {
+                uint64_t sum = 0;
+                for (int64_t m = 0; m < n2; m++) sum += i2[(size_t)m];
+                std::vector<uint8_t> b2((size_t)sum + 16);
+                const int64_t r = dsp_gz_inflate_members(bad.data(), o2.data(), i2.data(), 0, n2, b2.data(), b2.size(), 2);
+                CHECK(r >= 0 || r == DSP_EPARSE || r == DSP_ENOMEM);
+            }
+        }
+    }
+
+    // ---- fast5 reader (only when an HDF5 library is on this host): every F7 file, other groups, the region filter
+    if (dsp_fast5_available()) {
+        const char* files[] = {"read_00000-67ee_ch101_read0_strand.fast5", "read_00001-f97f_ch101_read1_strand.fast5",
+                               "read_00002-05ce_ch101_read2_strand.fast5", "read_00009-939b_ch101_read9_strand.fast5",
+                               "read_00010-d091_ch101_read10_strand.fast5", "sub/read_00011-c1cf_ch101_read11_strand.fast5",
+                               "not_hdf5.fast5", "absent.fast5"};
+        int ok = 0, failed = 0, skipped = 0;
+        for (const char* f : files) {
+            const std::string p = golden + "/fast5/reads/" + f;
+            for (const char* only : {(const char*)nullptr, "chr2"}) {
+                dsp_fast5_read rec;
+                const int32_t rc = dsp_fast5_load(p.c_str(), "RawGenomeCorrected_000", "BaseCalled_template", only, &rec);
+                if (rc == 0) {
+                    CHECK(rec.n_raw > 0 && rec.n_events > 0 && rec.raw && rec.ev_start && rec.ev_len && rec.ev_base);
+                    int64_t last = rec.ev_start[rec.n_events - 1] + rec.ev_len[rec.n_events - 1];
+                    CHECK(last <= rec.n_raw && rec.digitisation == 8192.0);
+                    ok++;
+                } else if (rc == DSP_FAST5_SKIPPED) {
+                    skipped++;
+                } else {
+                    CHECK(rc == DSP_EPARSE && !g_err.empty());
+                    failed++;
+                }
+                dsp_fast5_free(&rec);
+                dsp_fast5_free(&rec);  // idempotent
+            }
+            dsp_fast5_read rec;
+            CHECK(dsp_fast5_load(p.c_str(), "NoSuchGroup_000", "BaseCalled_template", nullptr, &rec) != 0);
+            dsp_fast5_free(&rec);
+        }
+        CHECK(ok >= 4 && failed >= 4 && skipped >= 4);
+        printf("fast5: %d loaded, %d failed, %d skipped\n", ok, failed, skipped);
+    }
     printf("host_asan: ok\n");
     return 0;
 }
