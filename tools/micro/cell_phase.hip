@@ -44,7 +44,7 @@ __device__ __forceinline__ void cell(const f32x16 (&acc)[4][2], f32x4* c_lds, co
                     cv[i] = cn;
                     hv[i] = og * fast_tanh(cn);
                 }
-            } else {
+            } else if (V == 1) {
                 // sigmoid(a) = 1/(1+ea), tanh(b) = (1-eb)/(1+eb) with ea = exp2(-log2e*a), eb = exp2(-2*log2e*b):
                 //   c' = f*c + i*g = [c*(1+ea)(1+eb) + (1-eb)(1+ef)] / [(1+ef)(1+ea)(1+eb)]
                 //   h  = o*tanh(c') = (1-ec) / [(1+eo)(1+ec)]
@@ -81,6 +81,46 @@ __device__ __forceinline__ void cell(const f32x16 (&acc)[4][2], f32x4* c_lds, co
                     f32x2 r2;
                     r2[0] = __builtin_amdgcn_rcpf(d2[0]); r2[1] = __builtin_amdgcn_rcpf(d2[1]);
                     const f32x2 h = nc * r2;
+                    cv[2 * j] = cn[0]; cv[2 * j + 1] = cn[1];
+                    hv[2 * j] = h[0]; hv[2 * j + 1] = h[1];
+                }
+            }
+            if (V == 2) {
+                // c' = c / (1+ef) + (1-eb) / ((1+ea)(1+eb)),  h = (1-ec) / ((1+eo)(1+ec)): 5 v_exp + 3 v_rcp; only the two
+                // tanh exponentials need a cap (an infinite sigmoid exponential gives rcp = 0, times a finite factor)
+                const f32x2 k1 = {-1.4426950408889634f, -1.4426950408889634f}, k2 = {-2.8853900817779268f, -2.8853900817779268f};
+                const f32x2 one = {1.f, 1.f};
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int r = 4 * aa + 2 * j;
+                    f32x2 xa = {acc[0][m][r], acc[0][m][r + 1]}, xf = {acc[1][m][r], acc[1][m][r + 1]};
+                    f32x2 xg = {acc[2][m][r], acc[2][m][r + 1]}, xo = {acc[3][m][r], acc[3][m][r + 1]};
+                    f32x2 ba = {bi[2 * j], bi[2 * j + 1]}, bff = {bf[2 * j], bf[2 * j + 1]}, bgg = {bg[2 * j], bg[2 * j + 1]}, boo = {bo[2 * j], bo[2 * j + 1]};
+                    f32x2 c = {cv[2 * j], cv[2 * j + 1]};
+                    f32x2 ta = __builtin_elementwise_fma(xa, k1, ba), tf = __builtin_elementwise_fma(xf, k1, bff);
+                    f32x2 tg = __builtin_elementwise_fma(xg, k2, bgg), to = __builtin_elementwise_fma(xo, k1, boo);
+                    f32x2 ea, ef, eb, eo;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        ea[e] = __builtin_amdgcn_exp2f(ta[e]);
+                        ef[e] = __builtin_amdgcn_exp2f(tf[e]);
+                        eb[e] = __builtin_amdgcn_exp2f(__builtin_fminf(tg[e], 30.f));
+                        eo[e] = __builtin_amdgcn_exp2f(to[e]);
+                    }
+                    const f32x2 A = one + ea, F = one + ef, B = one + eb, nb = one - eb;
+                    const f32x2 P = A * B;
+                    f32x2 r1, r2;
+                    r1[0] = __builtin_amdgcn_rcpf(F[0]); r1[1] = __builtin_amdgcn_rcpf(F[1]);
+                    r2[0] = __builtin_amdgcn_rcpf(P[0]); r2[1] = __builtin_amdgcn_rcpf(P[1]);
+                    const f32x2 cn = __builtin_elementwise_fma(c, r1, nb * r2);
+                    const f32x2 tc = cn * k2;
+                    f32x2 ec;
+                    ec[0] = __builtin_amdgcn_exp2f(__builtin_fminf(tc[0], 30.f)); ec[1] = __builtin_amdgcn_exp2f(__builtin_fminf(tc[1], 30.f));
+                    const f32x2 O = one + eo, C = one + ec, nc = one - ec;
+                    const f32x2 d2 = O * C;
+                    f32x2 r3;
+                    r3[0] = __builtin_amdgcn_rcpf(d2[0]); r3[1] = __builtin_amdgcn_rcpf(d2[1]);
+                    const f32x2 h = nc * r3;
                     cv[2 * j] = cn[0]; cv[2 * j + 1] = cn[1];
                     hv[2 * j] = h[0]; hv[2 * j + 1] = h[1];
                 }
@@ -130,17 +170,18 @@ int main() {
         for (auto& v : in) v = rnd() * scale;
         for (auto& v : bias) v = rnd() * -1.44f;
         for (auto& v : c0) v = rnd() * (pass == 0 ? 1.f : 12.f);
-        float *din, *db, *dc, *dout[2], *dcout[2]; long long* dcy;
+        float *din, *db, *dc, *dout[3], *dcout[3]; long long* dcy;
         hipMalloc(&din, nin * 4); hipMalloc(&db, 512 * 4); hipMalloc(&dc, nc * 4); hipMalloc(&dcy, 8);
         hipMemcpy(din, in.data(), nin * 4, hipMemcpyHostToDevice); hipMemcpy(db, bias.data(), 512 * 4, hipMemcpyHostToDevice);
         hipMemcpy(dc, c0.data(), nc * 4, hipMemcpyHostToDevice);
-        std::vector<float> h[2], c[2];
-        for (int v = 0; v < 2; ++v) {
+        std::vector<float> h[3], c[3];
+        for (int v = 0; v < 3; ++v) {
             hipMalloc(&dout[v], nc * 4); hipMalloc(&dcout[v], nc * 4);
             const size_t lds = 8 * nthr * 16 + 128 * 16;
             long long cy = 0;
             for (int iters : {1, 201}) {
                 if (v == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(nthr), lds, 0, din, db, dc, dout[v], dcout[v], dcy, iters);
+                else if (v == 2) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(nthr), lds, 0, din, db, dc, dout[v], dcout[v], dcy, iters);
                 else hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(nthr), lds, 0, din, db, dc, dout[v], dcout[v], dcy, iters);
                 hipDeviceSynchronize();
                 long long t; hipMemcpy(&t, dcy, 8, hipMemcpyDeviceToHost);
@@ -149,13 +190,15 @@ int main() {
             }
             printf("pass %d variant %d: %lld cycles per cell phase (32 elements per lane, one wave per SIMD)\n", pass, v, cy);
         }
-        double dh = 0, dcc = 0; int bad = 0;
-        for (size_t i = 0; i < nc; ++i) {
-            if (!std::isfinite(h[1][i]) || !std::isfinite(c[1][i])) ++bad;
-            dh = std::fmax(dh, std::fabs((double)h[0][i] - h[1][i]));
-            dcc = std::fmax(dcc, std::fabs((double)c[0][i] - c[1][i]) / (1.0 + std::fabs((double)c[0][i])));
+        for (int v = 1; v < 3; ++v) {
+            double dh = 0, dcc = 0; int bad = 0;
+            for (size_t i = 0; i < nc; ++i) {
+                if (!std::isfinite(h[v][i]) || !std::isfinite(c[v][i])) ++bad;
+                dh = std::fmax(dh, std::fabs((double)h[0][i] - h[v][i]));
+                dcc = std::fmax(dcc, std::fabs((double)c[0][i] - c[v][i]) / (1.0 + std::fabs((double)c[0][i])));
+            }
+            printf("pass %d variant %d vs 0: max |dh| %.3e, max rel |dc| %.3e, non-finite %d\n", pass, v, dh, dcc, bad);
         }
-        printf("pass %d: max |dh| %.3e, max rel |dc| %.3e, non-finite %d\n", pass, dh, dcc, bad);
     }
     return 0;
 }
