@@ -268,7 +268,7 @@ def _call_mods_reads(args, rank, local_rank, world):
     # loader: files -> batches of reads, decoded by a thread pool ahead of the GPU work
     batches = dsp_reads.ReadBatches(files, max(1, int(args.f5_batch_size)) * 8, args.corrected_group,
                                     args.basecall_subgroup, first_file_index=lo, workers=min(8, nthreads),
-                                    only_chrom=fx.regioninfo[0], procs=min(16, nthreads))  # reader processes once there are >= 256 files
+                                    only_chrom=fx.regioninfo[0], procs=int(os.environ.get("DSP_READER_PROCS", "0")))  # decoding scales on the loader threads; reader processes are opt-in
     rq = queue.Queue(maxsize=3)
 
     def load():

@@ -315,7 +315,7 @@ def extract_features(args):
                           seed=getattr(args, "seed", 0), round_stats=True, nthreads=nthreads)
     batches = dsp_reads.ReadBatches(files, max(1, int(args.f5_batch_size)) * 8, args.corrected_group,
                                     args.basecall_subgroup, workers=min(8, nthreads), only_chrom=fx.regioninfo[0],
-                                    procs=min(16, nthreads))  # --nproc reader processes once there are >= 256 files
+                                    procs=int(os.environ.get("DSP_READER_PROCS", "0")))  # decoding scales on the loader threads; reader processes are opt-in
     rq = queue.Queue(maxsize=3)
 
     def load():

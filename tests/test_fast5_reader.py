@@ -133,3 +133,18 @@ def test_reader_processes_deliver_what_the_threads_deliver():
         assert (x.readname, x.chrom, x.chrom_start, x.alignstrand, x.scaling, x.offset) == \
                (y.readname, y.chrom, y.chrom_start, y.alignstrand, y.scaling, y.offset)
         assert np.array_equal(x.raw, y.raw) and np.array_equal(x.ev_start, y.ev_start) and np.array_equal(x.ev_base, y.ev_base)
+
+
+def test_library_path_and_direct_chunk_path_agree():
+    """The chunks of Signal / Events are normally decoded outside libhdf5 (pread + inflate + un-shuffle, hand-decoded
+    records); DSP_FAST5_NO_DIRECT=1 sends both datasets through H5Dread and the library's type conversion instead, and
+    DSP_GZ_ZLIB=1 takes zlib instead of libdeflate: all must return what h5py returned (fresh interpreters: the switches are
+    read once per process)"""
+    _need_hdf5()
+    import subprocess
+    import sys
+    for env_extra in ({"DSP_FAST5_NO_DIRECT": "1"}, {"DSP_GZ_ZLIB": "1"}):
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", os.path.join(ROOT, "tests", "test_fast5_reader.py"), "-k",
+                            "test_every_fixture_file_reads_like_h5py_did or test_oracle_extraction"],
+                           capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, **env_extra), timeout=600)
+        assert r.returncode == 0 and "4 passed" in r.stdout, (env_extra, r.stdout[-1500:], r.stderr[-1500:])

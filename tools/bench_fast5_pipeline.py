@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """End-to-end `call_mods -i <directory of fast5 files>` on this box: synthetic single-read fast5 files written with h5py
-(tools/gen_fast5.py under /opt/conda/bin/python3.9) -> native HDF5 reads (reader processes) -> GPU feature extraction ->
-forward -> per-read calls.  Prints one JSON line per repetition, for 1 and for 16 reader processes."""
+(tools/gen_fast5.py under /opt/conda/bin/python3.9) -> native HDF5 reads (loader threads) -> GPU feature extraction ->
+forward -> per-read calls.  Prints one JSON line per repetition, for --nproc 1 and 16 (loader threads; set
+DSP_READER_PROCS=N for reader processes instead)."""
 import json
 import os
 import shutil
@@ -43,7 +44,7 @@ def main():
         secs = float(inner.split("costs")[1].split("seconds")[0])
         sites = sum(1 for _ in open(out))
         print(json.dumps({"pipeline": "fast5 -> native HDF5 reads -> extract (GPU) -> forward -> calls", "reads": n_reads,
-                          "reader_processes": nproc, "samples": samples, "bases": bases, "sites": sites,
+                          "nproc": nproc, "samples": samples, "bases": bases, "sites": sites,
                           "input_mb": round(in_bytes / 1e6, 1), "call_mods_s": secs, "process_wall_s": round(wall, 2),
                           "sites_per_s": round(sites / secs, 1), "files_per_s": round(n_reads / secs, 1),
                           "msamples_per_s": round(samples / secs / 1e6, 1), "gen_s": round(gen, 1)}), flush=True)
