@@ -21,3 +21,4 @@ export DSP_AMD_LIB=deepsignal_plant_amd/libdsp_amd_trace.so
 { for LW in "0 0" "1 0" "3 0" "3 4"; do set -- $LW; L=$1; W=$2; echo "== launch $L (0 lstm_seq, 1 lstm_signal, 3 combined layer 1), stamping wave $W"; DSP_TRACE_LAUNCH=$L DSP_TRACE_WAVE=$W timeout 200 python3 tools/trace_lstm.py --cus 1; done; } > gpurun_out/r2/lstm_wave_trace_s_memtime.txt 2>&1
 unset DSP_AMD_LIB
 python3 tools/bench_fast5_pipeline.py > gpurun_out/r2/pipeline_fast5.jsonl 2> gpurun_out/r2/pipeline_fast5.err
+python3 tools/parity_sweep.py 300 > gpurun_out/r2/parity_sweep.txt 2>&1
