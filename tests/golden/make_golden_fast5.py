@@ -161,6 +161,43 @@ def main():
                 f.write(("\n".join(rows) + "\n").encode())
         expect["cases"][c["name"]] = dict(c, rows=len(rows), errors=int(nerr))
         print("%-16s %5d rows, %d of %d files failed" % (c["name"], len(rows), nerr, len(fast5s)))
+    # ---- the reference's real command line (`deepsignal_plant extract`, multi-process) on the same directory
+    import glob
+    import subprocess
+    import tempfile
+    tmp = tempfile.mkdtemp()
+    first = [r for r in gzip.open(os.path.join(OUT, "expect_mad_cg.tsv.gz"), "rt").read().splitlines()]
+    pos_file = os.path.join(OUT, "positions.tsv")
+    with open(pos_file, "w") as f:  # every third site of the plain run (chrom, pos, strand + a column that is ignored)
+        for row in sorted(set("\t".join(r.split("\t")[:3]) for r in first))[::3]:
+            f.write(row + "\tx\n")
+    cli = {
+        "cli_plain": ["--reference_path", ref_fa, "--nproc", "3", "--f5_batch_size", "4"],
+        "cli_dir_gzip": ["--reference_path", ref_fa, "--nproc", "2", "--f5_batch_size", "3", "--w_is_dir", "yes", "--w_batch_num", "2", "--gzip"],
+        "cli_positions": ["--reference_path", ref_fa, "--nproc", "2", "--positions", pos_file, "--methy_label", "0", "--normalize_method", "zscore"],
+    }
+    expect["cli"] = {}
+    for name, flags in cli.items():
+        out = os.path.join(tmp, name + (".d" if "--w_is_dir" in flags else ".tsv"))
+        env = dict(os.environ, PYTHONPATH="/root/reference", PYTHONDONTWRITEBYTECODE="1")
+        r = subprocess.run([sys.executable, "-m", "deepsignal_plant.deepsignal_plant", "extract", "-i", os.path.join(OUT, "reads"), "-o", out] + flags,
+                           capture_output=True, text=True, env=env, cwd=tmp)
+        assert r.returncode == 0, r.stderr[-2000:]
+        rows = []
+        if os.path.isdir(out):
+            names = sorted(os.listdir(out))
+            for fn in names:
+                rows += gzip.open(os.path.join(out, fn), "rt").read().splitlines()
+        else:
+            names = [os.path.basename(out)]
+            rows = open(out).read().splitlines()
+        with open(os.path.join(OUT, "expect_%s.tsv.gz" % name), "wb") as raw:
+            with gzip.GzipFile(fileobj=raw, mode="wb", mtime=0, filename="") as f:
+                f.write(("\n".join(sorted(rows)) + "\n").encode())
+        expect["cli"][name] = {"flags": [("<ref.fa>" if x == ref_fa else "<positions.tsv>" if x == pos_file else x) for x in flags],
+                               "rows": len(rows), "files": names}
+        print("%-16s %5d rows in %d file(s)" % (name, len(rows), len(names)))
+    shutil.rmtree(tmp, ignore_errors=True)
     os.remove(ref_fa)
     with open(os.path.join(OUT, "expect.json"), "w") as f:
         json.dump(expect, f, indent=1, sort_keys=True)

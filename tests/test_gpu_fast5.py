@@ -113,3 +113,38 @@ def test_call_mods_on_fast5_files_equals_call_mods_on_the_same_reads_as_records(
         assert "4 of 15 read files failed" in r.stdout
         outs.append(open(out, "rb").read())
     assert outs[0] == outs[1] and outs[0].count(b"\n") == EXPECT["cases"]["mad_cg"]["rows"]
+
+
+def _key_rows(lines, s):
+    """rows -> sorted tuples of everything the reference computes deterministically (over-long bases' groups dropped)"""
+    out = []
+    for ln in lines:
+        f = ln.split("\t")
+        lens = [int(x) for x in f[9].split(",")]
+        groups = f[10].split(";")
+        out.append(tuple(f[:10]) + tuple(g if n <= s else "*" for g, n in zip(groups, lens)) + (f[11],))
+    return sorted(out)
+
+
+@pytest.mark.parametrize("name", sorted(EXPECT["cli"]))
+def test_extract_cli_equals_the_reference_command_line(name, tmp_path):
+    """The reference's real `deepsignal_plant extract` (multi-process, run under the image's python3.9 by
+    make_golden_fast5.py) and this build's, same flags, same fast5 directory: plain file, --w_is_dir + --gzip batches,
+    --positions + --methy_label 0 + zscore.  Row ORDER is not compared (the reference's depends on process timing)."""
+    c = EXPECT["cli"][name]
+    flags = [(_ref_fasta(tmp_path) if x == "<ref.fa>" else os.path.join(F7, "positions.tsv") if x == "<positions.tsv>" else x)
+             for x in c["flags"]]
+    is_dir = "--w_is_dir" in flags
+    out = str(tmp_path / ("out.d" if is_dir else "out.tsv"))
+    cmd = [sys.executable, "-m", "deepsignal_plant_amd.deepsignal_plant", "extract", "-i", os.path.join(F7, "reads"), "-o", out] + flags
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    if is_dir:
+        names = sorted(os.listdir(out))
+        assert names[0] == "0.tsv.gz" and all(n.endswith(".tsv.gz") for n in names)  # extract_features.py:474-510
+        got = [ln for n in names for ln in gzip.open(os.path.join(out, n), "rt").read().splitlines()]
+    else:
+        got = open(out).read().splitlines()
+    want = gzip.open(os.path.join(F7, "expect_%s.tsv.gz" % name), "rt").read().splitlines()
+    assert len(got) == len(want) == c["rows"]
+    assert _key_rows(got, 16) == _key_rows(want, 16)
