@@ -273,6 +273,9 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
     constexpr int NF = 4;                  // A fragments (gates) per k-group
     constexpr int DA = 4, DB = 4;          // ring depths in k-groups
     extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef DSP_TRACE
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
     const int nthr = blockDim.x;
     f32x4* c_lds = (f32x4*)smem;           // [NP][2 site tiles][4 groups][nthr] float4
     f32x4* b_lds = c_lds + NP * 8 * nthr;  // [unit tile][aa][gate][half] float4
@@ -429,6 +432,8 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
     if ((a.flags & 256) && tid == ((a.flags >> 9) & 7) * 64 && blockIdx.x < DSP_TRACE_WGS) {
         g_trace_hw[blockIdx.x][0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
         g_trace_hw[blockIdx.x][1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+        g_trace_hw[blockIdx.x][2] = (unsigned int)t_entry;                         // kernel entry of this workgroup
+        g_trace_hw[blockIdx.x][3] = (unsigned int)(t_entry >> 32);
     }
 #endif
     for (int step = 0; step < T; ++step) {

@@ -50,6 +50,19 @@ for k in np.unique(key[used]):
     shown += 1
     if shown >= a.cus:
         break
+# between workgroups on a CU: end of the previous one -> entry of the next (dispatch) -> its first step (prologue)
+entry = hw[:, 2].astype(np.int64) | (hw[:, 3].astype(np.int64) << 32)
+last = int(np.max(np.nonzero(t[used[0], :, 3])[0]))  # index of the last stamped step
+gaps = []
+for k in np.unique(key[used]):
+    wg = sorted([int(i) for i in used if key[i] == k], key=lambda i: t[i, 0, 0])
+    for a_, b_ in zip(wg[:-1], wg[1:]):
+        if entry[b_] >= t[a_, last, 3] > 0:  # b entered after a had finished: they followed each other on the same slot
+            gaps.append(int(entry[b_] - t[a_, last, 3]))
+pros = [int(t[i, 0, 0] - entry[i]) for i in used if entry[i] > 0]
+print("per workgroup: entry -> first step (prologue: initial states, h0 stores, ring fill) %d cycles; last stamp of the previous "
+      "workgroup on the slot -> entry (dispatch) %s cycles (median of %d)" % (
+          np.median(pros) if pros else -1, ("%d" % np.median(gaps)) if gaps else "n/a", len(gaps)))
 # aggregate over all traced workgroups: median per-phase cycles of the middle steps
 mid = t[used][:, 2:12, :]
 bar = np.median(mid[:, :, 1] - mid[:, :, 0]); kl = np.median(mid[:, :, 2] - mid[:, :, 1]); ce = np.median(mid[:, :, 3] - mid[:, :, 2])
