@@ -189,7 +189,7 @@ __device__ __forceinline__ f32x4 init_state4(const float* src, int mode, long lo
 // the backward direction, so each XCD's 4 MiB L2 holds one direction's weights.
 // (History, all measured on MI355X: first kernel -- 8 waves, h in LDS, one-deep prefetch -- 76 % of the fp32 MFMA
 // peak; ablation showed operand loads, not MFMA issue, cost ~25 %.  One wave per SIMD with register rings 90.4 %;
-// two waves per SIMD 93.6 %; round 2 94.7 %; profiles/README.md.)
+// two waves per SIMD 93.6 %; round 2 94.9 %; profiles/README.md.)
 //   * TWO waves per SIMD, 256 registers each.  A wave owns one unit tile (32 hidden units x 4 gates) x two site tiles
 //     (32 sites each): 8 accumulator tiles (128 registers), 32 MFMAs per k-group (8 k); a weight fragment feeds 8
 //     MFMAs; a workgroup has UT waves per 64 sites (UT = Hp/32 unit tiles) and SG such site groups.
@@ -211,8 +211,10 @@ __device__ __forceinline__ f32x4 init_state4(const float* src, int mode, long lo
 //     first groups of step t+1 (weights and x_{t+1} do not depend on h_t) before the cell phase.
 //   * The cell state c and the (pre-scaled) biases live in LDS (own-lane float4 slots, conflict-free), the
 //     accumulators start from literal zero (first MFMA of a step takes C = 0) and the biases are folded into
-//     the exp2 arguments of the activations; the per-step cost that does not scale with K is ~4.5 us
-//     (transcendental-bound: 10 v_exp/v_rcp per element, tools/micro/trans_rate.hip).
+//     the exp2 arguments of the activations.  The cell phase of a wave is 5.1 k cycles of VALU work (10 v_exp/v_rcp +
+//     15 VALU per element, tools/micro/cell_phase.hip) and fp32 MFMAs do NOT overlap VALU work of either wave of a SIMD
+//     on gfx950 (tools/micro/mfma_cell_overlap.hip: both = sum), so a step costs MFMA cycles + cell cycles whatever the
+//     schedule: 393.2 k + 2 x 5.1 k for the combined stack, measured 403.9 k.
 // SPARSE != 0 (front-end layers): the x part is padded from 8/16 to 32 features so that the first four k-groups never
 // depend on h_t; k-groups that are pure zero padding keep their operand requests but issue no MFMAs.
 //   SPARSE = 2, XL = 1..3 (the shipped front ends: hidden <= 256, features at the END of the 32-wide block): which of the
