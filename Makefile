@@ -18,6 +18,7 @@ bench:            ## config 1, one JSON line
 
 fixtures:         ## regenerate the reference fixtures (this container only: reads /root/reference)
 	$(PY) tests/golden/make_golden.py
+	$(PY) tests/golden/make_golden_text.py
 	$(PY) tests/golden/make_golden_extract.py
 	/opt/conda/bin/python3.9 tests/golden/make_golden_fast5.py
 
