@@ -291,6 +291,7 @@ def main(argv=None):
                          "whole_forward_tflops": round(value / world * flops_site / 1e12, 2),
                          "whole_forward_frac": round(value / world * flops_site / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4),
                          "hbm_gbps_algorithmic": round(value / world * 1048 / 1e9, 3),
+                         "hbm_frac_algorithmic": round(value / world * 1048 / 8e12, 6),  # of 8 TB/s: the north_star's "HBM roofline" does not bind
                          "kernel_time_frac_of_wall": round(all_ms * 1e-3 / dt, 4) if dt > 0 else None,
                          "ms_per_step_by_launch": {k: round(sum(v) / max(K, 1), 4) for k, v in per_launch.items()},
                          "kernel_src_sha16": kernel_source_hash(),
