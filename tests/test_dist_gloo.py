@@ -58,7 +58,7 @@ def _worker(rank, world, port, path, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_range_shard_covers_every_row_once(tmp_path, world):
     import torch.multiprocessing as mp
     path = os.path.join(ROOT, "tests", "golden", "f2_rows.tsv")
