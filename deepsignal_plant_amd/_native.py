@@ -24,7 +24,8 @@ class ModelCfg(ctypes.Structure):
 class InitState(ctypes.Structure):
     _fields_ = [("mode", ctypes.c_int32), ("seed", ctypes.c_uint64), ("site_offset", ctypes.c_uint64),
                 ("h_seq", ctypes.c_void_p), ("c_seq", ctypes.c_void_p), ("h_sig", ctypes.c_void_p),
-                ("c_sig", ctypes.c_void_p), ("h_comb", ctypes.c_void_p), ("c_comb", ctypes.c_void_p)]
+                ("c_sig", ctypes.c_void_p), ("h_comb", ctypes.c_void_p), ("c_comb", ctypes.c_void_p),
+                ("site_keys", ctypes.c_void_p)]
 
 
 _lib = None

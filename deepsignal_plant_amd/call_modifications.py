@@ -17,7 +17,8 @@ called_label, 5-mer; :175-188, :262-282).  What changed underneath:
 
 Multi-GPU: contiguous byte-range split of the file over ranks (dist.py); per-rank part files concatenated by
 rank 0.  Results do not depend on the number of GPUs or on batching: the in-kernel initial states are keyed
-by the global row index.  The fast5-directory branch (:559-583) extracts features on the GPU from read records (_call_mods_reads).
+by the global row index (feature files) or by (read uid, base index in the read) (the fast5-directory branch, :559-583,
+which extracts features on the GPU from read records: _call_mods_reads).
 """
 from __future__ import annotations
 
@@ -285,7 +286,8 @@ def _call_mods_reads(args, rank, local_rank, world):
     ring = [dict(cap=0, ev=None) for _ in range(6)]  # pinned result slots (the writer queue holds at most 4)
     fwd_chunk = 65536
     model.reserve(fwd_chunk)
-    row_base = rank << 44  # initial-state streams of different ranks never overlap
+    row_base = rank << 44  # row numbers for the output order only (rank-major = file order); the initial states of a
+    # site are keyed by (read uid, base index in the read): ExtractedBatch.site_keys -- independent of ranks and batching
     while True:
         batch = rq.get()
         if batch is None:
@@ -309,9 +311,9 @@ def _call_mods_reads(args, rank, local_rank, world):
         h_probs, h_labels, h_kmer = slot["probs"], slot["labels"], slot["kmer"][:n]
         for a in range(0, n, fwd_chunk):  # forward in chunks of the reserved workspace size
             b = min(n, a + fwd_chunk)
-            model.site_offset = row_base + n_rows + a
             _logits, probs, labels = model.forward(ext.kmer[a:b], ext.means[a:b], ext.stds[a:b], ext.lens[a:b],
-                                                   ext.signals[a:b], want_labels=True)
+                                                   ext.signals[a:b], want_labels=True,
+                                                   site_keys=ext.site_keys[a:b] if model.init_state == "randn" else None)
             h_probs[a:b].copy_(probs, non_blocking=True)
             h_labels[a:b].copy_(labels, non_blocking=True)
         h_kmer.copy_(ext.kmer, non_blocking=True)

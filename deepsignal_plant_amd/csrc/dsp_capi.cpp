@@ -452,6 +452,7 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
         a.SG = a.NP == 2 ? 1 : pick_site_groups(m, a.UT);
         a.init_mode = init ? init->mode : DSP_INIT_ZEROS;
         a.seed = init ? init->seed : 0; a.site_offset = init ? init->site_offset : 0;
+        a.site_keys = (init && init->mode == DSP_INIT_PHILOX) ? (const unsigned long long*)init->site_keys : nullptr;
         a.stream_base = lstm_id * 64 + (int)k * 4;
         a.flags = m->phase_prio ? 1 : 0;
         if (m->trace_launch >= 0 && m->trace_launch == m->lstm_launch_no) a.flags |= 256 | (m->trace_wave << 9);  // DSP_TRACE builds

@@ -34,6 +34,7 @@ struct LstmArgs {
     const float* h0;       // EXPLICIT: reference layout, already offset to this layer: [2 dirs][n][H]
     const float* c0;
     float* h0buf;          // K4 scratch [NTp][Fout/4][32][4] holding h0 (read by step 0 as "h_{-1}")
+    const unsigned long long* site_keys;  // PHILOX: per-site counter keys [n], or NULL = site_offset + site
     long long n;
     long long NTp;
     unsigned long long seed, site_offset;

@@ -165,8 +165,13 @@ __global__ __launch_bounds__(256) void dsp_pack_kernel(PackArgs a) {
 // initial LSTM state of 4 consecutive hidden units of one site (init_hidden, models.py:169-176):
 // zeros, explicit buffers in the reference layout (2*layers, n, H), or in-kernel Philox N(0,1)
 // ------------------------------------------------------------------------------------------------
+// (skey = the Philox counter key of the site: site_keys[site] when the caller names its sites, else site_offset + site)
+__device__ __forceinline__ uint64_t philox_site_key(const unsigned long long* keys, uint64_t site_offset, long long n,
+                                                    long long site) {
+    return (keys && site < n) ? (uint64_t)keys[site] : site_offset + (uint64_t)site;
+}
 __device__ __forceinline__ f32x4 init_state4(const float* src, int mode, long long n, long long site, int dir, int H,
-                                             int k4, uint64_t seed, uint64_t site_offset, uint32_t stream) {
+                                             int k4, uint64_t seed, uint64_t skey, uint32_t stream) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (site >= n || 4 * k4 >= H) return v;
     if (mode == 1) {
@@ -175,7 +180,7 @@ __device__ __forceinline__ f32x4 init_state4(const float* src, int mode, long lo
         for (int i = 0; i < 4; ++i)
             if (4 * k4 + i < H) v[i] = p[i];
     } else if (mode == 2) {
-        v = philox_normal4(seed, site_offset + (uint64_t)site, stream, (uint32_t)k4);
+        v = philox_normal4(seed, skey, stream, (uint32_t)k4);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (4 * k4 + i >= H) v[i] = 0.f;
@@ -318,14 +323,15 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const long long site = (gt0 + m) * 32 + ls;
+            const uint64_t skey = a.init_mode == 2 ? philox_site_key(a.site_keys, a.site_offset, a.n, site) : 0;
 #pragma unroll
             for (int aa = 0; aa < 4; ++aa) {
                 const int k4 = u * 8 + 2 * aa + half;
                 f32x4 hv = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
                 if (a.init_mode != 0) {
-                    hv = init_state4(a.h0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, a.site_offset,
+                    hv = init_state4(a.h0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, skey,
                                      (uint32_t)(a.stream_base + dir * 2 + 0));
-                    cv = init_state4(a.c0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, a.site_offset,
+                    cv = init_state4(a.c0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, skey,
                                      (uint32_t)(a.stream_base + dir * 2 + 1));
                 }
                 bst16(rh0, voff + aa * 1024u, (uint32_t)m * orow + (uint32_t)u * 4096u, hv);
@@ -586,14 +592,15 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm6_kernel(LstmArgs a) {
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         const long long site = (gt0 + m) * 32 + ls;
+        const uint64_t skey = a.init_mode == 2 ? philox_site_key(a.site_keys, a.site_offset, a.n, site) : 0;
 #pragma unroll
         for (int aa = 0; aa < 4; ++aa) {
             const int k4 = u * 8 + 2 * aa + half;
             f32x4 hv = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
             if (a.init_mode != 0) {
-                hv = init_state4(a.h0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, a.site_offset,
+                hv = init_state4(a.h0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, skey,
                                  (uint32_t)(a.stream_base + dir * 2 + 0));
-                cv = init_state4(a.c0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, a.site_offset,
+                cv = init_state4(a.c0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, skey,
                                  (uint32_t)(a.stream_base + dir * 2 + 1));
             }
             bst16(rh0, voff + aa * 1024u, (uint32_t)m * orow + (uint32_t)u * 4096u, hv);

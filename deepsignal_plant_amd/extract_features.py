@@ -37,8 +37,10 @@ class _Staged(object):
 
 class ExtractedBatch(object):
     """rows: textio.ParsedRows whose text/row_off/... address the sites' sampleinfo strings (host; its feature
-    arrays are filled only by to_host()); kmer/means/stds/lens/signals: device tensors [n, L(, S)]."""
-    __slots__ = ("rows", "n", "kmer", "means", "stds", "lens", "signals", "shift", "scale")
+    arrays are filled only by to_host()); kmer/means/stds/lens/signals: device tensors [n, L(, S)]; site_keys: int64 [n]
+    on the device, read uid << 24 | base index of the site in its read -- a name for the site that depends on neither the
+    batching nor the rank count (the in-kernel initial-state generator of the forward is keyed by it)."""
+    __slots__ = ("rows", "n", "kmer", "means", "stds", "lens", "signals", "shift", "scale", "site_keys")
 
     def to_host(self):
         r = self.rows
@@ -232,6 +234,8 @@ class FeatureExtractor(object):
             out.lens = torch.empty((n, self.L), dtype=torch.int32, device=dev)
             out.signals = torch.empty((n, self.L, self.S), dtype=fdt, device=dev)
             out.shift, out.scale = shift, scale
+            out.site_keys = (d["uid"][d["site_read"].long()] << 24) | d["site_loc"].long() if n else \
+                torch.empty(0, dtype=torch.int64, device=dev)
             if R:
                 L = nat.lib()
                 sp = ctypes.c_void_p(st.cuda_stream)

@@ -161,9 +161,12 @@ class ModelBiLSTM(object):
         nat.check(nat.lib().dsp_model_reserve(self._handle, int(max_sites)))
 
     # ---- forward ------------------------------------------------------------------------------------
-    def forward(self, kmer, base_means, base_stds, base_signal_lens, signals, init_states=None, want_labels=False):
+    def forward(self, kmer, base_means, base_stds, base_signal_lens, signals, init_states=None, want_labels=False,
+                site_keys=None):
         """(logits[B,C], softmax[B,C]) exactly like models.py:178-240.  Inputs are torch tensors on this
-        model's GPU; kmer / base_signal_lens may be float32 (reference convention) or uint8/uint16/int32."""
+        model's GPU; kmer / base_signal_lens may be float32 (reference convention) or uint8/uint16/int32.
+        site_keys (init_state="randn" only): int64 / uint64 tensor [B] on the GPU naming each site for the in-kernel
+        initial-state generator (dsp_init_state.site_keys); default = self.site_offset + row index."""
         self._ensure_handle()
         dev = torch.device("cuda", self._device_index())
         has_seq = self.module != "signal_bilstm"
@@ -207,6 +210,14 @@ class ModelBiLSTM(object):
             init.mode = nat.INIT_PHILOX
             init.seed = self.seed
             init.site_offset = self.site_offset
+            if site_keys is not None:
+                if not site_keys.is_cuda or site_keys.device != dev or site_keys.dtype not in (torch.int64, torch.uint64):
+                    raise RuntimeError("site_keys must be an int64 / uint64 tensor on %s" % dev)
+                if site_keys.numel() != n:
+                    raise RuntimeError("site_keys has %d elements, expected %d" % (site_keys.numel(), n))
+                site_keys = site_keys.contiguous()
+                keep.append(site_keys)
+                init.site_keys = site_keys.data_ptr()
 
         logits = torch.empty((n, self.num_classes), dtype=torch.float32, device=dev)
         probs = torch.empty((n, self.num_classes), dtype=torch.float32, device=dev)

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DSP_AMD_ABI_VERSION 1
+#define DSP_AMD_ABI_VERSION 2   /* 2: dsp_init_state.site_keys */
 
 typedef enum dsp_status {
     DSP_OK = 0,
@@ -42,7 +42,10 @@ enum { DSP_DT_F32 = 0, DSP_DT_U8 = 1, DSP_DT_U16 = 2, DSP_DT_I32 = 3 };
 
 /* LSTM initial-state policy.  The reference draws h0,c0 ~ N(0,1) with torch.randn on every forward
  * (models.py:169-176).  EXPLICIT pins them (parity runs); PHILOX is the in-kernel counter-based
- * stand-in (Philox4x32-10 + Box-Muller keyed by seed, global site index, stream, unit/4). */
+ * stand-in (Philox4x32-10 + Box-Muller keyed by seed, a 64-bit site key, stream, unit/4).  The site key is the site's
+ * global index (site_offset + i) or, when the caller names its sites, site_keys[i]: results then depend on neither the
+ * batching nor the number of ranks nor the order in which sites arrive (feature files: the global row index; the
+ * reads-directory branch of call_mods, call_modifications.py:285-358: read uid << 24 | base index in the read). */
 enum { DSP_INIT_ZEROS = 0, DSP_INIT_EXPLICIT = 1, DSP_INIT_PHILOX = 2 };
 
 /* Constructor arguments of ModelBiLSTM, deepsignal_plant/models.py:103-106 (dropout_rate and device
@@ -54,7 +57,7 @@ typedef struct dsp_model_cfg {
     int32_t num_layers1;    /* --layernum1: combined BiLSTM layers, default 3 */
     int32_t num_layers2;    /* --layernum2: seq / signal BiLSTM layers, default 1 */
     int32_t num_classes;    /* --class_num, default 2 */
-    int32_t hidden_size;    /* --hid_rnn, default 256 (this build: <= 256) */
+    int32_t hidden_size;    /* --hid_rnn, default 256 (this build: <= 512) */
     int32_t vocab_size;     /* --n_vocab, default 16 */
     int32_t embedding_size; /* --n_embed, default 4 */
     int32_t is_base;        /* --is_base */
@@ -73,6 +76,8 @@ typedef struct dsp_init_state {
     const float* h_seq;  const float* c_seq;
     const float* h_sig;  const float* c_sig;
     const float* h_comb; const float* c_comb;
+    /* PHILOX, optional: DEVICE pointer to n_sites 64-bit site keys; NULL = site_offset + site index (ABI >= 2) */
+    const uint64_t* site_keys;
 } dsp_init_state;
 
 typedef struct dsp_model dsp_model; /* opaque handle: repacked weights + scratch, bound to one device */

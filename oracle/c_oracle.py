@@ -39,6 +39,7 @@ def lib():
         build()
         _lib = ctypes.CDLL(LIB)
         _lib.orc_forward.restype = ctypes.c_int
+        _lib.orc_forward_keys.restype = ctypes.c_int
         _lib.orc_num_threads.restype = ctypes.c_int
     return _lib
 
@@ -48,8 +49,9 @@ def _fp(a):
 
 
 def forward(cfg: onp.OracleConfig, w, kmer, means, stds, lens, signals, states=None, init_mode="explicit",
-            seed=0, site_offset=0, nthreads=0):
-    """fp32 C oracle forward. init_mode: 'zeros' | 'explicit' (states dict) | 'philox' (seed, site_offset)."""
+            seed=0, site_offset=0, nthreads=0, site_keys=None):
+    """fp32 C oracle forward. init_mode: 'zeros' | 'explicit' (states dict) | 'philox' (seed, and either site_offset:
+    the Philox counter of site i is site_offset + i, or site_keys: a uint64 per site)."""
     L = lib()
     c = _Cfg(cfg.seq_len, cfg.signal_len, cfg.num_layers1, cfg.num_layers2, cfg.num_classes, cfg.hidden_size,
              cfg.vocab_size, cfg.embedding_size, int(cfg.is_base), int(cfg.is_signallen), _MODULE_CODE[cfg.module])
@@ -75,8 +77,14 @@ def forward(cfg: onp.OracleConfig, w, kmer, means, stds, lens, signals, states=N
         sptr = (ctypes.POINTER(ctypes.c_float) * 6)(*ptrs)
     logits = np.empty((n, cfg.num_classes), np.float32)
     probs = np.empty((n, cfg.num_classes), np.float32)
-    rc = L.orc_forward(ctypes.byref(c), wptr, len(arrs), ctypes.c_int64(n), *[_fp(a) for a in ins], mode, sptr,
-                       ctypes.c_uint64(seed), ctypes.c_uint64(site_offset), _fp(logits), _fp(probs), int(nthreads))
+    kptr = None
+    if site_keys is not None:
+        site_keys = np.ascontiguousarray(site_keys, np.uint64)
+        assert site_keys.shape == (n,)
+        kptr = site_keys.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+    rc = L.orc_forward_keys(ctypes.byref(c), wptr, len(arrs), ctypes.c_int64(n), *[_fp(a) for a in ins], mode, sptr,
+                            ctypes.c_uint64(seed), ctypes.c_uint64(site_offset), kptr, _fp(logits), _fp(probs),
+                            int(nthreads))
     if rc != 0:
         raise RuntimeError("orc_forward failed: %d" % rc)
     return logits, probs

@@ -186,7 +186,8 @@ static void free_lstm(lstm_pack* p) {
 
 /* initial state for a block: h0,c0 [SB][H] for (lstm,layer,dir) */
 static void fill_state(int mode, const float* hsrc, const float* csrc, int64_t n, int64_t site0, int nb, int H,
-                       int lstm, int layer, int dir, uint64_t seed, uint64_t site_offset, float* h, float* c) {
+                       int lstm, int layer, int dir, uint64_t seed, uint64_t site_offset, const uint64_t* site_keys,
+                       float* h, float* c) {
     for (int s = 0; s < nb; ++s) {
         float* hs = h + (size_t)s * H;
         float* cs = c + (size_t)s * H;
@@ -196,7 +197,9 @@ static void fill_state(int mode, const float* hsrc, const float* csrc, int64_t n
             const size_t off = ((size_t)(2 * layer + dir) * (size_t)n + (size_t)(site0 + s)) * H;
             memcpy(hs, hsrc + off, sizeof(float) * H); memcpy(cs, csrc + off, sizeof(float) * H);
         } else {
-            const uint64_t site = site_offset + (uint64_t)(site0 + s);
+            /* Philox counter of the site: its own 64-bit key when the caller names the sites (include/dsp_amd.h,
+             * dsp_init_state.site_keys), else its global index */
+            const uint64_t site = site_keys ? site_keys[site0 + s] : site_offset + (uint64_t)(site0 + s);
             float v[4];
             for (int g = 0; g < (H + 3) / 4; ++g) {
                 philox_normal4(seed, site, stream_id(lstm, layer, dir, 0), (uint32_t)g, v);
@@ -211,13 +214,13 @@ static void fill_state(int mode, const float* hsrc, const float* csrc, int64_t n
 /* run a (multi-layer) BiLSTM over a block; in [L][SB][I] -> out [L][SB][2H]; tmp same size as out */
 static void bilstm_block(const lstm_pack* p, int L, int nb, int lstm_idx, int mode, const float* hsrc,
                          const float* csrc, int64_t n, int64_t site0, uint64_t seed, uint64_t site_offset,
-                         const float* in, float* out, float* tmp, float* h, float* c, float* gates) {
+                         const uint64_t* site_keys, const float* in, float* out, float* tmp, float* h, float* c, float* gates) {
     const float* cur = in;
     int I = p->I;
     for (int k = 0; k < p->layers; ++k) {
         float* dst = ((p->layers - 1 - k) % 2 == 0) ? out : tmp; /* last layer lands in out */
         for (int d = 0; d < 2; ++d) {
-            fill_state(mode, hsrc, csrc, n, site0, nb, p->H, lstm_idx, k, d, seed, site_offset, h, c);
+            fill_state(mode, hsrc, csrc, n, site0, nb, p->H, lstm_idx, k, d, seed, site_offset, site_keys, h, c);
             lstm_dir_block(L, I, p->H, d, nb, cur, dst, h, c, p->wt[k * 2 + d], p->b[k * 2 + d], gates);
         }
         cur = dst; I = 2 * p->H;
@@ -246,10 +249,10 @@ static void linear_relu_block(int rows_t, int nb, int K, int O, const float* x, 
  * states (mode 1): h_seq,c_seq,h_sig,c_sig,h_comb,c_comb in the reference layout (absent ones NULL).
  * returns 0, or <0 on bad arguments / allocation failure.
  */
-int orc_forward(const orc_cfg* cfg, const float* const* weights, int n_weights, int64_t n, const float* kmer,
-                const float* means, const float* stds, const float* lens, const float* signals, int init_mode,
-                const float* const* states, uint64_t seed, uint64_t site_offset, float* logits, float* probs,
-                int nthreads) {
+int orc_forward_keys(const orc_cfg* cfg, const float* const* weights, int n_weights, int64_t n, const float* kmer,
+                     const float* means, const float* stds, const float* lens, const float* signals, int init_mode,
+                     const float* const* states, uint64_t seed, uint64_t site_offset, const uint64_t* site_keys,
+                     float* logits, float* probs, int nthreads) {
     const int L = cfg->seq_len, S = cfg->signal_len, H = cfg->hidden_size, C = cfg->num_classes;
     int hseq = 0, hsig = 0;
     if (cfg->module == 0) { hseq = H / 2; hsig = H - hseq; }
@@ -326,7 +329,7 @@ int orc_forward(const orc_cfg* cfg, const float* const* weights, int n_weights, 
                             if (cfg->is_signallen) xs[o++] = lens[r];
                         }
                     bilstm_block(&pseq, L, nb, 0, init_mode, states ? states[0] : NULL, states ? states[1] : NULL, n,
-                                 site0, seed, site_offset, xin, a, bb, hbuf, cbuf, gates);
+                                 site0, seed, site_offset, site_keys, xin, a, bb, hbuf, cbuf, gates);
                     linear_relu_block(L, nb, 2 * hseq, hseq, a, fcseq_w, fcseq_b, comb, H, 0);
                 }
                 if (hsig) { /* models.py:205-217 */
@@ -335,12 +338,12 @@ int orc_forward(const orc_cfg* cfg, const float* const* weights, int n_weights, 
                             memcpy(xin + ((size_t)t * SB + s) * S, signals + ((size_t)(site0 + s) * L + t) * S,
                                    sizeof(float) * S);
                     bilstm_block(&psig, L, nb, 1, init_mode, states ? states[2] : NULL, states ? states[3] : NULL, n,
-                                 site0, seed, site_offset, xin, a, bb, hbuf, cbuf, gates);
+                                 site0, seed, site_offset, site_keys, xin, a, bb, hbuf, cbuf, gates);
                     linear_relu_block(L, nb, 2 * hsig, hsig, a, fcsig_w, fcsig_b, comb, H, hseq);
                 }
                 /* models.py:219-231 */
                 bilstm_block(&pcomb, L, nb, 2, init_mode, states ? states[4] : NULL, states ? states[5] : NULL, n, site0,
-                             seed, site_offset, comb, a, bb, hbuf, cbuf, gates);
+                             seed, site_offset, site_keys, comb, a, bb, hbuf, cbuf, gates);
                 for (int s = 0; s < nb; ++s) {
                     memcpy(feat + (size_t)s * 2 * H, a + ((size_t)(L - 1) * SB + s) * 2 * H, sizeof(float) * H);
                     memcpy(feat + (size_t)s * 2 * H + H, a + ((size_t)0 * SB + s) * 2 * H + H, sizeof(float) * H);
@@ -377,6 +380,15 @@ int orc_forward(const orc_cfg* cfg, const float* const* weights, int n_weights, 
     }
     free_lstm(&pseq); free_lstm(&psig); free_lstm(&pcomb);
     return fail ? -6 : 0;
+}
+
+/* site_keys == NULL: the Philox counter of site i is site_offset + i */
+int orc_forward(const orc_cfg* cfg, const float* const* weights, int n_weights, int64_t n, const float* kmer,
+                const float* means, const float* stds, const float* lens, const float* signals, int init_mode,
+                const float* const* states, uint64_t seed, uint64_t site_offset, float* logits, float* probs,
+                int nthreads) {
+    return orc_forward_keys(cfg, weights, n_weights, n, kmer, means, stds, lens, signals, init_mode, states, seed,
+                            site_offset, NULL, logits, probs, nthreads);
 }
 
 int orc_num_threads(void) {

@@ -42,6 +42,13 @@ def load_f1(name):
                 n=n, raw=d)
 
 
+def noise_floor(name):
+    """max |dprob| between the reference's fp32 output and the float64 evaluation of the same model, as stored with the
+    fixture by make_golden.py (round 3 fixtures), else None"""
+    d = np.load(os.path.join(GOLDEN, "f1_%s.npz" % name))
+    return float(d["f64_dprob"]) if "f64_dprob" in d.files else None
+
+
 def f1_tolerances(name):
     """(oracle-vs-reference, HIP-vs-reference) bounds on |dprob| for fixture `name`.  Default: 1e-6 for the CPU
     restatements and 2e-5 for the HIP path (regression guards far inside the 1e-4 contract).  The saturating-weight
@@ -50,6 +57,10 @@ def f1_tolerances(name):
     (1e-4, BASELINE.json north_star) can be asserted, for the oracle and for the HIP path alike."""
     if "_x8" in name:
         return 1e-4, 1e-4
+    if "_x6p5" in name or "_x7" in name:
+        # round 3 ladder between x5 and x8: the fixture stores the reference's own fp32-vs-float64 distance (f64_dprob,
+        # 1.5e-5 / 1.7e-5); another fp32 evaluation order may sit that far on the other side of the float64 value
+        return 2.5 * noise_floor(name), min(1e-4, 4.0 * noise_floor(name))
     if "_x5" in name:
         return 1e-5, 1e-4
     if "_x4" in name or "_x3" in name:
