@@ -56,9 +56,9 @@ def kernel_source_hash():
 
 
 def committed_traffic(args):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/traffic.json, written by tools/make_traffic.py on the GPU box).  None unless the entry was measured on
-    the current kernel sources and on this workload."""
+    """The committed rocprofv3 PMC entry of this same command (profiles/traffic.json, written by tools/make_traffic.py on
+    the GPU box): HBM-side bytes per launch of the dominant kernel and per step over all kernels.  None unless the entry
+    was measured on the current kernel sources and on this workload."""
     try:
         entries = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     except Exception:
@@ -67,7 +67,7 @@ def committed_traffic(args):
             "precision": args.precision, "kernel_src_sha16": kernel_source_hash()}
     for e in entries:
         if all(e.get(k) == v for k, v in want.items()):
-            return e.get("hbm_bytes_per_launch")
+            return e
     return None
 
 
@@ -150,17 +150,11 @@ def main(argv=None):
     ndev = torch.cuda.device_count()
     assert ndev > 0, "bench.py needs an MI355X"
     dev_index = local_rank % ndev
-    # one process per GPU over RCCL; if fewer GPUs than ranks are visible (the 1-GPU dev box), the ranks share
-    # GPUs and the two control-plane collectives (barrier, max of the wall time) run over gloo instead
-    backend = "nccl" if ndev >= world else "gloo"
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(dev_index)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group("gloo")
+    # one process per GPU over RCCL; if fewer GPUs than ranks are visible (the 1-GPU dev box), the ranks share GPUs and
+    # the control-plane collectives (barrier, max of the wall time) run over gloo instead.  DSP_FORCE_DIST=1 makes a lone
+    # rank build its own one-rank RCCL group and take the same collective branches (deepsignal_plant_amd/dist.py)
+    backend = dsp_dist.init_process_group(world, rank, dev_index, ndev)
+    multi = dsp_dist.collective(world)
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
     cdev = dev if backend == "nccl" else None
@@ -189,14 +183,14 @@ def main(argv=None):
         step(i)
     torch.cuda.synchronize()
     model.profile(True)
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(K):
         outs = step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -204,7 +198,7 @@ def main(argv=None):
     model.profile(False)
 
     ranges = [[site0, site1]]
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -268,6 +262,14 @@ def main(argv=None):
         per_launch = {}
         for name, ms in prof:
             per_launch.setdefault(name, []).append(ms)
+        # HBM-side traffic from the committed PMC passes of this command, next to the bytes the algorithm needs: per launch
+        # of the dominant kernel its K4 activations (x read by both directions' workgroups + h written), per step SURVEY.md
+        # 8(d)'s 1,048 B per site (features in, probabilities out)
+        tr = committed_traffic(args)
+        traffic = tr.get("hbm_bytes_per_launch") if tr else None
+        step_traffic = tr.get("hbm_bytes_per_step_all_kernels") if tr else None
+        k4_site = sum(2 * (H if k == 0 else 2 * H) * T * 4 + 2 * H * T * 4 for k in range(model.num_layers1)) / max(model.num_layers1, 1)
+        algo_launch = k4_site * B
         cfg_idx = 2 if args.model_type == "seq_bilstm" else (1 if world == 1 else 3)
         line = {
             "metric": "methylation sites/sec, %s bn13_sn16" % args.model_type, "value": round(value, 1), "unit": "sites/s",
@@ -282,11 +284,15 @@ def main(argv=None):
                        "hid_rnn": args.hid_rnn,
                        "init_state": "in-kernel Philox N(0,1) (stand-in for torch.randn, models.py:169-176)",
                        "weights": "seeded random state_dict, PyTorch default-init scale", "parallelism": "range-shard x%d" % world,
-                       "backend": ("rccl" if backend == "nccl" else "gloo (ranks share %d GPU)" % ndev) if world > 1 else "none",
+                       "backend": ("rccl" if backend == "nccl" else "gloo (ranks share %d GPU)" % ndev) if multi else "none",
                        "rank_site_ranges": ranges, "flops_per_site": flops_site},
             "roofline": {"bound": "mfma", "kernel": "dsp_lstm_kernel (combined stack)" if nprod == 1 else "dsp_lstm_split_kernel<%d>" % nprod,
                          "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                         "traffic": committed_traffic(args), "avg_launch_ms": round(avg_ms, 4), "launches": len(comb_ms),
+                         "traffic": traffic, "algorithmic_bytes_per_launch": algo_launch,
+                         "traffic_over_algorithmic": round(traffic / algo_launch, 3) if traffic else None,
+                         "traffic_per_step_all_kernels": step_traffic, "algorithmic_bytes_per_step": 1048 * B,
+                         "step_traffic_over_algorithmic": round(step_traffic / (1048 * B), 1) if step_traffic else None,
+                         "avg_launch_ms": round(avg_ms, 4), "launches": len(comb_ms),
                          "flops_per_launch": flops_per_launch,
                          "whole_forward_tflops": round(value / world * flops_site / 1e12, 2),
                          "whole_forward_frac": round(value / world * flops_site / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4),
@@ -309,7 +315,7 @@ def main(argv=None):
                 line["cpu_baseline"] = {"value": None, "unit": "sites/s", "cores": 0, "kind": "port",
                                         "sample": "failed: %r" % (e,), "reference_proper": REFERENCE_CPU}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
     return 0
 

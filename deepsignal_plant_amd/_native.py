@@ -159,6 +159,30 @@ def lib():
     L.dsp_gz_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
     L.dsp_gz_close.restype = None
     L.dsp_gz_close.argtypes = [ctypes.c_void_p]
+    L.dsp_gz_bytes_in.restype = ctypes.c_uint64
+    L.dsp_gz_bytes_in.argtypes = [ctypes.c_void_p]
+    L.dsp_shm_ring_create.restype = ctypes.c_void_p
+    L.dsp_shm_ring_create.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_uint64]
+    L.dsp_shm_ring_attach.restype = ctypes.c_void_p
+    L.dsp_shm_ring_attach.argtypes = [ctypes.c_char_p, ctypes.c_double]
+    L.dsp_shm_ring_slot_bytes.restype = ctypes.c_uint64
+    L.dsp_shm_ring_slot_bytes.argtypes = [ctypes.c_void_p]
+    L.dsp_shm_ring_acquire.restype = ctypes.c_void_p
+    L.dsp_shm_ring_acquire.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_double]
+    L.dsp_shm_ring_publish.restype = ctypes.c_int32
+    L.dsp_shm_ring_publish.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64]
+    L.dsp_shm_ring_finish.restype = ctypes.c_int32
+    L.dsp_shm_ring_finish.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_char_p]
+    L.dsp_shm_ring_wait.restype = ctypes.c_int32
+    L.dsp_shm_ring_wait.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_double, ctypes.POINTER(ctypes.c_void_p),
+                                    ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
+                                    ctypes.POINTER(ctypes.c_uint64)]
+    L.dsp_shm_ring_release.restype = ctypes.c_int32
+    L.dsp_shm_ring_release.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
+    L.dsp_shm_ring_abort.restype = None
+    L.dsp_shm_ring_abort.argtypes = [ctypes.c_void_p]
+    L.dsp_shm_ring_close.restype = None
+    L.dsp_shm_ring_close.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     L.dsp_feat_writer_create.restype = ctypes.c_int32
     L.dsp_feat_writer_create.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
                                          ctypes.POINTER(ctypes.c_void_p)]

@@ -40,11 +40,9 @@ from .utils.process_utils import display_args, str2bool
 
 
 def _get_gpus():
-    """Visible GPUs (HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES honoured by the runtime); the reference's
-    round-robin list at call_modifications.py:523-529."""
-    import torch
-    n = torch.cuda.device_count()
-    return list(range(n))
+    """Visible GPUs (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES honoured); the reference's round-robin list at
+    call_modifications.py:523-529.  Counted without loading the HIP runtime (dist.visible_gpu_count)."""
+    return list(range(dsp_dist.visible_gpu_count()))
 
 
 def load_model(args, device):
@@ -76,20 +74,38 @@ class _Writer(threading.Thread):
         self.freq_dev = None  # optional (DeviceSiteFrequency, stream, first-row getter): the reads branch feeds it from here
         self.error = None
         self.rows = 0
+        self.mark_blocks = False   # remember where every block's output ends in the part file (interleaved sharding)
+        self.block_ends = []
 
     def run(self):
         try:
             wf = gzio.open_write(self.path, self.is_gzip, nthreads=self.nthreads)  # --gzip: BGZF, deflated on nthreads threads
+            pos = 0
             with wf:
                 while True:
                     item = self.q.get()
                     if item is None:
                         break
                     block, probs_t, labels_t, event = item
+                    if probs_t is None:   # a block without rows
+                        if self.mark_blocks:
+                            if self.is_gzip:
+                                wf.end_block()
+                            else:
+                                self.block_ends.append(pos)
+                        self.reader.release(block)
+                        continue
                     event.synchronize()
                     probs = probs_t.numpy()[:block.rows.n]
                     labels = labels_t.numpy()[:block.rows.n]
-                    wf.write(textio.format_calls(block.rows, probs, labels, nthreads=self.nthreads))
+                    text = textio.format_calls(block.rows, probs, labels, nthreads=self.nthreads)
+                    wf.write(text)
+                    if self.mark_blocks:
+                        if self.is_gzip:
+                            wf.end_block()
+                        else:
+                            pos += len(text)
+                            self.block_ends.append(pos)
                     if self.freq is not None:
                         self.freq.add_block(block.rows, probs, labels)
                     if self.freq_dev is not None:
@@ -97,6 +113,8 @@ class _Writer(threading.Thread):
                         agg.add_block(block.rows, probs, labels, block.first_row, stream=side_stream)
                     self.rows += block.rows.n
                     self.reader.release(block)
+            if self.mark_blocks and self.is_gzip:
+                self.block_ends = list(wf.block_ends)   # complete once the writer is closed
         except BaseException as e:
             self.error = e
             while self.q.get() is not None:  # drain so the producer never blocks on a dead writer
@@ -110,21 +128,33 @@ def _call_mods_file(args, rank, local_rank, world):
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     # control-plane collectives run on the GPU over RCCL, or on the host when the ranks had to fall back to gloo
-    coll_dev = dev if (world > 1 and dist.get_backend() == "nccl") else None
+    coll_dev = dev if (dsp_dist.collective(world) and dist.get_backend() == "nccl") else None
     model = load_model(args, local_rank)
     input_path = os.path.abspath(args.input_path)
-    nthreads = max(1, (args.nproc if args.nproc > 0 else 1))
-    nthreads = min(nthreads, os.cpu_count() or 1)
+    nthreads = dsp_dist.threads_per_rank(args.nproc)   # --nproc, capped by this rank's share of the node's CPUs
 
     # my byte range and the global index of my first row (plain text: a byte range of the file; BGZF .gz: a member range,
     # feed.FeatureReader._run_bgzf; a foreign single-stream .gz is inflated by every rank, which then knows all indices)
-    first_row, byte_range = 0, None
-    if input_path.endswith(".gz") and world > 1:
+    first_row, byte_range, gz_ring, interleaved = 0, None, None, False
+    multi = dsp_dist.collective(world)   # several ranks (or DSP_FORCE_DIST=1: the same collectives with one)
+    if input_path.endswith(".gz") and multi:
         mine = feed.count_rows_bgzf(input_path, world, rank, nthreads)
         if mine is not None:
             counts = dsp_dist.all_gather_ints(mine, world, coll_dev)
             first_row = dsp_dist.exclusive_prefix(counts, rank)
-    if not input_path.endswith(".gz") and world > 1 and not featfile.is_feature_file(input_path):
+        elif world > 1:
+            # a foreign single-stream .gz (what the reference's `extract --gzip` writes): inflated ONCE per node by its
+            # first rank into a shared-memory ring; every rank copies its own blocks out (feed.open_gz_ring).  Blocks are
+            # dealt round-robin (block i -> rank i % world), so a rank's part file is not a contiguous piece of the
+            # output: the writer remembers where each block's calls end and rank 0 interleaves the pieces again
+            interleaved = True
+            def gather(obj):
+                out = [None] * world
+                dist.all_gather_object(out, obj)
+                return out
+            gz_ring = feed.open_gz_ring(input_path, rank, world, int(os.environ.get("LOCAL_RANK", rank)),
+                                        int(os.environ.get("LOCAL_WORLD_SIZE", world)), gather)
+    if not input_path.endswith(".gz") and multi and not featfile.is_feature_file(input_path):
         import mmap
         size = os.path.getsize(input_path)
         if size:
@@ -140,9 +170,10 @@ def _call_mods_file(args, rank, local_rank, world):
     part_path = out_path if world == 1 else "%s.part%05d" % (out_path, rank)
 
     reader = feed.FeatureReader(input_path, args.seq_len, args.signal_len, rank=rank, world=world, nthreads=nthreads,
-                                nbuf=4, first_row=first_row, byte_range=byte_range)
+                                nbuf=4, first_row=first_row, byte_range=byte_range, gz_ring=gz_ring)
     freq, freq_dev = _make_freq(args, dev, world, nthreads)
     writer = _Writer(part_path, args.gzip, nthreads, reader, freq)
+    writer.mark_blocks = interleaved
     cap = reader.cap
     model.reserve(cap)
     reader.start()
@@ -161,7 +192,10 @@ def _call_mods_file(args, rank, local_rank, world):
         rows = block.rows
         n = rows.n
         if n == 0:
-            reader.release(block)
+            if interleaved:   # the piece table of the part file needs an (empty) entry for every block
+                writer.q.put((block, None, None, None))
+            else:
+                reader.release(block)
             continue
         if n > out_probs[0].shape[0]:  # a block grew past the pinned output capacity
             out_probs = [torch.empty((n, args.class_num), dtype=torch.float32, pin_memory=True) for _ in range(nout)]
@@ -198,6 +232,10 @@ def _call_mods_file(args, rank, local_rank, world):
     if writer.error is not None:
         raise writer.error
     _finish_freq(args, freq, freq_dev, rank, world)
+    if gz_ring is not None:
+        gz_ring["ring"].close()
+    if interleaved:
+        np.asarray(writer.block_ends, np.int64).tofile(part_path + ".blocks")
     return n_rows, part_path, out_path
 
 
@@ -215,6 +253,9 @@ def _make_freq(args, dev, world, nthreads):
 
 def _finish_freq(args, freq, freq_dev, rank, world):
     if freq_dev is not None:
+        if not freq_dev.can_finish(world):   # collective.  Too many calls for the records to stay in HBM: the host table
+            args._freq_from_file = True      # computes the same bytes from the per-read file once it is merged
+            return
         table = freq_dev.finish(rank, world)  # collective: every rank takes part
         if table is not None:
             table.write(args.freq_file, args.freq_sort, args.freq_bed, args.gzip)
@@ -251,7 +292,7 @@ def _call_mods_reads(args, rank, local_rank, world):
     files = files[lo:hi]
     chrom2len = get_contig2len(args.reference_path) if args.reference_path else None
     positions = _read_position_file(args.positions) if args.positions else None
-    nthreads = min(max(1, args.nproc if args.nproc > 0 else 1), os.cpu_count() or 1)
+    nthreads = dsp_dist.threads_per_rank(args.nproc)
     fx = FeatureExtractor(motifs=args.motifs, mod_loc=args.mod_loc, seq_len=args.seq_len, signal_len=args.signal_len,
                           normalize_method=args.normalize_method, chrom2len=chrom2len, positions=positions,
                           region=args.region, methy_label=1, is_dna=str2bool(args.is_dna), device=dev,
@@ -343,6 +384,26 @@ _BGZF_EOF = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0
 def _merge_parts(out_path, world):
     """concatenate the ranks' part files in rank order (gzip / BGZF members concatenate into a valid .gz; the empty
     end-of-file member of every part but the last is dropped so that the result is one well-formed BGZF file)"""
+    parts = ["%s.part%05d" % (out_path, r) for r in range(world)]
+    if all(os.path.exists(p + ".blocks") for p in parts):
+        # interleaved sharding (a foreign .gz): piece k of rank r is block k * world + r of the input.  Pieces of a
+        # --gzip part are whole BGZF members; the parts' end-of-file members are dropped and one is written at the end
+        ends = [np.fromfile(p + ".blocks", np.int64) for p in parts]
+        files = [open(p, "rb") for p in parts]
+        with open(out_path, "wb") as wf:
+            for k in range(max(len(e) for e in ends)):
+                for r in range(world):
+                    if k < len(ends[r]):
+                        a = int(ends[r][k - 1]) if k else 0
+                        files[r].seek(a)
+                        wf.write(files[r].read(int(ends[r][k]) - a))
+            if out_path.endswith(".gz"):
+                wf.write(_BGZF_EOF)
+        for f, p in zip(files, parts):
+            f.close()
+            os.remove(p)
+            os.remove(p + ".blocks")
+        return
     with open(out_path, "wb") as wf:
         for r in range(world):
             part = "%s.part%05d" % (out_path, r)
@@ -368,14 +429,19 @@ def _self_launch(args, argv=None):
     """The reference starts --nproc_gpu model processes itself and deals them to the visible GPUs round-robin
     (call_modifications.py:523-529, :613-621).  Here: when call_mods is started plainly (no torch.distributed
     launcher) on a node with several GPUs and --nproc_gpu > 1, it starts min(nproc_gpu, GPUs) ranks of itself under
-    torch.distributed.run as a CHILD process (nothing has touched the GPU yet in this one) and returns its exit
-    code; None = carry on in this process."""
+    torch.distributed.run as a CHILD process and returns its exit code; None = carry on in this process.  Like
+    bench.py's launcher the parent makes no GPU call at all -- it does not even import torch: the GPUs are counted from the
+    ROCm device filters or the KFD topology (dist.visible_gpu_count) -- because a process that has initialised the GPU must
+    never be the one that starts replacing itself."""
     import socket
     import subprocess
-    import torch
     if "RANK" in os.environ or "WORLD_SIZE" in os.environ or os.environ.get("DSP_NO_SELF_LAUNCH"):
         return None
-    n = min(int(getattr(args, "nproc_gpu", 1) or 1), torch.cuda.device_count())  # device_count() does not initialise the GPU
+    want = int(getattr(args, "nproc_gpu", 1) or 1)
+    if want <= 1:
+        return None
+    ngpu = dsp_dist.visible_gpu_count()   # environment filters / KFD topology / a fresh child: this process never loads HIP here
+    n = min(want, ngpu)
     if n <= 1:
         return None
     argv = list(sys.argv[1:] if argv is None else argv)
@@ -387,8 +453,7 @@ def _self_launch(args, argv=None):
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
            "127.0.0.1", "--master-port", str(port), "-m", "deepsignal_plant_amd.deepsignal_plant", "call_mods"] + argv
-    print("[main] %d GPUs visible, --nproc_gpu %s: starting %d ranks (one per GPU)" % (torch.cuda.device_count(),
-                                                                                     args.nproc_gpu, n))
+    print("[main] %d GPUs visible, --nproc_gpu %s: starting %d ranks (one per GPU)" % (ngpu, args.nproc_gpu, n))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     return subprocess.call(cmd, env=env)
 
@@ -419,28 +484,29 @@ def call_mods(args):
     rank, local_rank, world = dsp_dist.env_world()
     ndev = torch.cuda.device_count()
     local_rank = local_rank % ndev
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        if not dist.is_initialized():
-            if ndev >= world:  # one process per GPU: RCCL
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            else:              # more ranks than visible GPUs (dev box): ranks share GPUs, control plane over gloo
-                dist.init_process_group("gloo")
+    torch.cuda.set_device(local_rank)
+    pinned = dsp_dist.pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)),
+                               getattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id", None)
+                               if os.environ.get("DSP_RANK_AFFINITY") == "numa" else None)
+    if pinned is not None and rank == 0:
+        print("[main] DSP_RANK_AFFINITY: rank 0 on CPUs %s.." % ",".join(str(c) for c in pinned[:8]))
+    # one process per GPU over RCCL (gloo when ranks have to share GPUs; DSP_FORCE_DIST=1: a one-rank RCCL group)
+    dsp_dist.init_process_group(world, rank, local_rank, ndev)
+    dist_on = dsp_dist.collective(world)
     if os.path.isdir(input_path):  # reads in, calls out: extraction + forward on the GPU (:559-583)
         n_rows, part_path, out_path = _call_mods_reads(args, rank, local_rank, world)
     else:
         n_rows, part_path, out_path = _call_mods_file(args, rank, local_rank, world)
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         cdev = torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else None
         total = sum(dsp_dist.all_gather_ints(n_rows, world, cdev))
         dist.barrier()
+    if world > 1:
         if rank == 0:
             _merge_parts(out_path, world)
-            if getattr(args, "freq_file", None) and getattr(args, "freq_on", "device") == "host":
+            if getattr(args, "freq_file", None) and (getattr(args, "freq_on", "device") == "host" or
+                                                     getattr(args, "_freq_from_file", False)):
                 # --freq_on host with several ranks: aggregate the merged per-read calls in file order (the default,
                 # --freq_on device, has already reduced them on the GPUs: DeviceSiteFrequency.finish)
                 from .call_mods_freq import SiteFrequency
@@ -449,7 +515,15 @@ def call_mods(args):
                 agg.write(args.freq_file, args.freq_sort, args.freq_bed, args.gzip)
         dist.barrier()
     else:
-        total = n_rows
+        total = n_rows if not dist_on else total
+        if getattr(args, "_freq_from_file", False):
+            from .call_mods_freq import SiteFrequency
+            agg = SiteFrequency(args.prob_cf)
+            agg.add_calls_file(out_path)
+            agg.write(args.freq_file, args.freq_sort, args.freq_bed, args.gzip)
+    if dist_on:
+        import torch.distributed as dist
+        dist.destroy_process_group()
     if rank == 0:
         dt = time.time() - start
         print("[main] call_mods costs %.2f seconds.." % dt)

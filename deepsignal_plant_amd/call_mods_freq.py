@@ -124,6 +124,13 @@ class DeviceSiteFrequency(object):
         self.host = SiteFrequency(prob_cf, nthreads)   # chromosome dictionary + final table / formatter
         self.keys, self.packed, self.pis, self.rows = [], [], [], []
         self.count = 0
+        # Records stay resident (32 B per call) and finish() needs about five times that in temporaries (filter, exchange,
+        # two-key sort): past the budget the aggregator stops collecting, says so, and the caller computes --freq_file from
+        # the merged per-read file with the host table instead (same bytes) -- rather than running out of HBM after all the
+        # forward work is done.  DSP_FREQ_DEV_MAX_BYTES overrides the budget (default: a tenth of the GPU's memory).
+        env = os.environ.get("DSP_FREQ_DEV_MAX_BYTES")
+        self.budget = int(env) if env else int(torch.cuda.get_device_properties(self.dev).total_memory // 10)
+        self.overflow = False
 
     def add_block(self, rows, probs_dev, labels_dev, first_row, start=0, stop=None, stream=None):
         """rows: the parsed block (host); probs_dev [n, C] float32 and labels_dev [n] uint8: the forward's outputs,
@@ -133,6 +140,16 @@ class DeviceSiteFrequency(object):
         n = stop - start
         if n <= 0:
             return 0
+        if self.overflow:
+            self.count += n
+            return n
+        if (self.count + n) * 32 > self.budget:
+            sys.stderr.write("[call_freq] %d calls would exceed the device budget of %d bytes for resident records: "
+                             "--freq_file will be computed from the per-read file by the host table\n" % (self.count + n, self.budget))
+            self.overflow = True
+            self.keys, self.packed, self.pis, self.rows = [], [], [], []
+            self.count += n
+            return n
         key = np.empty(n, np.int64)
         pis = np.empty(n, np.int64)
         meta = np.empty(n, np.uint32)
@@ -177,34 +194,45 @@ class DeviceSiteFrequency(object):
         return out
 
     def _exchange(self, cols, dest, world, dist):
-        """deal the record columns to ranks by `dest`; what arrives is ordered by source rank, then source order"""
+        """deal the records (equally long int64 columns) to ranks by `dest`: the columns travel as ONE [n, k] tensor in one
+        all_to_all; what arrives is ordered by source rank, then source order"""
         torch = self.torch
         order = torch.sort(dest, stable=True)[1]
         counts = torch.bincount(dest, minlength=world)
-        cols = [c[order] for c in cols]
+        rec = torch.stack([c[order] for c in cols], dim=1).contiguous()
         if dist.get_backend() == "nccl":
             recv_counts = torch.empty_like(counts)
             dist.all_to_all_single(recv_counts, counts)
             ins, outs = counts.tolist(), recv_counts.tolist()
-            got = []
-            for c in cols:
-                o = torch.empty(sum(outs), dtype=c.dtype, device=c.device)
-                dist.all_to_all_single(o, c.contiguous(), outs, ins)
-                got.append(o)
-            return got
-        # gloo has no all_to_all: every rank publishes its columns, everybody keeps its own share (dev box only)
+            got = torch.empty((sum(outs), len(cols)), dtype=rec.dtype, device=rec.device)
+            dist.all_to_all_single(got, rec, outs, ins)
+            return [got[:, j].contiguous() for j in range(len(cols))]
+        # gloo has no all_to_all: every rank publishes its records, everybody keeps its own share (dev box / CPU tests)
         rank = dist.get_rank()
         objs = [None] * world
-        dist.all_gather_object(objs, (counts.cpu(), [c.cpu() for c in cols]))
-        got = []
-        for j in range(len(cols)):
-            parts = []
-            for src in range(world):
-                cnt, cc = objs[src]
-                off = int(cnt[:rank].sum())
-                parts.append(cc[j][off:off + int(cnt[rank])])
-            got.append(torch.cat(parts).to(self.dev))
-        return got
+        dist.all_gather_object(objs, (counts.cpu(), rec.cpu()))
+        parts = []
+        for src in range(world):
+            cnt, rr = objs[src]
+            off = int(cnt[:rank].sum())
+            parts.append(rr[off:off + int(cnt[rank])])
+        got = torch.cat(parts).to(self.dev)
+        return [got[:, j].contiguous() for j in range(len(cols))]
+
+    def can_finish(self, world=1):
+        """collective: True when every rank kept all its records and has room for finish()'s temporaries"""
+        torch = self.torch
+        ok = not self.overflow
+        if ok and self.dev.type == "cuda":
+            free, _total = torch.cuda.mem_get_info(self.dev)
+            ok = self.count * 32 * 5 <= free
+        from . import dist as dsp_dist
+        if dsp_dist.collective(world):
+            import torch.distributed as dist
+            t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=self.dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = bool(int(t.item()))
+        return ok
 
     def finish(self, rank=0, world=1):
         """-> the SiteFrequency holding every site on rank 0 (None on the other ranks)"""
@@ -220,7 +248,9 @@ class DeviceSiteFrequency(object):
         key, packed, pis, row = key[live], packed[live], pis[live], row[live]
         names = self._chrom_names()
         total = self.count
-        if world > 1:
+        from . import dist as dsp_dist
+        multi = dsp_dist.collective(world)   # several ranks, or a forced one-rank RCCL group (DSP_FORCE_DIST=1)
+        if multi:
             import torch.distributed as dist
             lists = [None] * world
             dist.all_gather_object(lists, names)
@@ -244,6 +274,12 @@ class DeviceSiteFrequency(object):
         n = int(key.numel())
         torch.cuda.set_device(dev)
         s = torch.cuda.current_stream(dev)
+        if multi:
+            # what arrived is ordered by source rank; ranks may own interleaved blocks of the input (a foreign .gz is dealt
+            # block i -> rank i % world), so restore the global input order first: a site's sums are then taken in file
+            # order -- the order `call_freq` sees on the merged per-read file -- whatever the sharding
+            o = torch.sort(row, stable=True)[1]
+            key, packed, pis, row = key[o], packed[o], pis[o], row[o]
         key, perm = torch.sort(key, stable=True)   # file order inside a site survives
         packed, pis, row = packed[perm], pis[perm], row[perm]
         cnt = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -257,9 +293,8 @@ class DeviceSiteFrequency(object):
                                             p(out_d[0].data_ptr()), p(out_d[1].data_ptr()), p(out_i[4].data_ptr()),
                                             p(out_i[5].data_ptr()))))
         cols = out_i + [o.view(torch.int64) for o in out_d]   # doubles travel as their bit patterns
-        if world > 1:
+        if multi:
             import torch.distributed as dist
-            from . import dist as dsp_dist
             gathered = dsp_dist.gather_columns(cols, world, dev if dist.get_backend() == "nccl" else None)
             if rank != 0:
                 return None

@@ -11,6 +11,10 @@
 #include "dsp_amd.h"
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -97,8 +101,18 @@ int inflate_member(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_
 
 }  // namespace
 
+// Streaming reader of a foreign .gz: the file is mmap'ed and run through zlib's inflate (gzip wrapper: header, CRC32
+// and ISIZE of every member checked), member after member like gzip.open.  Not gzread: that reports a stream cut in
+// the middle as a clean end of file (0 bytes + Z_BUF_ERROR) -- a half-copied feature file must fail, as it does under
+// the reference's gzip.open (EOFError).
 struct dsp_gz_stream {
-    gzFile f = nullptr;
+    int fd = -1;
+    const uint8_t* map = nullptr;
+    size_t size = 0, pos = 0;       // pos = compressed bytes handed to zlib so far
+    z_stream z;
+    bool z_live = false;            // inside a member
+    bool done = false;              // clean end of the file reached
+    uint64_t bytes_out = 0;
 };
 
 extern "C" {
@@ -258,39 +272,82 @@ int64_t dsp_bgzf_eof(uint8_t* out, size_t cap) {
 
 dsp_gz_stream* dsp_gz_open(const char* path) {
     if (!path) return nullptr;
-    gzFile f = gzopen(path, "rb");
-    if (!f) { gz_fail(DSP_EINVAL, "dsp_gz_open: cannot open the file"); return nullptr; }
-    gzbuffer(f, 1u << 20);
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) { gz_fail(DSP_EINVAL, "dsp_gz_open: cannot open the file"); return nullptr; }
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { close(fd); gz_fail(DSP_EINVAL, "dsp_gz_open: cannot stat the file"); return nullptr; }
     dsp_gz_stream* s = new (std::nothrow) dsp_gz_stream();
-    if (!s) { gzclose(f); return nullptr; }
-    s->f = f;
+    if (!s) { close(fd); return nullptr; }
+    s->fd = fd;
+    s->size = (size_t)sb.st_size;
+    memset(&s->z, 0, sizeof(s->z));
+    if (s->size) {
+        void* m = mmap(nullptr, s->size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { close(fd); delete s; gz_fail(DSP_EINVAL, "dsp_gz_open: cannot map the file"); return nullptr; }
+        madvise(m, s->size, MADV_SEQUENTIAL);
+        s->map = (const uint8_t*)m;
+    }
     return s;
 }
 
-// up to cap bytes of text (all members of the file, like gzip.open); 0 at the end, < 0 on a corrupt stream
+// up to cap bytes of text (all members of the file, like gzip.open); 0 at the end; DSP_EPARSE on a corrupt OR TRUNCATED
+// stream (the reference's gzip.open raises EOFError / BadGzipFile there)
 int64_t dsp_gz_read(dsp_gz_stream* s, uint8_t* out, size_t cap) {
-    if (!s || !s->f || !out) return gz_fail(DSP_EINVAL, "dsp_gz_read: NULL argument");
+    if (!s || s->fd < 0 || !out) return gz_fail(DSP_EINVAL, "dsp_gz_read: NULL argument");
     size_t got = 0;
-    while (got < cap) {
-        const unsigned want = (unsigned)std::min<size_t>(cap - got, 1u << 30);
-        const int k = gzread(s->f, out + got, want);
-        if (k < 0) {
-            int e = 0;
-            const char* msg = gzerror(s->f, &e);
-            char buf[200];
-            snprintf(buf, sizeof(buf), "corrupt gzip stream: %s", msg ? msg : "?");
-            dsp_set_error_(buf);
-            return DSP_EPARSE;
+    while (got < cap && !s->done) {
+        if (!s->z_live) {
+            // between members: zero padding is skipped (gzip.open does the same), the end of the file ends the stream,
+            // anything else must be another member
+            while (s->pos < s->size && s->map[s->pos] == 0) ++s->pos;
+            if (s->pos >= s->size) {
+                if (s->bytes_out == 0 && s->size == 0) { s->done = true; break; }  // an empty file reads as empty text
+                s->done = true;
+                break;
+            }
+            memset(&s->z, 0, sizeof(s->z));
+            if (inflateInit2(&s->z, 15 + 16) != Z_OK) return gz_fail(DSP_ENOMEM, "dsp_gz_read: inflateInit2 failed");
+            s->z_live = true;
         }
-        if (k == 0) break;
-        got += (size_t)k;
+        const size_t in_chunk = std::min<size_t>(s->size - s->pos, 1u << 30);
+        const size_t out_chunk = std::min<size_t>(cap - got, 1u << 30);
+        s->z.next_in = const_cast<Bytef*>(s->map + s->pos); s->z.avail_in = (uInt)in_chunk;
+        s->z.next_out = out + got; s->z.avail_out = (uInt)out_chunk;
+        const int rc = inflate(&s->z, Z_NO_FLUSH);
+        const size_t used = in_chunk - s->z.avail_in, made = out_chunk - s->z.avail_out;
+        s->pos += used; got += made; s->bytes_out += made;
+        if (rc == Z_STREAM_END) {
+            inflateEnd(&s->z);
+            s->z_live = false;
+            continue;
+        }
+        if (rc == Z_OK) continue;
+        if (rc == Z_BUF_ERROR && s->z.avail_out == 0) continue;  // output full: the caller comes back
+        char buf[256];
+        if (rc == Z_BUF_ERROR || (rc == Z_OK && used == 0 && made == 0)) {
+            // no progress possible with all the input there is: the file ends inside a member
+            snprintf(buf, sizeof(buf), "truncated gzip stream: Compressed file ended before the end-of-stream marker was reached "
+                                       "(%llu of %llu compressed bytes read)", (unsigned long long)s->pos, (unsigned long long)s->size);
+        } else {
+            snprintf(buf, sizeof(buf), "corrupt gzip stream: %s", s->z.msg ? s->z.msg : (rc == Z_DATA_ERROR ? "data error" : "zlib error"));
+        }
+        inflateEnd(&s->z);
+        s->z_live = false;
+        s->done = true;
+        dsp_set_error_(buf);
+        return DSP_EPARSE;
     }
     return (int64_t)got;
 }
 
+// compressed bytes consumed so far (tests: N ranks of a node inflate a foreign .gz once, not N times)
+uint64_t dsp_gz_bytes_in(const dsp_gz_stream* s) { return s ? (uint64_t)s->pos : 0; }
+
 void dsp_gz_close(dsp_gz_stream* s) {
     if (!s) return;
-    if (s->f) gzclose(s->f);
+    if (s->z_live) inflateEnd(&s->z);
+    if (s->map) munmap(const_cast<uint8_t*>(s->map), s->size);
+    if (s->fd >= 0) close(s->fd);
     delete s;
 }
 

@@ -17,6 +17,151 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def forced():
+    """DSP_FORCE_DIST=1: take the distributed branches (process group over RCCL, collectives, exchange) even with ONE
+    rank -- so that the RCCL code paths of bench.py / call_mods / the sharded call_freq execute on a 1-GPU box."""
+    return os.environ.get("DSP_FORCE_DIST") == "1"
+
+
+def collective(world):
+    """True when the collectives of the path must run: several ranks, or a forced one-rank process group"""
+    if world > 1:
+        return True
+    if not forced():
+        return False
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
+def init_process_group(world, rank, dev_index, ndev):
+    """One process per GPU: RCCL ("nccl" on ROCm) bound to this rank's device; when fewer GPUs than ranks are visible (the
+    1-GPU dev box) the ranks share GPUs and the control plane runs over gloo.  With DSP_FORCE_DIST=1 a lone rank builds
+    its own one-rank RCCL group.  Returns the backend name, or None when no group is needed."""
+    if world == 1 and not forced():
+        return None
+    import socket
+
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world == 1 and "MASTER_PORT" not in os.environ:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+        s.close()
+    if dist.is_initialized():
+        return dist.get_backend()
+    torch.cuda.set_device(dev_index)
+    if ndev >= world:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dist.get_backend()
+
+
+def visible_gpu_count():
+    """GPUs this process would see, WITHOUT loading the HIP runtime (the launchers decide how many ranks to start before
+    anything may touch the GPU: a process that initialised the GPU must not start replacing itself).  The device
+    filters of the ROCm stack first (HIP_VISIBLE_DEVICES on top of ROCR_VISIBLE_DEVICES; CUDA_VISIBLE_DEVICES is
+    honoured by HIP too), else the KFD topology (nodes with SIMDs are GPUs), else a fresh child process that asks torch."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            ids = [x for x in v.split(",") if x.strip() != ""]
+            if v.strip() in ("", "-1"):
+                return 0
+            return len(ids)
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        if n > 0:
+            return n
+    except (OSError, ValueError):
+        pass
+    import subprocess
+    import sys
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True,
+                             text=True, timeout=300)
+        return int(out.stdout.strip().splitlines()[-1])
+    except Exception:
+        return 0
+
+
+def available_cpus():
+    """host threads this process may use: CPU affinity, capped by the cgroup CPU quota"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def threads_per_rank(nproc, local_world=None):
+    """Host threads (parser / formatter / deflate) of ONE rank: --nproc, capped by this rank's share of the node's CPUs
+    (available CPUs // ranks on the node) -- 8 ranks must not each start --nproc threads on a node that has fewer than
+    8 x --nproc cores.  DSP_THREADS_PER_RANK overrides."""
+    env = os.environ.get("DSP_THREADS_PER_RANK")
+    if env:
+        return max(1, int(env))
+    if local_world is None:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    share = max(1, available_cpus() // max(1, local_world))
+    return max(1, min(nproc if nproc and nproc > 0 else 1, share))
+
+
+def _cpulist(text):
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out += list(range(int(a), int(b or a) + 1))
+    return out
+
+
+def pin_rank(local_rank, local_world, pci_bus_id=None):
+    """Optional CPU placement of a rank (DSP_RANK_AFFINITY = numa | slice; default: leave the scheduler alone).
+    numa: the CPUs of the NUMA node the rank's GPU hangs off (/sys/bus/pci/devices/<bdf>/numa_node), split among the ranks
+    whose GPUs share that node by the caller's slice of it; slice: the local_rank-th of local_world equal slices of the
+    allowed CPUs.  Returns the CPU list set, or None."""
+    mode = os.environ.get("DSP_RANK_AFFINITY", "")
+    if mode not in ("numa", "slice") or not hasattr(os, "sched_setaffinity"):
+        return None
+    allowed = sorted(os.sched_getaffinity(0))
+    cpus = None
+    if mode == "numa" and pci_bus_id:
+        try:
+            bdf = pci_bus_id.lower()
+            node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read().strip())
+            if node >= 0:
+                cand = [c for c in _cpulist(open("/sys/devices/system/node/node%d/cpulist" % node).read()) if c in allowed]
+                if cand:
+                    cpus = cand
+        except (OSError, ValueError):
+            cpus = None
+    if cpus is None:
+        k = max(1, len(allowed) // max(1, local_world))
+        cpus = allowed[local_rank * k:(local_rank + 1) * k] or allowed
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        return None
+    return cpus
+
+
 def split_range(n, world, rank):
     """Contiguous split of n items: rank r gets [r*ceil(n/world), (r+1)*ceil(n/world)) clipped to n
     (SURVEY.md 8(e) 'Partitioning')."""
@@ -50,7 +195,7 @@ def exclusive_prefix(counts, rank):
 
 def all_gather_ints(value, world, device=None):
     """One integer per rank -> list of all ranks' integers (torch.distributed must be initialised)."""
-    if world == 1:
+    if not collective(world):
         return [int(value)]
     import torch
     import torch.distributed as dist
@@ -63,7 +208,7 @@ def all_gather_ints(value, world, device=None):
 def gather_probs(probs, world, dst=0):
     """Optional final gather of per-site probabilities [n_r, C] to rank `dst` (ragged: sizes exchanged
     first).  One collective on RCCL over xGMI; ~8 B/site."""
-    if world == 1:
+    if not collective(world):
         return [probs]
     import torch
     import torch.distributed as dist
@@ -77,20 +222,20 @@ def gather_probs(probs, world, dst=0):
 
 
 def gather_columns(cols, world, device=None):
-    """Ragged gather of equally long 1-D int64 columns to rank 0: sizes exchanged first, then one padded all_gather
-    per column (RCCL when `device` is a GPU).  Returns the concatenated columns on rank 0, None elsewhere."""
+    """Ragged gather of equally long 1-D int64 columns to rank 0: sizes exchanged first, then ONE padded all_gather of
+    the columns stacked as [n, k] (RCCL when `device` is a GPU).  Returns the concatenated columns on rank 0, None
+    elsewhere."""
     import torch
     import torch.distributed as dist
     n = int(cols[0].numel())
     sizes = all_gather_ints(n, world, device)
     mx = max(max(sizes), 1)
-    out = []
-    for c in cols:
-        src = c if device is not None else c.cpu()
-        pad = torch.zeros(mx, dtype=src.dtype, device=src.device)
-        pad[:n] = src
-        got = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(got, pad)
-        if dist.get_rank() == 0:
-            out.append(torch.cat([g[:k] for g, k in zip(got, sizes)]))
-    return out if dist.get_rank() == 0 else None
+    rec = torch.stack([c if device is not None else c.cpu() for c in cols], dim=1)
+    pad = torch.zeros((mx, len(cols)), dtype=rec.dtype, device=rec.device)
+    pad[:n] = rec
+    got = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(got, pad)
+    if dist.get_rank() != 0:
+        return None
+    out = torch.cat([g[:k] for g, k in zip(got, sizes)])
+    return [out[:, j].contiguous() for j in range(len(cols))]

@@ -74,7 +74,7 @@ class FeatureReader(threading.Thread):
     """Producer thread: yields parsed blocks of this rank's rows, in file order, through a bounded queue."""
 
     def __init__(self, path, seq_len, signal_len, rank=0, world=1, nthreads=4, nbuf=3, block_bytes=BLOCK_BYTES,
-                 first_row=0, byte_range=None, pinned=True, max_rows_per_block=None):
+                 first_row=0, byte_range=None, pinned=True, max_rows_per_block=None, gz_ring=None):
         super().__init__(daemon=True)
         self.path, self.L, self.S = path, seq_len, signal_len
         self.ff = None
@@ -88,6 +88,8 @@ class FeatureReader(threading.Thread):
         self.block_bytes = block_bytes
         self.first_row = first_row
         self.byte_range = byte_range
+        self.gz_ring = gz_ring       # foreign .gz read by several ranks: the node's shared-memory ring (open_gz_ring)
+        self.gz_bytes_in = 0         # compressed bytes this rank inflated from a foreign .gz
         self.q = queue.Queue(maxsize=max(1, nbuf - 1))
         self.free = queue.Queue()
         cap = max_rows_per_block or max(1024, block_bytes // 600)
@@ -232,43 +234,164 @@ class FeatureReader(threading.Thread):
         e = int(np.searchsorted(bz.text_off, bz.text_off[m] + self.block_bytes, side="left"))
         return min(m1, max(m + 1, e))
 
-    def _run_gz_stream(self, row):
-        """A foreign .gz (one deflate stream): it cannot be range-split, so every rank inflates it -- natively, the GIL
-        released -- and keeps the blocks it owns (block i -> rank i % world), counting the rows of foreign blocks to
-        keep global row indices."""
+    # ---- foreign .gz (one deflate stream; what the reference's `extract --gzip` writes) --------------------------------
+    def _gz_cut(self, buf, n):
+        """index of the last newline of buf[:n], or -1"""
+        lo = max(0, n - (1 << 16))
+        pos = np.flatnonzero(buf[lo:n] == 10)
+        if len(pos):
+            return lo + int(pos[-1])
+        allpos = np.flatnonzero(buf[:n] == 10)
+        return int(allpos[-1]) if len(allpos) else -1
+
+    def _gz_inflate_blocks(self, get_buf, put_block):
+        """The one inflater of a foreign .gz: blocks of complete rows, inflated straight into the buffers get_buf(i)
+        hands out (private arrays, or slots of the node's shared-memory ring); put_block(i, buf, nbytes, first_row,
+        n_rows) passes block i on.  Returns (number of blocks, rows, compressed bytes read)."""
         from . import gzio
         st = gzio.GzStream(self.path)
         carry = np.zeros(0, np.uint8)
-        i = 0
+        i, row = 0, self.first_row
         try:
             while True:
-                buf = np.empty(len(carry) + self.block_bytes, np.uint8)
+                buf = get_buf(i)
+                room = min(len(buf), len(carry) + self.block_bytes)
+                if len(carry) >= room:
+                    raise ValueError("a row of %s is longer than a reader block (%d bytes)" % (self.path, room))
                 buf[:len(carry)] = carry
-                got = st.readinto(buf, len(carry))
-                if got == 0:
+                got = st.readinto(buf[:room], len(carry))
+                n = len(carry) + got
+                if got == 0:       # end of the stream: what is left is an unterminated last row (or nothing)
+                    if len(carry) and carry.tobytes().strip():
+                        put_block(i, buf, n, row, 1)
+                        i, row = i + 1, row + 1
                     break
-                data = buf[:len(carry) + got]
-                pos = np.flatnonzero(data[max(0, len(data) - (1 << 16)):] == 10)
-                if len(pos):
-                    nl = max(0, len(data) - (1 << 16)) + int(pos[-1])
-                else:
-                    allpos = np.flatnonzero(data == 10)
-                    nl = int(allpos[-1]) if len(allpos) else -1
+                nl = self._gz_cut(buf, n)
                 if nl < 0:
-                    carry = data.copy()
+                    carry = buf[:n].copy()
                     continue
-                carry = data[nl + 1:].copy()
-                data = data[:nl + 1]
-                if i % self.world == self.rank:
-                    row += self._emit(data, row)
-                else:
-                    row += textio.count_rows(data)
-                i += 1
+                carry = buf[nl + 1:n].copy()
+                k = textio.count_rows(buf[:nl + 1])
+                put_block(i, buf, nl + 1, row, k)
+                i, row = i + 1, row + k
+            self.gz_bytes_in = st.bytes_in()
         finally:
             st.close()
-        if len(carry) and carry.tobytes().strip():
-            if i % self.world == self.rank:
-                row += self._emit(carry, row)
-            else:
-                row += 1
+        return i, row
+
+    def _run_gz_stream(self, row):
+        """A foreign .gz cannot be range-split.  One rank: the inflater runs in its own thread, two blocks ahead of the
+        parser.  Several ranks: the first rank of the node inflates ONCE into a shared-memory ring (gz_ring, set up by
+        open_gz_ring) and every rank copies its blocks out (block i -> rank i % world), with the global index of the
+        block's first row attached; without a ring (no shared memory to be had) every rank inflates the stream itself
+        and keeps its blocks, as before round 3."""
+        if self.world > 1 and self.gz_ring is not None:
+            return self._run_gz_ring(row)
+        mine = lambda i: i % self.world == self.rank
+        bq = queue.Queue(maxsize=2)
+        slack = 1 << 20
+
+        def get_buf(i):
+            return np.empty(self.block_bytes + slack, np.uint8)
+
+        def put_block(i, buf, n, first_row, n_rows):
+            if mine(i):
+                bq.put((buf[:n], first_row))
+
+        def produce():
+            try:
+                _, end_row = self._gz_inflate_blocks(get_buf, put_block)
+                bq.put(("end", end_row))
+            except BaseException as e:
+                bq.put(("error", e))
+        t = threading.Thread(target=produce, daemon=True)
+        t.start()
+        while True:
+            data, info = bq.get()
+            if isinstance(data, str):
+                if data == "error":
+                    raise info
+                row = info
+                break
+            self._emit(data, info)
+        t.join()
         return row
+
+    def _run_gz_ring(self, row):
+        ring, li, lw = self.gz_ring["ring"], self.gz_ring["local_index"], self.gz_ring["local_world"]
+        first = self.rank - li            # global rank of this node's first rank
+        producer = None
+        if self.gz_ring.get("producer"):
+            def local_seq(i):             # dense numbering of the blocks this node's ranks own, or -1
+                o = i % self.world - first
+                return (i // self.world) * lw + o if 0 <= o < lw else -1
+            scratch = []
+
+            def get_buf(i):
+                s = local_seq(i)
+                if s >= 0:
+                    return ring.acquire(s)
+                if not scratch:
+                    scratch.append(np.empty(ring.slot_bytes, np.uint8))
+                return scratch[0]
+            published = [0]
+
+            def put_block(i, buf, n, first_row, n_rows):
+                s = local_seq(i)
+                if s >= 0:
+                    ring.publish(s, n, first_row, n_rows)
+                    published[0] = s + 1
+
+            def produce():
+                try:
+                    self._gz_inflate_blocks(get_buf, put_block)
+                    ring.finish(published[0], 0)
+                except BaseException as e:
+                    ring.finish(published[0], -5, "%s: %s" % (type(e).__name__, e))
+            producer = threading.Thread(target=produce, daemon=True)
+            producer.start()
+        k = 0
+        try:
+            while True:
+                got = ring.take(k * lw + li)
+                if got is None:
+                    break
+                data, first_row, n_rows = got
+                self._emit(data, first_row)
+                row = first_row + n_rows
+                k += 1
+        except BaseException:
+            ring.abort()
+            raise
+        finally:
+            if producer is not None:
+                producer.join()
+        return row
+
+
+def open_gz_ring(path, rank, world, local_rank, local_world, all_gather_object, block_bytes=BLOCK_BYTES):
+    """Collective over all ranks (call it on every rank, before the readers start): for a foreign single-stream .gz read
+    by several ranks, the first rank of every node creates a shared-memory ring; returns the `gz_ring` argument of
+    FeatureReader, or None when the file needs no ring (one rank) or a node could not reserve the shared memory (every
+    rank then inflates for itself).  all_gather_object(obj) -> list of every rank's obj (torch.distributed's, or a test's)."""
+    if world <= 1:
+        return None
+    import secrets
+    from . import gzio
+    ring, name = None, None
+    if local_rank == 0:
+        name = "/dsp_gz_%d_%s" % (os.getpid(), secrets.token_hex(6))
+        try:
+            ring = gzio.ShmRing.create(name, local_world + 2, block_bytes + (1 << 20))
+        except (MemoryError, OSError) as e:
+            import sys
+            sys.stderr.write("[feed] no shared-memory ring for %s (%s): every rank inflates the stream itself\n" % (path, e))
+            name = None
+    names = all_gather_object(name)
+    if any(names[r - lr] is None for r, lr in enumerate(all_gather_object(local_rank))):
+        if ring is not None:
+            ring.close()
+        return None
+    if ring is None:
+        ring = gzio.ShmRing.attach(names[rank - local_rank])
+    return dict(ring=ring, producer=local_rank == 0, local_index=local_rank, local_world=local_world)

@@ -28,6 +28,8 @@ class BgzfWriter(object):
         self.buf = bytearray()
         self.q = queue.Queue(maxsize=3)
         self.error = None
+        self.pos = 0            # compressed bytes written so far (worker thread)
+        self.block_ends = []    # file offsets recorded by end_block(), in order
         self.worker = threading.Thread(target=self._run, daemon=True)
         self.worker.start()
 
@@ -40,6 +42,9 @@ class BgzfWriter(object):
                 return
             if self.error is not None:
                 continue  # drain
+            if data is BgzfWriter._MARK:
+                self.block_ends.append(self.pos)
+                continue
             try:
                 n = len(data)
                 need = n + (n // 0xff00 + 2) * 64 + 65536
@@ -49,6 +54,7 @@ class BgzfWriter(object):
                 k = nat.check(int(L.dsp_bgzf_compress(ctypes.c_void_p(src.ctypes.data), n, ctypes.c_void_p(out.ctypes.data),
                                                       out.nbytes, self.level, self.nthreads)))
                 self.f.write(memoryview(out)[:k])
+                self.pos += k
             except BaseException as e:  # surfaced by the producer
                 self.error = e
 
@@ -71,6 +77,14 @@ class BgzfWriter(object):
             self.buf += data
             self._submit()
         return len(data)
+
+    _MARK = object()
+
+    def end_block(self):
+        """close the current member here and remember the file offset (block_ends, complete after close()): the caller
+        can later cut the file at these offsets into pieces that are whole BGZF members"""
+        self._submit(final=True)
+        self.q.put(BgzfWriter._MARK)
 
     def close(self):
         if self.f is None:
@@ -149,9 +163,82 @@ class GzStream(object):
     def readinto(self, arr, offset=0):
         return nat.check(int(nat.lib().dsp_gz_read(self.h, ctypes.c_void_p(arr.ctypes.data + offset), arr.nbytes - offset)))
 
+    def bytes_in(self):
+        """compressed bytes consumed so far"""
+        return int(nat.lib().dsp_gz_bytes_in(self.h)) if self.h else 0
+
     def close(self):
         if self.h:
             nat.lib().dsp_gz_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ShmRing(object):
+    """node-local ring of text blocks in POSIX shared memory (csrc/dsp_shmring.cpp): the node's first rank inflates a
+    foreign single-stream .gz ONCE into it, every rank of the node copies its own blocks out."""
+
+    TIMEOUT = float(os.environ.get("DSP_RING_TIMEOUT_S", 900.0))
+
+    def __init__(self, handle, name, owner):
+        self.h, self.name, self.owner = ctypes.c_void_p(handle), name, owner
+        self.slot_bytes = int(nat.lib().dsp_shm_ring_slot_bytes(self.h))
+
+    @classmethod
+    def create(cls, name, n_slots, slot_bytes):
+        h = nat.lib().dsp_shm_ring_create(name.encode(), int(n_slots), int(slot_bytes))
+        if not h:
+            raise MemoryError(nat.lib().dsp_last_error().decode())
+        return cls(h, name, True)
+
+    @classmethod
+    def attach(cls, name, timeout=60.0):
+        h = nat.lib().dsp_shm_ring_attach(name.encode(), float(timeout))
+        if not h:
+            raise RuntimeError(nat.lib().dsp_last_error().decode())
+        return cls(h, name, False)
+
+    # -- producer
+    def acquire(self, seq):
+        """writable uint8 view of the slot of block `seq` (blocks until its previous tenant has been released)"""
+        p = nat.lib().dsp_shm_ring_acquire(self.h, int(seq), self.TIMEOUT)
+        if not p:
+            raise RuntimeError(nat.lib().dsp_last_error().decode())
+        return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(self.slot_bytes,))
+
+    def publish(self, seq, length, first_row, n_rows):
+        nat.check(int(nat.lib().dsp_shm_ring_publish(self.h, int(seq), int(length), int(first_row), int(n_rows))))
+
+    def finish(self, n_blocks, status=0, message=None):
+        nat.lib().dsp_shm_ring_finish(self.h, int(n_blocks), int(status), message.encode()[:250] if message else None)
+
+    # -- consumer
+    def take(self, seq):
+        """(copy of block seq, global index of its first row, its row count), or None when the stream ended before it"""
+        L = nat.lib()
+        data, ln, fr, nr = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        rc = int(L.dsp_shm_ring_wait(self.h, int(seq), self.TIMEOUT, ctypes.byref(data), ctypes.byref(ln), ctypes.byref(fr),
+                                     ctypes.byref(nr)))
+        if rc == 1:
+            return None
+        nat.check(rc)
+        view = np.ctypeslib.as_array(ctypes.cast(data, ctypes.POINTER(ctypes.c_uint8)), shape=(int(ln.value),))
+        out = view.copy()     # the rows' sampleinfo strings are referenced until the block is written: own the bytes
+        L.dsp_shm_ring_release(self.h, int(seq))
+        return out, int(fr.value), int(nr.value)
+
+    def abort(self):
+        if self.h:
+            nat.lib().dsp_shm_ring_abort(self.h)
+
+    def close(self):
+        if self.h:
+            nat.lib().dsp_shm_ring_close(self.h, 1 if self.owner else 0)
             self.h = None
 
     def __del__(self):

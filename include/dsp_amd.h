@@ -360,8 +360,35 @@ int64_t dsp_gz_inflate_members(const uint8_t* src, const uint64_t* member_off, c
 int64_t dsp_bgzf_compress(const uint8_t* in, size_t len, uint8_t* out, size_t out_cap, int32_t level, int32_t nthreads);
 int64_t dsp_bgzf_eof(uint8_t* out, size_t cap);
 dsp_gz_stream* dsp_gz_open(const char* path);
-int64_t dsp_gz_read(dsp_gz_stream* s, uint8_t* out, size_t cap);
+int64_t dsp_gz_read(dsp_gz_stream* s, uint8_t* out, size_t cap);   /* 0 = end; DSP_EPARSE: corrupt or TRUNCATED stream */
+uint64_t dsp_gz_bytes_in(const dsp_gz_stream* s);                   /* compressed bytes consumed so far */
 void dsp_gz_close(dsp_gz_stream* s);
+
+/* ---- node-local ring of text blocks in POSIX shared memory (csrc/dsp_shmring.cpp) ---------------------------------
+ * A feature file written by the reference's `extract --gzip` is ONE gzip stream (read back with gzip.open at
+ * call_modifications.py:66-69): it cannot be range-split, so the first rank of a node inflates it once into this ring
+ * as blocks of complete rows and every rank of the node copies ITS blocks out (block i -> rank i % world).  One
+ * producer, any number of consumers, each block consumed by exactly one of them.  Sequence numbers are node-local and
+ * dense.  Names are shm_open names ("/..."); timeouts in seconds.
+ * create: reserves the memory up front (DSP_ENOMEM via dsp_last_error when /dev/shm is too small: the caller falls back
+ *   to per-rank inflation); attach: waits for the creator.
+ * acquire (producer): payload of block seq once the consumer of block seq - n_slots released it; publish: makes it
+ *   visible with its length, the global index of its first row and its row count; finish: end of stream after n_blocks
+ *   (status 0) or the producer's failure (status < 0, message).
+ * wait (consumer): 0 = block there (*data points into the ring: copy out, then release), 1 = stream ended before seq,
+ *   < 0 = producer failure (its message in dsp_last_error) or timeout.  abort: a failing consumer unblocks the producer. */
+typedef struct dsp_shm_ring dsp_shm_ring;
+dsp_shm_ring* dsp_shm_ring_create(const char* name, int32_t n_slots, uint64_t slot_bytes);
+dsp_shm_ring* dsp_shm_ring_attach(const char* name, double timeout_s);
+uint64_t dsp_shm_ring_slot_bytes(const dsp_shm_ring* r);
+uint8_t* dsp_shm_ring_acquire(dsp_shm_ring* r, uint64_t seq, double timeout_s);
+int32_t dsp_shm_ring_publish(dsp_shm_ring* r, uint64_t seq, uint64_t len, uint64_t first_row, uint64_t n_rows);
+int32_t dsp_shm_ring_finish(dsp_shm_ring* r, uint64_t n_blocks, int32_t status, const char* message);
+int32_t dsp_shm_ring_wait(dsp_shm_ring* r, uint64_t seq, double timeout_s, const uint8_t** data, uint64_t* len,
+                          uint64_t* first_row, uint64_t* n_rows);
+int32_t dsp_shm_ring_release(dsp_shm_ring* r, uint64_t seq);
+void dsp_shm_ring_abort(dsp_shm_ring* r);
+void dsp_shm_ring_close(dsp_shm_ring* r, int32_t unlink_it);
 
 /* ---- fast5 ingestion (csrc/dsp_fast5.cpp): what extract_features.py:44-91 (_get_label_raw), :94-176
  * (_get_alignment_info_from_fast5) and :255-270 (_get_scaling_of_a_read) read from one tombo-resquiggled single-read

@@ -19,6 +19,20 @@ def avg_of(path, kernel_re, counter):
     raise SystemExit("no %s line for %s in %s" % (counter, kernel_re, path))
 
 
+def all_kernels_per_forward(path, counter):
+    """sum of `counter` over the library's own kernels (dsp_*), per forward (= per dsp_head_kernel dispatch)"""
+    total, forwards = 0.0, 0
+    for line in open(path):
+        if counter not in line or "dsp_" not in line.split("dispatches=")[0]:
+            continue
+        total += float(line.split("sum=")[1].split()[0])
+        if "dsp_head_kernel" in line:
+            forwards = int(line.split("dispatches=")[1].split()[0])
+    if not forwards:
+        raise SystemExit("no dsp_head_kernel line in %s" % path)
+    return total / forwards
+
+
 def main():
     d = sys.argv[1]
     args = bench.parse_args(sys.argv[2:])
@@ -33,7 +47,10 @@ def main():
              "fetch_size_kb_per_launch": fetch_kb, "write_size_kb_per_launch": write_kb,
              "correction": "FETCH_SIZE doubled (gfx950 counts the 128-B requests of wide coalesced reads as 64 B, "
                            "MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported (uncalibrated); Infinity-Cache hits are included",
-             "hbm_bytes_per_launch": 2 * fetch_kb * 1024 + write_kb * 1024}
+             "hbm_bytes_per_launch": 2 * fetch_kb * 1024 + write_kb * 1024,
+             # all nine launches of one forward (pack, front ends, fc, combined stack, head), same correction
+             "hbm_bytes_per_step_all_kernels": 2 * 1024 * all_kernels_per_forward(os.path.join(d, "pmc_FETCH_SIZE.txt"), "FETCH_SIZE")
+             + 1024 * all_kernels_per_forward(os.path.join(d, "pmc_WRITE_SIZE.txt"), "WRITE_SIZE")}
     print(json.dumps(entry, indent=1))
 
 
