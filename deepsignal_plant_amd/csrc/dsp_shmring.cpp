@@ -59,8 +59,11 @@ double now_s() {
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
-void nap() {
-    timespec ts{0, 50 * 1000};
+// polling back-off: 50 us for the first ~2 ms of a wait (a slot about to be published), 1 ms after that (a block takes
+// > 100 ms to inflate: idle ranks must not keep eight cores busy waking up)
+void nap(int& spins) {
+    timespec ts{0, (spins < 40 ? 50 : 1000) * 1000};
+    ++spins;
     nanosleep(&ts, nullptr);
 }
 
@@ -124,6 +127,7 @@ dsp_shm_ring* dsp_shm_ring_create(const char* name, int32_t n_slots, uint64_t sl
 dsp_shm_ring* dsp_shm_ring_attach(const char* name, double timeout_s) {
     if (!name) { ring_fail(DSP_EINVAL, "dsp_shm_ring_attach: NULL name"); return nullptr; }
     const double t0 = now_s();
+    int spins = 0;
     for (;;) {
         const int fd = shm_open(name, O_RDWR, 0600);
         if (fd >= 0) {
@@ -134,7 +138,7 @@ dsp_shm_ring* dsp_shm_ring_attach(const char* name, double timeout_s) {
                 if (!r) { ring_fail(DSP_ENOMEM, "dsp_shm_ring_attach: mmap of %s failed", name); return nullptr; }
                 while (r->h->magic.load(std::memory_order_acquire) != kMagic) {
                     if (now_s() - t0 > timeout_s) { munmap(r->map, r->bytes); delete r; ring_fail(DSP_EINVAL, "dsp_shm_ring_attach: %s never initialised", name); return nullptr; }
-                    nap();
+                    nap(spins);
                 }
                 bind_slots(r);
                 return r;
@@ -142,7 +146,7 @@ dsp_shm_ring* dsp_shm_ring_attach(const char* name, double timeout_s) {
             close(fd);
         }
         if (now_s() - t0 > timeout_s) { ring_fail(DSP_EINVAL, "dsp_shm_ring_attach: %s did not appear", name); return nullptr; }
-        nap();
+        nap(spins);
     }
 }
 
@@ -154,10 +158,11 @@ uint8_t* dsp_shm_ring_acquire(dsp_shm_ring* r, uint64_t seq, double timeout_s) {
     const uint64_t n = r->h->n_slots;
     SlotHeader& s = r->slots[seq % n];
     const double t0 = now_s();
+    int spins = 0;
     while (seq >= n && s.released.load(std::memory_order_acquire) != seq - n + 1) {
         if (r->h->aborted.load(std::memory_order_acquire)) { ring_fail(DSP_EINVAL, "dsp_shm_ring_acquire: a consumer of %s failed", r->name.c_str()); return nullptr; }
         if (now_s() - t0 > timeout_s) { ring_fail(DSP_EINVAL, "dsp_shm_ring_acquire: %s: slot not released in time", r->name.c_str()); return nullptr; }
-        nap();
+        nap(spins);
     }
     return r->payload + (seq % n) * r->h->slot_bytes;
 }
@@ -186,6 +191,7 @@ int32_t dsp_shm_ring_wait(dsp_shm_ring* r, uint64_t seq, double timeout_s, const
     if (!r || !data || !len) return ring_fail(DSP_EINVAL, "dsp_shm_ring_wait: NULL argument");
     SlotHeader& s = r->slots[seq % r->h->n_slots];
     const double t0 = now_s();
+    int spins = 0;
     for (;;) {
         if (s.published.load(std::memory_order_acquire) == seq + 1) {
             *data = r->payload + (seq % r->h->n_slots) * r->h->slot_bytes;
@@ -198,7 +204,7 @@ int32_t dsp_shm_ring_wait(dsp_shm_ring* r, uint64_t seq, double timeout_s, const
         if (fin < 0) { dsp_set_error_(r->h->message); return fin; }
         if (fin > 0 && seq >= r->h->n_blocks.load(std::memory_order_relaxed)) return 1;
         if (now_s() - t0 > timeout_s) return ring_fail(DSP_EINVAL, "dsp_shm_ring_wait: %s: block %lld not published in time", r->name.c_str(), (long long)seq);
-        nap();
+        nap(spins);
     }
 }
 
