@@ -14,6 +14,7 @@
 // VBZ-compressed signals need ONT's HDF5 filter plugin on HDF5_PLUGIN_PATH, like h5py does.
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -23,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <exception>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -310,7 +312,9 @@ void plan_direct(hid_t file, hid_t ds, size_t elem, hsize_t n, Direct& d, Closer
     if (layout != 2) return;  // H5D_CHUNKED
     hsize_t chunk = 0;
     if (g_h5.Pget_chunk(dcpl, 1, &chunk) != 1 || chunk == 0) return;
-    const hsize_t nchunks = (n + chunk - 1) / chunk;  // (an unallocated chunk -- read as the fill value -- has no address: left to the library)
+    const hsize_t nchunks = (n + chunk - 1) / chunk;
+    if (nchunks > (hsize_t)(1u << 24)) return;         // absurd metadata: left to the library (which will refuse it)
+    // (an unallocated chunk -- read as the fill value -- has no address: left to the library)
     d.chunk = chunk;
     d.cks.resize((size_t)nchunks);
     for (hsize_t k = 0; k < nchunks; ++k) {  // by coordinate: one index lookup each (by index it is a walk from the first chunk)
@@ -328,6 +332,7 @@ void plan_direct(hid_t file, hid_t ds, size_t elem, hsize_t n, Direct& d, Closer
 // time like in dsp_gz.cpp, one decompressor per thread), else zlib
 struct Deflater {
     void* (*alloc_d)() = nullptr;
+    void (*free_d)(void*) = nullptr;
     int (*zlib_decompress)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
     bool ok = false;
     Deflater() {
@@ -336,15 +341,21 @@ struct Deflater {
         if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
         if (!h) return;
         alloc_d = (void* (*)())dlsym(h, "libdeflate_alloc_decompressor");
+        free_d = (void (*)(void*))dlsym(h, "libdeflate_free_decompressor");
         zlib_decompress = (int (*)(void*, const void*, size_t, void*, size_t, size_t*))dlsym(h, "libdeflate_zlib_decompress");
-        ok = alloc_d && zlib_decompress;
+        ok = alloc_d && free_d && zlib_decompress;
     }
 };
 bool zlib_inflate(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_n) {
     static const Deflater ld;
     if (ld.ok) {
-        thread_local void* d = ld.alloc_d();  // lives as long as the thread
-        if (d) return ld.zlib_decompress(d, src, n, dst, cap, out_n) == 0;
+        struct PerThread {  // one decompressor per loader thread, freed when the thread ends
+            void* d;
+            PerThread() : d(ld.alloc_d()) {}
+            ~PerThread() { if (d) ld.free_d(d); }
+        };
+        thread_local PerThread pt;
+        if (pt.d) return ld.zlib_decompress(pt.d, src, n, dst, cap, out_n) == 0;
     }
     uLongf len = (uLongf)cap;
     if (uncompress(dst, &len, src, (uLong)n) != Z_OK) return false;
@@ -353,10 +364,17 @@ bool zlib_inflate(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t
 }
 
 // read + decode the planned chunks into dst (n * elem bytes); false on any I/O or zlib error
+// Sizes come straight from the file's metadata: a damaged or hostile file must fail the READ (the reference counts the
+// file as failed and carries on, extract_features.py:373-375), not the process -- every size is checked against the file
+// itself before anything is allocated (HDF5 caps a chunk at 4 GiB; a stored chunk cannot be larger than the file).
 bool read_direct(int fd, const Direct& d, uint8_t* dst) {
     std::vector<uint8_t> comp, plain;
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || d.elem == 0 || d.chunk == 0 || d.chunk > (hsize_t)(1ull << 32) / d.elem) return false;
+    const uint64_t fsize = (uint64_t)sb.st_size;
     const size_t cbytes = (size_t)d.chunk * d.elem;
     for (const Direct::Ck& k : d.cks) {
+        if (k.elem0 >= d.n || k.size > fsize || k.addr > fsize - k.size) return false;
         const size_t want = (size_t)std::min<hsize_t>(d.chunk, d.n - k.elem0) * d.elem;
         comp.resize((size_t)k.size);
         size_t got = 0;
@@ -435,10 +453,26 @@ void dsp_fast5_free(dsp_fast5_read* r) {
     r->n_raw = r->n_events = 0;
 }
 
+static int32_t fast5_load_impl(const char* path, const char* corrected_group, const char* basecall_subgroup,
+                               const char* only_chrom, dsp_fast5_read* out);
+
 int32_t dsp_fast5_load(const char* path, const char* corrected_group, const char* basecall_subgroup, const char* only_chrom,
                        dsp_fast5_read* out) {
     if (!path || !corrected_group || !basecall_subgroup || !out) return f5_fail(DSP_EINVAL, "dsp_fast5_load: NULL argument");
     memset(out, 0, sizeof(*out));
+    try {  // no C++ exception (an allocation sized by damaged metadata) may cross the C boundary
+        return fast5_load_impl(path, corrected_group, basecall_subgroup, only_chrom, out);
+    } catch (const std::exception& e) {
+        dsp_fast5_free(out);
+        return f5_fail(DSP_EPARSE, "damaged fast5 file (%s while decoding it)", e.what());
+    } catch (...) {
+        dsp_fast5_free(out);
+        return f5_fail(DSP_EPARSE, "damaged fast5 file");
+    }
+}
+
+static int32_t fast5_load_impl(const char* path, const char* corrected_group, const char* basecall_subgroup,
+                               const char* only_chrom, dsp_fast5_read* out) {
     Direct dsig, dev;                  // chunk plans of Signal and Events (decoded after the library lock is released)
     IntField f_start, f_len;
     size_t base_off = 0, rec_size = 0;

@@ -6,6 +6,11 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <atomic>
+#include <thread>
 
 #include <string>
 #include <vector>
@@ -265,6 +270,106 @@ int main(int argc, char** argv) {
         }
     }
 
+    // ---- streaming reader of a foreign .gz (zlib gzip members over an mmap): multi-member, zero padding, truncation at
+    //      every region of the file, byte flips -- must deliver the text or fail with DSP_EPARSE, never over-read
+    {
+        std::string text;
+        for (int i = 0; i < 30000; i++) text += "chr2\t" + std::to_string(rnd() % 1000000) + "\t-\t0.654321\tACGTA\n";
+        auto gz_member = [](const std::string& t) {
+            std::vector<uint8_t> o(compressBound((uLong)t.size()) + 64);
+            z_stream z;
+            memset(&z, 0, sizeof(z));
+            deflateInit2(&z, 1, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY);
+            z.next_in = (Bytef*)t.data(); z.avail_in = (uInt)t.size();
+            z.next_out = o.data(); z.avail_out = (uInt)o.size();
+            deflate(&z, Z_FINISH);
+            o.resize(z.total_out);
+            deflateEnd(&z);
+            return o;
+        };
+        std::vector<uint8_t> file = gz_member(text.substr(0, text.size() / 3));
+        const std::vector<uint8_t> m2 = gz_member(text.substr(text.size() / 3));
+        file.insert(file.end(), m2.begin(), m2.end());
+        file.insert(file.end(), 300, 0);  // zero padding after the last member is legal
+        const std::string p = tmp + "/foreign.gz";
+        auto write_file = [&](const std::vector<uint8_t>& b) { FILE* f = fopen(p.c_str(), "wb"); if (!b.empty()) fwrite(b.data(), 1, b.size(), f); fclose(f); };
+        auto read_all = [&](std::string& got) -> int64_t {
+            dsp_gz_stream* st = dsp_gz_open(p.c_str());
+            CHECK(st != nullptr);
+            std::vector<uint8_t> buf(70001);
+            got.clear();
+            int64_t rc;
+            while ((rc = dsp_gz_read(st, buf.data(), buf.size())) > 0) got.append((const char*)buf.data(), (size_t)rc);
+            CHECK(dsp_gz_bytes_in(st) <= file.size());
+            dsp_gz_close(st);
+            return rc;
+        };
+        std::string got;
+        write_file(file);
+        CHECK(read_all(got) == 0 && got == text);
+        for (size_t cut : {(size_t)0, (size_t)5, (size_t)17, file.size() / 5, file.size() / 3, file.size() / 2, file.size() - 310, file.size() - 301}) {
+            write_file(std::vector<uint8_t>(file.begin(), file.begin() + (long)cut));
+            const int64_t rc = read_all(got);
+            if (cut == 0) CHECK(rc == 0 && got.empty());                       // an empty file reads as empty text
+            else CHECK(rc == DSP_EPARSE && g_err.find("gzip stream") != std::string::npos);
+        }
+        for (int it = 0; it < 30; it++) {
+            std::vector<uint8_t> bad = file;
+            bad[rnd() % (bad.size() - 300)] ^= (uint8_t)(1 + rnd() % 255);
+            write_file(bad);
+            const int64_t rc = read_all(got);
+            CHECK(rc == DSP_EPARSE || (rc == 0 && got.size() == text.size()));  // (a flip in a header's MTIME / OS byte changes nothing)
+        }
+        dsp_gz_close(nullptr);
+        CHECK(dsp_gz_open((tmp + "/absent.gz").c_str()) == nullptr);
+    }
+    // ---- shared-memory ring: one producer thread, two consumer threads, more blocks than slots, then a failing producer
+    {
+        const std::string name = "/dsp_asan_ring_" + std::to_string((long)getpid());
+        dsp_shm_ring* prod = dsp_shm_ring_create(name.c_str(), 3, 5000);
+        CHECK(prod != nullptr && dsp_shm_ring_slot_bytes(prod) >= 5000);
+        const int nblocks = 17;
+        std::atomic<uint64_t> sum_got{0};
+        auto consumer = [&](int li) {
+            dsp_shm_ring* c = dsp_shm_ring_attach(name.c_str(), 10.0);
+            CHECK(c != nullptr);
+            for (uint64_t k = 0;; k++) {
+                const uint8_t* data; uint64_t len, first, rows;
+                const int32_t rc = dsp_shm_ring_wait(c, k * 2 + (uint64_t)li, 10.0, &data, &len, &first, &rows);
+                if (rc == 1) break;
+                CHECK(rc == 0 && len == 100 + (k * 2 + (uint64_t)li) * 10 && first == 7 * (k * 2 + (uint64_t)li) && rows == 3);
+                for (uint64_t i = 0; i < len; i++) sum_got += data[i];
+                dsp_shm_ring_release(c, k * 2 + (uint64_t)li);
+            }
+            dsp_shm_ring_close(c, 0);
+        };
+        std::thread c0(consumer, 0), c1(consumer, 1);
+        uint64_t sum_put = 0;
+        for (int i = 0; i < nblocks; i++) {
+            uint8_t* slot = dsp_shm_ring_acquire(prod, (uint64_t)i, 10.0);
+            CHECK(slot != nullptr);
+            const uint64_t len = 100 + (uint64_t)i * 10;
+            for (uint64_t j = 0; j < len; j++) { slot[j] = (uint8_t)(i + j); sum_put += slot[j]; }
+            CHECK(dsp_shm_ring_publish(prod, (uint64_t)i, len, 7 * (uint64_t)i, 3) == 0);
+        }
+        CHECK(dsp_shm_ring_publish(prod, 99, 1u << 30, 0, 0) == DSP_EINVAL);   // larger than a slot
+        dsp_shm_ring_finish(prod, (uint64_t)nblocks, 0, nullptr);
+        c0.join(); c1.join();
+        CHECK(sum_got.load() == sum_put);
+        dsp_shm_ring_close(prod, 1);
+        CHECK(dsp_shm_ring_attach(name.c_str(), 0.05) == nullptr);               // unlinked
+        prod = dsp_shm_ring_create(name.c_str(), 2, 64);
+        dsp_shm_ring* c = dsp_shm_ring_attach(name.c_str(), 5.0);
+        CHECK(prod && c);
+        dsp_shm_ring_finish(prod, 0, DSP_EPARSE, "truncated gzip stream: test");
+        const uint8_t* data; uint64_t len;
+        CHECK(dsp_shm_ring_wait(c, 0, 5.0, &data, &len, nullptr, nullptr) == DSP_EPARSE && g_err.find("truncated") != std::string::npos);
+        dsp_shm_ring_abort(c);
+        CHECK(dsp_shm_ring_acquire(prod, 2, 5.0) == nullptr);                   // a consumer gave up: the producer stops waiting
+        dsp_shm_ring_close(c, 0);
+        dsp_shm_ring_close(prod, 1);
+    }
+
     // ---- fast5 reader (only when an HDF5 library is on this host): every F7 file, other groups, the region filter
     if (dsp_fast5_available()) {
         const char* files[] = {"read_00000-67ee_ch101_read0_strand.fast5", "read_00001-f97f_ch101_read1_strand.fast5",
@@ -296,6 +401,37 @@ int main(int argc, char** argv) {
             dsp_fast5_free(&rec);
         }
         CHECK(ok >= 4 && failed >= 4 && skipped >= 4);
+        // damaged copies: truncated at several lengths (chunk addresses then point past the end of the file: the reader
+        // checks every size against the file before allocating) and byte flips in the chunk payloads (the zlib streams'
+        // Adler-32 catches them, or the values change): a read fails or loads, the process survives
+        {
+            std::vector<uint8_t> good;
+            {
+                FILE* f = fopen((golden + "/fast5/reads/" + files[0]).c_str(), "rb");
+                CHECK(f != nullptr);
+                uint8_t buf[65536];
+                size_t k;
+                while ((k = fread(buf, 1, sizeof(buf), f)) > 0) good.insert(good.end(), buf, buf + k);
+                fclose(f);
+            }
+            const std::string p = tmp + "/damaged.fast5";
+            int n_fail = 0, n_ok = 0;
+            for (int it = 0; it < 24; it++) {
+                std::vector<uint8_t> bad = good;
+                if (it < 8) bad.resize(good.size() * (size_t)(it + 1) / 10);
+                else bad[good.size() / 2 + rnd() % (good.size() / 2)] ^= (uint8_t)(1 + rnd() % 255);
+                FILE* f = fopen(p.c_str(), "wb");
+                fwrite(bad.data(), 1, bad.size(), f);
+                fclose(f);
+                dsp_fast5_read rec;
+                const int32_t rc = dsp_fast5_load(p.c_str(), "RawGenomeCorrected_000", "BaseCalled_template", nullptr, &rec);
+                CHECK(rc == 0 || rc == DSP_EPARSE);
+                (rc == 0 ? n_ok : n_fail)++;
+                dsp_fast5_free(&rec);
+            }
+            CHECK(n_fail >= 8);
+            printf("fast5 damaged copies: %d failed cleanly, %d still loaded\n", n_fail, n_ok);
+        }
         printf("fast5: %d loaded, %d failed, %d skipped\n", ok, failed, skipped);
     }
     printf("host_asan: ok\n");

@@ -7,7 +7,7 @@ import subprocess
 
 from tests.helpers import GOLDEN, ROOT
 
-SRCS = ["dsp_text.cpp", "dsp_freq.cpp", "dsp_featfile.cpp", "dsp_sites.cpp", "dsp_gz.cpp", "dsp_fast5.cpp"]
+SRCS = ["dsp_text.cpp", "dsp_freq.cpp", "dsp_featfile.cpp", "dsp_sites.cpp", "dsp_gz.cpp", "dsp_fast5.cpp", "dsp_shmring.cpp"]
 
 
 def test_host_code_is_clean_under_asan_and_ubsan(tmp_path):
@@ -15,7 +15,7 @@ def test_host_code_is_clean_under_asan_and_ubsan(tmp_path):
     csrc = os.path.join(ROOT, "deepsignal_plant_amd", "csrc")
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
            "-fno-sanitize-recover=undefined", "-ffp-contract=off", "-pthread", "-I", os.path.join(ROOT, "include"), "-I", csrc,
-           os.path.join(ROOT, "tests", "native", "host_asan.cpp")] + [os.path.join(csrc, s) for s in SRCS] + ["-lz", "-ldl", "-o", exe]
+           os.path.join(ROOT, "tests", "native", "host_asan.cpp")] + [os.path.join(csrc, s) for s in SRCS] + ["-lz", "-ldl", "-lrt", "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-4000:]
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
