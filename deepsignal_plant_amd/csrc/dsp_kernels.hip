@@ -853,78 +853,138 @@ __global__ __launch_bounds__(256, 2) void dsp_linear_kernel(LinArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // head_kernel: [h_fwd(t=T-1) | h_bwd(t=0)] -> fc1 + ReLU -> fc2 -> softmax (+argmax)
-// (models.py:229-240; dropouts are identity in eval).  One workgroup per 32-site tile.
+// (models.py:229-240; dropouts are identity in eval).  One 4-wave workgroup per FOUR 32-site tiles.
+// Round 3: a wave computes 2 row tiles (64 hidden rows of fc1) x 4 site tiles = 8 accumulator tiles, 32 MFMAs per
+// k-group against 6 fragment loads (round 2: one site tile per workgroup, 8 MFMAs per 3 loads: every workgroup streamed
+// the 512 KB of fc1 weights out of L2 for 32 sites -- 5.5 TB/s of L2 traffic, 57 % of the MFMA peak, and fc2 was a
+// 256-iteration scalar loop on a quarter of the threads).  fc2 never leaves the registers: a lane holds 16 rows of each
+// of its row tiles for one site, multiplies them by the matching fc2 weights, the two half-waves are added with one
+// cross-lane move, the row-tile groups with a 4 KB LDS exchange; softmax on the first 128 threads.
+// Hidden sizes above 256 (more than 8 row tiles) loop over pairs of row tiles per wave.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dsp_head_kernel(HeadArgs a) {
+constexpr int kHeadST = 4;  // site tiles per workgroup
+__global__ __launch_bounds__(256, 2) void dsp_head_kernel(HeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* hid = smem;                 // [Hp][32]
-    float* lg = smem + a.Hp * 32;      // [C][32]
+    float* part = smem;                         // [4 waves][C][kHeadST * 32]
+    float* lg = smem + 4 * a.C * kHeadST * 32;  // [C][kHeadST * 32]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, ls = lane & 31;
-    const size_t tile = blockIdx.x;
+    const size_t tile0 = (size_t)blockIdx.x * kHeadST;
     const int F4 = (2 * a.Hp) >> 2;
     const int nq = (2 * a.Hp) >> 3;
     const int nqf = a.Hp >> 3;  // k-groups that come from the forward half (t = T-1)
-    const f32x4* x4 = (const f32x4*)a.x;
-    const f32x4* xf = x4 + ((tile * a.T + (a.T - 1)) * F4 + half) * 32 + ls;
-    const f32x4* xr = x4 + ((tile * a.T + 0) * F4 + half) * 32 + ls;
     const f32x4* bias4 = (const f32x4*)a.b1;
-    // a wave takes its row tiles two at a time (they share the B fragment: 8 MFMAs per 3 fragment loads) and requests
-    // the fragments of k-group q+1 before the MFMAs of group q (round 1: one tile, one k-group at a time, 47 % of peak)
     const int NRT = a.Hp >> 5;
-    for (int rt = w; rt < NRT; rt += 8) {
-        const bool two = rt + 4 < NRT;
-        const f32x4* wq0 = (const f32x4*)a.w1pk + (size_t)rt * nq * 64 + lane;
-        const f32x4* wq1 = two ? wq0 + (size_t)4 * nq * 64 : wq0;
-        f32x16 acc0, acc1;
+    // every operand through a buffer descriptor + SGPR offset + lane*16, like the LSTM kernel: no 64-bit pointer VGPRs
+    const uint32_t voff = (uint32_t)lane * 16u;
+    const uint32_t xrow = (uint32_t)F4 * 512u;                           // bytes of one (tile, t) block
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)a.x + tile0 * a.T * (size_t)xrow);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w1pk);
+    uint32_t xfo[kHeadST], xro[kHeadST];                                 // h_fwd at t = T-1, h_bwd at t = 0
 #pragma unroll
-        for (int aa = 0; aa < 4; ++aa) {
-            const f32x4 b0 = bias4[rt * 8 + 2 * aa + half];
-            const f32x4 b1 = two ? bias4[(rt + 4) * 8 + 2 * aa + half] : b0;
+    for (int st = 0; st < kHeadST; ++st) {
+        xfo[st] = (uint32_t)(st * a.T + (a.T - 1)) * xrow;
+        xro[st] = (uint32_t)(st * a.T) * xrow;
+    }
+    // per class partial sums need C x kHeadST registers: classes are processed in chunks of 2 (the reference has 2)
+    for (int c0 = 0; c0 < a.C; c0 += 2) {
+        float s0[kHeadST], s1[kHeadST];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { acc0[4 * aa + i] = b0[i]; acc1[4 * aa + i] = b1[i]; }
-        }
-        f32x4 A0n = wq0[0], A1n = wq1[0], Bn = xf[0];
-        for (int q = 0; q < nq; ++q) {
-            const f32x4 A0 = A0n, A1 = A1n, B = Bn;
-            const int qn = q + 1 < nq ? q + 1 : q;
-            A0n = wq0[(size_t)qn * 64]; A1n = wq1[(size_t)qn * 64];
-            Bn = (qn < nqf) ? xf[(size_t)qn * 64] : xr[(size_t)qn * 64];
+        for (int st = 0; st < kHeadST; ++st) { s0[st] = 0.f; s1[st] = 0.f; }
+        const bool has1 = c0 + 1 < a.C;
+        for (int rt = w; rt < NRT; rt += 8) {  // row tiles rt and rt + 4 (when present) share the B fragments
+            const bool two = rt + 4 < NRT;
+            const uint32_t wo0 = (uint32_t)rt * (uint32_t)nq * 1024u;
+            const uint32_t wo1 = two ? wo0 + 4u * (uint32_t)nq * 1024u : wo0;
+            f32x16 acc0[kHeadST], acc1[kHeadST];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[i], B[i], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[i], B[i], acc1, 0, 0, 0);
+            for (int aa = 0; aa < 4; ++aa) {
+                const f32x4 b0 = bias4[rt * 8 + 2 * aa + half];
+                const f32x4 b1 = two ? bias4[(rt + 4) * 8 + 2 * aa + half] : b0;
+#pragma unroll
+                for (int st = 0; st < kHeadST; ++st)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { acc0[st][4 * aa + i] = b0[i]; acc1[st][4 * aa + i] = b1[i]; }
+            }
+            f32x4 A0n = bld16(rw, voff, wo0), A1n = bld16(rw, voff, wo1), Bn[kHeadST];
+#pragma unroll
+            for (int st = 0; st < kHeadST; ++st) Bn[st] = bld16(rx, voff, xfo[st]);
+            for (int q = 0; q < nq; ++q) {
+                const f32x4 A0 = A0n, A1 = A1n;
+                f32x4 B[kHeadST];
+#pragma unroll
+                for (int st = 0; st < kHeadST; ++st) B[st] = Bn[st];
+                const int qn = q + 1 < nq ? q + 1 : q;
+                A0n = bld16(rw, voff, wo0 + (uint32_t)qn * 1024u); A1n = bld16(rw, voff, wo1 + (uint32_t)qn * 1024u);
+#pragma unroll
+                for (int st = 0; st < kHeadST; ++st) Bn[st] = bld16(rx, voff, ((qn < nqf) ? xfo[st] : xro[st]) + (uint32_t)qn * 1024u);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int st = 0; st < kHeadST; ++st) {
+                        acc0[st] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[i], B[st][i], acc0[st], 0, 0, 0);
+                        acc1[st] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[i], B[st][i], acc1[st], 0, 0, 0);
+                    }
+            }
+            // fc2 on the registers: rows 8*aa + 4*half + i of row tile rt (and rt + 4) of this lane's site
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa) {
+                const int r0 = rt * 32 + 8 * aa + 4 * half;
+                const f32x4 u0 = *(const f32x4*)(a.w2 + (size_t)c0 * a.Hp + r0);
+                const f32x4 u1 = has1 ? *(const f32x4*)(a.w2 + (size_t)(c0 + 1) * a.Hp + r0) : f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+                if (two) {
+                    v0 = *(const f32x4*)(a.w2 + (size_t)c0 * a.Hp + r0 + 128);
+                    if (has1) v1 = *(const f32x4*)(a.w2 + (size_t)(c0 + 1) * a.Hp + r0 + 128);
+                }
+#pragma unroll
+                for (int st = 0; st < kHeadST; ++st)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float h0 = fmaxf(acc0[st][4 * aa + i], 0.f);
+                        const float h1 = two ? fmaxf(acc1[st][4 * aa + i], 0.f) : 0.f;
+                        s0[st] = __builtin_fmaf(h0, u0[i], s0[st]);
+                        s0[st] = __builtin_fmaf(h1, v0[i], s0[st]);
+                        s1[st] = __builtin_fmaf(h0, u1[i], s1[st]);
+                        s1[st] = __builtin_fmaf(h1, v1[i], s1[st]);
+                    }
             }
         }
+        // lanes l and l + 32 hold the two halves of a site's rows: add them, then the four waves through LDS
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = rt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-            hid[row * 32 + ls] = fmaxf(acc0[r], 0.f);
-            if (two) hid[(row + 128) * 32 + ls] = fmaxf(acc1[r], 0.f);
+        for (int st = 0; st < kHeadST; ++st) {
+            s0[st] += __shfl_xor(s0[st], 32);
+            s1[st] += __shfl_xor(s1[st], 32);
+            if (half == 0) {
+                part[(w * a.C + c0) * (kHeadST * 32) + st * 32 + ls] = s0[st];
+                if (has1) part[(w * a.C + c0 + 1) * (kHeadST * 32) + st * 32 + ls] = s1[st];
+            }
         }
     }
     __syncthreads();
-    for (int cc = tid >> 5; cc < a.C; cc += 8) {
-        const float* w2 = a.w2 + (size_t)cc * a.Hp;
-        float s = 0.f;
-        for (int k = 0; k < a.Hp; ++k) s = __builtin_fmaf(hid[k * 32 + ls], w2[k], s);
-        lg[cc * 32 + ls] = s + a.b2[cc];
+    for (int i = tid; i < a.C * kHeadST * 32; i += 256) {
+        const int cc = i / (kHeadST * 32), col = i % (kHeadST * 32);
+        float s = a.b2[cc];
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) s += part[(ww * a.C + cc) * (kHeadST * 32) + col];  // fixed order: deterministic
+        lg[cc * (kHeadST * 32) + col] = s;
     }
     __syncthreads();
-    if (tid < 32) {
-        const long long site = (long long)tile * 32 + tid;
+    if (tid < kHeadST * 32) {
+        const long long site = (long long)tile0 * 32 + tid;
         if (site < a.n) {
+            const int stride = kHeadST * 32;
             float mx = -INFINITY;
-            for (int cc = 0; cc < a.C; ++cc) mx = fmaxf(mx, lg[cc * 32 + tid]);
+            for (int cc = 0; cc < a.C; ++cc) mx = fmaxf(mx, lg[cc * stride + tid]);
             float sum = 0.f;
-            for (int cc = 0; cc < a.C; ++cc) sum += expf(lg[cc * 32 + tid] - mx);
+            for (int cc = 0; cc < a.C; ++cc) sum += expf(lg[cc * stride + tid] - mx);
             const float inv = 1.0f / sum;
             int best = 0;
             float bp = -1.f;
             for (int cc = 0; cc < a.C; ++cc) {
-                const float l = lg[cc * 32 + tid];
+                const float l = lg[cc * stride + tid];
                 const float p = expf(l - mx) * inv;
                 if (a.logits) a.logits[(size_t)site * a.C + cc] = l;
                 if (a.probs) a.probs[(size_t)site * a.C + cc] = p;
@@ -1002,8 +1062,8 @@ extern "C" int dsp_k_linear(const LinArgs* a, hipStream_t s) {
 }
 
 extern "C" int dsp_k_head(const HeadArgs* a, hipStream_t s) {
-    const size_t lds = (size_t)(a->Hp * 32 + a->C * 32) * sizeof(float);
-    const unsigned tiles = (unsigned)((a->n + 31) / 32);
-    hipLaunchKernelGGL(dsp_head_kernel, dim3(tiles), dim3(256), lds, s, *a);
+    const size_t lds = (size_t)(5 * a->C * kHeadST * 32) * sizeof(float);
+    const unsigned groups = (unsigned)((a->n + 32 * kHeadST - 1) / (32 * kHeadST));  // the K4 buffers are padded to 16 tiles
+    hipLaunchKernelGGL(dsp_head_kernel, dim3(groups), dim3(256), lds, s, *a);
     return (int)hipGetLastError();
 }
