@@ -218,6 +218,125 @@ int parse_row(const char* text, const char* ls, const char* le, int L, int S, in
     return 0;
 }
 
+// ---- fast path of the row parser (round 3) -----------------------------------------------------------------------
+// One forward pass over a row that sticks to what the reference's writer emits (_features_to_str,
+// extract_features.py:381-395): single tabs, no blanks, numbers of the form [-]digits[.digits][e[+-]digits] with at most
+// 18 digits.  Digits are accumulated while the delimiter is being looked for (the general parser above runs memchr per
+// token, then walks the token again) and the value is produced by the SAME single correctly rounded operation as the
+// general parser's Clinger branch -- integer mantissa times / divided by an exact power of ten -- so the two paths cannot
+// disagree on a value.  Anything else (blanks, '+', inf / nan, longer mantissas, a different field count, CR in the
+// middle of a line, ...) returns -1 and the row is parsed again by parse_row, which also produces the error codes.
+// Needs one readable byte after the row (its '\n'): the caller sends an unterminated last row to parse_row.
+struct FastNum { const char* p; bool ok; };
+
+inline FastNum fast_float(const char* p, float* dst) {
+    const bool neg = *p == '-';
+    p += neg;
+    const char* s = p;
+    uint64_t m = 0;
+    unsigned d;
+    while ((d = (unsigned)(*p - '0')) < 10u) { m = m * 10 + d; ++p; }
+    if (p == s) return {p, false};
+    int nd = (int)(p - s), e10 = 0;
+    if (*p == '.') {
+        ++p;
+        const char* f = p;
+        while ((d = (unsigned)(*p - '0')) < 10u) { m = m * 10 + d; ++p; }
+        e10 = -(int)(p - f);
+        nd += (int)(p - f);
+    }
+    if (nd > 18) return {p, false};
+    if (*p == 'e' || *p == 'E') {
+        ++p;
+        const bool eneg = *p == '-';
+        p += (*p == '-' || *p == '+');
+        const char* es = p;
+        int ex = 0;
+        while ((d = (unsigned)(*p - '0')) < 10u && p - es < 4) { ex = ex * 10 + (int)d; ++p; }
+        if (p == es || (unsigned)(*p - '0') < 10u) return {p, false};
+        e10 += eneg ? -ex : ex;
+    }
+    if (m >= (1ull << 53) || e10 < -22 || e10 > 22) {
+        if (m != 0) return {p, false};
+        e10 = 0;
+    }
+    double v = (double)m;
+    v = e10 < 0 ? v / kPow10[-e10] : v * kPow10[e10];
+    *dst = (float)(neg ? -v : v);
+    return {p, true};
+}
+
+inline FastNum fast_int(const char* p, long long* out) {
+    const bool neg = *p == '-';
+    p += neg;
+    const char* s = p;
+    long long v = 0;
+    unsigned d;
+    while ((d = (unsigned)(*p - '0')) < 10u && p - s < 9) { v = v * 10 + (long long)d; ++p; }  // 9 digits fit an int32
+    if (p == s || (unsigned)(*p - '0') < 10u) return {p, false};
+    *out = neg ? -v : v;
+    return {p, true};
+}
+
+// n numbers separated by `sep`, the last one followed by `term`; returns the position AFTER the terminator or NULL
+inline const char* fast_float_list(const char* p, int n, char sep, char term, float* dst) {
+    for (int i = 0; i < n; ++i) {
+        const FastNum r = fast_float(p, dst + i);
+        if (!r.ok || *r.p != (i == n - 1 ? term : sep)) return nullptr;
+        p = r.p + 1;
+    }
+    return p;
+}
+
+// 0 = parsed; -1 = not a plain row: let parse_row decide
+int parse_row_fast(const char* text, const char* ls, const char* le, int L, int S, int64_t r, const RowOut& o) {
+    if (le - ls < 12 + L || is_space(*ls)) return -1;
+    const char* p = ls;
+    const char* tab[6];
+    for (int k = 0; k < 6; ++k) {   // the six sampleinfo fields, kept verbatim
+        const char* t = (const char*)memchr(p, '\t', (size_t)(le - p));
+        if (!t) return -1;
+        tab[k] = t;
+        p = t + 1;
+    }
+    if (le - p < L + 1 || p[L] != '\t') return -1;
+    uint8_t* km = o.kmer + r * L;
+    for (int i = 0; i < L; ++i) {
+        const int8_t c = g_codes.t[(unsigned char)p[i]];
+        if (c < 0) return -1;
+        km[i] = (uint8_t)c;
+    }
+    p += L + 1;
+    if (!(p = fast_float_list(p, L, ',', '\t', o.means + r * L))) return -1;
+    if (!(p = fast_float_list(p, L, ',', '\t', o.stds + r * L))) return -1;
+    int32_t* ln = o.lens + r * L;
+    for (int i = 0; i < L; ++i) {
+        long long v;
+        const FastNum q = fast_int(p, &v);
+        if (!q.ok || *q.p != (i == L - 1 ? '\t' : ',')) return -1;
+        ln[i] = (int32_t)v;
+        p = q.p + 1;
+    }
+    float* sg = o.signals + (size_t)r * L * S;
+    for (int i = 0; i < L; ++i)
+        if (!(p = fast_float_list(p, S, ',', i == L - 1 ? '\t' : ';', sg + (size_t)i * S))) return -1;
+    long long lab;
+    const FastNum q = fast_int(p, &lab);
+    if (!q.ok || q.p > le) return -1;
+    // the 12th field ends at the line end (LF or CRLF) or at a tab (extra columns are ignored, as words[11] would be)
+    if (!(q.p == le || *q.p == '\t' || (*q.p == '\r' && q.p + 1 == le))) return -1;
+    if (p > le) return -1;
+    o.labels[r] = (int32_t)lab;
+    o.row_off[r] = (uint64_t)(ls - text);
+    o.info_len[r] = (uint32_t)(tab[5] - ls);
+    o.read_off[r] = (uint32_t)(tab[3] + 1 - ls);
+    o.read_len[r] = (uint32_t)(tab[4] - tab[3] - 1);
+    return 0;
+}
+
+// DSP_NO_FAST_ROWS=1: every row through the general parser (A/B switch; the tests compare the two paths)
+bool g_no_fast_rows = getenv("DSP_NO_FAST_ROWS") != nullptr;
+
 const char* kFieldName[] = {"", "field count (need 12 tab-separated columns)", "k_mer (length/alphabet)", "signal_means",
                             "signal_stds", "signal_lens", "k_signals", "label"};
 
@@ -323,6 +442,7 @@ extern "C" {
 
 // shared with dsp_freq.cpp (the fused call_mods -> call_freq path re-derives the printed probabilities)
 int dsp_format_prob_f32_(float x, char* out) { return format_f32_numpy(x, out); }
+void dsp_text_set_fast_rows_(int on) { g_no_fast_rows = !on; }  // test hook: the one-pass row parser on / off
 float dsp_np_round6_f32_(float x) { return np_round6_f32(x); }
 
 int64_t dsp_count_rows(const char* text, size_t len) {
@@ -385,7 +505,10 @@ int64_t dsp_parse_feature_rows(const char* text, size_t len, int32_t seq_len, in
             const char* ce = cut[t + 1];
             while (p < ce) {
                 const char* nl = find_ch(p, ce, '\n');  // the '\n' (or the end of the range = end of the text)
-                const int rc = parse_row(text, p, nl, seq_len, signal_len, r, o);
+                // plain rows take the one-pass parser (the byte at nl must be readable: not for an unterminated last row);
+                // everything else -- and every error -- goes through the general one
+                int rc = (nl < e && *nl == '\n' && !g_no_fast_rows) ? parse_row_fast(text, p, nl, seq_len, signal_len, r, o) : -1;
+                if (rc < 0) rc = parse_row(text, p, nl, seq_len, signal_len, r, o);
                 if (rc) { bad_row[t] = r; bad_code[t] = rc; break; }
                 ++r;
                 p = nl + 1;

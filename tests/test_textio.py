@@ -114,3 +114,70 @@ def test_formatter_exhaustive_rounding_grid_vs_numpy():
         z0 = round(a / (a + b), 6)
         z1 = round(1 - z0, 6)
         assert got[i] == "x\t%s\t%s\t0\tAAAAA" % (str(z0), str(z1)), (i, got[i], z0, z1)
+
+
+def test_one_pass_row_parser_agrees_with_the_general_parser_on_everything():
+    """Round 3: plain rows take a one-pass parser (digits accumulated while the delimiter is looked for); anything it
+    does not recognise -- and every malformed row -- is parsed again by the general parser.  Differential test: the
+    golden rows, rows with odd but legal number spellings, and byte-mutated rows give the same arrays, the same
+    sampleinfo addressing and the same error text with the fast path on and off."""
+    from deepsignal_plant_amd import _native as nat
+    L = nat.lib()
+    rng = np.random.default_rng(11)
+    rows = open(os.path.join(GOLDEN, "f2_rows.tsv")).read().splitlines()[:60]
+
+    def both(data):
+        out = []
+        for fast in (1, 0):
+            L.dsp_text_set_fast_rows_(fast)
+            try:
+                r = textio.parse_rows(data, 13, 16, nthreads=2)
+                out.append(("ok", r.n, r.kmer.tobytes(), r.means.tobytes(), r.stds.tobytes(), r.lens.tobytes(), r.signals.tobytes(),
+                            r.labels.tobytes(), r.row_off.tobytes(), r.info_len.tobytes(), r.read_off.tobytes(), r.read_len.tobytes()))
+            except ValueError as e:
+                out.append(("error", str(e)))
+        L.dsp_text_set_fast_rows_(1)
+        return out
+    try:
+        a, b = both(("\n".join(rows) + "\n").encode())
+        assert a == b and a[0] == "ok" and a[1] == 60
+        a, b = both("\n".join(rows).encode())                       # unterminated last row
+        assert a == b and a[1] == 60
+        a, b = both(("\r\n".join(rows) + "\r\n").encode())          # CRLF
+        assert a == b and a[1] == 60
+        # legal but unusual spellings inside otherwise plain rows
+        spell = ["1e-05", "-2.5E-6", "1.", "007.50", "-0.0", "0", "123456789012345678", "1234567890123456789", "1e22", "1e23",
+                 "4e-324", "+1.5", " 1.5", "1.5 ", ".5", "inf", "-inf", "nan", "1e", "1e+", "--1", "1.2.3", "0x10", "1_0",
+                 "9007199254740993", "0.000000000000000000001", "1e400", "-1e-400", "3.4028235e38", "3.4028236e38"]
+        w = rows[0].split("\t")
+        for i in range(0, len(spell), 3):
+            m = w[7].split(",")
+            m[0:3] = (spell + ["0", "0"])[i:i + 3]
+            sg = w[10].split(";")
+            g0 = sg[2].split(",")
+            g0[5] = spell[i]
+            sg[2] = ",".join(g0)
+            a, b = both(("\t".join(w[:7] + [",".join(m)] + w[8:10] + [";".join(sg)] + w[11:]) + "\n").encode())
+            assert a == b, spell[i:i + 3]
+        for lens_tok in ("12", "-3", "999999999", "9999999999", "2147483648", "1.0", ""):
+            ln = w[9].split(",")
+            ln[4] = lens_tok
+            a, b = both(("\t".join(w[:9] + [",".join(ln)] + w[10:]) + "\n" + rows[1] + "\n").encode())
+            assert a == b, lens_tok
+        for label in ("1", "0", "-1", "7\textra", "1 ", "1\r", "1\rx", "", "x"):
+            a, b = both(("\t".join(w[:11] + [label]) + "\n" + rows[1] + "\n").encode())
+            assert a == b, label
+        # byte mutations: any single-byte damage gives the same outcome on both paths
+        base = ("\n".join(rows[:6]) + "\n").encode()
+        pool = b"\t,;.-+e0123456789 \nACGTX\r"
+        n_err = 0
+        for _ in range(1500):
+            bad = bytearray(base)
+            for _k in range(int(rng.integers(1, 3))):
+                bad[int(rng.integers(0, len(bad)))] = pool[int(rng.integers(0, len(pool)))]
+            a, b = both(bytes(bad))
+            assert a == b
+            n_err += a[0] == "error"
+        assert 300 < n_err < 1500
+    finally:
+        L.dsp_text_set_fast_rows_(1)
