@@ -25,7 +25,7 @@ def main():
         t0 = time.time()
         subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_tsv.py"), tsv, str(n)])
         gen = time.time() - t0
-        for nproc in (16, 64):
+        for nproc in [int(x) for x in os.environ.get("DSP_BENCH_THREADS", "2,4,8,16").split(",")]:  # host threads of the one rank
             out = os.path.join(work, "calls_%d.tsv" % n)
             t0 = time.time()
             r = subprocess.run([sys.executable, "-m", "deepsignal_plant_amd.deepsignal_plant", "call_mods", "-i", tsv, "-m", ck,
