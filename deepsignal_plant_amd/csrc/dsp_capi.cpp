@@ -284,6 +284,8 @@ struct dsp_model {
     int trace_wave = 0;  // DSP_TRACE_WAVE: the wave of each workgroup that stamps
     int trace_launch = -1, lstm_launch_no = 0;  // DSP_TRACE_LAUNCH: index of the LSTM launch (within a forward) to stamp
     int sg_override = 0;  // DSP_LSTM_SG: site groups per LSTM workgroup (0 = default policy)
+    int np8 = 1;          // DSP_LSTM_NP8: passes per step for layers of exactly 8 unit tiles (hidden 193..256): 1 = one
+                          // 8-wave workgroup per 64 sites; 2 = 4-wave workgroups, two unit tiles per wave and step (A/B switch)
     bool phase_prio = true;  // s_setprio by phase in the LSTM kernel (DSP_LSTM_PRIO=0 turns it off: A/B switch)
     bool fp16_safe = true;         // every operand of the combined stack provably inside the fp16 range (fp16x3 only then)
     int precision = DSP_PREC_FP32; // products of the combined stack: fp32 MFMA, or split-bf16 emulation (dsp_lstm6_kernel)
@@ -448,7 +450,7 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
         a.nqx_used = (ly.Iused + 7) / 8; a.nqx_lo = ly.Ilo / 8;
         a.h0buf = m->h0buf;
         a.UT = ly.Hp / 32;
-        a.NP = a.UT > 8 ? 2 : 1;
+        a.NP = a.UT > 8 ? 2 : (a.UT == 8 && lstm_id == 2 ? m->np8 : 1);
         a.SG = a.NP == 2 ? 1 : pick_site_groups(m, a.UT);
         a.init_mode = init ? init->mode : DSP_INIT_ZEROS;
         a.seed = init ? init->seed : 0; a.site_offset = init ? init->site_offset : 0;
@@ -558,6 +560,7 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
     if (const char* v = getenv("DSP_TRACE_LAUNCH")) m->trace_launch = atoi(v);
     if (const char* v = getenv("DSP_TRACE_WAVE")) m->trace_wave = atoi(v) & 7;
     if (const char* v = getenv("DSP_LSTM_SG")) m->sg_override = atoi(v);  // A/B switch
+    if (const char* v = getenv("DSP_LSTM_NP8")) m->np8 = atoi(v) == 2 ? 2 : 1;  // A/B switch
     if (const char* v = getenv("DSP_LSTM_PRIO")) m->phase_prio = atoi(v) != 0;    // A/B switch
     if (const char* v = getenv("DSP_PRECISION"))
         m->precision = !strcmp(v, "bf16x6") ? DSP_PREC_BF16X6 : (!strcmp(v, "bf16x9") ? DSP_PREC_BF16X9 :
