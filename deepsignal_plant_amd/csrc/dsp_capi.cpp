@@ -43,10 +43,12 @@ int fail(int code, const char* fmt, ...) {
 inline int rup(int x, int m) { return (x + m - 1) / m * m; }
 // hidden sizes are zero-padded to whole unit tiles: 32 units, pairs of them (64) above 32, and 16 tiles (512) above
 // 256, where every wave of the LSTM kernel computes two unit tiles per step (dsp_kernels.hip, NP = 2)
-inline int pad_hidden(int h) { return h <= 32 ? 32 : (h <= 256 ? rup(h, 64) : 512); }
+inline int pad_hidden(int h) { return h <= 32 ? 32 : (h <= 256 ? rup(h, 64) : rup(h, 256)); }
 // one workgroup (at most 8 waves: two per SIMD, 256 registers each) holds a direction's whole hidden state, which its
-// waves exchange every step through a workgroup barrier: 8 waves x 2 passes x 32 units
-constexpr int kMaxHidden = 512;
+// waves exchange every step through a workgroup barrier: 8 waves x NP passes x 32 units.  Up to 512 the cell state sits
+// in LDS (64 KiB per pass); above, in a global scratch (round 3).  2,048 keeps every buffer offset of the kernels far
+// inside 32 bits; nothing else limits it.
+constexpr int kMaxHidden = 2048;
 
 struct Dims {
     int T, S, H, C, V, E, l1, l2;
@@ -61,8 +63,8 @@ int derive(const dsp_model_cfg* c, Dims* d) {
         c->hidden_size < 2 || c->vocab_size < 1 || c->embedding_size < 1)
         return fail(DSP_EINVAL, "non-positive model dimension");
     if (c->hidden_size > kMaxHidden)
-        return fail(DSP_EINVAL, "hidden_size %d > %d is not supported by this build (one workgroup of 8 waves x 2 passes x 32 "
-                                "units holds a direction's whole hidden state)", c->hidden_size, kMaxHidden);
+        return fail(DSP_EINVAL, "hidden_size %d > %d is not supported by this build (one workgroup of 8 waves holds a "
+                                "direction's whole hidden state, 256 units per pass)", c->hidden_size, kMaxHidden);
     if (c->num_classes > 64) return fail(DSP_EINVAL, "num_classes %d > 64 is not supported", c->num_classes);
     if (c->num_layers1 > 15 || c->num_layers2 > 15) return fail(DSP_EINVAL, "too many LSTM layers");
     d->T = c->seq_len; d->S = c->signal_len; d->H = c->hidden_size; d->C = c->num_classes;
@@ -292,7 +294,7 @@ struct dsp_model {
     // scratch
     void* ws = nullptr;
     int64_t ws_sites = 0;
-    float *xseq = nullptr, *xsig = nullptr, *bufA = nullptr, *bufB = nullptr, *comb_in = nullptr, *h0buf = nullptr;
+    float *xseq = nullptr, *xsig = nullptr, *bufA = nullptr, *bufB = nullptr, *comb_in = nullptr, *h0buf = nullptr, *cbuf = nullptr;
     float* last_out = nullptr;
     // profiling
     bool prof = false;
@@ -356,7 +358,7 @@ int build_stack(dsp_model* m, const float* const* w, int in, int hid, int layers
     return 0;
 }
 
-size_t ws_layout(const dsp_model* m, int64_t sites, long long* NTp_out, size_t off[6]) {
+size_t ws_layout(const dsp_model* m, int64_t sites, long long* NTp_out, size_t off[7]) {
     long long nt = (sites + 31) / 32;
     long long NTp = (nt + 15) / 16 * 16;
     if (NTp == 0) NTp = 16;
@@ -369,6 +371,10 @@ size_t ws_layout(const dsp_model* m, int64_t sites, long long* NTp_out, size_t o
     off[3] = take(m->Fwide);
     off[4] = take(m->Fcomb);
     off[5] = o; o += ((size_t)NTp * m->Fwide * 32 * sizeof(float) + 255) / 256 * 256;  // h0 scratch (no T)
+    // cell-state scratch of the many-pass LSTM kernel (hidden > 512): one 8-wave workgroup per tile pair and direction =
+    // NTp workgroups x passes x 64 KiB
+    const int hmax = std::max(m->Hp, std::max(m->hseq_p, m->hsig_p));
+    off[6] = o; if (hmax > 512) o += (size_t)NTp * (size_t)(hmax / 256) * 65536;
     if (NTp_out) *NTp_out = NTp;
     return o;
 }
@@ -381,7 +387,7 @@ int ensure_ws(dsp_model* m, int64_t sites, hipStream_t stream) {
         HIP_TRY(hipFree(m->ws));
         m->ws = nullptr; m->ws_sites = 0;
     }
-    size_t off[6];
+    size_t off[7];
     long long NTp;
     const size_t bytes = ws_layout(m, sites, &NTp, off);
     hipError_t e = hipMalloc(&m->ws, bytes);
@@ -390,6 +396,7 @@ int ensure_ws(dsp_model* m, int64_t sites, hipStream_t stream) {
     m->xseq = (float*)(b + off[0]); m->xsig = (float*)(b + off[1]);
     m->bufA = (float*)(b + off[2]); m->bufB = (float*)(b + off[3]); m->comb_in = (float*)(b + off[4]);
     m->h0buf = (float*)(b + off[5]);
+    m->cbuf = (float*)(b + off[6]);
     m->ws_sites = (int64_t)NTp * 32;
     return 0;
 }
@@ -449,9 +456,10 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
         a.NQ = rup((ly.Ipad + ly.Hp) / 8, 4);
         a.nqx_used = (ly.Iused + 7) / 8; a.nqx_lo = ly.Ilo / 8;
         a.h0buf = m->h0buf;
+        a.cbuf = m->cbuf;
         a.UT = ly.Hp / 32;
-        a.NP = a.UT > 8 ? 2 : (a.UT == 8 && lstm_id == 2 ? m->np8 : 1);
-        a.SG = a.NP == 2 ? 1 : pick_site_groups(m, a.UT);
+        a.NP = a.UT > 8 ? a.UT / 8 : (a.UT == 8 && lstm_id == 2 ? m->np8 : 1);
+        a.SG = a.NP >= 2 ? 1 : pick_site_groups(m, a.UT);
         a.init_mode = init ? init->mode : DSP_INIT_ZEROS;
         a.seed = init ? init->seed : 0; a.site_offset = init ? init->site_offset : 0;
         a.site_keys = (init && init->mode == DSP_INIT_PHILOX) ? (const unsigned long long*)init->site_keys : nullptr;
@@ -639,7 +647,7 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
 
 size_t dsp_workspace_bytes(const dsp_model* m, int64_t max_sites) {
     if (!m) return 0;
-    size_t off[6];
+    size_t off[7];
     return ws_layout(m, max_sites, nullptr, off);
 }
 

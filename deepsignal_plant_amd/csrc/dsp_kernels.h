@@ -35,6 +35,7 @@ struct LstmArgs {
     const float* c0;
     float* h0buf;          // K4 scratch [NTp][Fout/4][32][4] holding h0 (read by step 0 as "h_{-1}")
     const unsigned long long* site_keys;  // PHILOX: per-site counter keys [n], or NULL = site_offset + site
+    float* cbuf;           // NP > 2 only: cell-state scratch, [workgroup][pass][2 site tiles][4 groups][threads] float4
     long long n;
     long long NTp;
     unsigned long long seed, site_offset;
@@ -42,7 +43,7 @@ struct LstmArgs {
     int nqx_lo, nqx_used;  // x-part k-groups [nqx_lo, nqx_used) carry real features (the rest of Ipad/8 is zero padding)
     int NQ;                // k-groups per unit tile in wpk: (Ipad+Hp)/8 padded to a multiple of 4 (zero weights)
     int UT, SG;            // unit tiles (Hp/32), site groups (of two 32-site tiles) per workgroup
-    int NP;                // passes over the unit tiles per time step (1, or 2 for UT = 16); block = 64*(UT/NP)*SG threads
+    int NP;                // passes over the unit tiles per time step (UT / 8 above 8 unit tiles, else 1); block = 64*(UT/NP)*SG threads
     int init_mode;         // DSP_INIT_*
     int stream_base;       // philox stream of (lstm, layer, dir=0, h): lstm*64 + layer*4
     int flags;             // bit 0: issue priority by phase (k-loop 2, cell 0); bit 8: stamp this launch, bits 9..11: its stamping wave (DSP_TRACE builds only)

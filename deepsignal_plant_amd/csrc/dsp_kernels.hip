@@ -310,7 +310,11 @@ extern "C" int dsp_k_trace_read(unsigned long long* t, unsigned int* hw) {
 template <int SPARSE, int NP, int XL = 0>
 __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
     // NP = passes over the unit tiles per time step: 1 for hidden sizes up to 256 (8 unit tiles, one per wave); 2 for
-    // 257..512 (16 unit tiles: a wave computes unit tile w in pass 0 and w + 8 in pass 1, one barrier per step)
+    // 257..512 (16 unit tiles: a wave computes unit tile w in pass 0 and w + 8 in pass 1, one barrier per step);
+    // 0 = a.NP passes (hidden sizes above 512, round 3): the same loop not unrolled, and the cell state -- 64 KiB per pass,
+    // beyond the LDS from three passes on -- in a global scratch with own-lane slots (no exchange, so no barrier for it)
+    constexpr bool CG = NP == 0;
+    const int np = CG ? a.NP : NP;
     constexpr int NF = 4;                  // A fragments (gates) per k-group
     constexpr int DA = 4, DB = 4;          // ring depths in k-groups
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -318,13 +322,13 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
 #endif
     const int nthr = blockDim.x;
-    f32x4* c_lds = (f32x4*)smem;           // [NP][2 site tiles][4 groups][nthr] float4
-    f32x4* b_lds = c_lds + NP * 8 * nthr;  // [unit tile][aa][gate][half] float4
+    f32x4* c_lds = (f32x4*)smem;           // [NP][2 site tiles][4 groups][nthr] float4 (not with CG)
+    f32x4* b_lds = c_lds + (CG ? 0 : NP * 8 * nthr);  // [unit tile][aa][gate][half] float4
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const uint32_t voff = (uint32_t)lane * 16u;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int UTW = a.UT / NP;             // waves per site group = unit tiles per pass
+    const int UTW = a.UT / np;             // waves per site group = unit tiles per pass
     const int ug = w % UTW, sg = w / UTW;
     const int dir = blockIdx.x & 1;
     const int grp = blockIdx.x >> 1;
@@ -345,6 +349,11 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
     const __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)a.out + (size_t)gt0 * T * orow + (size_t)dir * HQ * 512);
     const __amdgpu_buffer_rsrc_t rh0 = make_rsrc((const char*)a.h0buf + (size_t)gt0 * orow + (size_t)dir * HQ * 512);
     const f32x4* bias4 = (const f32x4*)(dir ? a.sbias1 : a.sbias0);
+    // CG: this workgroup's slice of the cell-state scratch, [pass][2 site tiles][4 groups][nthr] float4
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc((const char*)a.cbuf + (CG ? (size_t)blockIdx.x * (size_t)np * 8 * nthr * 16 : 0));
+    auto c_off = [&](int p, int m, int aa) __attribute__((always_inline)) {
+        return (uint32_t)((((p * 2 + m) * 4 + aa) * nthr + w * 64) * 16);
+    };
 
     // ---- initial state: c0 -> LDS, h0 -> the K4 scratch that step 0 reads as "h_{-1}"; biases -> LDS
     for (int i = tid; i < a.Hp; i += nthr) {
@@ -352,7 +361,7 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
         b_lds[i] = bias4[g * HQ + ut * 8 + 2 * aa + h];
     }
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
+    for (int p = 0; p < np; ++p) {
         const int u = ug + p * UTW;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -369,7 +378,8 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
                                      (uint32_t)(a.stream_base + dir * 2 + 1));
                 }
                 bst16(rh0, voff + aa * 1024u, (uint32_t)m * orow + (uint32_t)u * 4096u, hv);
-                c_lds[((p * 2 + m) * 4 + aa) * nthr + tid] = cv;
+                if constexpr (CG) bst16(rc, voff, c_off(p, m, aa), cv);
+                else c_lds[((p * 2 + m) * 4 + aa) * nthr + tid] = cv;
             }
         }
     }
@@ -401,7 +411,7 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
     };
     // weights of (this pass's unit tile, gate g, k-group q); k-groups >= NQ belong to the NEXT pass (or the next step's
     // first pass): po_cur / po_next are the byte offsets of the two unit tiles
-    uint32_t po_cur = 0, po_next = NP > 1 ? pstride : 0;
+    uint32_t po_cur = 0, po_next = NP != 1 ? pstride : 0;
     auto ldA = [&](int g, int q) __attribute__((always_inline)) {
         const uint32_t so = q < NQ ? po_cur + (uint32_t)q * 4096u : po_next + (uint32_t)(q - NQ) * 4096u;
         return bld16(rw, voff + (uint32_t)g * 1024u, so);
@@ -488,20 +498,20 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
         // (measured on the combined stack: +0.45 %; no setting of the two priorities changes the front ends)
         if (prio) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
+        for (int p = 0; p < np; ++p) {
             const int u = ug + p * UTW;
-            if (NP > 1) { po_cur = (uint32_t)p * pstride; po_next = p + 1 < NP ? (uint32_t)(p + 1) * pstride : 0u; }
+            if (NP != 1) { po_cur = (uint32_t)p * pstride; po_next = p + 1 < np ? (uint32_t)(p + 1) * pstride : 0u; }
             stage4_first();
             TSTAMP(4);
             for (int q = 4; q < NQ - 4; q += 4) stage4(q, std::false_type{}, rest_mode{});
             TSTAMP(5);
             // B requests from here on belong to the next pass of this step (same rows) or to the next step
-            if (p == NP - 1) set_bases(step + 1 < T ? step + 1 : step);
+            if (p == np - 1) set_bases(step + 1 < T ? step + 1 : step);
             stage4(NQ - 4, std::false_type{}, rest_mode{});
             // (stage NQ-1 leaves the last fragment of its ring slot, for the next k-loop's k-group 3, to "the next
             // stage": request it here, ahead of the cell phase)
             A[DA - 1][NF - 1] = ldA(NF - 1, NQ + DA - 1);
-            if (p == NP - 1) TSTAMP(2);
+            if (p == np - 1) TSTAMP(2);
             if (prio) __builtin_amdgcn_s_setprio(0);
 
             // LSTM cell.  b_lds holds the PRE-SCALED biases (-log2e*b for i,f,o; -2*log2e*b for g), so
@@ -512,7 +522,9 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
                 const f32x4 bi = b_my[aa * 8 + 0], bf = b_my[aa * 8 + 2], bg = b_my[aa * 8 + 4], bo = b_my[aa * 8 + 6];
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    f32x4 cv = c_lds[((p * 2 + m) * 4 + aa) * nthr + tid];
+                    f32x4 cv;
+                    if constexpr (CG) cv = bld16(rc, voff, c_off(p, m, aa));
+                    else cv = c_lds[((p * 2 + m) * 4 + aa) * nthr + tid];
                     f32x4 hv;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -525,7 +537,8 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
                         cv[i] = cn;
                         hv[i] = og * fast_tanh(cn);
                     }
-                    c_lds[((p * 2 + m) * 4 + aa) * nthr + tid] = cv;
+                    if constexpr (CG) bst16(rc, voff, c_off(p, m, aa), cv);
+                    else c_lds[((p * 2 + m) * 4 + aa) * nthr + tid] = cv;
                     bst16(ro, voff + aa * 1024u, (uint32_t)(m * T + t) * orow + (uint32_t)u * 4096u, hv);
                 }
 #ifdef DSP_TRACE
@@ -1002,6 +1015,7 @@ extern "C" int dsp_k_init(void) {
     const void* fns[] = {(const void*)dsp_lstm_kernel<0, 1>, (const void*)dsp_lstm_kernel<1, 1>,
                          (const void*)dsp_lstm_kernel<2, 1, 1>, (const void*)dsp_lstm_kernel<2, 1, 2>, (const void*)dsp_lstm_kernel<2, 1, 3>,
                          (const void*)dsp_lstm_kernel<0, 2>, (const void*)dsp_lstm_kernel<1, 2>,
+                         (const void*)dsp_lstm_kernel<0, 0>, (const void*)dsp_lstm_kernel<1, 0>,
                          (const void*)dsp_lstm6_kernel<6>, (const void*)dsp_lstm6_kernel<9>, (const void*)dsp_lstm6_kernel<3>};
     for (const void* f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1019,10 +1033,11 @@ extern "C" int dsp_k_pack(const PackArgs* a, hipStream_t s) {
 
 // a wave owns one unit tile (per pass) x two site tiles; a->SG site groups (of two tiles) per workgroup; a->NP passes
 extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
-    const int np = a->NP == 2 ? 2 : 1;
+    const int np = a->NP < 1 ? 1 : a->NP;   // 1, 2: the cell state in LDS; more: in a->cbuf (dsp_lstm_kernel<., 0>)
     const int threads = (a->UT / np) * a->SG * 64;
     const unsigned groups = (unsigned)(a->NTp / (a->SG * 2));
-    const size_t lds = (size_t)np * 8 * threads * 16 + (size_t)a->Hp * 16;
+    const size_t lds = (np <= 2 ? (size_t)np * 8 * threads * 16 : 0) + (size_t)a->Hp * 16;
+    if (np > 2 && !a->cbuf) return (int)hipErrorInvalidValue;
     const int nqx = a->Ipad >> 3, nq = (a->Ipad + a->Hp) >> 3;
     if (nqx < 4 || threads > 512 || a->UT % np) return (int)hipErrorInvalidValue;  // see the SPARSE note: four x-part k-groups are required
     // 0: no padded k-groups; 2: the front-end shape (dead k-groups first, inside the first four); 1: padding anywhere else
@@ -1034,6 +1049,9 @@ extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
         if (a->nqx_lo == 3) hipLaunchKernelGGL((dsp_lstm_kernel<2, 1, 1>), g, b, lds, s, *a);
         else if (a->nqx_lo == 2) hipLaunchKernelGGL((dsp_lstm_kernel<2, 1, 2>), g, b, lds, s, *a);
         else hipLaunchKernelGGL((dsp_lstm_kernel<2, 1, 3>), g, b, lds, s, *a);
+    } else if (np > 2) {
+        if (sparse) hipLaunchKernelGGL((dsp_lstm_kernel<1, 0>), g, b, lds, s, *a);
+        else hipLaunchKernelGGL((dsp_lstm_kernel<0, 0>), g, b, lds, s, *a);
     } else if (np == 2) {
         if (sparse) hipLaunchKernelGGL((dsp_lstm_kernel<1, 2>), g, b, lds, s, *a);
         else hipLaunchKernelGGL((dsp_lstm_kernel<0, 2>), g, b, lds, s, *a);

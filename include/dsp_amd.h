@@ -57,7 +57,7 @@ typedef struct dsp_model_cfg {
     int32_t num_layers1;    /* --layernum1: combined BiLSTM layers, default 3 */
     int32_t num_layers2;    /* --layernum2: seq / signal BiLSTM layers, default 1 */
     int32_t num_classes;    /* --class_num, default 2 */
-    int32_t hidden_size;    /* --hid_rnn, default 256 (this build: <= 512) */
+    int32_t hidden_size;    /* --hid_rnn, default 256 (this build: <= 2048) */
     int32_t vocab_size;     /* --n_vocab, default 16 */
     int32_t embedding_size; /* --n_embed, default 4 */
     int32_t is_base;        /* --is_base */
@@ -116,9 +116,9 @@ size_t dsp_workspace_bytes(const dsp_model* m, int64_t max_sites);
  * Threading / ownership: a handle owns ONE scratch workspace (activations of the forward in flight), so forwards on
  * the same handle must be issued by one host thread at a time and are ordered by the streams they are given; use one
  * handle per stream for concurrent forwards (the repacked weights are 19 MB).  Launch geometry is derived per call and
- * never stored in the handle.  hidden_size <= 512 is the one model-shape limit of this build (one workgroup holds a
- * direction's whole hidden state: 8 waves x 2 passes x 32 units); the split-precision modes cover hidden_size <= 256
- * and fall back to the fp32 kernels above it. */
+ * never stored in the handle.  hidden_size <= 2048 is the one model-shape limit of this build (one workgroup of 8 waves
+ * holds a direction's whole hidden state, 256 units per pass over the step; above 512 the cell state moves from LDS to a
+ * global scratch); the split-precision modes cover hidden_size <= 256 and fall back to the fp32 kernels above it. */
 int32_t dsp_forward(dsp_model* m, void* stream, int64_t n_sites, const void* kmer, int32_t kmer_dtype,
                     const float* means, const float* stds, const void* lens, int32_t lens_dtype,
                     const float* signals, const dsp_init_state* init, float* logits, float* probs,

@@ -125,7 +125,7 @@ def test_errors_are_loud():
     with pytest.raises(ValueError):
         ModelBiLSTM(module="bogus")
     with pytest.raises(ValueError):
-        ModelBiLSTM(hidden_size=514).cuda(0)  # the one documented limit: hid_rnn <= 512 (include/dsp_amd.h)
+        ModelBiLSTM(hidden_size=2050).cuda(0)  # the one documented limit: hid_rnn <= 2048 (include/dsp_amd.h)
     cfg = onp.OracleConfig()
     m = build_model(cfg, onp.make_weights(cfg, 1))
     cpu_ins = [torch.from_numpy(a) for a in onp.make_inputs(cfg, 4, 2)]
@@ -337,11 +337,15 @@ def test_philox_states_at_several_batches_are_deterministic_and_match_the_oracle
 
 
 @pytest.mark.parametrize("hidden,module,n", [(320, "both_bilstm", 70), (384, "seq_bilstm", 130), (512, "both_bilstm", 70),
-                                             (512, "signal_bilstm", 33), (258, "both_bilstm", 200)])
+                                             (512, "signal_bilstm", 33), (258, "both_bilstm", 200),
+                                             (640, "both_bilstm", 70), (768, "seq_bilstm", 40), (1024, "both_bilstm", 40),
+                                             (1100, "signal_bilstm", 70), (2048, "seq_bilstm", 33)])
 def test_hidden_sizes_above_256(hidden, module, n):
     """hid_rnn > 256 (models.py:103-128 accepts any hidden_size): the hidden state is padded to 16 unit tiles and every
-    wave of the LSTM kernel computes two of them per step (dsp_lstm_kernel<.., NP = 2>); against the oracle with explicit
-    N(0,1) states, and with in-kernel Philox states (non-zero initial states through the h0 scratch)"""
+    wave of the LSTM kernel computes two of them per step (dsp_lstm_kernel<.., NP = 2>); above 512 (round 3) to a multiple
+    of 8 unit tiles, hidden / 256 passes per step with the cell state in a global scratch (dsp_lstm_kernel<.., 0>), the
+    front ends of a both_bilstm model taking whichever kernel their half of the hidden size selects; against the oracle
+    with explicit N(0,1) states, and with in-kernel Philox states (non-zero initial states through the h0 scratch)"""
     torch = _torch()
     from oracle import c_oracle as oc
     from oracle import forward_np as onp
