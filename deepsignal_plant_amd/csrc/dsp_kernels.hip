@@ -287,7 +287,7 @@ template <int N> using ic = std::integral_constant<int, N>;
 //   (2) intact store DATA -- the gfx950 store-data hazard described at bst16 above, guarded in the source and gated in
 //       the build;
 //   (3) tests that would see either break: contiguous 2,304-site windows at five depths of 300k-site batches with
-//       N(0,1) states against the oracle, bit-exact permutation equivariance at full batch under non-zero states
+//       N(0,1) states against the CPU restatement of the reference, bit-exact permutation equivariance at full batch under non-zero states
 //       (tests/test_gpu_windows.py), five-fold determinism at 300 k sites (tests/test_gpu_parity.py).
 __device__ __forceinline__ void barrier_after_global_stores() { __syncthreads(); }
 
