@@ -161,6 +161,16 @@ def lib():
     L.dsp_gz_close.argtypes = [ctypes.c_void_p]
     L.dsp_gz_bytes_in.restype = ctypes.c_uint64
     L.dsp_gz_bytes_in.argtypes = [ctypes.c_void_p]
+    L.dsp_pgz_open.restype = ctypes.c_void_p
+    L.dsp_pgz_open.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_uint64]
+    L.dsp_pgz_read.restype = ctypes.c_int64
+    L.dsp_pgz_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    L.dsp_pgz_bytes_in.restype = ctypes.c_uint64
+    L.dsp_pgz_bytes_in.argtypes = [ctypes.c_void_p]
+    L.dsp_pgz_stats.restype = None
+    L.dsp_pgz_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    L.dsp_pgz_close.restype = None
+    L.dsp_pgz_close.argtypes = [ctypes.c_void_p]
     L.dsp_shm_ring_create.restype = ctypes.c_void_p
     L.dsp_shm_ring_create.argtypes = [ctypes.c_char_p, ctypes.c_int32, ctypes.c_uint64]
     L.dsp_shm_ring_attach.restype = ctypes.c_void_p

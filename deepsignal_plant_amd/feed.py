@@ -90,6 +90,7 @@ class FeatureReader(threading.Thread):
         self.byte_range = byte_range
         self.gz_ring = gz_ring       # foreign .gz read by several ranks: the node's shared-memory ring (open_gz_ring)
         self.gz_bytes_in = 0         # compressed bytes this rank inflated from a foreign .gz
+        self.gz_parallel = False     # ... through the parallel inflater (csrc/dsp_pgz.cpp) rather than zlib
         self.q = queue.Queue(maxsize=max(1, nbuf - 1))
         self.free = queue.Queue()
         cap = max_rows_per_block or max(1024, block_bytes // 600)
@@ -249,7 +250,8 @@ class FeatureReader(threading.Thread):
         hands out (private arrays, or slots of the node's shared-memory ring); put_block(i, buf, nbytes, first_row,
         n_rows) passes block i on.  Returns (number of blocks, rows, compressed bytes read)."""
         from . import gzio
-        st = gzio.GzStream(self.path)
+        st = gzio.open_gz_stream(self.path, self.nthreads)   # several host threads and a big file: the parallel inflater
+        self.gz_parallel = isinstance(st, gzio.PgzStream)
         carry = np.zeros(0, np.uint8)
         i, row = 0, self.first_row
         try:

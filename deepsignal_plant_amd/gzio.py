@@ -179,6 +179,48 @@ class GzStream(object):
             pass
 
 
+class PgzStream(object):
+    """one gzip stream inflated on `nthreads` threads (csrc/dsp_pgz.cpp): same reading contract as GzStream"""
+
+    def __init__(self, path, nthreads=4, chunk_bytes=0):
+        self.h = ctypes.c_void_p(nat.lib().dsp_pgz_open(os.fsencode(path), int(nthreads), int(chunk_bytes)))
+        if not self.h:
+            raise ValueError("cannot open %s: %s" % (path, nat.lib().dsp_last_error().decode()))
+
+    def readinto(self, arr, offset=0):
+        return nat.check(int(nat.lib().dsp_pgz_read(self.h, ctypes.c_void_p(arr.ctypes.data + offset), arr.nbytes - offset)))
+
+    def bytes_in(self):
+        return int(nat.lib().dsp_pgz_bytes_in(self.h)) if self.h else 0
+
+    def stats(self):
+        r, d = ctypes.c_uint64(), ctypes.c_uint64()
+        nat.lib().dsp_pgz_stats(self.h, ctypes.byref(r), ctypes.byref(d))
+        return int(r.value), int(d.value)
+
+    def close(self):
+        if self.h:
+            nat.lib().dsp_pgz_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+PGZ_MIN_BYTES = 16 << 20   # smaller files are done before the second chunk would have found its start
+
+
+def open_gz_stream(path, nthreads=1):
+    """the reader of a foreign .gz: the parallel inflater when there are threads to use and the file is big enough to
+    hold more than a chunk or two, else the sequential zlib reader (DSP_GZ_SEQUENTIAL=1 forces that one)"""
+    if nthreads >= 2 and not os.environ.get("DSP_GZ_SEQUENTIAL") and os.path.getsize(path) >= PGZ_MIN_BYTES:
+        return PgzStream(path, nthreads)
+    return GzStream(path)
+
+
 class ShmRing(object):
     """node-local ring of text blocks in POSIX shared memory (csrc/dsp_shmring.cpp): the node's first rank inflates a
     foreign single-stream .gz ONCE into it, every rank of the node copies its own blocks out."""

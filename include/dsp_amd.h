@@ -364,6 +364,17 @@ int64_t dsp_gz_read(dsp_gz_stream* s, uint8_t* out, size_t cap);   /* 0 = end; D
 uint64_t dsp_gz_bytes_in(const dsp_gz_stream* s);                   /* compressed bytes consumed so far */
 void dsp_gz_close(dsp_gz_stream* s);
 
+/* ---- parallel inflate of ONE gzip stream (csrc/dsp_pgz.cpp): chunks of the compressed bytes are inflated concurrently
+ * from block starts found by search, back-references into the unknown 32 KiB before a chunk kept as markers and resolved
+ * front to back; every member's CRC-32 and ISIZE verified like zlib does.  Same reading contract as dsp_gz_read (0 = end,
+ * DSP_EPARSE with the same messages on a corrupt or truncated stream).  open: NULL when the file is not a gzip file. */
+typedef struct dsp_pgz dsp_pgz;
+dsp_pgz* dsp_pgz_open(const char* path, int32_t nthreads, uint64_t chunk_bytes /* 0 = default */);
+int64_t dsp_pgz_read(dsp_pgz* z, uint8_t* out, size_t cap);
+uint64_t dsp_pgz_bytes_in(const dsp_pgz* z);
+void dsp_pgz_stats(const dsp_pgz* z, uint64_t* rounds, uint64_t* dropped_chunks);
+void dsp_pgz_close(dsp_pgz* z);
+
 /* ---- node-local ring of text blocks in POSIX shared memory (csrc/dsp_shmring.cpp) ---------------------------------
  * A feature file written by the reference's `extract --gzip` is ONE gzip stream (read back with gzip.open at
  * call_modifications.py:66-69): it cannot be range-split, so the first rank of a node inflates it once into this ring

@@ -323,6 +323,58 @@ int main(int argc, char** argv) {
         dsp_gz_close(nullptr);
         CHECK(dsp_gz_open((tmp + "/absent.gz").c_str()) == nullptr);
     }
+    // ---- parallel inflater of one gzip stream (its own deflate decoder): small chunks so that many chunks start in the
+    //      middle of the stream with unknown windows; then truncations and byte flips -- text out or DSP_EPARSE, no over-read
+    {
+        std::string text;
+        for (int i = 0; i < 60000; i++) text += "chr3\t" + std::to_string(rnd() % 1000000) + "\t+\t0." + std::to_string(rnd() % 1000000) + "\tACGTACGTACGTA\n";
+        auto gz_member = [](const std::string& t, int level) {
+            std::vector<uint8_t> o(compressBound((uLong)t.size()) + 64);
+            z_stream z;
+            memset(&z, 0, sizeof(z));
+            deflateInit2(&z, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY);
+            z.next_in = (Bytef*)t.data(); z.avail_in = (uInt)t.size();
+            z.next_out = o.data(); z.avail_out = (uInt)o.size();
+            deflate(&z, Z_FINISH);
+            o.resize(z.total_out);
+            deflateEnd(&z);
+            return o;
+        };
+        std::vector<uint8_t> file = gz_member(text.substr(0, text.size() / 2), 6);
+        const std::vector<uint8_t> m2 = gz_member(text.substr(text.size() / 2), 1);
+        file.insert(file.end(), m2.begin(), m2.end());
+        const std::string p = tmp + "/pgz.gz";
+        auto write_file = [&](const std::vector<uint8_t>& b) { FILE* f = fopen(p.c_str(), "wb"); if (!b.empty()) fwrite(b.data(), 1, b.size(), f); fclose(f); };
+        auto read_all = [&](std::string& got, int nt, uint64_t chunk) -> int64_t {
+            dsp_pgz* z = dsp_pgz_open(p.c_str(), nt, chunk);
+            if (!z) return DSP_EINVAL;
+            std::vector<uint8_t> buf(50021);
+            got.clear();
+            int64_t rc;
+            while ((rc = dsp_pgz_read(z, buf.data(), buf.size())) > 0) got.append((const char*)buf.data(), (size_t)rc);
+            dsp_pgz_close(z);
+            return rc;
+        };
+        std::string got;
+        write_file(file);
+        for (int nt : {1, 3, 6}) {
+            CHECK(read_all(got, nt, 65536) == 0 && got == text);
+        }
+        CHECK(read_all(got, 4, 0) == 0 && got == text);
+        for (size_t cut : {(size_t)10, (size_t)19, file.size() / 7, file.size() / 2, file.size() - 9, file.size() - 1}) {
+            write_file(std::vector<uint8_t>(file.begin(), file.begin() + (long)cut));
+            const int64_t rc = read_all(got, 4, 65536);
+            CHECK(rc == DSP_EPARSE || rc == DSP_EINVAL);
+        }
+        for (int it = 0; it < 60; it++) {
+            std::vector<uint8_t> bad = file;
+            const int flips = 1 + (int)(rnd() % 3);
+            for (int k = 0; k < flips; k++) bad[rnd() % bad.size()] ^= (uint8_t)(1 + rnd() % 255);
+            write_file(bad);
+            const int64_t rc = read_all(got, 1 + (int)(rnd() % 5), 65536 + (rnd() % 3) * 40000);
+            CHECK(rc == DSP_EPARSE || rc == DSP_EINVAL || (rc == 0 && got.size() == text.size()));
+        }
+    }
     // ---- shared-memory ring: one producer thread, two consumer threads, more blocks than slots, then a failing producer
     {
         const std::string name = "/dsp_asan_ring_" + std::to_string((long)getpid());

@@ -7,7 +7,7 @@ import subprocess
 
 from tests.helpers import GOLDEN, ROOT
 
-SRCS = ["dsp_text.cpp", "dsp_freq.cpp", "dsp_featfile.cpp", "dsp_sites.cpp", "dsp_gz.cpp", "dsp_fast5.cpp", "dsp_shmring.cpp"]
+SRCS = ["dsp_text.cpp", "dsp_freq.cpp", "dsp_featfile.cpp", "dsp_sites.cpp", "dsp_gz.cpp", "dsp_fast5.cpp", "dsp_shmring.cpp", "dsp_pgz.cpp"]
 
 
 def test_host_code_is_clean_under_asan_and_ubsan(tmp_path):
