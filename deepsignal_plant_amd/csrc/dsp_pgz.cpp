@@ -490,8 +490,8 @@ struct dsp_pgz {
     size_t chunk_bytes = 8u << 20;
     // decoding state (owned by the decoder thread)
     uint64_t next_bit = 0;             // a true block boundary: where the next round starts
-    std::vector<uint8_t> window;       // last <= 32 KiB of output before next_bit (empty at a member start)
-    bool at_member_start = true;
+    std::vector<uint16_t> window;      // the 32 Ki symbols before next_bit, resolved (kPoison = before the stream's start)
+    std::string pending_error;
     uint32_t member_crc = 0;           // running CRC-32 / size of the member being decoded
     uint64_t member_len = 0;
     bool finished = false;
@@ -516,8 +516,10 @@ namespace {
 
 void pgz_fail(dsp_pgz* z, int code, const std::string& msg) {
     std::lock_guard<std::mutex> lk(z->mu);
-    z->status = code;
-    z->error = msg;
+    if (!z->status) {   // the first error is the one that is reported
+        z->status = code;
+        z->error = msg;
+    }
     z->eof = true;
     z->cv_get.notify_all();
 }
@@ -533,8 +535,73 @@ void run_parallel(int nthreads, int n, const std::function<void(int)>& fn) {
     for (auto& x : th) x.join();
 }
 
-// one round: up to nthreads chunks from z->next_bit.  Returns false when the stream is finished or failed.
-bool decode_round(dsp_pgz* z) {
+// The second half of a round, run by a finisher thread while the decoder threads are already inflating the next round:
+// every kept chunk's markers resolved against the window before it (parallel), CRC-32 of its pieces (parallel), then -- in
+// stream order -- the members' CRC-32 / ISIZE checked against their trailers and the text handed to the reader.
+struct Round {
+    std::vector<Chunk> ch;                       // the kept chunks
+    std::vector<std::vector<uint16_t>> win;      // win[i] = the 32 Ki symbols before chunk i, resolved
+    bool last = false;                           // the stream ends with this round
+};
+
+void finish_round(dsp_pgz* z, Round* r) {
+    const int keep = (int)r->ch.size();
+    std::atomic<int> bad{0};
+    run_parallel(std::max(1, z->nthreads), keep, [&](int i) {
+        Chunk& c = r->ch[(size_t)i];
+        const size_t m = c.sym.size() - kWin;
+        c.out.resize(m);
+        const uint16_t* s = c.sym.data() + kWin;
+        const uint16_t* w = r->win[(size_t)i].data();
+        uint8_t* o = c.out.data();
+        uint32_t any = 0;
+        for (size_t k = 0; k < m; ++k) {
+            uint32_t v = s[k];
+            if (v & 0x8000u) v = w[v & 0x7fffu];
+            any |= v;
+            o[k] = (uint8_t)v;
+        }
+        if (any > 255) bad.store(1);   // a marker that led to a position before the start of the member, or to nothing
+        std::vector<uint16_t>().swap(c.sym);
+        size_t a = 0;
+        for (const MemberEnd& me : c.ends) { c.crc_parts.push_back(fast_crc32(o + a, me.sym_pos - a)); a = me.sym_pos; }
+        c.crc_tail = fast_crc32(o + a, m - a);
+    });
+    if (bad.load()) { pgz_fail(z, DSP_EPARSE, "corrupt gzip stream: invalid distance too far back"); return; }
+    for (int i = 0; i < keep; ++i) {
+        Chunk& c = r->ch[(size_t)i];
+        size_t a = 0;
+        for (size_t e = 0; e < c.ends.size(); ++e) {
+            const size_t len = c.ends[e].sym_pos - a;
+            z->member_crc = (uint32_t)crc32_combine(z->member_crc, c.crc_parts[e], (z_off_t)len);
+            z->member_len += len;
+            if (z->member_crc != c.ends[e].crc) { pgz_fail(z, DSP_EPARSE, "corrupt gzip stream: incorrect data check"); return; }
+            if ((uint32_t)z->member_len != c.ends[e].isize) { pgz_fail(z, DSP_EPARSE, "corrupt gzip stream: incorrect length check"); return; }
+            z->member_crc = 0; z->member_len = 0;
+            a = c.ends[e].sym_pos;
+        }
+        const size_t tail = c.out.size() - a;
+        z->member_crc = (uint32_t)crc32_combine(z->member_crc, c.crc_tail, (z_off_t)tail);
+        z->member_len += tail;
+        std::unique_lock<std::mutex> lk(z->mu);
+        z->cv_put.wait(lk, [&] { return z->stop || z->q_bytes < (size_t)z->nthreads * z->chunk_bytes * 6; });
+        if (z->stop) return;
+        z->q_bytes += c.out.size();
+        z->q.emplace_back(std::move(c.out));
+        z->cv_get.notify_all();
+    }
+    if (r->last) {
+        if (z->member_len != 0) { pgz_fail(z, DSP_EPARSE, "truncated gzip stream: Compressed file ended before the end-of-stream marker was reached"); return; }
+        std::lock_guard<std::mutex> lk(z->mu);
+        z->eof = true;
+        z->cv_get.notify_all();
+    }
+}
+
+// The first half of a round: up to nthreads chunks inflated concurrently from z->next_bit, the consistent prefix kept, the
+// windows resolved front to back (32 Ki symbols per chunk: cheap, and the next round's first chunk needs the last one).
+// Returns the round to finish, or NULL when the stream has failed.
+Round* decode_round(dsp_pgz* z) {
     const uint8_t* base = z->map;
     const size_t size = z->size;
     const int T = std::max(1, z->nthreads);
@@ -561,13 +628,8 @@ bool decode_round(dsp_pgz* z) {
         }
         if (!c.found) return;
         c.sym.resize(kWin + (size_t)(z->chunk_bytes * 3));   // decode_chunk trims it to what was written
-        if (c.exact_start) {   // known window: real bytes (positions before the stream / member start stay unreachable)
-            const size_t w = z->window.size();
-            for (size_t k = 0; k < kWin - w; ++k) c.sym[k] = kPoison;   // a valid stream never reads it
-            for (size_t k = 0; k < w; ++k) c.sym[kWin - w + k] = z->window[k];
-        } else {
-            for (uint32_t k = 0; k < kWin; ++k) c.sym[k] = (uint16_t)(0x8000u | k);
-        }
+        if (c.exact_start) memcpy(c.sym.data(), z->window.data(), kWin * sizeof(uint16_t));   // known: bytes (or kPoison)
+        else for (uint32_t k = 0; k < kWin; ++k) c.sym[k] = (uint16_t)(0x8000u | k);
         decode_chunk(base, size, c, max_out);
     });
     // keep the consistent prefix: chunk i+1 must have started exactly where chunk i stopped
@@ -586,113 +648,62 @@ bool decode_round(dsp_pgz* z) {
         keep = i + 1;
         if (c.hit_eof) break;
     }
-    if (keep < 0) { pgz_fail(z, DSP_EPARSE, fail_why); return false; }
-    if (keep == 0) { pgz_fail(z, DSP_EPARSE, "corrupt gzip stream: no progress"); return false; }
+    if (keep < 0) { z->pending_error = fail_why; return nullptr; }
+    if (keep == 0) { z->pending_error = "corrupt gzip stream: no progress"; return nullptr; }
     z->dropped_chunks += (uint64_t)(n - keep);
     ++z->rounds;
-    // resolve the windows front to back, then everything in parallel
-    // (kPoison travels through the windows like a byte and is an error only if something in the OUTPUT still carries it)
-    std::vector<std::vector<uint16_t>> win((size_t)keep);   // window BEFORE chunk i, resolved (chunk 0: its own prefix)
-    for (int i = 1; i < keep; ++i) {
+    Round* r = new Round();
+    r->win.resize((size_t)keep + 1);
+    r->win[0] = z->window;
+    for (int i = 1; i <= keep; ++i) {   // win[i] = the resolved tail of chunk i-1 (kPoison travels like a byte)
         const Chunk& p = ch[(size_t)i - 1];
-        std::vector<uint16_t>& w = win[(size_t)i];
+        const std::vector<uint16_t>& pw = r->win[(size_t)i - 1];
+        std::vector<uint16_t>& w = r->win[(size_t)i];
         w.resize(kWin);
         const size_t total = p.sym.size();   // window + output
         for (uint32_t k = 0; k < kWin; ++k) {
             uint16_t v = p.sym[total - kWin + k];
-            if (v & 0x8000u) v = i - 1 > 0 ? win[(size_t)i - 1][v & 0x7fffu] : kPoison;
+            if (v & 0x8000u) v = pw[v & 0x7fffu];
             w[k] = v;
         }
     }
-    std::atomic<int> bad{0};
-    run_parallel(T, keep, [&](int i) {
-        Chunk& c = ch[(size_t)i];
-        const size_t m = c.sym.size() - kWin;
-        c.out.resize(m);
-        const uint16_t* s = c.sym.data() + kWin;
-        const uint16_t* w = i > 0 ? win[(size_t)i].data() : nullptr;
-        uint8_t* o = c.out.data();
-        for (size_t k = 0; k < m; ++k) {
-            uint16_t v = s[k];
-            if (v & 0x8000u) v = w ? w[v & 0x7fffu] : kPoison;
-            if (v > 255) { bad.store(1); v = 0; }
-            o[k] = (uint8_t)v;
-        }
-        std::vector<uint16_t>().swap(c.sym);
-        // CRC-32 of the pieces between member ends
-        size_t a = 0;
-        for (const MemberEnd& me : c.ends) { c.crc_parts.push_back(fast_crc32(o + a, me.sym_pos - a)); a = me.sym_pos; }
-        c.crc_tail = fast_crc32(o + a, m - a);
-    });
-    if (bad.load()) { pgz_fail(z, DSP_EPARSE, "corrupt gzip stream: invalid distance too far back"); return false; }
-    // member accounting in order, then hand the text over
-    for (int i = 0; i < keep; ++i) {
-        Chunk& c = ch[(size_t)i];
-        size_t a = 0;
-        for (size_t e = 0; e < c.ends.size(); ++e) {
-            const size_t len = c.ends[e].sym_pos - a;
-            z->member_crc = (uint32_t)crc32_combine(z->member_crc, c.crc_parts[e], (z_off_t)len);
-            z->member_len += len;
-            if (z->member_crc != c.ends[e].crc) { pgz_fail(z, DSP_EPARSE, "corrupt gzip stream: incorrect data check"); return false; }
-            if ((uint32_t)z->member_len != c.ends[e].isize) { pgz_fail(z, DSP_EPARSE, "corrupt gzip stream: incorrect length check"); return false; }
-            z->member_crc = 0; z->member_len = 0;
-            a = c.ends[e].sym_pos;
-        }
-        const size_t tail = c.out.size() - a;
-        z->member_crc = (uint32_t)crc32_combine(z->member_crc, c.crc_tail, (z_off_t)tail);
-        z->member_len += tail;
-    }
+    z->window = r->win[(size_t)keep];
     const Chunk& last = ch[(size_t)keep - 1];
-    // the window for the next round: the last 32 KiB of output (within the current member only)
-    {
-        std::vector<uint8_t> w;
-        size_t need = kWin;
-        for (int i = keep - 1; i >= 0 && need; --i) {
-            const Chunk& c = ch[(size_t)i];
-            const size_t floor = c.ends.empty() ? 0 : c.ends.back().sym_pos;   // bytes before a member end are unreachable
-            const size_t avail = c.out.size() - floor;
-            const size_t take = std::min(need, avail);
-            w.insert(w.begin(), c.out.end() - (long)take, c.out.end());
-            need -= take;
-            if (!c.ends.empty()) { need = 0; break; }
-        }
-        if (need && keep > 0) {   // reaches into the previous round's window (same member)
-            bool crossed = false;
-            for (int i = 0; i < keep; ++i) if (!ch[(size_t)i].ends.empty()) crossed = true;
-            if (!crossed) {
-                const size_t take = std::min(need, z->window.size());
-                w.insert(w.begin(), z->window.end() - (long)take, z->window.end());
-            }
-        }
-        z->window.swap(w);
-    }
     z->next_bit = last.end_bit;
     z->bytes_in.store((uint64_t)std::min<uint64_t>(z->size, (last.end_bit + 7) >> 3));
-    const bool done = last.hit_eof;
-    for (int i = 0; i < keep; ++i) {
-        std::unique_lock<std::mutex> lk(z->mu);
-        z->cv_put.wait(lk, [&] { return z->stop || z->q_bytes < (size_t)z->nthreads * z->chunk_bytes * 6; });
-        if (z->stop) return false;
-        z->q_bytes += ch[(size_t)i].out.size();
-        z->q.emplace_back(std::move(ch[(size_t)i].out));
-        z->cv_get.notify_all();
-    }
-    if (done) {
-        if (z->member_len != 0) { pgz_fail(z, DSP_EPARSE, "truncated gzip stream: Compressed file ended before the end-of-stream marker was reached"); return false; }
-        std::lock_guard<std::mutex> lk(z->mu);
-        z->eof = true;
-        z->cv_get.notify_all();
-        return false;
-    }
-    return true;
+    r->last = last.hit_eof;
+    r->ch.reserve((size_t)keep);
+    for (int i = 0; i < keep; ++i) r->ch.emplace_back(std::move(ch[(size_t)i]));
+    return r;
 }
 
 void decoder_main(dsp_pgz* z) {
+    std::thread finisher;
+    auto join_finisher = [&] { if (finisher.joinable()) finisher.join(); };
     try {
-        while (!z->stop && decode_round(z)) {}
+        for (;;) {
+            {
+                std::lock_guard<std::mutex> lk(z->mu);
+                if (z->stop || z->status) break;
+            }
+            Round* r = decode_round(z);
+            join_finisher();                 // rounds finish in order; at most one round waits while the next is inflated
+            if (!r) {                        // what was decoded before the failure has been delivered: now the error
+                pgz_fail(z, DSP_EPARSE, z->pending_error);
+                break;
+            }
+            const bool last = r->last;
+            finisher = std::thread([z, r] {
+                try { finish_round(z, r); }
+                catch (const std::exception& e) { pgz_fail(z, DSP_ENOMEM, std::string("parallel inflate: ") + e.what()); }
+                delete r;
+            });
+            if (last) break;
+        }
     } catch (const std::exception& e) {
         pgz_fail(z, DSP_ENOMEM, std::string("parallel inflate: ") + e.what());
     }
+    join_finisher();
 }
 
 }  // namespace
@@ -716,6 +727,8 @@ dsp_pgz* dsp_pgz_open(const char* path, int32_t nthreads, uint64_t chunk_bytes) 
     z->nthreads = nthreads < 1 ? 1 : nthreads;
     if (chunk_bytes >= (1u << 16)) z->chunk_bytes = (size_t)chunk_bytes;
     z->next_bit = (uint64_t)q * 8;
+    z->window.assign(kWin, kPoison);
+    if (chunk_bytes < (1u << 16) && z->nthreads >= 8) z->chunk_bytes = 4u << 20;   // two rounds are in flight: keep their memory bounded
     z->decoder = std::thread(decoder_main, z);
     return z;
 }

@@ -250,7 +250,12 @@ class FeatureReader(threading.Thread):
         hands out (private arrays, or slots of the node's shared-memory ring); put_block(i, buf, nbytes, first_row,
         n_rows) passes block i on.  Returns (number of blocks, rows, compressed bytes read)."""
         from . import gzio
-        st = gzio.open_gz_stream(self.path, self.nthreads)   # several host threads and a big file: the parallel inflater
+        # several host threads and a big file: the parallel inflater.  The node's ONE inflater feeds every rank of the
+        # node, so with a ring it takes the CPUs the ranks' parsers leave idle while they wait for it (one stays per rank)
+        nt = self.nthreads
+        if self.gz_ring is not None and self.gz_ring.get("producer"):
+            nt = max(nt, dsp_dist.available_cpus() - self.gz_ring["local_world"])
+        st = gzio.open_gz_stream(self.path, nt)
         self.gz_parallel = isinstance(st, gzio.PgzStream)
         carry = np.zeros(0, np.uint8)
         i, row = 0, self.first_row
