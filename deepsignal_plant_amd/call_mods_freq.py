@@ -46,20 +46,29 @@ class SiteFrequency(object):
         return nat.check(int(nat.lib().dsp_freq_add_calls_text(self._h, ctypes.c_void_p(arr.ctypes.data), arr.nbytes, c)))
 
     def add_calls_file(self, path, contig=None, chunk_bytes=64 << 20):
-        op = gzip.open if path.endswith(".gz") else open  # call_mods_freq.py:46-49
+        """a per-read call file, plain or .gz (call_mods_freq.py:46-49 opens the latter with gzip.open; here BGZF members
+        are inflated in parallel and a single gzip stream goes through the parallel inflater, gzio.read_text_chunks)"""
+        def chunks():
+            if path.endswith(".gz"):
+                from . import gzio
+                for arr in gzio.read_text_chunks(path, chunk_bytes, nthreads=min(16, os.cpu_count() or 1)):
+                    yield arr.tobytes()
+            else:
+                with open(path, "rb") as f:
+                    while True:
+                        chunk = f.read(chunk_bytes)
+                        if not chunk:
+                            return
+                        yield chunk
         carry = b""
-        with op(path, "rb") as f:
-            while True:
-                chunk = f.read(chunk_bytes)
-                if not chunk:
-                    break
-                data = carry + chunk
-                nl = data.rfind(b"\n")
-                if nl < 0:
-                    carry = data
-                    continue
-                carry = data[nl + 1:]
-                self.add_calls_text(data[:nl + 1], contig)
+        for chunk in chunks():
+            data = carry + chunk
+            nl = data.rfind(b"\n")
+            if nl < 0:
+                carry = data
+                continue
+            carry = data[nl + 1:]
+            self.add_calls_text(data[:nl + 1], contig)
         if carry.strip():
             self.add_calls_text(carry, contig)
 

@@ -238,3 +238,25 @@ def test_host_side_of_the_device_aggregator_on_the_reference_outputs(tag, kw):
     with pytest.raises(ValueError, match="host aggregator"):
         nat.check(int(L.dsp_freq_block_keys(agg._h, p(bad.text.ctypes.data), p(bad.row_off.ctypes.data), p(bad.info_len.ctypes.data),
                                             p(bad.kmer.ctypes.data), 5, 1, p(key.ctypes.data), p(pis.ctypes.data), p(meta.ctypes.data))))
+
+
+def test_call_freq_reads_gz_inputs_through_the_fast_gzip_layer(tmp_path, monkeypatch):
+    """per-read call files as .gz (call_mods_freq.py:46-49 opens them with gzip.open): a BGZF file (what call_mods --gzip
+    writes: members inflated in parallel), a plain single-member gzip through zlib, and the same through the parallel
+    inflater (forced for this small file): the same bytes as from the text file"""
+    from deepsignal_plant_amd import gzio
+    want = open(os.path.join(GOLDEN, "f5_freq_tsv.txt"), "rb").read()
+    calls = open(CALLS, "rb").read()
+    bg = str(tmp_path / "calls.bgzf.tsv.gz")
+    with gzio.BgzfWriter(bg, nthreads=3, chunk=1 << 16) as w:
+        w.write(calls)
+    sg = str(tmp_path / "calls.single.tsv.gz")
+    open(sg, "wb").write(gzip.compress(calls, 6))
+    for path, force_parallel in ((bg, False), (sg, False), (sg, True)):
+        if force_parallel:
+            monkeypatch.setattr(gzio, "PGZ_MIN_BYTES", 0)
+        out = str(tmp_path / "freq.tsv")
+        cf.call_mods_frequency_to_file(_args(out, input_path=[path]))
+        assert open(out, "rb").read() == want, (path, force_parallel)
+    assert [bytes(a) for a in gzio.read_text_chunks(sg, 50_000, nthreads=3)] != []
+    assert b"".join(bytes(a) for a in gzio.read_text_chunks(bg, 50_000, nthreads=3)) == calls
