@@ -41,13 +41,14 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 inline int rup(int x, int m) { return (x + m - 1) / m * m; }
-// hidden sizes are zero-padded to whole unit tiles: 32 units, pairs of them (64) above 32, and 16 tiles (512) above
-// 256, where every wave of the LSTM kernel computes two unit tiles per step (dsp_kernels.hip, NP = 2)
+// hidden sizes are zero-padded to whole unit tiles: 32 units, pairs of them (64) above 32, and multiples of 8 tiles (256)
+// above 256, where every wave of the LSTM kernel computes one unit tile per pass and hidden / 256 passes per step
+// (dsp_kernels.hip, NP = 0)
 inline int pad_hidden(int h) { return h <= 32 ? 32 : (h <= 256 ? rup(h, 64) : rup(h, 256)); }
 // one workgroup (at most 8 waves: two per SIMD, 256 registers each) holds a direction's whole hidden state, which its
-// waves exchange every step through a workgroup barrier: 8 waves x NP passes x 32 units.  Up to 512 the cell state sits
-// in LDS (64 KiB per pass); above, in a global scratch (round 3).  2,048 keeps every buffer offset of the kernels far
-// inside 32 bits; nothing else limits it.
+// waves exchange every step through a workgroup barrier: 8 waves x NP passes x 32 units.  Up to 256 (one pass) the cell
+// state sits in LDS; above, in a global scratch (round 3).  2,048 keeps every buffer offset of the kernels far inside 32
+// bits; nothing else limits it.
 constexpr int kMaxHidden = 2048;
 
 struct Dims {
@@ -371,10 +372,10 @@ size_t ws_layout(const dsp_model* m, int64_t sites, long long* NTp_out, size_t o
     off[3] = take(m->Fwide);
     off[4] = take(m->Fcomb);
     off[5] = o; o += ((size_t)NTp * m->Fwide * 32 * sizeof(float) + 255) / 256 * 256;  // h0 scratch (no T)
-    // cell-state scratch of the many-pass LSTM kernel (hidden > 512): one 8-wave workgroup per tile pair and direction =
+    // cell-state scratch of the many-pass LSTM kernel (hidden > 256): one 8-wave workgroup per tile pair and direction =
     // NTp workgroups x passes x 64 KiB
     const int hmax = std::max(m->Hp, std::max(m->hseq_p, m->hsig_p));
-    off[6] = o; if (hmax > 512) o += (size_t)NTp * (size_t)(hmax / 256) * 65536;
+    off[6] = o; if (hmax > 256) o += (size_t)NTp * (size_t)(hmax / 256) * 65536;
     if (NTp_out) *NTp_out = NTp;
     return o;
 }

@@ -309,10 +309,11 @@ extern "C" int dsp_k_trace_read(unsigned long long* t, unsigned int* hw) {
 
 template <int SPARSE, int NP, int XL = 0>
 __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
-    // NP = passes over the unit tiles per time step: 1 for hidden sizes up to 256 (8 unit tiles, one per wave); 2 for
-    // 257..512 (16 unit tiles: a wave computes unit tile w in pass 0 and w + 8 in pass 1, one barrier per step);
-    // 0 = a.NP passes (hidden sizes above 512, round 3): the same loop not unrolled, and the cell state -- 64 KiB per pass,
-    // beyond the LDS from three passes on -- in a global scratch with own-lane slots (no exchange, so no barrier for it)
+    // NP = passes over the unit tiles per time step: 1 for hidden sizes up to 256 (8 unit tiles, one per wave);
+    // 0 = a.NP passes (hidden sizes above 256, 8 unit tiles per pass: a wave computes unit tile w in pass 0, w + 8 in pass 1,
+    // ..., one barrier per step): the pass loop is not unrolled and the cell state -- 64 KiB per pass, beyond the LDS from
+    // three passes on -- lives in a global scratch with own-lane slots (no exchange between waves, so no barrier for it).
+    // (NP = 2, unrolled with the cell state in LDS, compiles too but is no longer instantiated: same speed, 21 spills.)
     constexpr bool CG = NP == 0;
     const int np = CG ? a.NP : NP;
     constexpr int NF = 4;                  // A fragments (gates) per k-group
@@ -1014,7 +1015,6 @@ __global__ __launch_bounds__(256, 2) void dsp_head_kernel(HeadArgs a) {
 extern "C" int dsp_k_init(void) {
     const void* fns[] = {(const void*)dsp_lstm_kernel<0, 1>, (const void*)dsp_lstm_kernel<1, 1>,
                          (const void*)dsp_lstm_kernel<2, 1, 1>, (const void*)dsp_lstm_kernel<2, 1, 2>, (const void*)dsp_lstm_kernel<2, 1, 3>,
-                         (const void*)dsp_lstm_kernel<0, 2>, (const void*)dsp_lstm_kernel<1, 2>,
                          (const void*)dsp_lstm_kernel<0, 0>, (const void*)dsp_lstm_kernel<1, 0>,
                          (const void*)dsp_lstm6_kernel<6>, (const void*)dsp_lstm6_kernel<9>, (const void*)dsp_lstm6_kernel<3>};
     for (const void* f : fns) {
@@ -1036,8 +1036,12 @@ extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
     const int np = a->NP < 1 ? 1 : a->NP;   // 1, 2: the cell state in LDS; more: in a->cbuf (dsp_lstm_kernel<., 0>)
     const int threads = (a->UT / np) * a->SG * 64;
     const unsigned groups = (unsigned)(a->NTp / (a->SG * 2));
-    const size_t lds = (np <= 2 ? (size_t)np * 8 * threads * 16 : 0) + (size_t)a->Hp * 16;
-    if (np > 2 && !a->cbuf) return (int)hipErrorInvalidValue;
+    // Several passes (hidden > 256): dsp_lstm_kernel<., 0>, the pass loop not unrolled and the cell state in a->cbuf.  (Until
+    // round 3 two passes had their own unrolled instantiation with the cell state in 128 KiB of LDS: 21 spilled registers,
+    // the same speed -- 35.62 vs 35.63 ms per launch at hidden 512 -- and one more kernel to keep correct: removed.)
+    const bool many = np >= 2;
+    const size_t lds = (!many ? (size_t)np * 8 * threads * 16 : 0) + (size_t)a->Hp * 16;
+    if (many && !a->cbuf) return (int)hipErrorInvalidValue;
     const int nqx = a->Ipad >> 3, nq = (a->Ipad + a->Hp) >> 3;
     if (nqx < 4 || threads > 512 || a->UT % np) return (int)hipErrorInvalidValue;  // see the SPARSE note: four x-part k-groups are required
     // 0: no padded k-groups; 2: the front-end shape (dead k-groups first, inside the first four); 1: padding anywhere else
@@ -1049,12 +1053,9 @@ extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
         if (a->nqx_lo == 3) hipLaunchKernelGGL((dsp_lstm_kernel<2, 1, 1>), g, b, lds, s, *a);
         else if (a->nqx_lo == 2) hipLaunchKernelGGL((dsp_lstm_kernel<2, 1, 2>), g, b, lds, s, *a);
         else hipLaunchKernelGGL((dsp_lstm_kernel<2, 1, 3>), g, b, lds, s, *a);
-    } else if (np > 2) {
+    } else if (many) {
         if (sparse) hipLaunchKernelGGL((dsp_lstm_kernel<1, 0>), g, b, lds, s, *a);
         else hipLaunchKernelGGL((dsp_lstm_kernel<0, 0>), g, b, lds, s, *a);
-    } else if (np == 2) {
-        if (sparse) hipLaunchKernelGGL((dsp_lstm_kernel<1, 2>), g, b, lds, s, *a);
-        else hipLaunchKernelGGL((dsp_lstm_kernel<0, 2>), g, b, lds, s, *a);
     } else {
         if (sparse) hipLaunchKernelGGL((dsp_lstm_kernel<1, 1>), g, b, lds, s, *a);
         else hipLaunchKernelGGL((dsp_lstm_kernel<0, 1>), g, b, lds, s, *a);

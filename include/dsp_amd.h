@@ -117,7 +117,7 @@ size_t dsp_workspace_bytes(const dsp_model* m, int64_t max_sites);
  * the same handle must be issued by one host thread at a time and are ordered by the streams they are given; use one
  * handle per stream for concurrent forwards (the repacked weights are 19 MB).  Launch geometry is derived per call and
  * never stored in the handle.  hidden_size <= 2048 is the one model-shape limit of this build (one workgroup of 8 waves
- * holds a direction's whole hidden state, 256 units per pass over the step; above 512 the cell state moves from LDS to a
+ * holds a direction's whole hidden state, 256 units per pass over the step; above 256 the cell state moves from LDS to a
  * global scratch); the split-precision modes cover hidden_size <= 256 and fall back to the fp32 kernels above it. */
 int32_t dsp_forward(dsp_model* m, void* stream, int64_t n_sites, const void* kmer, int32_t kmer_dtype,
                     const float* means, const float* stds, const void* lens, int32_t lens_dtype,

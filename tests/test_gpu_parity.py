@@ -341,10 +341,10 @@ def test_philox_states_at_several_batches_are_deterministic_and_match_the_oracle
                                              (640, "both_bilstm", 70), (768, "seq_bilstm", 40), (1024, "both_bilstm", 40),
                                              (1100, "signal_bilstm", 70), (2048, "seq_bilstm", 33)])
 def test_hidden_sizes_above_256(hidden, module, n):
-    """hid_rnn > 256 (models.py:103-128 accepts any hidden_size): the hidden state is padded to 16 unit tiles and every
-    wave of the LSTM kernel computes two of them per step (dsp_lstm_kernel<.., NP = 2>); above 512 (round 3) to a multiple
-    of 8 unit tiles, hidden / 256 passes per step with the cell state in a global scratch (dsp_lstm_kernel<.., 0>), the
-    front ends of a both_bilstm model taking whichever kernel their half of the hidden size selects; against the oracle
+    """hid_rnn > 256 (models.py:103-128 accepts any hidden_size): the hidden state is padded to a multiple of 8 unit
+    tiles and a step runs hidden / 256 passes, every wave computing one unit tile per pass, with the cell state in a global
+    scratch (dsp_lstm_kernel<.., 0>); the front ends of a both_bilstm model take whichever kernel their half of the hidden
+    size selects; against the oracle
     with explicit N(0,1) states, and with in-kernel Philox states (non-zero initial states through the h0 scratch)"""
     torch = _torch()
     from oracle import c_oracle as oc
@@ -373,7 +373,7 @@ def test_hidden_sizes_above_256(hidden, module, n):
     (32, True, True, 64, "both_bilstm", "signal block full: the dense kernel (<0, 1>)"),
     (40, True, True, 64, "both_bilstm", "signal block of 40: padding in the tail k-groups, the tested kernel (<1, 1>)"),
     (16, False, False, 128, "both_bilstm", "seq branch of 2 features (mean, std)"),
-    (20, True, True, 320, "signal_bilstm", "hidden 320: two passes, features at the front (<1, 2>)"),
+    (20, True, True, 320, "signal_bilstm", "hidden 320: two passes, features at the front (<1, 0>)"),
 ])
 def test_front_end_shapes(signal_len, is_base, is_signallen, hidden, module, what):
     """Every instantiation of the LSTM kernel that a front end can select: the features sit at the end of the 32-wide
