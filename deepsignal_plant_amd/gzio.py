@@ -211,13 +211,14 @@ class PgzStream(object):
 
 
 PGZ_MIN_BYTES = 16 << 20   # smaller files are done before the second chunk would have found its start
+PGZ_MAX_THREADS = 32        # a round holds one chunk per thread in memory (4 MB compressed -> ~30 MB each), two rounds in flight
 
 
 def open_gz_stream(path, nthreads=1):
     """the reader of a foreign .gz: the parallel inflater when there are threads to use and the file is big enough to
     hold more than a chunk or two, else the sequential zlib reader (DSP_GZ_SEQUENTIAL=1 forces that one)"""
     if nthreads >= 2 and not os.environ.get("DSP_GZ_SEQUENTIAL") and os.path.getsize(path) >= PGZ_MIN_BYTES:
-        return PgzStream(path, nthreads)
+        return PgzStream(path, min(nthreads, PGZ_MAX_THREADS))
     return GzStream(path)
 
 

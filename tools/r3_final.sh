@@ -5,6 +5,8 @@ cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out/r3
 bash tools/profile.sh r3 5 > gpurun_out/prof_r3.log 2>&1
 bash tools/profile.sh r3_cfg3 5 --model_type seq_bilstm --layernum1 2 > gpurun_out/prof_r3_cfg3.log 2>&1
+# the bench lines below quote the traffic of THIS build: put the fresh entries where bench.py looks for them
+python3 -c "import json; json.dump([json.load(open(\"gpurun_out/prof_%s/traffic_entry.json\" % d)) for d in (\"r3\", \"r3_cfg3\")], open(\"profiles/traffic.json\", \"w\"), indent=1)"
 python3 bench.py > gpurun_out/r3/bench_default_153steps.json 2> gpurun_out/r3/bench_default.err
 python3 bench.py --model_type seq_bilstm --layernum1 2 > gpurun_out/r3/bench_cfg3_153steps.json 2> gpurun_out/r3/bench_cfg3.err
 python3 bench.py --steps 191 --no_cpu_baseline --no_alt > gpurun_out/r3/bench_config4_share_of_one_gpu_191steps.json 2>/dev/null
