@@ -38,6 +38,7 @@
 #include <functional>
 #include <mutex>
 #include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -509,7 +510,8 @@ struct dsp_pgz {
     std::vector<uint8_t> cur;
     size_t cur_pos = 0;
     std::atomic<uint64_t> bytes_in{0};
-    uint64_t rounds = 0, dropped_chunks = 0;
+    std::atomic<uint64_t> rounds{0}, dropped_chunks{0};
+    int strikes = 0, solo_rounds = 0;   // rounds in which no chunk found a start -> a spell of one-chunk rounds (non-text data)
 };
 
 namespace {
@@ -527,12 +529,17 @@ void pgz_fail(dsp_pgz* z, int code, const std::string& msg) {
 void run_parallel(int nthreads, int n, const std::function<void(int)>& fn) {
     if (n <= 0) return;
     std::atomic<int> next{0};
-    auto work = [&] { for (int i; (i = next.fetch_add(1)) < n;) fn(i); };
+    std::atomic<bool> threw{false};
+    auto work = [&] {   // (an exception must not leave a std::thread: remember it, rethrow after the join)
+        try { for (int i; (i = next.fetch_add(1)) < n;) fn(i); }
+        catch (...) { threw.store(true); }
+    };
     std::vector<std::thread> th;
     const int nt = std::min(nthreads, n);
     for (int t = 1; t < nt; ++t) th.emplace_back(work);
     work();
     for (auto& x : th) x.join();
+    if (threw.load()) throw std::runtime_error("out of memory");
 }
 
 // The second half of a round, run by a finisher thread while the decoder threads are already inflating the next round:
@@ -608,7 +615,11 @@ Round* decode_round(dsp_pgz* z) {
     const uint64_t start_byte = z->next_bit >> 3;
     std::vector<Chunk> ch((size_t)T);
     int n = 0;
-    for (; n < T; ++n) {
+    // data that is not text never offers a block start: after two rounds in which no chunk found one, a spell of
+    // one-chunk rounds (the searching threads would only make the true decoder wait for them), then another try
+    const int Tn = z->solo_rounds > 0 ? 1 : T;
+    if (z->solo_rounds > 0) --z->solo_rounds;
+    for (; n < Tn; ++n) {
         const uint64_t from = n == 0 ? z->next_bit : (start_byte + (uint64_t)n * z->chunk_bytes) * 8;
         if (n > 0 && (from >> 3) + 64 >= size) break;
         ch[(size_t)n].search_from = from;
@@ -622,7 +633,8 @@ Round* decode_round(dsp_pgz* z) {
         Chunk& c = ch[(size_t)i];
         if (c.exact_start) { c.found = true; c.start_bit = c.search_from; }
         else {
-            const uint64_t limit = std::min<uint64_t>((uint64_t)size * 8, c.search_from + (uint64_t)z->chunk_bytes * 8);
+            // a deflate block of text is tens of KiB (zlib: <= 32 Ki symbols): no start within 2 MiB means there is none to find
+            const uint64_t limit = std::min<uint64_t>((uint64_t)size * 8, c.search_from + (uint64_t)std::min<size_t>(z->chunk_bytes, 2u << 20) * 8);
             for (uint64_t bit = c.search_from; bit + 64 < limit; ++bit)
                 if (plausible_block_start(base, size, bit)) { c.found = true; c.start_bit = bit; break; }
         }
@@ -648,10 +660,20 @@ Round* decode_round(dsp_pgz* z) {
         keep = i + 1;
         if (c.hit_eof) break;
     }
+    if (getenv("DSP_PGZ_DEBUG")) {
+        fprintf(stderr, "[pgz] round %llu: n=%d keep=%d", (unsigned long long)z->rounds.load(), n, keep);
+        for (int i = 0; i < n; ++i)
+            fprintf(stderr, " | %d: found=%d start=%llu end=%llu out=%zu failed=%d eof=%d", i, (int)ch[(size_t)i].found,
+                    (unsigned long long)ch[(size_t)i].start_bit, (unsigned long long)ch[(size_t)i].end_bit,
+                    ch[(size_t)i].sym.size(), (int)ch[(size_t)i].failed, (int)ch[(size_t)i].hit_eof);
+        fprintf(stderr, "\n");
+    }
     if (keep < 0) { z->pending_error = fail_why; return nullptr; }
     if (keep == 0) { z->pending_error = "corrupt gzip stream: no progress"; return nullptr; }
     z->dropped_chunks += (uint64_t)(n - keep);
     ++z->rounds;
+    if (n > 1 && keep == 1 && !ch[0].hit_eof) { if (++z->strikes >= 2) { z->solo_rounds = 32; z->strikes = 0; } }
+    else if (n > 1) z->strikes = 0;
     Round* r = new Round();
     r->win.resize((size_t)keep + 1);
     r->win[0] = z->window;
@@ -763,8 +785,8 @@ int64_t dsp_pgz_read(dsp_pgz* z, uint8_t* out, size_t cap) {
 uint64_t dsp_pgz_bytes_in(const dsp_pgz* z) { return z ? z->bytes_in.load() : 0; }
 // rounds decoded / chunks dropped because their start was a false positive (diagnostics, tests)
 void dsp_pgz_stats(const dsp_pgz* z, uint64_t* rounds, uint64_t* dropped) {
-    if (rounds) *rounds = z ? z->rounds : 0;
-    if (dropped) *dropped = z ? z->dropped_chunks : 0;
+    if (rounds) *rounds = z ? z->rounds.load() : 0;
+    if (dropped) *dropped = z ? z->dropped_chunks.load() : 0;
 }
 
 void dsp_pgz_close(dsp_pgz* z) {

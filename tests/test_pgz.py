@@ -141,3 +141,16 @@ def test_reader_uses_the_parallel_inflater_and_yields_the_same_rows(tmp_path, mo
         assert n == ref.n and np.array_equal(np.concatenate(sig), ref.signals)
         assert reader.gz_bytes_in == os.path.getsize(p)
         assert reader.gz_parallel == (not seq)
+
+
+def test_streams_without_recognisable_block_starts_fall_back_to_one_decoder(tmp_path):
+    """incompressible high-bit data: every literal fails the ASCII check, so no chunk but the first ever finds a start;
+    after two such rounds the inflater stops sending threads to search (they would only make the true decoder wait) and
+    still delivers the exact bytes"""
+    rng = np.random.default_rng(3)
+    data = rng.integers(128, 256, 1_500_000, dtype=np.uint16).astype(np.uint8).tobytes()
+    p = str(tmp_path / "hi.gz")
+    open(p, "wb").write(gzip.compress(data, 6))
+    got, (rounds, dropped) = _read_all(p, 4, 65536)
+    assert got == data
+    assert rounds >= 6 and dropped == 6          # two rounds of 4 chunks lost their 3 searchers, then one-chunk rounds
