@@ -361,8 +361,7 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
         const int h = i & 1, g = (i >> 1) & 3, aa = (i >> 3) & 3, ut = i >> 5;
         b_lds[i] = bias4[g * HQ + ut * 8 + 2 * aa + h];
     }
-#pragma unroll
-    for (int p = 0; p < np; ++p) {
+    for (int p = 0; p < np; ++p) {   // (one pass, or a loop that is not unrolled)
         const int u = ug + p * UTW;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -498,7 +497,6 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
         // VALU / transcendental stream takes the issue slots the MFMA stream leaves and not the other way round
         // (measured on the combined stack: +0.45 %; no setting of the two priorities changes the front ends)
         if (prio) __builtin_amdgcn_s_setprio(2);
-#pragma unroll
         for (int p = 0; p < np; ++p) {
             const int u = ug + p * UTW;
             if (NP != 1) { po_cur = (uint32_t)p * pstride; po_next = p + 1 < np ? (uint32_t)(p + 1) * pstride : 0u; }
