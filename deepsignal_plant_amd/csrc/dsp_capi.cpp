@@ -290,7 +290,6 @@ struct dsp_model {
     int np8 = 1;          // DSP_LSTM_NP8: passes per step for layers of exactly 8 unit tiles (hidden 193..256): 1 = one
                           // 8-wave workgroup per 64 sites; 2 = 4-wave workgroups, two unit tiles per wave and step (A/B switch)
     bool phase_prio = true;  // s_setprio by phase in the LSTM kernel (DSP_LSTM_PRIO=0 turns it off: A/B switch)
-    bool tiling21 = false;   // DSP_LSTM_TILING=21: <2 unit tiles, 1 site tile> per wave on the dense one-pass layers (A/B switch)
     bool fp16_safe = true;         // every operand of the combined stack provably inside the fp16 range (fp16x3 only then)
     int precision = DSP_PREC_FP32; // products of the combined stack: fp32 MFMA, or split-bf16 emulation (dsp_lstm6_kernel)
     // scratch
@@ -466,7 +465,7 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
         a.seed = init ? init->seed : 0; a.site_offset = init ? init->site_offset : 0;
         a.site_keys = (init && init->mode == DSP_INIT_PHILOX) ? (const unsigned long long*)init->site_keys : nullptr;
         a.stream_base = lstm_id * 64 + (int)k * 4;
-        a.flags = (m->phase_prio ? 1 : 0) | (m->tiling21 ? 2 : 0);
+        a.flags = m->phase_prio ? 1 : 0;
         if (m->trace_launch >= 0 && m->trace_launch == m->lstm_launch_no) a.flags |= 256 | (m->trace_wave << 9);  // DSP_TRACE builds
         ++m->lstm_launch_no;
         if (a.init_mode == DSP_INIT_EXPLICIT) {
@@ -572,7 +571,6 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
     if (const char* v = getenv("DSP_LSTM_SG")) m->sg_override = atoi(v);  // A/B switch
     if (const char* v = getenv("DSP_LSTM_NP8")) m->np8 = atoi(v) == 2 ? 2 : 1;  // A/B switch
     if (const char* v = getenv("DSP_LSTM_PRIO")) m->phase_prio = atoi(v) != 0;    // A/B switch
-    if (const char* v = getenv("DSP_LSTM_TILING")) m->tiling21 = atoi(v) == 21;     // A/B switch
     if (const char* v = getenv("DSP_PRECISION"))
         m->precision = !strcmp(v, "bf16x6") ? DSP_PREC_BF16X6 : (!strcmp(v, "bf16x9") ? DSP_PREC_BF16X9 :
                        (!strcmp(v, "fp16x3") ? DSP_PREC_FP16X3 : DSP_PREC_FP32));
