@@ -226,6 +226,8 @@ __device__ __forceinline__ f32x4 init_state4(const float* src, int mode, long lo
 //     bst16 / gst16 (store, s_nop 1, data registers held live across the nop) and the build fails if the pattern appears
 //     in the assembly (tools/check_store_hazard.py, tests/test_store_hazard.py).  The shipped round-2 binaries held the
 //     pattern twice (the NP = 2 kernels, zeros overwriting stored zeros: harmless) and 19 times at one wait state (safe).
+//     Rebuilt in round 3 with guarded stores (commit cc91d02, reverted): bit-identical results, 0.25 % SLOWER than this
+//     tiling in an alternating same-box A/B -- the +0.6 % of round 2 did not survive.
 //     The exchange itself -- stores, ONE s_barrier without s_waitcnt vmcnt(0), loads by the other waves -- showed 0
 //     mismatches in 3e11 checked values with guarded stores, for 4- and 8-wave workgroups, with and without vmcnt(0), and
 //     also when the destination rows had been pulled into the CU's L1 before the stores (no stale lines).
