@@ -540,3 +540,29 @@ def test_device_call_freq_falls_back_to_the_host_table_past_its_hbm_budget(tmp_p
     r = _two_ranks(["-i", inp, "-m", ck, "-o", out3, "--freq_file", fq3, "--prob_cf", "0.02", "--seed", "8"], env=small)
     assert r.returncode == 0, r.stderr[-3000:]
     assert open(fq3, "rb").read() == open(fq, "rb").read() and open(out3, "rb").read() == open(out, "rb").read()
+
+
+@pytest.mark.parametrize("model_type,hid,l1,l2", [("seq_bilstm", 640, 1, 2), ("signal_bilstm", 96, 2, 1), ("both_bilstm", 320, 1, 1)])
+def test_cli_other_model_shapes_match_the_cpu_restatement(tmp_path, model_type, hid, l1, l2):
+    """the model flags of the reference's call_mods (--model_type, --hid_rnn, --layernum1, --layernum2;
+    deepsignal_plant.py:204-316) reach the kernels: a seq-only model with hidden 640 (several passes per step, cell state
+    in the global scratch), a signal-only one, a combined one with hidden 320 -- the CLI's calls equal the CPU restatement
+    with the same Philox states"""
+    import torch
+    from deepsignal_plant_amd import textio
+    from oracle import c_oracle as oc
+    from oracle import forward_np as onp
+    cfg = onp.OracleConfig(module=model_type, hidden_size=hid, num_layers1=l1, num_layers2=l2)
+    w = onp.make_weights(cfg, 31, 2.0)
+    ck = str(tmp_path / "m.ckpt")
+    torch.save({k: torch.from_numpy(v) for k, v in w.items()}, ck)
+    inp = os.path.join(GOLDEN, "f2_rows.tsv")
+    out = str(tmp_path / "calls.tsv")
+    r = _run_cli(["-i", inp, "-m", ck, "-o", out, "--seed", "13", "--model_type", model_type, "--hid_rnn", str(hid),
+                  "--layernum1", str(l1), "--layernum2", str(l2)])
+    assert r.returncode == 0, r.stderr[-3000:]
+    rows = textio.parse_rows(open(inp, "rb").read(), 13, 16)
+    _, po = oc.forward(cfg, w, rows.kmer.astype(np.float32), rows.means, rows.stds, rows.lens.astype(np.float32), rows.signals,
+                       init_mode="philox", seed=13)
+    got = np.array([[float(x) for x in l.split("\t")[6:8]] for l in open(out).read().splitlines()])
+    assert got.shape == (200, 2) and np.abs(got[:, 1] - po[:, 1] / (po[:, 0] + po[:, 1])).max() <= 2e-6
