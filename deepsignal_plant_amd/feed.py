@@ -248,7 +248,8 @@ class FeatureReader(threading.Thread):
     def _gz_inflate_blocks(self, get_buf, put_block):
         """The one inflater of a foreign .gz: blocks of complete rows, inflated straight into the buffers get_buf(i)
         hands out (private arrays, or slots of the node's shared-memory ring); put_block(i, buf, nbytes, first_row,
-        n_rows) passes block i on.  Returns (number of blocks, rows, compressed bytes read)."""
+        n_rows) passes block i on.  Returns (number of blocks, global index after the last row); the compressed bytes read
+        are left in self.gz_bytes_in."""
         from . import gzio
         # several host threads and a big file: the parallel inflater.  The node's ONE inflater feeds every rank of the
         # node, so with a ring it takes the CPUs the ranks' parsers leave idle while they wait for it (one stays per rank)
@@ -297,31 +298,45 @@ class FeatureReader(threading.Thread):
         mine = lambda i: i % self.world == self.rank
         bq = queue.Queue(maxsize=2)
         slack = 1 << 20
+        stop = threading.Event()   # the consumer failed (a malformed row, ...): the inflater must not wait on a full queue
+
+        def hand_over(item):
+            while not stop.is_set():
+                try:
+                    bq.put(item, timeout=0.2)
+                    return
+                except queue.Full:
+                    pass
+            raise RuntimeError("reader stopped")
 
         def get_buf(i):
             return np.empty(self.block_bytes + slack, np.uint8)
 
         def put_block(i, buf, n, first_row, n_rows):
             if mine(i):
-                bq.put((buf[:n], first_row))
+                hand_over((buf[:n], first_row))
 
         def produce():
             try:
                 _, end_row = self._gz_inflate_blocks(get_buf, put_block)
-                bq.put(("end", end_row))
+                hand_over(("end", end_row))
             except BaseException as e:
-                bq.put(("error", e))
+                if not stop.is_set():
+                    hand_over(("error", e))
         t = threading.Thread(target=produce, daemon=True)
         t.start()
-        while True:
-            data, info = bq.get()
-            if isinstance(data, str):
-                if data == "error":
-                    raise info
-                row = info
-                break
-            self._emit(data, info)
-        t.join()
+        try:
+            while True:
+                data, info = bq.get()
+                if isinstance(data, str):
+                    if data == "error":
+                        raise info
+                    row = info
+                    break
+                self._emit(data, info)
+        finally:
+            stop.set()
+            t.join()
         return row
 
     def _run_gz_ring(self, row):
