@@ -191,6 +191,8 @@ def lib():
     L.dsp_shm_ring_release.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
     L.dsp_shm_ring_abort.restype = None
     L.dsp_shm_ring_abort.argtypes = [ctypes.c_void_p]
+    L.dsp_shm_ring_unlink.restype = None
+    L.dsp_shm_ring_unlink.argtypes = [ctypes.c_void_p]
     L.dsp_shm_ring_close.restype = None
     L.dsp_shm_ring_close.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     L.dsp_feat_writer_create.restype = ctypes.c_int32

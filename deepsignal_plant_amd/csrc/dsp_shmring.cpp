@@ -217,10 +217,16 @@ int32_t dsp_shm_ring_release(dsp_shm_ring* r, uint64_t seq) {
 // a failing consumer tells the producer to stop waiting for it
 void dsp_shm_ring_abort(dsp_shm_ring* r) { if (r) r->h->aborted.store(1, std::memory_order_release); }
 
+// remove the NAME once every consumer has attached: the memory lives on while it is mapped and goes away with the last
+// process, however that process ends (a killed run leaves nothing behind in /dev/shm)
+void dsp_shm_ring_unlink(dsp_shm_ring* r) {
+    if (r && r->owner) { shm_unlink(r->name.c_str()); r->owner = false; }
+}
+
 void dsp_shm_ring_close(dsp_shm_ring* r, int32_t unlink_it) {
     if (!r) return;
     if (r->map) munmap(r->map, r->bytes);
-    if (unlink_it) shm_unlink(r->name.c_str());
+    if (unlink_it && r->owner) shm_unlink(r->name.c_str());
     delete r;
 }
 

@@ -414,6 +414,10 @@ def open_gz_ring(path, rank, world, local_rank, local_world, all_gather_object, 
         if ring is not None:
             ring.close()
         return None
+    producer = ring is not None
     if ring is None:
         ring = gzio.ShmRing.attach(names[rank - local_rank])
-    return dict(ring=ring, producer=local_rank == 0, local_index=local_rank, local_world=local_world)
+    all_gather_object(True)   # everybody has attached: the names can go, so that even a killed run leaves nothing in /dev/shm
+    if producer:
+        ring.unlink()
+    return dict(ring=ring, producer=producer, local_index=local_rank, local_world=local_world)

@@ -279,6 +279,12 @@ class ShmRing(object):
         if self.h:
             nat.lib().dsp_shm_ring_abort(self.h)
 
+    def unlink(self):
+        """creator, once every consumer has attached: drop the name (the memory lives as long as it is mapped)"""
+        if self.h and self.owner:
+            nat.lib().dsp_shm_ring_unlink(self.h)
+            self.owner = False
+
     def close(self):
         if self.h:
             nat.lib().dsp_shm_ring_close(self.h, 1 if self.owner else 0)

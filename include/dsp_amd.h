@@ -399,6 +399,7 @@ int32_t dsp_shm_ring_wait(dsp_shm_ring* r, uint64_t seq, double timeout_s, const
                           uint64_t* first_row, uint64_t* n_rows);
 int32_t dsp_shm_ring_release(dsp_shm_ring* r, uint64_t seq);
 void dsp_shm_ring_abort(dsp_shm_ring* r);
+void dsp_shm_ring_unlink(dsp_shm_ring* r);   /* creator: drop the name once everybody has attached (a killed run leaves nothing) */
 void dsp_shm_ring_close(dsp_shm_ring* r, int32_t unlink_it);
 
 /* ---- fast5 ingestion (csrc/dsp_fast5.cpp): what extract_features.py:44-91 (_get_label_raw), :94-176
