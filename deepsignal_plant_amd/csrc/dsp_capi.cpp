@@ -375,7 +375,9 @@ size_t ws_layout(const dsp_model* m, int64_t sites, long long* NTp_out, size_t o
     // cell-state scratch of the many-pass LSTM kernel (hidden > 256): one 8-wave workgroup per tile pair and direction =
     // NTp workgroups x passes x 64 KiB
     const int hmax = std::max(m->Hp, std::max(m->hseq_p, m->hsig_p));
-    off[6] = o; if (hmax > 256) o += (size_t)NTp * (size_t)(hmax / 256) * 65536;
+    // (the DSP_LSTM_NP8=2 experiment runs two passes of four waves on a hidden-256 layer: 64 KiB per workgroup as well)
+    const size_t cunits = std::max<size_t>(hmax > 256 ? (size_t)(hmax / 256) : 0, m->np8 == 2 ? 1 : 0);
+    off[6] = o; o += (size_t)NTp * cunits * 65536;
     if (NTp_out) *NTp_out = NTp;
     return o;
 }
