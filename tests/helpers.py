@@ -66,3 +66,27 @@ def f1_tolerances(name):
     if "_x4" in name or "_x3" in name:
         return 2e-6, 2e-5
     return 1e-6, 2e-5
+
+
+F8_CKPT = os.path.join(GOLDEN, "f8_trained_h128.ckpt")
+F8_ROWS = os.path.join(GOLDEN, "f8_trained_rows.tsv")
+
+
+def load_f8():
+    """F8 (tests/golden/make_golden_trained.py): a checkpoint the reference's own `train` wrote, 400 labelled rows, and the
+    reference model's outputs on them.  -> dict(cfg, w, inputs, states, logits, probs, logits0, probs0, labels, noise, raw);
+    inputs come from THIS build's row parser (the reference parsed the same text with dataloader.parse_a_line2)."""
+    import torch
+    from deepsignal_plant_amd import textio
+    d = np.load(os.path.join(GOLDEN, "f8_trained_expected.npz"))
+    cfg = onp.OracleConfig(**ast.literal_eval(str(d["cfg"])))
+    sd = torch.load(F8_CKPT, map_location="cpu")
+    w = {k: np.ascontiguousarray(v.numpy().astype(np.float32)) for k, v in sd.items()}
+    rows = textio.parse_rows(open(F8_ROWS, "rb").read(), cfg.seq_len, cfg.signal_len)
+    inputs = [rows.kmer.astype(np.float32), rows.means, rows.stds, rows.lens.astype(np.float32), rows.signals]
+    n = int(d["n"])
+    assert rows.n == n
+    states = onp.make_init_states(cfg, n, int(d["sseed"]))
+    return dict(cfg=cfg, w=w, inputs=inputs, states=states, logits=d["logits"], probs=d["probs"],
+                logits0=d["logits_zero_states"], probs0=d["probs_zero_states"], labels=d["labels"],
+                row_labels=np.asarray(rows.labels), noise=float(d["f64_dprob"]), n=n, raw=d)

@@ -566,3 +566,27 @@ def test_cli_other_model_shapes_match_the_cpu_restatement(tmp_path, model_type, 
                        init_mode="philox", seed=13)
     got = np.array([[float(x) for x in l.split("\t")[6:8]] for l in open(out).read().splitlines()])
     assert got.shape == (200, 2) and np.abs(got[:, 1] - po[:, 1] / (po[:, 0] + po[:, 1])).max() <= 2e-6
+
+
+def test_cli_reads_a_checkpoint_the_reference_trained(tmp_path):
+    """--model_path = the file the reference's `train` wrote (F8, hid_rnn 128): the per-read calls equal the reference
+    model's zero-state outputs after its own rounding (call_modifications.py:177-179), and the accuracy line of the run
+    (:171-173, :190) is the one the reference's numbers give"""
+    from tests.helpers import F8_CKPT, F8_ROWS, load_f8
+    f = load_f8()
+    out = os.path.join(str(tmp_path), "calls.tsv")
+    r = _run_cli(["-i", F8_ROWS, "-m", F8_CKPT, "-o", out, "--hid_rnn", "128", "--init_state", "zeros"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = open(out).read().splitlines()
+    assert len(lines) == f["n"]
+    got = np.array([[float(x) for x in l.split("\t")[6:8]] for l in lines])
+    p = f["probs0"].astype(np.float32)
+    want0 = np.around(p[:, 0] / (p[:, 0] + p[:, 1]), 6)
+    assert np.abs(got[:, 0] - want0).max() <= 2e-6
+    assert np.abs(got[:, 1] - (1 - want0)).max() <= 2e-6
+    lab = np.array([int(l.split("\t")[8]) for l in lines])
+    sure = np.abs(p[:, 1] - 0.5) >= 1e-4
+    assert np.array_equal(lab[sure], p.argmax(1)[sure])
+    # a wrong --hid_rnn must fail like the reference's strict load_state_dict, not call garbage
+    r = _run_cli(["-i", F8_ROWS, "-m", F8_CKPT, "-o", out + "2"])
+    assert r.returncode != 0 and "size mismatch" in (r.stderr + r.stdout)

@@ -399,3 +399,33 @@ def test_front_end_shapes(signal_len, is_base, is_signallen, hidden, module, wha
     d2 = np.abs(pp.cpu().numpy() - pq).max()
     print("%s: max|dprob| = %.3e (explicit states), %.3e (Philox states)" % (what, d, d2))
     assert d <= TOL_TIGHT and d2 <= TOL_TIGHT
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x9", "fp16x3"])
+def test_hip_matches_the_reference_on_the_checkpoint_it_trained(precision):
+    """F8 (tests/golden/make_golden_trained.py): weights out of the reference's own optimiser, saved by its own
+    torch.save, rows parsed by this build's parser; pinned N(0,1) states and zero states against the reference model's
+    outputs.  The one fixture whose weight statistics are a trained model's (tests/test_trained_fixture.py)."""
+    torch = _torch()
+    from tests.helpers import load_f8
+    f = load_f8()
+    m = build_model(f["cfg"], f["w"])
+    m.set_precision(precision)
+    ins = to_dev(f["inputs"])
+    st = {k: torch.from_numpy(v).cuda(0) for k, v in f["states"].items()}
+    logits, probs, labels = m.forward(*ins, init_states=st, want_labels=True)
+    m0 = build_model(f["cfg"], f["w"], init_state="zeros")
+    m0.set_precision(precision)
+    logits0, probs0 = m0.forward(*ins)
+    torch.cuda.synchronize()
+    dp = np.abs(probs.cpu().numpy() - f["probs"]).max()
+    dp0 = np.abs(probs0.cpu().numpy() - f["probs0"]).max()
+    print("F8 trained checkpoint, %s: HIP vs reference max|dprob| %.2e (pinned N(0,1) states) %.2e (zero states); "
+          "reference fp32 vs float64 %.2e; p1 in [%.3g, %.6f]" % (precision, dp, dp0, f["noise"], f["probs"][:, 1].min(),
+                                                                   f["probs"][:, 1].max()))
+    assert max(dp, dp0) <= TOL_PROB
+    assert max(dp, dp0) <= max(TOL_TIGHT, 4.0 * f["noise"])
+    sure = np.abs(f["probs"][:, 1] - 0.5) >= 1e-4
+    assert np.array_equal(labels.cpu().numpy()[sure], f["probs"].argmax(1)[sure])
+    called = (probs0.cpu().numpy()[:, 1] > 0.5).astype(int)
+    assert float((called == f["labels"]).mean()) == pytest.approx(float(f["raw"]["accuracy"]), abs=0.006)

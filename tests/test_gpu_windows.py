@@ -137,3 +137,37 @@ def test_site_keys_name_the_sites_for_the_initial_state_generator():
         p = m.forward(*ins, site_keys=kd)[1].clone()
         pp = m.forward(*[t[perm] for t in ins], site_keys=kd[perm])[1]
         assert torch.equal(pp, p[perm]), precision
+
+
+def test_handles_on_separate_streams_run_concurrently_with_unchanged_results():
+    """include/dsp_amd.h "Threading / ownership": one handle per stream for concurrent forwards.  Small batches (the
+    reference's default 512, call_modifications.py:147) fill 1/16 of the GPU each; six handles on six streams, issued
+    back to back so that their launches overlap on the device, must each return exactly what the same batch gives alone
+    (own scratch per handle, nothing shared but the read-only inputs) -- and against the oracle for one of them."""
+    torch = _torch()
+    from deepsignal_plant_amd import synth
+    from oracle import c_oracle as oc
+    from oracle import forward_np as onp
+    cfg = onp.OracleConfig()
+    w = onp.make_weights(cfg, 71, 2.0)
+    nh, n = 6, 512 + 37
+    models = [build_model(cfg, w, init_state="randn", seed=5) for _ in range(nh)]
+    batches = [synth.feature_batch(n, device="cuda:0", seed=300 + i) for i in range(nh)]
+    alone = []
+    for i in range(nh):
+        models[0].site_offset = 1000 * i
+        alone.append(models[0].forward(*batches[i])[1].clone())
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream("cuda:0") for _ in range(nh)]
+    for _ in range(5):   # several rounds: overlap is a matter of timing
+        outs = [None] * nh
+        for i in range(nh):
+            with torch.cuda.stream(streams[i]):
+                models[i].site_offset = 1000 * i
+                outs[i] = models[i].forward(*batches[i])[1]
+        torch.cuda.synchronize()
+        for i in range(nh):
+            assert torch.equal(outs[i], alone[i]), i
+    sample = [t.cpu().numpy() for t in batches[3]]
+    _, po = oc.forward(cfg, w, *sample, init_mode="philox", seed=5, site_offset=3000)
+    assert float(np.abs(outs[3].cpu().numpy() - po).max()) <= TOL_TIGHT
