@@ -232,6 +232,10 @@ def lib():
     L.dsp_format_feature_rows.restype = ctypes.c_int64
     L.dsp_format_feature_rows.argtypes = ([ctypes.c_void_p] * 9 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
                                           ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32])
+    L.dsp_format_feature_rows_parts.restype = ctypes.c_int64
+    L.dsp_format_feature_rows_parts.argtypes = L.dsp_format_feature_rows.argtypes + [ctypes.c_void_p, ctypes.c_void_p]
+    L.dsp_feature_row_bound.restype = ctypes.c_uint64
+    L.dsp_feature_row_bound.argtypes = [ctypes.c_int32, ctypes.c_int32]
     _lib = L
     return L
 

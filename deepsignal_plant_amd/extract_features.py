@@ -295,6 +295,7 @@ def extract_features(args):
     import gzip
     import os
     import queue
+    import sys
     import threading
     import time
     import torch
@@ -331,46 +332,101 @@ def extract_features(args):
     threading.Thread(target=load, daemon=True).start()
 
     is_dir, is_gzip = str2bool(args.w_is_dir), args.gzip
-    n_rows, file_count, batch_count = 0, 0, 0
-    writer = wf = None
+    n_rows = 0
+    writer = None
+    # three stages behind the loader thread: this thread runs the GPU half and brings the rows to the host, `sink`
+    # formats them (nthreads threads inside the library) and the writer's own thread appends the text to the file
+    # (plain: gzio.BackgroundFileWriter; --gzip: BgzfWriter deflates there as well)
+    sq = queue.Queue(maxsize=2)
+    sink_error = []
+    stage_s = {"wait for reads": 0.0, "gpu + to host": 0.0, "hand over": 0.0, "format": 0.0, "write (wait)": 0.0}  # DSP_TIMING=1
     if to_dspf:
         writer = featfile.FeatureFileWriter(args.write_path, args.seq_len, args.signal_len)
     else:
         from . import gzio
-        op = lambda p: gzio.open_write(p, is_gzip, nthreads=nthreads)  # --gzip: BGZF members (seekable by call_mods ranks)
+        op = lambda p: gzio.open_write(p, is_gzip, nthreads=nthreads, background=True)  # --gzip: BGZF members (seekable by call_mods ranks)
         if is_dir:  # :474-510
             if os.path.isfile(args.write_path):
                 raise FileExistsError("{} already exists as a file, please use another write_dir".format(args.write_path))
             os.makedirs(args.write_path, exist_ok=True)
-            wf = op(os.path.join(args.write_path, "0.tsv" + (".gz" if is_gzip else "")))
+            first_path = os.path.join(args.write_path, "0.tsv" + (".gz" if is_gzip else ""))
         else:  # :451-471
-            path = args.write_path + (".gz" if is_gzip and not args.write_path.endswith(".gz") else "")
-            wf = op(path)
+            first_path = args.write_path + (".gz" if is_gzip and not args.write_path.endswith(".gz") else "")
+
+        bufs = queue.Queue()
+        for _ in range(3):
+            bufs.put(None)
+
+        def sink():
+            wf = None
+            file_count, batch_count = 0, 0
+            try:
+                wf = op(first_path)
+                while True:
+                    rows = sq.get()
+                    if rows is None:
+                        break
+                    if is_dir and batch_count >= args.w_batch_num:
+                        wf.close()
+                        file_count += 1
+                        batch_count = 0
+                        wf = op(os.path.join(args.write_path, "%d.tsv%s" % (file_count, ".gz" if is_gzip else "")))
+                    t0 = time.time()
+                    # the formatting threads' parts go to the writer as they are, out of three rotating buffers: no
+                    # compaction, no fresh pages after the first batches (plain: appended; --gzip: deflated part by part)
+                    buf = bufs.get()
+                    parts, buf = textio.format_feature_rows_parts(rows, rows.means, rows.stds, rows.signals,
+                                                                  nthreads=nthreads, out=buf)
+                    t1 = time.time()
+                    wf.write(parts, on_done=lambda b=buf: bufs.put(b))
+                    stage_s["format"] += t1 - t0
+                    stage_s["write (wait)"] += time.time() - t1
+                    batch_count += 1
+            except BaseException as e:
+                sink_error.append(e)
+                while sq.get() is not None:  # drain so that the producer never blocks on a dead sink
+                    pass
+            finally:
+                if wf is not None:
+                    try:
+                        wf.close()
+                    except BaseException as e:
+                        if not sink_error:
+                            sink_error.append(e)
+        sink_thread = threading.Thread(target=sink, daemon=True)
+        sink_thread.start()
     try:
         while True:
+            t0 = time.time()
             item = rq.get()
+            t1 = time.time()
+            stage_s["wait for reads"] += t1 - t0
             if item is None:
+                break
+            if sink_error:
                 break
             out = fx.launch(item, f64=not to_dspf)
             if out.n == 0:
                 continue
             rows = out.to_host()
+            t2 = time.time()
+            stage_s["gpu + to host"] += t2 - t1
             if to_dspf:
                 writer.add(rows)
             else:
-                if is_dir and batch_count >= args.w_batch_num:
-                    wf.close()
-                    file_count += 1
-                    batch_count = 0
-                    wf = op(os.path.join(args.write_path, "%d.tsv%s" % (file_count, ".gz" if is_gzip else "")))
-                wf.write(textio.format_feature_rows(rows, rows.means, rows.stds, rows.signals, nthreads=nthreads))
-                batch_count += 1
+                sq.put(rows)
+            stage_s["hand over"] += time.time() - t2
             n_rows += out.n
     finally:
         if writer is not None:
             writer.close()
-        if wf is not None:
-            wf.close()
+        if not to_dspf:
+            sq.put(None)
+            sink_thread.join()
+    if sink_error:
+        raise sink_error[0]
+    if os.environ.get("DSP_TIMING"):
+        print("[extract] seconds per stage: " + ", ".join("%s %.2f" % kv for kv in stage_s.items()), file=sys.stderr)
     print("%d of %d read files failed.." % (batches.failed, len(files)))
     print("[main] extract_features costs %.1f seconds.. (%d feature rows)" % (time.time() - start, n_rows))
     return n_rows

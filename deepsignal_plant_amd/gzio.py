@@ -40,6 +40,9 @@ class BgzfWriter(object):
             data = self.q.get()
             if data is None:
                 return
+            if callable(data):   # write(..., on_done=): everything queued before it has been dealt with
+                data()
+                continue
             if self.error is not None:
                 continue  # drain
             if data is BgzfWriter._MARK:
@@ -68,9 +71,24 @@ class BgzfWriter(object):
             if self.error is not None:
                 raise self.error
 
-    def write(self, data):
+    def write(self, data, on_done=None):
+        """data: a buffer, or a list of buffers that go to the deflater as they are (no copy through the carry buffer; every
+        one ends its own member); on_done() runs on the writer's thread once they have been compressed and written --
+        the caller's signal that their memory may be reused (without it the caller must not touch a listed buffer again)"""
         if self.error is not None:
             raise self.error
+        if isinstance(data, (list, tuple)):
+            self._submit(final=True)
+            for piece in data:
+                if len(piece):
+                    self.q.put(piece)
+            if on_done is not None:
+                self.q.put(on_done)
+            if self.error is not None:
+                raise self.error
+            return sum(len(x) for x in data)
+        if on_done is not None:
+            raise ValueError("on_done needs a list of buffers")
         if not self.buf and len(data) >= self.chunk and len(data) % 0xff00 == 0:
             self.q.put(bytes(data))  # already member-aligned: no copy through the carry buffer
         else:
@@ -323,6 +341,62 @@ def read_text_chunks(path, chunk_bytes=64 << 20, nthreads=8):
         st.close()
 
 
-def open_write(path, is_gzip, nthreads=8, level=4):
-    """binary writer: plain file or BGZF"""
-    return BgzfWriter(path, level=level, nthreads=nthreads) if is_gzip else open(path, "wb")
+class BackgroundFileWriter(object):
+    """file-like, write-only, plain bytes: write() hands the buffer to a background thread that appends it to the file
+    (the page-cache copy of a gigabyte of rows takes as long as formatting the next one), so the caller must not modify
+    a buffer after writing it; errors surface at the next write() / close()."""
+
+    def __init__(self, path, depth=2):
+        import queue
+        import threading
+        self.f = open(path, "wb")
+        self.q = queue.Queue(maxsize=depth)
+        self.error = None
+        self.worker = threading.Thread(target=self._run, daemon=True)
+        self.worker.start()
+
+    def _run(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            data, on_done = item
+            if self.error is None:
+                try:
+                    for piece in (data if isinstance(data, (list, tuple)) else (data,)):
+                        self.f.write(piece)
+                except BaseException as e:
+                    self.error = e
+            if on_done is not None:
+                on_done()
+
+    def write(self, data, on_done=None):
+        """data: a buffer or a list of buffers (written in order); on_done() runs on the writer's thread once they are in
+        the file -- the caller's signal that their memory may be reused"""
+        if self.error is not None:
+            raise self.error
+        self.q.put((data, on_done))
+        return sum(len(x) for x in data) if isinstance(data, (list, tuple)) else len(data)
+
+    def close(self):
+        if self.f is None:
+            return
+        self.q.put(None)
+        self.worker.join()
+        self.f.close()
+        self.f = None
+        if self.error is not None:
+            raise self.error
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def open_write(path, is_gzip, nthreads=8, level=4, background=False):
+    """binary writer: plain file (background=True: written by its own thread) or BGZF"""
+    if is_gzip:
+        return BgzfWriter(path, level=level, nthreads=nthreads)
+    return BackgroundFileWriter(path) if background else open(path, "wb")

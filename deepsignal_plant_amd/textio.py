@@ -113,9 +113,10 @@ def format_calls(rows, probs, labels, nthreads=4, start=0, stop=None):
     return out[:k].tobytes()
 
 
-def format_feature_rows(rows, means, stds, signals, nthreads=4):
+def format_feature_rows(rows, means, stds, signals, nthreads=4, as_view=False):
     """bytes of the feature-TSV rows (extract_features.py:381-395) for `rows` (sampleinfo, kmer, lens, labels from
-    the ParsedRows; means / stds / signals as the float64 values the row prints)."""
+    the ParsedRows; means / stds / signals as the float64 values the row prints).  as_view: a memoryview of the
+    formatter's own buffer instead of a bytes copy (gigabytes per batch in `extract`)."""
     n = rows.n
     if n <= 0:
         return b""
@@ -134,4 +135,41 @@ def format_feature_rows(rows, means, stds, signals, nthreads=4):
                                           _ptr(stds), _ptr(lens), _ptr(signals), _ptr(labels), L, S, n, _ptr(out), cap,
                                           int(nthreads))
     k = nat.check(int(k))
-    return out[:k].tobytes()
+    return memoryview(out)[:k] if as_view else out[:k].tobytes()
+
+
+def feature_rows_capacity(rows):
+    """bytes format_feature_rows_parts needs for `rows` (worst case: every number at its longest)"""
+    n = rows.n
+    return int(rows.info_len[:n].sum()) + n * int(nat.lib().dsp_feature_row_bound(rows.seq_len, rows.signal_len))
+
+
+def format_feature_rows_parts(rows, means, stds, signals, nthreads=4, out=None):
+    """The same text as format_feature_rows, as a list of memoryviews into `out` (a uint8 array of at least
+    feature_rows_capacity(rows) bytes; allocated when None): every formatting thread leaves its rows where it wrote them,
+    so nothing is copied and a caller that reuses `out` touches no fresh memory.  -> (parts, out)"""
+    n = rows.n
+    if n <= 0:
+        return [], out
+    L, S = rows.seq_len, rows.signal_len
+    means = np.ascontiguousarray(means, np.float64)
+    stds = np.ascontiguousarray(stds, np.float64)
+    signals = np.ascontiguousarray(signals, np.float64)
+    kmer = np.ascontiguousarray(rows.kmer, np.uint8)
+    lens = np.ascontiguousarray(rows.lens, np.int32)
+    labels = np.ascontiguousarray(rows.labels, np.int32)
+    assert means.shape == (n, L) and stds.shape == (n, L) and signals.shape == (n, L, S)
+    cap = feature_rows_capacity(rows)
+    if out is None or out.nbytes < cap:
+        out = np.empty(cap, np.uint8)
+    nthreads = max(1, int(nthreads))
+    off = np.zeros(nthreads, np.uint64)
+    ln = np.zeros(nthreads, np.uint64)
+    tp, _, _keep = _buf_ptr(rows.text)
+    k = nat.lib().dsp_format_feature_rows_parts(tp, _ptr(rows.row_off[:n]), _ptr(rows.info_len[:n]), _ptr(kmer), _ptr(means),
+                                                _ptr(stds), _ptr(lens), _ptr(signals), _ptr(labels), L, S, n, _ptr(out),
+                                                out.nbytes, nthreads, _ptr(off), _ptr(ln))
+    k = nat.check(int(k))
+    mv = memoryview(out)
+    return [mv[int(off[t]):int(off[t]) + int(ln[t])] for t in range(k)], out
+

@@ -272,6 +272,16 @@ int64_t dsp_format_feature_rows(const char* text, const uint64_t* row_off, const
                                 const double* means, const double* stds, const int32_t* lens, const double* signals,
                                 const int32_t* labels, int32_t seq_len, int32_t signal_len, int64_t n, char* out,
                                 size_t out_cap, int32_t nthreads);
+/* The same rows, left where the formatting threads wrote them (no compaction, no allocation: `extract` keeps `out`
+ * across batches).  Thread t's rows start at out + part_off[t] and take part_len[t] bytes; the text is the parts in
+ * order.  out_cap >= sum(info_len) + n * dsp_feature_row_bound(seq_len, signal_len); part_off / part_len hold nthreads
+ * entries.  Returns the number of parts. */
+int64_t dsp_format_feature_rows_parts(const char* text, const uint64_t* row_off, const uint32_t* info_len,
+                                      const uint8_t* kmer, const double* means, const double* stds, const int32_t* lens,
+                                      const double* signals, const int32_t* labels, int32_t seq_len, int32_t signal_len,
+                                      int64_t n, char* out, size_t out_cap, int32_t nthreads, uint64_t* part_off,
+                                      uint64_t* part_len);
+uint64_t dsp_feature_row_bound(int32_t seq_len, int32_t signal_len);
 /* HOST side of the same stage: motif sites of every read (get_refloc_of_methysite_in_motif,
  * utils/process_utils.py:97-112), the +/- strand coordinates and window bounds of _extract_features
  * (:346-358) and the per-read region bounds [rg_lo, rg_hi) (NULL = no region).  All pointers are HOST pointers.

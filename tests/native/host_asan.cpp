@@ -116,6 +116,28 @@ int main(int argc, char** argv) {
         CHECK(dsp_format_feature_rows(tsv.data(), rows.row_off.data(), rows.info_len.data(), rows.kmer.data(), m.data(),
                                       s.data(), rows.lens.data(), g.data(), rows.labels.data(), 13, 16, nrows, o2.data(), 1000,
                                       4) == DSP_ENOMEM);
+        // the parts form: worst-case values (the longest float64 / int32) in an EXACTLY sized buffer -- ASan watches the end
+        for (auto& v : m) v = -2.2250738585072014e-308;
+        for (auto& v : g) v = -1.7976931348623157e308;
+        std::vector<int32_t> lmin(nrows * 13, INT32_MIN), labmin(nrows, INT32_MIN);
+        size_t cap = (size_t)nrows * dsp_feature_row_bound(13, 16);
+        for (int64_t r = 0; r < nrows; ++r) cap += rows.info_len[r];
+        std::vector<char> o3(cap);
+        uint64_t off[5], len[5];
+        const int64_t np = dsp_format_feature_rows_parts(tsv.data(), rows.row_off.data(), rows.info_len.data(), rows.kmer.data(),
+                                                         m.data(), m.data(), lmin.data(), g.data(), labmin.data(), 13, 16, nrows,
+                                                         o3.data(), o3.size(), 5, off, len);
+        CHECK(np >= 1 && np <= 5);
+        std::string joined;
+        for (int64_t t = 0; t < np; ++t) { CHECK(off[t] + len[t] <= cap); joined.append(o3.data() + off[t], len[t]); }
+        std::vector<char> o4(cap);
+        const int64_t k2 = dsp_format_feature_rows(tsv.data(), rows.row_off.data(), rows.info_len.data(), rows.kmer.data(), m.data(),
+                                                   m.data(), lmin.data(), g.data(), labmin.data(), 13, 16, nrows, o4.data(),
+                                                   o4.size(), 3);
+        CHECK(k2 == (int64_t)joined.size() && !memcmp(joined.data(), o4.data(), joined.size()));
+        CHECK(dsp_format_feature_rows_parts(tsv.data(), rows.row_off.data(), rows.info_len.data(), rows.kmer.data(), m.data(),
+                                            m.data(), lmin.data(), g.data(), labmin.data(), 13, 16, nrows, o3.data(), cap - 1, 5,
+                                            off, len) == DSP_ENOMEM);
     }
 
     // ---- feature container: write (several block sizes), read back, corrupt

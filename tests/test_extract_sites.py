@@ -80,6 +80,28 @@ def test_feature_row_formatter_reproduces_the_reference_rows():
         # the row prints means/stds rounded to 6 decimals, signals as they are
         got = textio.format_feature_rows(rows, np.around(g("means"), 6), np.around(g("stds"), 6), g("signals"), nthreads=3)
         assert got.decode().splitlines() == g("rows").tolist()
+        view = textio.format_feature_rows(rows, np.around(g("means"), 6), np.around(g("stds"), 6), g("signals"), nthreads=2,
+                                          as_view=True)   # the zero-copy form `extract` writes
+        assert isinstance(view, memoryview) and bytes(view) == got
+        # the form `extract` writes: every thread's rows left where it formatted them, in a buffer the caller keeps
+        buf = None
+        for nt in (1, 3, 64):
+            parts, buf = textio.format_feature_rows_parts(rows, np.around(g("means"), 6), np.around(g("stds"), 6), g("signals"),
+                                                          nthreads=nt, out=buf)
+            assert 1 <= len(parts) <= min(nt, n) and b"".join(bytes(x) for x in parts) == got
+            assert buf.nbytes >= textio.feature_rows_capacity(rows)
+    # the capacity is a true bound: the longest float64 and int32 there are, in every position
+    rows = textio.ParsedRows()
+    rows.text, rows.n, rows.seq_len, rows.signal_len = np.frombuffer(b"c\t1\t+\t2\tr\tt", np.uint8), 3, 5, 4
+    rows.info_len, rows.row_off = np.full(3, 11, np.uint32), np.zeros(3, np.uint64)
+    rows.kmer = np.zeros((3, 5), np.uint8)
+    rows.lens, rows.labels = np.full((3, 5), -2147483648, np.int32), np.full(3, -2147483648, np.int32)
+    worst = -2.2250738585072014e-308
+    m, sg = np.full((3, 5), worst), np.full((3, 5, 4), worst)
+    parts, buf = textio.format_feature_rows_parts(rows, m, m, sg, nthreads=3)
+    text = b"".join(bytes(x) for x in parts)
+    assert text == textio.format_feature_rows(rows, m, m, sg, nthreads=2)
+    assert len(text) <= textio.feature_rows_capacity(rows) and text.count(b"-2.2250738585072014e-308") == 3 * (5 + 5 + 20)
     # float64 -> str corner cases against numpy itself
     L = nat.lib()
     L.dsp_format_f64_.restype = ctypes.c_int

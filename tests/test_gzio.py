@@ -110,3 +110,41 @@ def test_streaming_inflater_reads_concatenated_members(tmp_path):
     st.close()
     assert textio.count_newlines(np.frombuffer(a, np.uint8)) == a.count(b"\n")
     assert textio.count_newlines(np.frombuffer(a[:-1], np.uint8)) == a.count(b"\n") - 1
+
+
+def test_background_file_writer_keeps_order_and_surfaces_errors(tmp_path):
+    """the plain-text writer of `extract`: buffers (bytes, memoryviews, arrays) appended by its own thread, in order"""
+    p = str(tmp_path / "o.tsv")
+    parts = [b"abc\n" * 1000, memoryview(b"defg\n" * 7), np.frombuffer(b"xyz\n" * 3, np.uint8), b""]
+    with gzio.open_write(p, False, background=True) as wf:
+        assert isinstance(wf, gzio.BackgroundFileWriter)
+        for x in parts:
+            wf.write(x)
+    assert open(p, "rb").read() == b"".join(bytes(x) for x in parts)
+    done = []
+    with gzio.open_write(p, False, background=True) as wf:   # lists of buffers, and the callback that frees them
+        wf.write([b"12", memoryview(b"34")], on_done=lambda: done.append(1))
+        wf.write(b"5", on_done=lambda: done.append(2))
+    assert open(p, "rb").read() == b"12345" and done == [1, 2]
+    wf = gzio.open_write(str(tmp_path / "e.tsv"), False, background=True)
+    wf.write("not bytes")            # the worker's TypeError must come back to the caller, not vanish
+    with pytest.raises(TypeError):
+        wf.close()
+
+
+def test_bgzf_writer_takes_lists_of_buffers_without_copying_them_through_the_carry(tmp_path):
+    """`extract --gzip`: the formatter's parts are deflated as they are; a part ends its own member, the file is still
+    one BGZF chain that any gzip reader reads, and on_done fires after the parts are in the file"""
+    p = str(tmp_path / "parts.tsv.gz")
+    a, b, c = _text(2), _text(1)[:70001], b"tail\n"
+    done = []
+    with gzio.open_write(p, True, nthreads=3) as wf:
+        wf.write(b"head\n")
+        wf.write([memoryview(a), np.frombuffer(b, np.uint8), b""], on_done=lambda: done.append(len(done)))
+        wf.write(c)
+        wf.write([c, c], on_done=lambda: done.append(len(done)))
+        with pytest.raises(ValueError):
+            wf.write(c, on_done=lambda: None)
+    want = b"head\n" + a + b + c + c + c
+    assert gzip.open(p, "rb").read() == want and done == [0, 1]
+    assert gzio.BgzfFile(p).ok

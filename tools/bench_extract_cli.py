@@ -29,15 +29,18 @@ def main():
         path = os.path.join(work, out)
         t0 = time.time()
         r = subprocess.run([sys.executable, "-m", "deepsignal_plant_amd.deepsignal_plant", "extract", "-i", os.path.join(work, "reads"),
-                            "-o", path, "-p", "16", "--f5_batch_size", "32"] + extra, cwd=ROOT, capture_output=True, text=True)
+                            "-o", path, "-p", "16", "--f5_batch_size", "32"] + extra, cwd=ROOT, capture_output=True, text=True,
+                           env=dict(os.environ, DSP_TIMING="1"))
         wall = time.time() - t0
         assert r.returncode == 0, r.stderr[-3000:]
         inner = [l for l in r.stdout.splitlines() if "extract_features costs" in l][0]
         secs = float(inner.split("costs")[1].split("seconds")[0])
         rows = int(inner.split("(")[1].split()[0])
         real = path + (".gz" if extra and not path.endswith(".gz") else "")
+        stages = [l.split(": ", 1)[1] for l in r.stderr.splitlines() if l.startswith("[extract] seconds per stage")]
         print(json.dumps({"extract_to": kind, "reads": n_reads, "samples": samples, "rows": rows, "out_mb": round(os.path.getsize(real) / 1e6, 1),
-                          "extract_s": secs, "process_wall_s": round(wall, 2), "rows_per_s": round(rows / secs, 1)}), flush=True)
+                          "extract_s": secs, "process_wall_s": round(wall, 2), "rows_per_s": round(rows / secs, 1),
+                          "stage_seconds": stages[0] if stages else None}), flush=True)
     shutil.rmtree(work, ignore_errors=True)
 
 
