@@ -23,10 +23,8 @@ which extracts features on the GPU from read records: _call_mods_reads).
 from __future__ import annotations
 
 import argparse
-import gzip
 import os
 import queue
-import shutil
 import sys
 import threading
 import time
@@ -37,6 +35,14 @@ from . import dist as dsp_dist
 from . import featfile, feed, gzio, textio
 from .models import ModelBiLSTM
 from .utils.process_utils import display_args, str2bool
+
+
+_TICKS = []   # DSP_TIMING=1: (label, seconds since call_mods started) of the run's milestones, printed by rank 0 at the end
+
+
+def _tick(label):
+    if os.environ.get("DSP_TIMING"):
+        _TICKS.append((label, time.time()))
 
 
 def _get_gpus():
@@ -130,6 +136,7 @@ def _call_mods_file(args, rank, local_rank, world):
     # control-plane collectives run on the GPU over RCCL, or on the host when the ranks had to fall back to gloo
     coll_dev = dev if (dsp_dist.collective(world) and dist.get_backend() == "nccl") else None
     model = load_model(args, local_rank)
+    _tick("model loaded")
     input_path = os.path.abspath(args.input_path)
     nthreads = dsp_dist.threads_per_rank(args.nproc)   # --nproc, capped by this rank's share of the node's CPUs
 
@@ -175,7 +182,9 @@ def _call_mods_file(args, rank, local_rank, world):
     writer = _Writer(part_path, args.gzip, nthreads, reader, freq)
     writer.mark_blocks = interleaved
     cap = reader.cap
+    _tick("reader built")
     model.reserve(cap)
+    _tick("workspace reserved")
     reader.start()
     writer.start()
     stream = torch.cuda.current_stream(dev)
@@ -186,9 +195,12 @@ def _call_mods_file(args, rank, local_rank, world):
     out_events = [torch.cuda.Event() for _ in range(nout)]
     k = 0
     n_rows = 0
+    _tick("pinned output buffers")
     for block in reader:
         if writer.error is not None:
             break
+        if k == 0:
+            _tick("first block parsed")
         rows = block.rows
         n = rows.n
         if n == 0:
@@ -226,12 +238,15 @@ def _call_mods_file(args, rank, local_rank, world):
         writer.q.put((block, out_probs[slot], out_labels[slot], out_events[slot]))
         k += 1
         n_rows += n
+    _tick("last forward issued")
     writer.q.put(None)
     writer.join()
     torch.cuda.synchronize(dev)
+    _tick("writer joined")
     if writer.error is not None:
         raise writer.error
     _finish_freq(args, freq, freq_dev, rank, world)
+    _tick("frequencies finished")
     if gz_ring is not None:
         gz_ring["ring"].close()
     if interleaved:
@@ -467,6 +482,8 @@ def call_mods(args):
         return None
     print("[main] call_mods starts..")
     start = time.time()
+    del _TICKS[:]
+    _tick("start")
     import torch
     from . import _native
     _native.lib()  # fail loudly before any work if the HIP library is missing
@@ -493,6 +510,7 @@ def call_mods(args):
     # one process per GPU over RCCL (gloo when ranks have to share GPUs; DSP_FORCE_DIST=1: a one-rank RCCL group)
     dsp_dist.init_process_group(world, rank, local_rank, ndev)
     dist_on = dsp_dist.collective(world)
+    _tick("imports, checks, process group")
     if os.path.isdir(input_path):  # reads in, calls out: extraction + forward on the GPU (:559-583)
         n_rows, part_path, out_path = _call_mods_reads(args, rank, local_rank, world)
     else:
@@ -526,6 +544,9 @@ def call_mods(args):
         dist.destroy_process_group()
     if rank == 0:
         dt = time.time() - start
+        if _TICKS:
+            _tick("merged / finished")
+            print("[call_mods] seconds at: " + ", ".join("%s %.2f" % (k, t - start) for k, t in _TICKS[1:]), file=sys.stderr)
         print("[main] call_mods costs %.2f seconds.." % dt)
         print("[main] %d sites on %d GPU(s): %.0f sites/s" % (total, world, total / max(dt, 1e-9)))
     return total

@@ -292,7 +292,6 @@ def extract_features(args):
     """Reads in (a directory of *.fast5 / *.reads.npz), feature rows out: the reference's `extract`.
     Output: the feature TSV (plain / --gzip / --w_is_dir batches, byte-compatible with _features_to_str), or the
     binary container when --write_path ends with .dspf (what call_mods reads fastest)."""
-    import gzip
     import os
     import queue
     import sys

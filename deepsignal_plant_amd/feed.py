@@ -9,7 +9,6 @@ issues async H2D copies on a HIP stream.  NBUF buffer sets rotate, so parse(k+1)
 format/write(k-1) overlap."""
 from __future__ import annotations
 
-import gzip
 import mmap
 import os
 import queue

@@ -1,6 +1,5 @@
 """CPU: the C-ABI library loads and exports every symbol include/dsp_amd.h declares (no compute calls),
 and its metadata entry points agree with the oracle's spec."""
-import ctypes
 import os
 import re
 

@@ -11,6 +11,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def timeline(stderr):
+    """the run's milestones (DSP_TIMING=1: seconds since call_mods started)"""
+    lines = [l.split(": ", 1)[1] for l in stderr.splitlines() if l.startswith("[call_mods] seconds at")]
+    return lines[0] if lines else None
+
+
 def main():
     import torch
     from deepsignal_plant_amd import synth
@@ -29,7 +35,8 @@ def main():
             out = os.path.join(work, "calls_%d.tsv" % n)
             t0 = time.time()
             r = subprocess.run([sys.executable, "-m", "deepsignal_plant_amd.deepsignal_plant", "call_mods", "-i", tsv, "-m", ck,
-                                "-o", out, "-p", str(nproc)], cwd=ROOT, capture_output=True, text=True)
+                                "-o", out, "-p", str(nproc)], cwd=ROOT, capture_output=True, text=True,
+                               env=dict(os.environ, DSP_TIMING="1"))
             wall = time.time() - t0
             assert r.returncode == 0, r.stderr[-3000:]
             inner = [l for l in r.stdout.splitlines() if "call_mods costs" in l][0]
@@ -38,7 +45,8 @@ def main():
             assert rows == n
             print(json.dumps({"rows": n, "tsv_mb": round(os.path.getsize(tsv) / 1e6, 1), "parse_threads": nproc,
                               "call_mods_s": secs, "process_wall_s": round(wall, 2), "sites_per_s": round(n / secs, 1),
-                              "text_mb_per_s": round(os.path.getsize(tsv) / 1e6 / secs, 1), "gen_s": round(gen, 1)}), flush=True)
+                              "text_mb_per_s": round(os.path.getsize(tsv) / 1e6 / secs, 1), "gen_s": round(gen, 1),
+                              "timeline": timeline(r.stderr)}), flush=True)
             os.remove(out)
         # the same rows as a binary feature container (pack_features): no parsing on the call_mods side
         packed = os.path.join(work, "feat_%d.dspf" % n)
@@ -51,7 +59,8 @@ def main():
             out = os.path.join(work, "calls_%d.tsv" % n)
             t0 = time.time()
             r = subprocess.run([sys.executable, "-m", "deepsignal_plant_amd.deepsignal_plant", "call_mods", "-i", packed,
-                                "-m", ck, "-o", out, "-p", "16"], cwd=ROOT, capture_output=True, text=True)
+                                "-m", ck, "-o", out, "-p", "16"], cwd=ROOT, capture_output=True, text=True,
+                               env=dict(os.environ, DSP_TIMING="1"))
             wall = time.time() - t0
             assert r.returncode == 0, r.stderr[-3000:]
             inner = [l for l in r.stdout.splitlines() if "call_mods costs" in l][0]
@@ -59,7 +68,7 @@ def main():
             assert sum(1 for _ in open(out)) == n
             print(json.dumps({"rows": n, "input": "dspf", "dspf_mb": round(os.path.getsize(packed) / 1e6, 1),
                               "pack_s": round(pack_s, 2), "call_mods_s": secs, "process_wall_s": round(wall, 2),
-                              "sites_per_s": round(n / secs, 1)}), flush=True)
+                              "sites_per_s": round(n / secs, 1), "timeline": timeline(r.stderr)}), flush=True)
             os.remove(out)
         os.remove(packed)
 

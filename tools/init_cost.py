@@ -1,4 +1,4 @@
-import os, sys
+import sys
 sys.path.insert(0, "/root/repo")
 import torch
 from deepsignal_plant_amd import synth
