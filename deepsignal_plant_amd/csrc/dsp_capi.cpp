@@ -290,6 +290,10 @@ struct dsp_model {
     int np8 = 1;          // DSP_LSTM_NP8: passes per step for layers of exactly 8 unit tiles (hidden 193..256): 1 = one
                           // 8-wave workgroup per 64 sites; 2 = 4-wave workgroups, two unit tiles per wave and step (A/B switch)
     bool phase_prio = true;  // s_setprio by phase in the LSTM kernel (DSP_LSTM_PRIO=0 turns it off: A/B switch)
+    int tiling21 = -1;       // <2 unit tiles, 1 site tile> per wave on the dense one-pass layers (dsp_lstm21_kernel): -1 = for
+                             // batches whose 32-site tiles x 2 directions fit the CUs at once (small-batch latency); DSP_LSTM_TILING=21
+                             // always, =0 never (A/B switch)
+    int n_cus = 256;         // compute units of the handle's device
     bool fp16_safe = true;         // every operand of the combined stack provably inside the fp16 range (fp16x3 only then)
     int precision = DSP_PREC_FP32; // products of the combined stack: fp32 MFMA, or split-bf16 emulation (dsp_lstm6_kernel)
     // scratch
@@ -467,7 +471,13 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
         a.seed = init ? init->seed : 0; a.site_offset = init ? init->site_offset : 0;
         a.site_keys = (init && init->mode == DSP_INIT_PHILOX) ? (const unsigned long long*)init->site_keys : nullptr;
         a.stream_base = lstm_id * 64 + (int)k * 4;
-        a.flags = m->phase_prio ? 1 : 0;
+        // small batches: 32-site workgroups of UT/2 waves put twice as many CUs to work and halve the launch's latency (a
+        // batch of 512 sites: 32 workgroups of one wave per SIMD instead of 16 of two); from the size where every CU has
+        // its 64-site workgroup the shipped tiling is the faster one (0.25 %: dsp_kernels.hip)
+        const bool use21 = m->tiling21 > 0 || (m->tiling21 < 0 && L.NTp * 2 <= (long long)m->n_cus);
+        // (automatic choice: one such workgroup per CU -- bit 2 -- so that forwards issued concurrently on other streams
+        // spread over the idle CUs instead of doubling up on busy ones)
+        a.flags = (m->phase_prio ? 1 : 0) | (use21 ? 2 : 0) | (use21 && m->tiling21 < 0 ? 4 : 0);
         if (m->trace_launch >= 0 && m->trace_launch == m->lstm_launch_no) a.flags |= 256 | (m->trace_wave << 9);  // DSP_TRACE builds
         ++m->lstm_launch_no;
         if (a.init_mode == DSP_INIT_EXPLICIT) {
@@ -573,6 +583,11 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
     if (const char* v = getenv("DSP_LSTM_SG")) m->sg_override = atoi(v);  // A/B switch
     if (const char* v = getenv("DSP_LSTM_NP8")) m->np8 = atoi(v) == 2 ? 2 : 1;  // A/B switch
     if (const char* v = getenv("DSP_LSTM_PRIO")) m->phase_prio = atoi(v) != 0;    // A/B switch
+    if (const char* v = getenv("DSP_LSTM_TILING")) m->tiling21 = atoi(v) == 21 ? 1 : 0;   // A/B switch
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) m->n_cus = prop.multiProcessorCount;
+    }
     if (const char* v = getenv("DSP_PRECISION"))
         m->precision = !strcmp(v, "bf16x6") ? DSP_PREC_BF16X6 : (!strcmp(v, "bf16x9") ? DSP_PREC_BF16X9 :
                        (!strcmp(v, "fp16x3") ? DSP_PREC_FP16X3 : DSP_PREC_FP32));

@@ -46,7 +46,7 @@ struct LstmArgs {
     int NP;                // passes over the unit tiles per time step (UT / 8 above 8 unit tiles, else 1); block = 64*(UT/NP)*SG threads
     int init_mode;         // DSP_INIT_*
     int stream_base;       // philox stream of (lstm, layer, dir=0, h): lstm*64 + layer*4
-    int flags;             // bit 0: issue priority by phase (k-loop 2, cell 0); bit 8: stamp this launch, bits 9..11: its stamping wave (DSP_TRACE builds only)
+    int flags;             // bit 0: issue priority by phase (k-loop 2, cell 0); bit 1: <2 unit tiles, 1 site tile> per wave; bit 2: ... and one such workgroup per CU; bit 8: stamp this launch, bits 9..11: its stamping wave (DSP_TRACE builds only)
 };
 
 struct LinArgs {

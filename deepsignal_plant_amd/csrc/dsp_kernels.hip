@@ -226,8 +226,9 @@ __device__ __forceinline__ f32x4 init_state4(const float* src, int mode, long lo
 //     bst16 / gst16 (store, s_nop 1, data registers held live across the nop) and the build fails if the pattern appears
 //     in the assembly (tools/check_store_hazard.py, tests/test_store_hazard.py).  The shipped round-2 binaries held the
 //     pattern twice (the NP = 2 kernels, zeros overwriting stored zeros: harmless) and 19 times at one wait state (safe).
-//     Rebuilt in round 3 with guarded stores (commit cc91d02, reverted): bit-identical results, 0.25 % SLOWER than this
-//     tiling in an alternating same-box A/B -- the +0.6 % of round 2 did not survive.
+//     Rebuilt in round 3 with guarded stores (dsp_lstm21_kernel below): bit-identical results, 0.25 % SLOWER than this
+//     tiling on full batches in an alternating same-box A/B -- the +0.6 % of round 2 did not survive -- but HALF the
+//     latency on batches that leave CUs idle, which is where it runs.
 //     The exchange itself -- stores, ONE s_barrier without s_waitcnt vmcnt(0), loads by the other waves -- showed 0
 //     mismatches in 3e11 checked values with guarded stores, for 4- and 8-wave workgroups, with and without vmcnt(0), and
 //     also when the destination rows had been pulled into the CU's L1 before the stores (no stale lines).
@@ -551,6 +552,176 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
             }
         }
         TSTAMP(3);
+    }
+#undef QW
+}
+
+// ------------------------------------------------------------------------------------------------
+// dsp_lstm21_kernel (round 3; dense one-pass layers with an even unit-tile count): the other way to cut a step's
+// 8 unit tiles x 2 site tiles among waves -- a wave owns TWO unit tiles x ONE site tile (still 8 accumulator tiles), a
+// workgroup is UT/2 waves for 32 sites.  Same data layout, weights, cell arithmetic and summation order per accumulator
+// as dsp_lstm_kernel<0, 1>: bit-identical results (test_small_batch_tiling_does_not_change_a_bit).
+// WHERE IT RUNS: batches whose 32-site tiles x 2 directions fit the CUs at once (<= 4,096 sites on 256 CUs; the host
+// decides per call, dsp_capi.cpp).  A forward of up to 8,192 sites is ONE round of 64-site workgroups and takes 6.6 ms
+// whatever its size; with 32-site workgroups of one wave per SIMD a round takes half as long: 3.7 ms per forward, 512
+// sites 77 k -> 137 k sites/s, 2,048 sites 0.31 -> 0.54 M (profiles/r3/batch_sweep.jsonl).  In that mode the launch asks
+// for more than half a CU's LDS (flags bit 2), so that one workgroup sits on a CU: forwards issued concurrently on other
+// streams then spread over the idle CUs instead of doubling up on busy ones (4 x 512 sites: 0.30 -> 0.49 M sites/s,
+// 16 x 512: 0.88 -> 0.99 M; profiles/r3/small_batches.jsonl).
+// ON FULL BATCHES (DSP_LSTM_TILING=21 forces it, =0 forbids it: A/B switch) two independent 4-wave workgroups share a CU
+// and one's barrier / cell phase runs under the other's k-loop, but an A fragment feeds 4 MFMAs instead of 8 (twice the
+// weight stream out of L2 per site): 0.25 % slower than <1, 2>, same-box A/B.  Round 2 measured +0.6 % with a build whose
+// h0 read-back was corrupted by the store-data hazard (see bst16); with guarded stores it is sound.
+// 8 A fragments per k-group, ring two k-groups deep (64 VGPRs), B ring four deep (16 VGPRs); 246 VGPRs, no spills.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void dsp_lstm21_kernel(LstmArgs a) {
+    constexpr int NF = 8;                  // A fragments per k-group: 2 unit tiles x 4 gates
+    constexpr int DA = 2, DB = 4;          // ring depths in k-groups
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nthr = blockDim.x;
+    f32x4* c_lds = (f32x4*)smem;           // [2 unit tiles][4 groups][nthr] float4
+    f32x4* b_lds = c_lds + 8 * nthr;       // [unit tile][aa][gate][half] float4
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const uint32_t voff = (uint32_t)lane * 16u;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int UTW = a.UT / 2;              // waves per site tile
+    const int ug = w % UTW, sg = w / UTW;
+    const int dir = blockIdx.x & 1;
+    const int grp = blockIdx.x >> 1;
+    const int half = lane >> 5, ls = lane & 31;
+    const int HQ = a.Hp >> 2;
+    const int nqx = a.Ipad >> 3, nq = nqx + (a.Hp >> 3), NQ = a.NQ;
+    const int T = a.T;
+    const int F4 = a.Fout >> 2;
+    const uint32_t xrow = (uint32_t)(a.Ipad >> 2) * 512u;
+    const uint32_t orow = (uint32_t)F4 * 512u;
+    const uint32_t ustride = (uint32_t)NQ * 4096u;   // bytes between the wave's two (adjacent) unit tiles in wpk
+    const bool prio = (a.flags & 1) != 0;
+    const int u0 = 2 * ug;
+
+    const long long gt0 = (long long)grp * a.SG + sg;   // this wave's site tile
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc((const char*)(dir ? a.wpk1 : a.wpk0) + (size_t)u0 * NQ * 4096);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)a.x + (size_t)gt0 * T * xrow);
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)a.out + (size_t)gt0 * T * orow + (size_t)dir * HQ * 512);
+    const __amdgpu_buffer_rsrc_t rh0 = make_rsrc((const char*)a.h0buf + (size_t)gt0 * orow + (size_t)dir * HQ * 512);
+    const f32x4* bias4 = (const f32x4*)(dir ? a.sbias1 : a.sbias0);
+
+    for (int i = tid; i < a.Hp; i += nthr) {
+        const int h = i & 1, g = (i >> 1) & 3, aa = (i >> 3) & 3, ut = i >> 5;
+        b_lds[i] = bias4[g * HQ + ut * 8 + 2 * aa + h];
+    }
+    {
+        const long long site = gt0 * 32 + ls;
+        const uint64_t skey = a.init_mode == 2 ? philox_site_key(a.site_keys, a.site_offset, a.n, site) : 0;
+#pragma unroll
+        for (int ut = 0; ut < 2; ++ut) {
+            const int u = u0 + ut;
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa) {
+                const int k4 = u * 8 + 2 * aa + half;
+                f32x4 hv = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
+                if (a.init_mode != 0) {
+                    hv = init_state4(a.h0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, skey, (uint32_t)(a.stream_base + dir * 2 + 0));
+                    cv = init_state4(a.c0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, skey, (uint32_t)(a.stream_base + dir * 2 + 1));
+                }
+                bst16(rh0, voff + aa * 1024u, (uint32_t)u * 4096u, hv);
+                c_lds[(ut * 4 + aa) * nthr + tid] = cv;
+            }
+        }
+    }
+    barrier_after_global_stores();
+
+    __amdgpu_buffer_rsrc_t rhp = rh0;
+    uint32_t xo = 0, ho = 0;
+    auto set_bases = [&](int step) __attribute__((always_inline)) {
+        const int t = dir ? (T - 1 - step) : step;
+        const int tp = dir ? (t + 1) : (t - 1);
+        rhp = step == 0 ? rh0 : ro;
+        xo = (uint32_t)t * xrow;
+        ho = (step == 0 ? 0u : (uint32_t)tp * orow) - (uint32_t)nqx * 1024u;
+    };
+    f32x4 A[DA][NF], B[DB];
+    f32x16 acc[NF];
+    auto loadB = [&](f32x4& Bs, int q) __attribute__((always_inline)) {
+        const int qc = q < nq ? q : nq - 1;
+        const bool isx = qc < nqx;
+        Bs = bld16(isx ? rx : rhp, voff, (isx ? xo : ho) + (uint32_t)qc * 1024u);
+    };
+    auto ldA = [&](int f, int q) __attribute__((always_inline)) {   // fragment f = unit tile f / 4, gate f % 4
+        const uint32_t so = (uint32_t)(f >> 2) * ustride + (uint32_t)(q < NQ ? q : q - NQ) * 4096u;
+        return bld16(rw, voff + (uint32_t)(f & 3) * 1024u, so);
+    };
+#define QW(x) ((x) < NQ ? (x) : (x) - NQ)
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto stage = [&](auto qs, int q, auto first) __attribute__((always_inline)) {
+        constexpr int QS = decltype(qs)::value;
+        constexpr int sa = QS % DA, sp = (QS + DA - 1) % DA, sb = QS % DB;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (decltype(first)::value && i == 0)
+                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[sa][f][i], B[sb][i], zero16, 0, 0, 0);
+                else
+                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[sa][f][i], B[sb][i], acc[f], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (f == 0) A[sp][NF - 1] = ldA(NF - 1, q + DA - 1);
+            else A[sa][f - 1] = ldA(f - 1, q + DA);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto stage4 = [&](int q, auto first) __attribute__((always_inline)) {
+        stage(ic<0>{}, q + 0, first); loadB(B[0], QW(q + 0 + DB)); __builtin_amdgcn_sched_barrier(0);
+        stage(ic<1>{}, q + 1, std::false_type{}); loadB(B[1], QW(q + 1 + DB)); __builtin_amdgcn_sched_barrier(0);
+        stage(ic<2>{}, q + 2, std::false_type{}); loadB(B[2], QW(q + 2 + DB)); __builtin_amdgcn_sched_barrier(0);
+        stage(ic<3>{}, q + 3, std::false_type{}); loadB(B[3], QW(q + 3 + DB)); __builtin_amdgcn_sched_barrier(0);
+    };
+
+    set_bases(0);
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+        if (d < DA) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) A[d][f] = ldA(f, d);
+        }
+        loadB(B[d], d);
+    }
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? (T - 1 - step) : step;
+        if (step > 0) barrier_after_global_stores();
+        if (prio) __builtin_amdgcn_s_setprio(2);
+        stage4(0, std::true_type{});
+        for (int q = 4; q < NQ - 4; q += 4) stage4(q, std::false_type{});
+        set_bases(step + 1 < T ? step + 1 : step);
+        stage4(NQ - 4, std::false_type{});
+        A[DA - 1][NF - 1] = ldA(NF - 1, NQ + DA - 1);
+        if (prio) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int ut = 0; ut < 2; ++ut) {
+            const int u = u0 + ut;
+            const f32x4* b_my = b_lds + (size_t)u * 32 + half;
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa) {
+                const f32x4 bi = b_my[aa * 8 + 0], bf = b_my[aa * 8 + 2], bg = b_my[aa * 8 + 4], bo = b_my[aa * 8 + 6];
+                f32x4 cv = c_lds[(ut * 4 + aa) * nthr + tid];
+                f32x4 hv;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 4 * aa + i;
+                    const float ig = sigmoid_pre(acc[ut * 4 + 0][r], bi[i]);
+                    const float fg = sigmoid_pre(acc[ut * 4 + 1][r], bf[i]);
+                    const float gg = tanh_pre(acc[ut * 4 + 2][r], bg[i]);
+                    const float og = sigmoid_pre(acc[ut * 4 + 3][r], bo[i]);
+                    const float cn = __builtin_fmaf(fg, cv[i], ig * gg);
+                    cv[i] = cn;
+                    hv[i] = og * fast_tanh(cn);
+                }
+                c_lds[(ut * 4 + aa) * nthr + tid] = cv;
+                bst16(ro, voff + aa * 1024u, (uint32_t)t * orow + (uint32_t)u * 4096u, hv);
+            }
+        }
     }
 #undef QW
 }
@@ -1015,7 +1186,7 @@ __global__ __launch_bounds__(256, 2) void dsp_head_kernel(HeadArgs a) {
 extern "C" int dsp_k_init(void) {
     const void* fns[] = {(const void*)dsp_lstm_kernel<0, 1>, (const void*)dsp_lstm_kernel<1, 1>,
                          (const void*)dsp_lstm_kernel<2, 1, 1>, (const void*)dsp_lstm_kernel<2, 1, 2>, (const void*)dsp_lstm_kernel<2, 1, 3>,
-                         (const void*)dsp_lstm_kernel<0, 0>, (const void*)dsp_lstm_kernel<1, 0>,
+                         (const void*)dsp_lstm_kernel<0, 0>, (const void*)dsp_lstm_kernel<1, 0>, (const void*)dsp_lstm21_kernel,
                          (const void*)dsp_lstm6_kernel<6>, (const void*)dsp_lstm6_kernel<9>, (const void*)dsp_lstm6_kernel<3>};
     for (const void* f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1033,6 +1204,18 @@ extern "C" int dsp_k_pack(const PackArgs* a, hipStream_t s) {
 
 // a wave owns one unit tile (per pass) x two site tiles; a->SG site groups (of two tiles) per workgroup; a->NP passes
 extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
+    if ((a->flags & 2) && a->NP <= 1 && a->UT >= 2 && a->UT % 2 == 0 && a->nqx_lo == 0 && a->nqx_used == (a->Ipad >> 3) &&
+        a->NQ == ((a->Ipad + a->Hp) >> 3) && (a->Ipad >> 3) >= 4) {
+        // <2 unit tiles, 1 site tile> per wave: UT/2 waves x SG single-tile site groups per workgroup
+        const int sg = a->UT >= 8 ? 1 : 8 / a->UT;
+        LstmArgs b = *a;
+        b.SG = sg;
+        const int threads = (a->UT / 2) * sg * 64;
+        size_t lds = (size_t)8 * threads * 16 + (size_t)a->Hp * 16;
+        if (a->flags & 4) lds = lds < 84 * 1024 ? 84 * 1024 : lds;   // more than half a CU's LDS: one workgroup per CU
+        hipLaunchKernelGGL(dsp_lstm21_kernel, dim3((unsigned)(a->NTp / sg) * 2), dim3(threads), lds, s, b);
+        return (int)hipGetLastError();
+    }
     const int np = a->NP < 1 ? 1 : a->NP;   // 1, 2: the cell state in LDS; more: in a->cbuf (dsp_lstm_kernel<., 0>)
     const int threads = (a->UT / np) * a->SG * 64;
     const unsigned groups = (unsigned)(a->NTp / (a->SG * 2));

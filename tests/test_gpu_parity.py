@@ -429,3 +429,45 @@ def test_hip_matches_the_reference_on_the_checkpoint_it_trained(precision):
     assert np.array_equal(labels.cpu().numpy()[sure], f["probs"].argmax(1)[sure])
     called = (probs0.cpu().numpy()[:, 1] > 0.5).astype(int)
     assert float((called == f["labels"]).mean()) == pytest.approx(float(f["raw"]["accuracy"]), abs=0.006)
+
+
+@pytest.mark.parametrize("kw,label", [
+    (dict(), "configs1"),
+    (dict(module="seq_bilstm", num_layers1=2), "configs2_seq_only"),
+    (dict(hidden_size=128), "hidden128_UT4"),
+    (dict(hidden_size=64, num_layers1=2), "hidden64_UT2"),
+    (dict(hidden_size=160), "hidden160_UT6"),
+    (dict(hidden_size=32, num_layers1=1), "hidden32_UT1_not_eligible"),
+])
+def test_small_batch_tiling_does_not_change_a_bit(kw, label, monkeypatch):
+    """Batches whose 32-site tiles x 2 directions fit the CUs at once (<= 4,096 sites on 256 CUs) run the combined stack
+    with <2 unit tiles, 1 site tile> per wave (dsp_lstm21_kernel: twice the workgroups, half the latency of a launch);
+    larger ones with the shipped <1, 2> tiling.  Same fragments, same order of every sum: DSP_LSTM_TILING=0 (never) and
+    =21 (always) give the bytes of the automatic choice at every size around the switch, with N(0,1) Philox states, and
+    the oracle agrees.  (Round 2's build of this tiling returned wrong h0 for some lanes: the store-data hazard,
+    DESIGN.md section 3a; the guarded stores are what this test now also watches.)"""
+    torch = _torch()
+    from deepsignal_plant_amd import synth
+    from oracle import c_oracle as oc
+    from oracle import forward_np as onp
+    cfg = onp.OracleConfig(**kw)
+    w = onp.make_weights(cfg, 91, 2.0)
+    sizes = (1, 33, 513, 2000, 4096, 4097, 8200)
+    ins = {n: synth.feature_batch(n, device="cuda:0", seed=400 + n) for n in sizes}
+    res = {}
+    for mode in (None, "0", "21"):
+        if mode is None:
+            monkeypatch.delenv("DSP_LSTM_TILING", raising=False)
+        else:
+            monkeypatch.setenv("DSP_LSTM_TILING", mode)
+        m = build_model(cfg, w, init_state="randn", seed=17)
+        for n in sizes:
+            m.site_offset = 10 * n
+            res[mode, n] = m.forward(*ins[n])[1].clone()
+    torch.cuda.synchronize()
+    for n in sizes:
+        assert torch.equal(res[None, n], res["0", n]) and torch.equal(res[None, n], res["21", n]), (label, n)
+    n = 2000
+    sample = [t.cpu().numpy() for t in ins[n]]
+    _, po = oc.forward(cfg, w, *sample, init_mode="philox", seed=17, site_offset=10 * n)
+    assert np.abs(res[None, n].cpu().numpy() - po).max() <= TOL_TIGHT
