@@ -16,6 +16,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "dsp_kernels.h"
@@ -134,7 +135,16 @@ std::vector<int> map_bidir(int H, int Hp) {  // [fwd Hp | bwd Hp] -> [fwd H | bw
     return m;
 }
 
-struct DevLstmLayer { int Ipad, Ilo, Iused, H, Hp; float* wpk[2]; float* sbias[2]; float* wsplit[2]; float* wsplit16[2]; };  // wsplit: see pack_lstm_dir_split
+struct DevLstmLayer {
+    int Ipad, Ilo, Iused, H, Hp;
+    float* wpk[2]; float* sbias[2];
+    float* wsplit[2]; float* wsplit16[2];   // see pack_lstm_dir_split; built at the first switch to a split precision
+    // what ensure_split needs (released once the pieces are on the device): the reference-layout weights and the input map
+    int split_kinds = 0;                     // 0: no split form of this layer, 1: bf16 pieces, 2: + fp16 pieces
+    int I = 0;
+    std::vector<int> in_map;
+    std::vector<float> host_wih[2], host_whh[2];
+};
 struct DevLinear { int Fin, ORT; float* wpk; float* bias; };
 
 // A fragments for gates^T = W * act^T :  [UT][NQ][4 gates][64 lanes][4]
@@ -145,7 +155,7 @@ void pack_lstm_dir(const float* wih, const float* whh, const float* bih, const f
     const int UT = Hp / 32, NQ = rup((Ipad + Hp) / 8, 4);  // padded k-groups keep zero weights
     wpk.assign((size_t)UT * NQ * 4 * 64 * 4, 0.f);
     bias.assign((size_t)4 * Hp, 0.f);
-    for (int u = 0; u < UT; ++u)
+    auto pack_tile = [&](int u) {   // unit tiles are disjoint pieces of wpk: one thread each
         for (int q = 0; q < (Ipad + Hp) / 8; ++q)
             for (int g = 0; g < 4; ++g)
                 for (int lane = 0; lane < 64; ++lane) {
@@ -164,6 +174,15 @@ void pack_lstm_dir(const float* wih, const float* whh, const float* bih, const f
                         }
                     }
                 }
+    };
+    if (UT >= 4 && (size_t)UT * NQ >= 256) {
+        std::vector<std::thread> th;
+        for (int u = 1; u < UT; ++u) th.emplace_back(pack_tile, u);
+        pack_tile(0);
+        for (auto& t : th) t.join();
+    } else {
+        for (int u = 0; u < UT; ++u) pack_tile(u);
+    }
     for (int g = 0; g < 4; ++g)
         for (int unit = 0; unit < H; ++unit) bias[(size_t)g * Hp + unit] = bih[g * H + unit] + bhh[g * H + unit];
 }
@@ -294,6 +313,7 @@ struct dsp_model {
                              // batches whose 32-site tiles x 2 directions fit the CUs at once (small-batch latency); DSP_LSTM_TILING=21
                              // always, =0 never (A/B switch)
     int n_cus = 256;         // compute units of the handle's device
+    bool split_ready = false;  // the split-precision weight pieces are on the device (ensure_split)
     bool fp16_safe = true;         // every operand of the combined stack provably inside the fp16 range (fp16x3 only then)
     int precision = DSP_PREC_FP32; // products of the combined stack: fp32 MFMA, or split-bf16 emulation (dsp_lstm6_kernel)
     // scratch
@@ -347,20 +367,49 @@ int build_stack(dsp_model* m, const float* const* w, int in, int hid, int layers
             if (rc) return rc;
             L.wsplit[d] = L.wsplit16[d] = nullptr;
             if (with_split && L.Ipad % 16 == 0 && Hp % 16 == 0 && Hp / 32 <= 8 && L.Ipad >= 16) {
-                std::vector<float> ws;
-                pack_lstm_dir_split(p[0], p[1], I, hid, Hp, in_map, ws);
-                rc = upload(m, ws, &L.wsplit[d]);
-                if (rc) return rc;
-                if (with_split >= 2) {
-                    pack_lstm_dir_split(p[0], p[1], I, hid, Hp, in_map, ws, true);
-                    rc = upload(m, ws, &L.wsplit16[d]);
-                    if (rc) return rc;
-                }
+                // the split pieces (3 bf16 / 2 fp16 per weight: 2.5 x the packing work of the fp32 form) are only built when
+                // a split precision is asked for (ensure_split): the default fp32 path never pays for them
+                L.split_kinds = with_split >= 2 ? 2 : 1;
+                L.I = I; L.in_map = in_map;
+                L.host_wih[d].assign(p[0], p[0] + (size_t)4 * hid * I);
+                L.host_whh[d].assign(p[1], p[1] + (size_t)4 * hid * hid);
             }
         }
         out.push_back(L);
     }
     return 0;
+}
+
+// the split-precision weight pieces of every layer that has them, built and uploaded on first use
+int ensure_split(dsp_model* m) {
+    if (m->split_ready) return 0;
+    int prev = 0;
+    HIP_TRY(hipGetDevice(&prev));
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = 0;
+    for (std::vector<DevLstmLayer>* stack : {&m->seq, &m->sig, &m->comb})
+        for (DevLstmLayer& L : *stack) {
+            if (!L.split_kinds) continue;
+            std::vector<float> ws[2][2];
+            std::vector<std::thread> th;
+            for (int d = 0; d < 2; ++d)
+                for (int k = 0; k < L.split_kinds; ++k)
+                    th.emplace_back([&L, &ws, d, k] {
+                        pack_lstm_dir_split(L.host_wih[d].data(), L.host_whh[d].data(), L.I, L.H, L.Hp, L.in_map, ws[d][k], k == 1);
+                    });
+            for (auto& t : th) t.join();
+            for (int d = 0; d < 2 && !rc; ++d) {
+                rc = upload(m, ws[d][0], &L.wsplit[d]);
+                if (!rc && L.split_kinds >= 2) rc = upload(m, ws[d][1], &L.wsplit16[d]);
+                std::vector<float>().swap(L.host_wih[d]);
+                std::vector<float>().swap(L.host_whh[d]);
+            }
+            if (rc) break;
+            L.split_kinds = 0;
+        }
+    hipSetDevice(prev);
+    if (!rc) m->split_ready = true;
+    return rc;
 }
 
 size_t ws_layout(const dsp_model* m, int64_t sites, long long* NTp_out, size_t off[7]) {
@@ -645,6 +694,7 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
         }
     rc = build_stack(m, w + wi, d.H, d.H, d.l1, m->comb_in_map, m->comb, 2); if (rc) return done(rc);
     if (m->precision == DSP_PREC_FP16X3 && !m->fp16_safe) m->precision = DSP_PREC_BF16X6;  // DSP_PRECISION asked for it
+    if (m->precision != DSP_PREC_FP32) { rc = ensure_split(m); if (rc) return done(rc); }
     wi += 8 * d.l1;
     {
         std::vector<float> wpk, bias;
@@ -807,6 +857,10 @@ int32_t dsp_model_set_precision(dsp_model* m, int32_t precision) {
     if (precision == DSP_PREC_FP16X3 && !m->fp16_safe)
         return fail(DSP_EINVAL, "dsp_model_set_precision: this checkpoint's combined-stack operands are not provably inside the "
                                 "fp16 range (weights or fc outputs above 3e4): use bf16x6");
+    if (precision != DSP_PREC_FP32) {
+        const int rc = ensure_split(m);
+        if (rc) return rc;
+    }
     m->precision = precision;
     return DSP_OK;
 }
