@@ -145,3 +145,34 @@ def test_read_container_roundtrip_and_ordered_batches(tmp_path):
     assert [u for x in out for u in x[1]] == [(5 << 20) + i for i in range(3)] + [6 << 20] + [(8 << 20) + i for i in range(6)]
     with pytest.raises(RuntimeError, match="Error opening file"):
         R.from_fast5(d + "/c.fast5")
+
+
+def test_feature_row_formatter_parts_equal_the_contiguous_form_on_random_rows():
+    """differential: the in-place parts formatter (what `extract` writes) against the contiguous one (pinned to the
+    reference's rows above), on values of every magnitude and sign, ragged sampleinfo lengths, several shapes and thread
+    counts; and the text parses back to the values (round trip through this build's parser)"""
+    from deepsignal_plant_amd import textio
+    rng = np.random.default_rng(12)
+    for L, S, n in ((13, 16, 701), (5, 4, 64), (21, 1, 33), (9, 40, 17)):
+        infos = ["chr%d\t%d\t%s\t%d\tread_%d\tt" % (rng.integers(1, 30), rng.integers(0, 10 ** int(rng.integers(1, 10))), "+-"[int(rng.integers(0, 2))],
+                                                   rng.integers(0, 10 ** 9), rng.integers(0, 10 ** 6)) for _ in range(n)]
+        rows = textio.ParsedRows()
+        rows.text = np.frombuffer("".join(infos).encode(), np.uint8)
+        rows.n, rows.seq_len, rows.signal_len = n, L, S
+        rows.info_len = np.array([len(x) for x in infos], np.uint32)
+        rows.row_off = np.concatenate([[0], np.cumsum(rows.info_len)[:-1]]).astype(np.uint64)
+        rows.kmer = rng.integers(0, 16, size=(n, L)).astype(np.uint8)
+        rows.lens = rng.integers(-5, 100000, size=(n, L)).astype(np.int32)
+        rows.labels = rng.integers(0, 2, size=n).astype(np.int32)
+        mag = 10.0 ** rng.integers(-9, 12, size=(n, L))
+        means = np.around(rng.standard_normal((n, L)) * mag, 6)
+        stds = np.abs(rng.standard_normal((n, L))) * 10.0 ** rng.integers(-320, 300, size=(n, L)).astype(np.float64)
+        signals = np.where(rng.random((n, L, S)) < 0.3, 0.0, np.around(rng.standard_normal((n, L, S)) * 3, 6))
+        want = textio.format_feature_rows(rows, means, stds, signals, nthreads=2)
+        buf = None
+        for nt in (1, 2, 7, 16):
+            parts, buf = textio.format_feature_rows_parts(rows, means, stds, signals, nthreads=nt, out=buf)
+            assert b"".join(bytes(x) for x in parts) == want, (L, S, nt)
+        back = textio.parse_rows(want, L, S)
+        assert back.n == n and np.array_equal(back.kmer, rows.kmer) and np.array_equal(back.lens, rows.lens)
+        assert np.array_equal(back.signals, signals.astype(np.float32))
