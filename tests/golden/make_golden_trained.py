@@ -16,6 +16,9 @@ come out of the reference's optimiser (Adam, gradient clipping, dropout 0.5, tra
 gate biases and recurrent weights have moved away from their U(-1/sqrt(H), 1/sqrt(H)) start, probabilities saturate the
 way a trained caller's do -- and the checkpoint file is one the reference wrote, which is what `--model_path` reads
 (call_modifications.py:219-223).  hid_rnn 128 keeps the file at 4.7 MB; the default 256 would be 18.8 MB.
+`--hid_rnn 256` makes the same fixture for the reference's default architecture into tests/golden/local/ (git-ignored:
+18.8 MB; it travels with the working tree to the GPU box like the built libraries, and the tests that use it skip when it
+is absent).
 
 The training data are synthetic and build-defined: every base's level follows from its 3-mer (a stand-in for the pore
 model, which the sequence branch has to learn) plus noise; label 1 shifts the centre base's level, spread and dwell the
@@ -94,7 +97,14 @@ def main():
     ap.add_argument("--train_rows", type=int, default=60000)
     ap.add_argument("--epochs", type=int, default=8)
     ap.add_argument("--skip_training", action="store_true", help="reuse the checkpoint already in the work directory")
+    ap.add_argument("--hid_rnn", type=int, default=HID, help="128: the committed fixture.  256 (the reference's default "
+                    "architecture, an 18.8 MB checkpoint): written to tests/golden/local/, which is kept out of the history "
+                    "for its size but travels with the working tree; the tests use it when it is there")
     args = ap.parse_args()
+    hid = args.hid_rnn
+    out_dir = HERE if hid == HID else os.path.join(HERE, "local")
+    os.makedirs(out_dir, exist_ok=True)
+    tag = "f8_trained_h%d" % hid
     os.makedirs(args.workdir, exist_ok=True)
     train_file = os.path.join(args.workdir, "train.tsv")
     valid_file = os.path.join(args.workdir, "valid.tsv")
@@ -108,7 +118,7 @@ def main():
         from deepsignal_plant import deepsignal_plant as ref_cli
         argv = sys.argv
         sys.argv = ["deepsignal_plant", "train", "--train_file", train_file, "--valid_file", valid_file, "--model_dir",
-                    model_dir, "--hid_rnn", str(HID), "--batch_size", "256", "--lr", "0.002", "--lr_decay", "0.5",
+                    model_dir, "--hid_rnn", str(hid), "--batch_size", "256", "--lr", "0.002", "--lr_decay", "0.5",
                     "--lr_decay_step", "3", "--max_epoch_num", str(args.epochs), "--min_epoch_num", str(args.epochs),
                     "--step_interval", "100"]
         try:
@@ -118,20 +128,21 @@ def main():
     ckpts = glob.glob(os.path.join(model_dir, "both_bilstm.b13_s16_epoch*.ckpt"))
     assert ckpts, "the reference wrote no checkpoint"
     last = max(ckpts, key=lambda p: int(re.search(r"epoch(\d+)\.ckpt", p).group(1)))
-    shutil.copyfile(last, os.path.join(HERE, "f8_trained_h128.ckpt"))
+    shutil.copyfile(last, os.path.join(out_dir, tag + ".ckpt"))
 
     import torch
     from oracle import forward_np as onp
     sys.path.insert(0, HERE)
     from make_golden import build_ref, pin_states, run_ref
-    cfg = onp.OracleConfig(hidden_size=HID)
-    sd = torch.load(os.path.join(HERE, "f8_trained_h128.ckpt"), map_location="cpu")
+    cfg = onp.OracleConfig(hidden_size=hid)
+    sd = torch.load(os.path.join(out_dir, tag + ".ckpt"), map_location="cpu")
     w = {k: v.numpy().astype(np.float32) for k, v in sd.items()}
     assert [k for k in w] == [k for k, _ in onp.state_dict_spec(cfg)]
 
     rows = labelled_rows(400, 803)
-    with open(os.path.join(HERE, "f8_trained_rows.tsv"), "w") as f:
-        f.write("\n".join(rows) + "\n")
+    if hid == HID:   # the rows are the same for every model size
+        with open(os.path.join(HERE, "f8_trained_rows.tsv"), "w") as f:
+            f.write("\n".join(rows) + "\n")
     # what the reference's reader makes of the rows (dataloader.parse_a_line2 = the grammar of call_modifications.py:75-92)
     from deepsignal_plant.dataloader import parse_a_line2
     parsed = [parse_a_line2(r) for r in rows]
@@ -148,11 +159,11 @@ def main():
     _, po = onp.forward(cfg, w, *inputs, states, dtype=np.float64)
     acc = float(((probs0[:, 1] > 0.5).astype(int) == labels).mean())
     stats = {k: (float(np.abs(v).max()), float(v.std())) for k, v in w.items()}
-    init_k = 1.0 / np.sqrt(HID)
+    init_k = 1.0 / np.sqrt(hid)
     print("checkpoint %s; accuracy on the 400 rows %.3f; max|w| %.3f (initial bound %.3f); p1 in [%.2e, %.6f]; "
           "fp32 vs float64 %.2e" % (os.path.basename(last), acc, max(s[0] for s in stats.values()), init_k,
                                     probs[:, 1].min(), probs[:, 1].max(), np.abs(po - probs).max()))
-    np.savez_compressed(os.path.join(HERE, "f8_trained_expected.npz"), cfg=np.array(repr(cfg.as_dict())), n=n, sseed=804,
+    np.savez_compressed(os.path.join(out_dir, "f8_trained_expected.npz" if hid == HID else tag + "_expected.npz"), cfg=np.array(repr(cfg.as_dict())), n=n, sseed=804,
                         logits=logits.astype(np.float32), probs=probs.astype(np.float32),
                         logits_zero_states=logits0.astype(np.float32), probs_zero_states=probs0.astype(np.float32),
                         labels=labels.astype(np.int64), accuracy=acc, f64_dprob=float(np.abs(po - probs).max()),

@@ -70,17 +70,32 @@ def f1_tolerances(name):
 
 F8_CKPT = os.path.join(GOLDEN, "f8_trained_h128.ckpt")
 F8_ROWS = os.path.join(GOLDEN, "f8_trained_rows.tsv")
+# the same for the reference's DEFAULT architecture (hid_rnn 256): an 18.8 MB checkpoint, generated in the build container
+# (make_golden_trained.py --hid_rnn 256) into tests/golden/local/, which stays out of the history for its size but travels
+# with the working tree like the built libraries; tests that want it skip when it is not there
+F8_LOCAL = os.path.join(GOLDEN, "local")
 
 
-def load_f8():
+def f8_paths(hid=128):
+    if hid == 128:
+        return F8_CKPT, os.path.join(GOLDEN, "f8_trained_expected.npz")
+    return os.path.join(F8_LOCAL, "f8_trained_h%d.ckpt" % hid), os.path.join(F8_LOCAL, "f8_trained_h%d_expected.npz" % hid)
+
+
+def have_f8(hid=128):
+    return all(os.path.exists(p) for p in f8_paths(hid))
+
+
+def load_f8(hid=128):
     """F8 (tests/golden/make_golden_trained.py): a checkpoint the reference's own `train` wrote, 400 labelled rows, and the
     reference model's outputs on them.  -> dict(cfg, w, inputs, states, logits, probs, logits0, probs0, labels, noise, raw);
     inputs come from THIS build's row parser (the reference parsed the same text with dataloader.parse_a_line2)."""
     import torch
     from deepsignal_plant_amd import textio
-    d = np.load(os.path.join(GOLDEN, "f8_trained_expected.npz"))
+    ckpt, expected = f8_paths(hid)
+    d = np.load(expected)
     cfg = onp.OracleConfig(**ast.literal_eval(str(d["cfg"])))
-    sd = torch.load(F8_CKPT, map_location="cpu")
+    sd = torch.load(ckpt, map_location="cpu")
     w = {k: np.ascontiguousarray(v.numpy().astype(np.float32)) for k, v in sd.items()}
     rows = textio.parse_rows(open(F8_ROWS, "rb").read(), cfg.seq_len, cfg.signal_len)
     inputs = [rows.kmer.astype(np.float32), rows.means, rows.stds, rows.lens.astype(np.float32), rows.signals]
@@ -89,4 +104,4 @@ def load_f8():
     states = onp.make_init_states(cfg, n, int(d["sseed"]))
     return dict(cfg=cfg, w=w, inputs=inputs, states=states, logits=d["logits"], probs=d["probs"],
                 logits0=d["logits_zero_states"], probs0=d["probs_zero_states"], labels=d["labels"],
-                row_labels=np.asarray(rows.labels), noise=float(d["f64_dprob"]), n=n, raw=d)
+                row_labels=np.asarray(rows.labels), noise=float(d["f64_dprob"]), n=n, raw=d, ckpt=ckpt)

@@ -568,14 +568,18 @@ def test_cli_other_model_shapes_match_the_cpu_restatement(tmp_path, model_type, 
     assert got.shape == (200, 2) and np.abs(got[:, 1] - po[:, 1] / (po[:, 0] + po[:, 1])).max() <= 2e-6
 
 
-def test_cli_reads_a_checkpoint_the_reference_trained(tmp_path):
+@pytest.mark.parametrize("hid", [128, 256])
+def test_cli_reads_a_checkpoint_the_reference_trained(tmp_path, hid):
     """--model_path = the file the reference's `train` wrote (F8, hid_rnn 128): the per-read calls equal the reference
     model's zero-state outputs after its own rounding (call_modifications.py:177-179), and the accuracy line of the run
     (:171-173, :190) is the one the reference's numbers give"""
-    from tests.helpers import F8_CKPT, F8_ROWS, load_f8
-    f = load_f8()
+    from tests.helpers import F8_ROWS, have_f8, load_f8
+    if not have_f8(hid):   # hid_rnn 256 (the default architecture) lives in tests/golden/local/, outside the history
+        pytest.skip("no hid_rnn %d checkpoint in tests/golden/local/" % hid)
+    f = load_f8(hid)
+    F8_CKPT = f["ckpt"]
     out = os.path.join(str(tmp_path), "calls.tsv")
-    r = _run_cli(["-i", F8_ROWS, "-m", F8_CKPT, "-o", out, "--hid_rnn", "128", "--init_state", "zeros"])
+    r = _run_cli(["-i", F8_ROWS, "-m", F8_CKPT, "-o", out, "--hid_rnn", str(hid), "--init_state", "zeros"])
     assert r.returncode == 0, r.stderr[-2000:]
     lines = open(out).read().splitlines()
     assert len(lines) == f["n"]
@@ -588,5 +592,5 @@ def test_cli_reads_a_checkpoint_the_reference_trained(tmp_path):
     sure = np.abs(p[:, 1] - 0.5) >= 1e-4
     assert np.array_equal(lab[sure], p.argmax(1)[sure])
     # a wrong --hid_rnn must fail like the reference's strict load_state_dict, not call garbage
-    r = _run_cli(["-i", F8_ROWS, "-m", F8_CKPT, "-o", out + "2"])
+    r = _run_cli(["-i", F8_ROWS, "-m", F8_CKPT, "-o", out + "2", "--hid_rnn", str(384 - hid)])
     assert r.returncode != 0 and "size mismatch" in (r.stderr + r.stdout)

@@ -401,14 +401,17 @@ def test_front_end_shapes(signal_len, is_base, is_signallen, hidden, module, wha
     assert d <= TOL_TIGHT and d2 <= TOL_TIGHT
 
 
+@pytest.mark.parametrize("hid", [128, 256])
 @pytest.mark.parametrize("precision", ["fp32", "bf16x9", "fp16x3"])
-def test_hip_matches_the_reference_on_the_checkpoint_it_trained(precision):
+def test_hip_matches_the_reference_on_the_checkpoint_it_trained(precision, hid, monkeypatch):
     """F8 (tests/golden/make_golden_trained.py): weights out of the reference's own optimiser, saved by its own
     torch.save, rows parsed by this build's parser; pinned N(0,1) states and zero states against the reference model's
     outputs.  The one fixture whose weight statistics are a trained model's (tests/test_trained_fixture.py)."""
     torch = _torch()
-    from tests.helpers import load_f8
-    f = load_f8()
+    from tests.helpers import have_f8, load_f8
+    if not have_f8(hid):   # hid_rnn 256 = the reference's default architecture: 18.8 MB, tests/golden/local/ (tests/helpers.py)
+        pytest.skip("no hid_rnn %d checkpoint in tests/golden/local/" % hid)
+    f = load_f8(hid)
     m = build_model(f["cfg"], f["w"])
     m.set_precision(precision)
     ins = to_dev(f["inputs"])
@@ -420,8 +423,8 @@ def test_hip_matches_the_reference_on_the_checkpoint_it_trained(precision):
     torch.cuda.synchronize()
     dp = np.abs(probs.cpu().numpy() - f["probs"]).max()
     dp0 = np.abs(probs0.cpu().numpy() - f["probs0"]).max()
-    print("F8 trained checkpoint, %s: HIP vs reference max|dprob| %.2e (pinned N(0,1) states) %.2e (zero states); "
-          "reference fp32 vs float64 %.2e; p1 in [%.3g, %.6f]" % (precision, dp, dp0, f["noise"], f["probs"][:, 1].min(),
+    print("F8 trained checkpoint hid_rnn %d, %s: HIP vs reference max|dprob| %.2e (pinned N(0,1) states) %.2e (zero states); "
+          "reference fp32 vs float64 %.2e; p1 in [%.3g, %.6f]" % (hid, precision, dp, dp0, f["noise"], f["probs"][:, 1].min(),
                                                                    f["probs"][:, 1].max()))
     assert max(dp, dp0) <= TOL_PROB
     assert max(dp, dp0) <= max(TOL_TIGHT, 4.0 * f["noise"])
@@ -429,6 +432,10 @@ def test_hip_matches_the_reference_on_the_checkpoint_it_trained(precision):
     assert np.array_equal(labels.cpu().numpy()[sure], f["probs"].argmax(1)[sure])
     called = (probs0.cpu().numpy()[:, 1] > 0.5).astype(int)
     assert float((called == f["labels"]).mean()) == pytest.approx(float(f["raw"]["accuracy"]), abs=0.006)
+    if precision == "fp32":   # 400 sites run the small-batch tiling: the full-batch kernel must give the same bytes
+        monkeypatch.setenv("DSP_LSTM_TILING", "0")
+        _, probs64 = build_model(f["cfg"], f["w"]).forward(*ins, init_states=st)
+        assert torch.equal(probs64, probs)
 
 
 @pytest.mark.parametrize("kw,label", [
