@@ -594,3 +594,36 @@ def test_cli_reads_a_checkpoint_the_reference_trained(tmp_path, hid):
     # a wrong --hid_rnn must fail like the reference's strict load_state_dict, not call garbage
     r = _run_cli(["-i", F8_ROWS, "-m", F8_CKPT, "-o", out + "2", "--hid_rnn", str(384 - hid)])
     assert r.returncode != 0 and "size mismatch" in (r.stderr + r.stdout)
+
+
+def test_cli_on_empty_one_row_and_fewer_rows_than_ranks(tmp_path):
+    """degenerate inputs end to end: an empty feature file gives an empty result (the reference writes nothing either), one
+    row without a newline is called, and two ranks on a three-row file (one rank gets nothing) equal one rank"""
+    import socket
+    ck = _ckpt(tmp_path)
+    rows = open(os.path.join(GOLDEN, "f2_rows.tsv"), "rb").read().split(b"\n")[:3]
+    empty, one, three = (str(tmp_path / n) for n in ("empty.tsv", "one.tsv", "three.tsv"))
+    open(empty, "wb").write(b"")
+    open(one, "wb").write(rows[0])
+    open(three, "wb").write(b"\n".join(rows) + b"\n")
+    out = str(tmp_path / "o.tsv")
+    r = _run_cli(["-i", empty, "-m", ck, "-o", out])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert open(out).read() == ""
+    r = _run_cli(["-i", one, "-m", ck, "-o", out, "--seed", "3"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(open(out).read().splitlines()) == 1
+    r = _run_cli(["-i", three, "-m", ck, "-o", out, "--seed", "3", "--freq_file", str(tmp_path / "freq1.tsv"), "--prob_cf", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = open(out).read()
+    assert len(want.splitlines()) == 3
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    two = str(tmp_path / "two.tsv")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), "-m", "deepsignal_plant_amd.deepsignal_plant", "call_mods",
+           "-i", three, "-m", ck, "-o", two, "--seed", "3", "--freq_file", str(tmp_path / "freq.tsv"), "--prob_cf", "0"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert open(two).read() == want
+    freq = open(str(tmp_path / "freq.tsv")).read()
+    assert len(freq.splitlines()) == 3 and freq == open(str(tmp_path / "freq1.tsv")).read()
