@@ -24,6 +24,8 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--handles", default="1,2,4,8,16,32")
     ap.add_argument("--rounds", type=int, default=50)
+    ap.add_argument("--check_every_round", action="store_true", help="soak: compare every handle's output of every round "
+                    "with the sequential result (slower: a synchronisation per round)")
     args = ap.parse_args(argv)
 
     import torch
@@ -54,6 +56,7 @@ def main(argv=None):
 
     for k in ks:
         outs = [None] * k
+        bad_rounds = 0
         for it in range(3 + args.rounds):
             if it == 3:
                 torch.cuda.synchronize()
@@ -62,11 +65,16 @@ def main(argv=None):
                 with torch.cuda.stream(streams[i]):
                     models[i].site_offset = i * B
                     outs[i] = models[i](*batches[i])[1]
+            if args.check_every_round:
+                torch.cuda.synchronize()
+                bad_rounds += int(not all(bool(torch.equal(outs[i], alone[i])) for i in range(k)))
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         same = all(bool(torch.equal(outs[i], alone[i])) for i in range(k))
         print(json.dumps({"batch": B, "handles": k, "rounds": args.rounds, "sites_per_s": round(k * B * args.rounds / dt, 1),
-                          "ms_per_round": round(dt / args.rounds * 1e3, 3), "identical_to_sequential": same}), flush=True)
+                          "ms_per_round": round(dt / args.rounds * 1e3, 3), "identical_to_sequential": same,
+                          **({"rounds_that_differed": bad_rounds} if args.check_every_round else {})}), flush=True)
+        assert bad_rounds == 0
         assert same, "concurrent forwards on separate handles changed the results"
     return 0
 
