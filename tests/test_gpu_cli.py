@@ -627,3 +627,26 @@ def test_cli_on_empty_one_row_and_fewer_rows_than_ranks(tmp_path):
     assert open(two).read() == want
     freq = open(str(tmp_path / "freq.tsv")).read()
     assert len(freq.splitlines()) == 3 and freq == open(str(tmp_path / "freq1.tsv")).read()
+
+
+def test_two_ranks_fail_together_when_one_meets_a_malformed_row(tmp_path):
+    """a damaged row in the second rank's byte range: that rank raises, the launcher ends the other one, the run exits
+    non-zero with the parser's message within seconds -- no rank is left waiting in a collective"""
+    import socket
+    import time
+    ck = _ckpt(tmp_path)
+    rows = open(os.path.join(GOLDEN, "f2_rows.tsv"), "rb").read().split(b"\n")[:200]
+    bad = rows[150].split(b"\t")
+    bad[7] = bad[7].replace(b",", b";", 1)          # a means list with a foreign separator
+    rows[150] = b"\t".join(bad)
+    inp = str(tmp_path / "bad.tsv")
+    open(inp, "wb").write(b"\n".join(rows) + b"\n")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), "-m", "deepsignal_plant_amd.deepsignal_plant", "call_mods",
+           "-i", inp, "-m", ck, "-o", str(tmp_path / "o.tsv")]
+    t0 = time.time()
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "malformed feature row" in r.stderr
+    assert time.time() - t0 < 120
