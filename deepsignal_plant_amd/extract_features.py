@@ -409,8 +409,13 @@ def extract_features(args):
                     batch_count += 1
             except BaseException as e:
                 sink_error.append(e)
-                while sq.get() is not None:  # drain so that the producer never blocks on a dead sink
-                    pass
+                # a dead sink must not strand the producer: give it landing buffers and text buffers for as long as it
+                # keeps handing over rows (it stops at its next look at sink_error), and empty the queue
+                for _ in range(4):
+                    host_sets.put({})
+                    bufs.put(None)
+                while sq.get() is not None:
+                    host_sets.put({})
             finally:
                 if wf is not None:
                     try:

@@ -650,3 +650,24 @@ def test_two_ranks_fail_together_when_one_meets_a_malformed_row(tmp_path):
     assert r.returncode != 0
     assert "malformed feature row" in r.stderr
     assert time.time() - t0 < 120
+
+
+@pytest.mark.parametrize("extra", [[], ["--gzip"]])
+def test_extract_fails_loudly_when_the_output_cannot_be_written(tmp_path, extra):
+    """the writer of `extract` runs on its own thread behind the formatter: a write that fails (here: a full device)
+    must come back as a non-zero exit with the OS's message, not as a hang of the stages waiting for each other's buffers"""
+    from deepsignal_plant_amd import reads as R
+    d = tmp_path / "reads"
+    d.mkdir()
+    for i in range(6):   # several batches: the error arrives while later batches are in flight
+        R.save_reads(str(d / ("r%d.reads.npz" % i)), R.synth_reads(4, seed=80 + i, mean_bases=400))
+    if extra:            # --gzip appends ".gz" to the name: give it a name that resolves to the full device
+        os.symlink("/dev/full", str(tmp_path / "full.tsv.gz"))
+        out = str(tmp_path / "full.tsv")
+    else:
+        out = "/dev/full"
+    cmd = [sys.executable, "-m", "deepsignal_plant_amd.deepsignal_plant", "extract", "-i", str(d), "-o", out,
+           "--f5_batch_size", "1", "-p", "3"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "No space left on device" in r.stderr
