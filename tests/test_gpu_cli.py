@@ -671,3 +671,13 @@ def test_extract_fails_loudly_when_the_output_cannot_be_written(tmp_path, extra)
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert "No space left on device" in r.stderr
+
+
+def test_call_mods_fails_loudly_when_an_output_cannot_be_written(tmp_path):
+    """per-read calls or the frequency file onto a full device: non-zero exit with the OS's message"""
+    ck = _ckpt(tmp_path)
+    inp = os.path.join(GOLDEN, "f2_rows.tsv")
+    r = _run_cli(["-i", inp, "-m", ck, "-o", "/dev/full"], env={"DSP_BLOCK_BYTES": "100000"})
+    assert r.returncode != 0 and "No space left on device" in r.stderr
+    r = _run_cli(["-i", inp, "-m", ck, "-o", str(tmp_path / "o.tsv"), "--freq_file", "/dev/full", "--prob_cf", "0"])
+    assert r.returncode != 0 and "No space left on device" in r.stderr
