@@ -681,3 +681,37 @@ def test_call_mods_fails_loudly_when_an_output_cannot_be_written(tmp_path):
     assert r.returncode != 0 and "No space left on device" in r.stderr
     r = _run_cli(["-i", inp, "-m", ck, "-o", str(tmp_path / "o.tsv"), "--freq_file", "/dev/full", "--prob_cf", "0"])
     assert r.returncode != 0 and "No space left on device" in r.stderr
+
+
+def test_the_ctypes_stub_of_integration_md_runs_as_printed(tmp_path):
+    """INTEGRATION.md section B promises that its ctypes stub "is the whole binding": run the code block as printed (a
+    fresh interpreter, only the names it leaves open defined around it) and compare with the mirror class on the same
+    checkpoint, rows and Philox key -- the document cannot drift from the header without this failing"""
+    import re
+    ck = _ckpt(tmp_path)
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = text[text.index("## B. Binding the C ABI directly"):]
+    block = re.search(r"```python\n(.*?)```", sec, re.S).group(1)
+    assert "lib.dsp_forward(" in block and "dsp_model_create" in block
+    block = block.replace('ctypes.CDLL("libdsp_amd.so")', 'ctypes.CDLL(%r)' % os.path.join(ROOT, "deepsignal_plant_amd", "libdsp_amd.so"))
+    head, tail = block.split("# per chunk, replacing :159-163")
+    script = "\n".join([
+        "import sys, numpy as np", "sys.path.insert(0, %r)" % ROOT,
+        "model_path, device, seed, first_site_index = %r, 0, 77, 1000" % ck,
+        head,
+        "import torch", "from deepsignal_plant_amd import synth", "dev = torch.device('cuda', 0)",
+        "kmer, means, stds, lens, signals = synth.feature_batch(700, device='cuda:0', seed=5)",
+        "kmer, lens = kmer.float(), lens.float()   # the reference hands codes and lengths over as float32 (dtype code 0)",
+        "# per chunk, replacing :159-163" + tail,
+        "assert rc == 0, lib.dsp_last_error()",
+        "torch.cuda.synchronize()",
+        "from deepsignal_plant_amd.models import ModelBiLSTM",
+        "m = ModelBiLSTM(13, 16, 3, 1, 2, 0, 256, 16, 4, True, True, device=0, init_state='randn', seed=seed)",
+        "m.load_state_dict(sd); m.cuda(0).eval(); m.site_offset = first_site_index",
+        "lo, po, la = m.forward(kmer, means, stds, lens, signals, want_labels=True)",
+        "assert torch.equal(po, probs) and torch.equal(lo, logits) and torch.equal(la, labels)",
+        "print('stub ok', float(probs[:, 1].min()), float(probs[:, 1].max()))"])
+    p = tmp_path / "stub.py"
+    p.write_text(script)
+    r = subprocess.run([sys.executable, str(p)], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "stub ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
