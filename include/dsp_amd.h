@@ -116,7 +116,10 @@ size_t dsp_workspace_bytes(const dsp_model* m, int64_t max_sites);
  * Threading / ownership: a handle owns ONE scratch workspace (activations of the forward in flight), so forwards on
  * the same handle must be issued by one host thread at a time and are ordered by the streams they are given; use one
  * handle per stream for concurrent forwards (the repacked weights are 19 MB).  Launch geometry is derived per call and
- * never stored in the handle.  hidden_size <= 2048 is the one model-shape limit of this build (one workgroup of 8 waves
+ * never stored in the handle: batches of up to 4,096 sites (on 256 CUs) run the combined stack with 32-site workgroups,
+ * one per CU -- 3.7 ms per forward instead of the 6.6 ms of one round of 64-site workgroups, the same bytes out
+ * (DSP_LSTM_TILING=0 / =21 force either tiling); the rate is flat from 16,384 sites on (INTEGRATION.md "Batch size").
+ * hidden_size <= 2048 is the one model-shape limit of this build (one workgroup of 8 waves
  * holds a direction's whole hidden state, 256 units per pass over the step; above 256 the cell state moves from LDS to a
  * global scratch); the split-precision modes cover hidden_size <= 256 and fall back to the fp32 kernels above it. */
 int32_t dsp_forward(dsp_model* m, void* stream, int64_t n_sites, const void* kmer, int32_t kmer_dtype,
