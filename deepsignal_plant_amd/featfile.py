@@ -8,7 +8,6 @@ do not depend on which of the two formats fed them."""
 from __future__ import annotations
 
 import ctypes
-import gzip
 
 import numpy as np
 
@@ -136,50 +135,16 @@ class FeatureFile(object):
 
 
 def pack_features(tsv_path, out_path, seq_len=13, signal_len=16, block_rows=32768, nthreads=8, chunk_bytes=64 << 20):
-    """Feature TSV (plain or .gz) -> .dspf.  Returns the row count.  Parsing (native, multi-threaded) and writing
-    run in two threads so that neither waits for the other."""
-    import queue
-    import threading
-    opener = gzip.open if tsv_path.endswith(".gz") else open
-    q = queue.Queue(maxsize=2)
-    err = []
-
-    def write(w):
-        try:
-            while True:
-                rows = q.get()
-                if rows is None:
-                    return
-                if not err:
-                    w.add(rows)
-        except BaseException as e:  # surfaced by the producer
-            err.append(e)
-            while q.get() is not None:
-                pass
-
-    carry = b""
-    with FeatureFileWriter(out_path, seq_len, signal_len, block_rows) as w, opener(tsv_path, "rb") as f:
-        wt = threading.Thread(target=write, args=(w,), daemon=True)
-        wt.start()
-        try:
-            while not err:
-                chunk = f.read(chunk_bytes)
-                if not chunk:
-                    break
-                data = carry + chunk if carry else chunk
-                nl = data.rfind(b"\n")
-                if nl < 0:
-                    carry = data
-                    continue
-                carry = data[nl + 1:]
-                q.put(textio.parse_rows(memoryview(data)[:nl + 1], seq_len, signal_len, nthreads=nthreads))
-            if carry.strip() and not err:
-                q.put(textio.parse_rows(carry, seq_len, signal_len, nthreads=nthreads))
-        finally:
-            q.put(None)
-            wt.join()
-        if err:
-            raise err[0]
+    """Feature TSV (plain, BGZF or any .gz) -> .dspf.  Returns the row count.  The rows come from the reader call_mods
+    itself uses (feed.FeatureReader: the file mapped, complete-row blocks parsed on `nthreads` threads into rotating
+    buffers, a foreign .gz through the parallel inflater) and are appended by this thread while the next block is parsed."""
+    from . import feed
+    reader = feed.FeatureReader(tsv_path, seq_len, signal_len, nthreads=nthreads, nbuf=3, block_bytes=chunk_bytes, pinned=False)
+    with FeatureFileWriter(out_path, seq_len, signal_len, block_rows) as w:
+        reader.start()
+        for block in reader:
+            w.add(block.rows)
+            reader.release(block)
         return w.rows
 
 
