@@ -440,6 +440,65 @@ def _merge_parts(out_path, world):
             os.remove(part)
 
 
+def _copy_range(src_fd, dst_fd, count, dst_off):
+    """count bytes from the start of src_fd to dst_off of dst_fd: in the kernel where the file system allows it"""
+    src_off, left = 0, count
+    use_cfr = hasattr(os, "copy_file_range")
+    while left > 0:
+        n = 0
+        if use_cfr:
+            try:
+                n = os.copy_file_range(src_fd, dst_fd, min(left, 1 << 30), src_off, dst_off)
+            except OSError:   # EXDEV / EINVAL / ENOSYS: different file systems or a kernel without it
+                use_cfr = False
+                continue
+            if n == 0:
+                use_cfr = False
+                continue
+        else:
+            chunk = os.pread(src_fd, min(left, 16 << 20), src_off)
+            if not chunk:
+                raise IOError("part file ended %d bytes early" % left)
+            n = os.pwrite(dst_fd, chunk, dst_off)
+        src_off += n
+        dst_off += n
+        left -= n
+
+
+def _merge_parts_by_all_ranks(out_path, part_path, rank, world, coll_dev):
+    """Collective.  The per-read calls of N ranks become one file without funnelling them through rank 0: the ranks agree
+    on the sizes (one all_gather), rank 0 sizes the result, and EVERY rank copies its own part to its offset at the same
+    time (config 5's shape: 1 G rows = 60 GB of calls; one process copying them was a quarter of the run, with seven GPUs
+    idle behind the barrier).  --gzip: the empty end-of-file member of every part but the last is left out, so that the
+    result is one well-formed BGZF file.  The interleaved pieces of a foreign .gz input keep the rank-0 merge."""
+    import torch.distributed as dist
+    if os.path.exists(part_path + ".blocks"):
+        dist.barrier()
+        if rank == 0:
+            _merge_parts(out_path, world)
+        return
+    size = os.path.getsize(part_path)
+    keep = size
+    if out_path.endswith(".gz") and rank < world - 1 and size >= 28:
+        with open(part_path, "rb") as rf:
+            rf.seek(size - 28)
+            if rf.read(28) == _BGZF_EOF:
+                keep = size - 28
+    keeps = dsp_dist.all_gather_ints(keep, world, coll_dev)
+    if rank == 0:
+        with open(out_path, "wb") as wf:
+            wf.truncate(sum(keeps))
+    dist.barrier()
+    src = os.open(part_path, os.O_RDONLY)
+    dst = os.open(out_path, os.O_WRONLY)
+    try:
+        _copy_range(src, dst, keep, sum(keeps[:rank]))
+    finally:
+        os.close(src)
+        os.close(dst)
+    os.remove(part_path)
+
+
 def _self_launch(args, argv=None):
     """The reference starts --nproc_gpu model processes itself and deals them to the visible GPUs round-robin
     (call_modifications.py:523-529, :613-621).  Here: when call_mods is started plainly (no torch.distributed
@@ -520,9 +579,11 @@ def call_mods(args):
         cdev = torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else None
         total = sum(dsp_dist.all_gather_ints(n_rows, world, cdev))
         dist.barrier()
+        _tick("all ranks done")
     if world > 1:
+        _merge_parts_by_all_ranks(out_path, part_path, rank, world, cdev)
+        dist.barrier()
         if rank == 0:
-            _merge_parts(out_path, world)
             if getattr(args, "freq_file", None) and (getattr(args, "freq_on", "device") == "host" or
                                                      getattr(args, "_freq_from_file", False)):
                 # --freq_on host with several ranks: aggregate the merged per-read calls in file order (the default,

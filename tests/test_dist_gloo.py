@@ -235,3 +235,42 @@ def test_gpu_count_and_thread_budget_without_the_hip_runtime(monkeypatch, tmp_pa
             assert got == allowed[len(allowed) // 2:2 * (len(allowed) // 2)] and _os.sched_getaffinity(0) == set(got)
         finally:
             _os.sched_setaffinity(0, before)
+
+
+def _merge_worker(rank, world, port, outdir, gz):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from deepsignal_plant_amd import call_modifications as cm
+    from deepsignal_plant_amd import gzio
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = os.path.join(outdir, "calls.tsv" + (".gz" if gz else ""))
+    part = "%s.part%05d" % (out, rank)
+    body = b"".join(b"rank%d line %d\n" % (rank, i) for i in range([70000, 0, 3, 12345][rank]))   # one rank has nothing
+    with gzio.open_write(part, gz, nthreads=2) as wf:
+        wf.write(body)
+    cm._merge_parts_by_all_ranks(out, part, rank, world, None)
+    dist.barrier()
+    assert not os.path.exists(part)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_every_rank_copies_its_part_into_the_result(tmp_path, gz):
+    """the merge of the ranks' per-read calls (call_modifications._merge_parts_by_all_ranks): sizes agreed by one
+    all_gather, every rank copies its own part to its offset at once; plain and --gzip (one BGZF end-of-file member, at
+    the end), a rank without rows included"""
+    import gzip
+    import torch.multiprocessing as mp
+    from deepsignal_plant_amd import gzio
+    port = _free_port()
+    mp.start_processes(_merge_worker, args=(4, port, str(tmp_path), gz), nprocs=4, join=True, start_method="spawn")
+    out = os.path.join(str(tmp_path), "calls.tsv" + (".gz" if gz else ""))
+    want = b"".join(b"rank%d line %d\n" % (r, i) for r, n in enumerate([70000, 0, 3, 12345]) for i in range(n))
+    got = gzip.open(out, "rb").read() if gz else open(out, "rb").read()
+    assert got == want
+    if gz:
+        raw = open(out, "rb").read()
+        assert gzio.BgzfFile(out).ok and raw.count(bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0])) == 1
+    assert [f for f in os.listdir(str(tmp_path)) if ".part" in f] == []
