@@ -167,7 +167,7 @@ def _call_mods_file(args, rank, local_rank, world):
         if size:
             with open(input_path, "rb") as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as mm:
                 byte_range = dsp_dist.byte_range_for_rank(mm, size, world, rank)
-            mine = feed.count_rows_in_range(input_path, *byte_range)
+            mine = feed.count_rows_in_range(input_path, *byte_range, nthreads=nthreads)
             counts = dsp_dist.all_gather_ints(mine, world, coll_dev)
             first_row = dsp_dist.exclusive_prefix(counts, rank)
 

@@ -48,7 +48,7 @@ def _worker(rank, world, port, path, nproc, affinity, q):
     dist.barrier()
     t0 = time.time()
     if byte_range is not None and world > 1:   # the counting pass call_mods makes to learn the global row indices
-        mine = feed.count_rows_in_range(path, *byte_range)
+        mine = feed.count_rows_in_range(path, *byte_range, nthreads=nthreads)
         first_row = dd.exclusive_prefix(dd.all_gather_ints(mine, world), rank)
     reader = feed.FeatureReader(path, 13, 16, rank=rank, world=world, nthreads=nthreads, nbuf=4, first_row=first_row,
                                 byte_range=byte_range, pinned=False, gz_ring=ring)
