@@ -1,5 +1,6 @@
 """CPU: the host half of the library (parser, formatters, feature container, site enumerator, call_freq, gzip layer, fast5 reader) built
-with AddressSanitizer + UBSan and driven over the fixtures plus mutated / truncated inputs
+with AddressSanitizer + UBSan, and again with ThreadSanitizer (the parser / formatter thread teams, the parallel
+inflater's decoder and finisher threads, the shared-memory ring), and driven over the fixtures plus mutated / truncated inputs
 (tests/native/host_asan.cpp).  GPU sanitizers are not available on this pool; the HIP kernels are covered by the
 parity suites instead."""
 import os
@@ -10,16 +11,22 @@ from tests.helpers import GOLDEN, ROOT
 SRCS = ["dsp_text.cpp", "dsp_freq.cpp", "dsp_featfile.cpp", "dsp_sites.cpp", "dsp_gz.cpp", "dsp_fast5.cpp", "dsp_shmring.cpp", "dsp_pgz.cpp"]
 
 
-def test_host_code_is_clean_under_asan_and_ubsan(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("sanitizers", ["address,undefined", "thread"])
+def test_host_code_is_clean_under_asan_and_ubsan(tmp_path, sanitizers):
     exe = os.path.join(str(tmp_path), "host_asan")
     csrc = os.path.join(ROOT, "deepsignal_plant_amd", "csrc")
-    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
-           "-fno-sanitize-recover=undefined", "-ffp-contract=off", "-pthread", "-I", os.path.join(ROOT, "include"), "-I", csrc,
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=" + sanitizers] + (
+        ["-fno-sanitize-recover=undefined"] if "undefined" in sanitizers else []) + ["-ffp-contract=off", "-pthread", "-I", os.path.join(ROOT, "include"), "-I", csrc,
            os.path.join(ROOT, "tests", "native", "host_asan.cpp")] + [os.path.join(csrc, s) for s in SRCS] + ["-lz", "-ldl", "-lrt", "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-4000:]
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
-    r = subprocess.run([exe, GOLDEN, str(tmp_path)], capture_output=True, text=True, timeout=600, env=env)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1",
+               TSAN_OPTIONS="halt_on_error=0:exitcode=66")
+    r = subprocess.run([exe, GOLDEN, str(tmp_path)], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "host_asan: ok" in r.stdout, (r.stdout[-2000:], r.stderr[-6000:])
+    assert "WARNING: ThreadSanitizer" not in r.stderr, r.stderr[-6000:]
     if os.path.exists("/opt/conda/lib/libhdf5.so"):  # the image's HDF5: the fast5 section must have run
         assert "fast5: " in r.stdout, r.stdout[-2000:]
