@@ -67,3 +67,18 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "oracle" not in txt.replace("# oracle-free", ""), "%s mentions the oracle" % f
+
+
+def test_a_missing_library_is_an_error_not_a_fallback(monkeypatch, tmp_path):
+    """no libdsp_amd.so: every entry of the product path raises and says how to build it -- nothing computes on the CPU"""
+    from deepsignal_plant_amd import _native as nat
+    monkeypatch.setattr(nat, "_lib", None)
+    monkeypatch.setattr(nat, "LIB_PATH", str(tmp_path / "libdsp_amd.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        nat.lib()
+    from deepsignal_plant_amd import textio
+    from deepsignal_plant_amd.models import ModelBiLSTM
+    with pytest.raises(RuntimeError, match="libdsp_amd.so not found"):
+        ModelBiLSTM()
+    with pytest.raises(RuntimeError, match="libdsp_amd.so not found"):
+        textio.parse_rows(b"x\n", 13, 16)
