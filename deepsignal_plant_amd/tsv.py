@@ -11,8 +11,10 @@ _BASES = "ACGT"
 
 
 def synth_rows(n, seq_len=13, signal_len=16, seed=0, sites_per_read=50, n_chroms=5, wide_alphabet=False,
-               first_index=0):
-    """Yield n text rows (no trailing newline), SURVEY.md 8(d) statistics."""
+               first_index=0, n_sites=None):
+    """Yield n text rows (no trailing newline), SURVEY.md 8(d) statistics.  n_sites: the rows cycle over that many
+    genome sites (row i calls site i % n_sites, from read i // sites_per_read), i.e. every site is covered by
+    n / n_sites different reads -- what call_freq aggregates; default: every row its own site."""
     rng = np.random.default_rng(seed)
     alphabet = "ACGTNWSMKRYBVDHZ" if wide_alphabet else _BASES
     for i in range(first_index, first_index + n):
@@ -20,6 +22,11 @@ def synth_rows(n, seq_len=13, signal_len=16, seed=0, sites_per_read=50, n_chroms
         chrom = "chr%d" % (read % n_chroms + 1)
         pos = 1000 + 7 * i
         strand = "+" if read % 2 == 0 else "-"
+        if n_sites:
+            j = i % n_sites
+            chrom = "chr%d" % ((j // sites_per_read) % n_chroms + 1)
+            pos = 1000 + 7 * j
+            strand = "+" if (j // sites_per_read) % 2 == 0 else "-"
         kmer = [alphabet[j] for j in rng.integers(0, len(alphabet), size=seq_len)]
         kmer[seq_len // 2] = "C"
         means = np.around(rng.standard_normal(seq_len), decimals=6)

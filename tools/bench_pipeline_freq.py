@@ -2,7 +2,8 @@
 """BASELINE.json configs[4] scaled to one GPU: feature TSV -> call_mods -> per-read calls, with the per-site frequency
 (`--freq_file`, what the reference gets by piping the calls into call_mods_freq) from the device-side reduction and from
 the host table, next to the plain call_mods run and to `call_freq` on the written file.  One JSON line per run.
-usage: bench_pipeline_freq.py [rows]"""
+usage: bench_pipeline_freq.py [rows] [coverage]   (coverage: calls per genome site; default 1 = every call its own site, the
+worst case for the frequency printer)"""
 import json
 import os
 import subprocess
@@ -31,12 +32,14 @@ def main():
     ck = os.path.join(work, "model.ckpt")
     torch.save(synth.random_state_dict(ModelBiLSTM(), seed=1234), ck)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4000000
-    tsv = os.path.join(work, "feat_%d.tsv" % n)
-    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_tsv.py"), tsv, str(n)])
+    cov = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    tsv = os.path.join(work, "feat_%d_cov%d.tsv" % (n, cov))
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_tsv.py"), tsv, str(n)] +
+                          (["--sites", str(n // cov)] if cov > 1 else []))
     out = os.path.join(work, "calls.tsv")
     base = ["call_mods", "-i", tsv, "-m", ck, "-o", out, "-p", "16"]
     secs, wall = run(base)
-    print(json.dumps({"rows": n, "run": "call_mods", "call_mods_s": secs, "process_wall_s": round(wall, 2), "sites_per_s": round(n / secs, 1)}), flush=True)
+    print(json.dumps({"rows": n, "coverage": cov, "run": "call_mods", "call_mods_s": secs, "process_wall_s": round(wall, 2), "sites_per_s": round(n / secs, 1)}), flush=True)
     outs = {}
     for where in ("device", "host"):
         fq = os.path.join(work, "freq_%s.tsv" % where)
