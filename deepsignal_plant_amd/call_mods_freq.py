@@ -140,6 +140,28 @@ class DeviceSiteFrequency(object):
         env = os.environ.get("DSP_FREQ_DEV_MAX_BYTES")
         self.budget = int(env) if env else int(torch.cuda.get_device_properties(self.dev).total_memory // 10)
         self.overflow = False
+        # finish() is the first user of a handful of torch operators (cat, masked indexing, the stable sort, gathers): the
+        # HIP runtime loads their code objects on first use, 0.25 s measured -- after the last forward, when nothing can
+        # hide it.  A daemon thread runs them once on 2 M elements (a millisecond of GPU time) while the forwards keep the GPU busy.
+        import threading
+        self._warm = threading.Thread(target=self._warm_up, daemon=True)
+        self._warm.start()
+
+    def _warm_up(self):
+        torch = self.torch
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(self.dev)):
+                a = torch.arange(1 << 21, dtype=torch.int64, device=self.dev)   # large enough for the large-input sort kernels
+                b = torch.cat([a, a])
+                b = b[b != 3]
+                k, perm = torch.sort(b, stable=True)
+                o = torch.sort(k[perm], stable=True)[1]
+                c = torch.zeros(1, dtype=torch.int64, device=self.dev)
+                d = torch.empty(4, dtype=torch.float64, device=self.dev).view(torch.int64)
+                _ = (k[o] + c).cpu(), d.numel(), (a << 40) | (a & 7), ((a * -7046029254386353131) >> 24) % 3
+                torch.cuda.current_stream(self.dev).synchronize()
+        except Exception:   # a warm-up must never be the reason a run fails
+            pass
 
     def add_block(self, rows, probs_dev, labels_dev, first_row, start=0, stop=None, stream=None):
         """rows: the parsed block (host); probs_dev [n, C] float32 and labels_dev [n] uint8: the forward's outputs,
@@ -231,6 +253,7 @@ class DeviceSiteFrequency(object):
     def can_finish(self, world=1):
         """collective: True when every rank kept all its records and has room for finish()'s temporaries"""
         torch = self.torch
+        self._warm.join()
         ok = not self.overflow
         if ok and self.dev.type == "cuda":
             free, _total = torch.cuda.mem_get_info(self.dev)
@@ -249,6 +272,13 @@ class DeviceSiteFrequency(object):
         L = nat.lib()
         p = ctypes.c_void_p
         dev = self.dev
+        self._warm.join()
+        marks = [("start", time.time())] if os.environ.get("DSP_TIMING") else None
+
+        def mark(label):
+            if marks is not None:
+                torch.cuda.synchronize(dev)
+                marks.append((label, time.time()))
         cat = lambda xs, dt: torch.cat(xs) if xs else torch.empty(0, dtype=dt, device=dev)
         key, packed = cat(self.keys, torch.int64), cat(self.packed, torch.int64)
         pis, row = cat(self.pis, torch.int64), cat(self.rows, torch.int64)
@@ -257,6 +287,7 @@ class DeviceSiteFrequency(object):
         key, packed, pis, row = key[live], packed[live], pis[live], row[live]
         names = self._chrom_names()
         total = self.count
+        mark("records gathered and filtered")
         from . import dist as dsp_dist
         multi = dsp_dist.collective(world)   # several ranks, or a forced one-rank RCCL group (DSP_FORCE_DIST=1)
         if multi:
@@ -291,6 +322,7 @@ class DeviceSiteFrequency(object):
             key, packed, pis, row = key[o], packed[o], pis[o], row[o]
         key, perm = torch.sort(key, stable=True)   # file order inside a site survives
         packed, pis, row = packed[perm], pis[perm], row[perm]
+        mark("exchanged and sorted")
         cnt = torch.zeros(1, dtype=torch.int64, device=dev)
         nat.check(int(L.dsp_freq_dev_count_sites(p(s.cuda_stream), n, p(key.data_ptr()), p(cnt.data_ptr()))))
         ns = int(cnt.item())
@@ -302,6 +334,7 @@ class DeviceSiteFrequency(object):
                                             p(out_d[0].data_ptr()), p(out_d[1].data_ptr()), p(out_i[4].data_ptr()),
                                             p(out_i[5].data_ptr()))))
         cols = out_i + [o.view(torch.int64) for o in out_d]   # doubles travel as their bit patterns
+        mark("sites reduced")
         if multi:
             import torch.distributed as dist
             gathered = dsp_dist.gather_columns(cols, world, dev if dist.get_backend() == "nccl" else None)
@@ -310,6 +343,7 @@ class DeviceSiteFrequency(object):
             cols = gathered
         order = torch.sort(cols[1], stable=True)[1]   # by first row: deterministic whatever order the slots were taken in
         host = [np.ascontiguousarray(c[order].cpu().numpy()) for c in cols]
+        mark("sites on the host")
         table = SiteFrequency(self.prob_cf)
         for nm in names:
             L.dsp_freq_intern_chrom(table._h, nm, len(nm))
@@ -319,6 +353,10 @@ class DeviceSiteFrequency(object):
                                            p(host[7].view(np.float64).ctypes.data), p(host[4].ctypes.data),
                                            p(host[5].ctypes.data))))
         L.dsp_freq_add_counts(table._h, total)
+        if marks is not None and rank == 0:
+            mark("host table filled")
+            print("[call_freq on the device] seconds: " + ", ".join("%s %.3f" % (b[0], b[1] - a[1]) for a, b in zip(marks, marks[1:])),
+                  file=sys.stderr)
         return table
 
 
