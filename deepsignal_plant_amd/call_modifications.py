@@ -81,6 +81,7 @@ class _Writer(threading.Thread):
         self.error = None
         self.rows = 0
         self.mark_blocks = False   # remember where every block's output ends in the part file (interleaved sharding)
+        self.n_vocab = 16          # --n_vocab: rows whose k-mer holds a code beyond it are an error (set by the caller)
         self.block_ends = []
 
     def run(self):
@@ -104,6 +105,10 @@ class _Writer(threading.Thread):
                     event.synchronize()
                     probs = probs_t.numpy()[:block.rows.n]
                     labels = labels_t.numpy()[:block.rows.n]
+                    if self.n_vocab < 16 and block.rows.n and int(np.asarray(block.rows.kmer)[:block.rows.n].max()) >= self.n_vocab:
+                        # a base code the embedding table does not hold: the reference's nn.Embedding raises this
+                        # (models.py:186); the kernel clamps the index for memory safety, the run ends here
+                        raise IndexError("index out of range in self")
                     text = textio.format_calls(block.rows, probs, labels, nthreads=self.nthreads)
                     wf.write(text)
                     if self.mark_blocks:
@@ -181,6 +186,7 @@ def _call_mods_file(args, rank, local_rank, world):
     freq, freq_dev = _make_freq(args, dev, world, nthreads)
     writer = _Writer(part_path, args.gzip, nthreads, reader, freq)
     writer.mark_blocks = interleaved
+    writer.n_vocab = int(args.n_vocab)
     cap = reader.cap
     _tick("reader built")
     model.reserve(cap)
@@ -318,6 +324,7 @@ def _call_mods_reads(args, rank, local_rank, world):
     part_path = out_path if world == 1 else "%s.part%05d" % (out_path, rank)
     freq, freq_dev = _make_freq(args, dev, world, nthreads)
     writer = _Writer(part_path, args.gzip, nthreads, _NoRelease(), freq)
+    writer.n_vocab = int(args.n_vocab)
     if freq_dev is not None:  # fed from the writer thread (the k-mer codes reach the host with the results)
         writer.freq_dev = (freq_dev, torch.cuda.Stream(dev))
     writer.start()

@@ -333,7 +333,10 @@ namespace {
 int upload(dsp_model* m, const std::vector<float>& h, float** out) {
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, h.size() * sizeof(float));
-    if (e != hipSuccess) return fail(DSP_ENOMEM, "hipMalloc(%zu) failed: %s", h.size() * sizeof(float), hipGetErrorString(e));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(DSP_ENOMEM, "hipMalloc(%zu) failed: %s", h.size() * sizeof(float), hipGetErrorString(e));
+    }
     m->dev_allocs.push_back(p);
     HIP_TRY(hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
     *out = (float*)p;
@@ -447,7 +450,11 @@ int ensure_ws(dsp_model* m, int64_t sites, hipStream_t stream) {
     long long NTp;
     const size_t bytes = ws_layout(m, sites, &NTp, off);
     hipError_t e = hipMalloc(&m->ws, bytes);
-    if (e != hipSuccess) { m->ws = nullptr; return fail(DSP_ENOMEM, "workspace hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+    if (e != hipSuccess) {
+        m->ws = nullptr;
+        (void)hipGetLastError();   // the runtime remembers the failure until it is read: the next launch's check must not see it
+        return fail(DSP_ENOMEM, "workspace hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    }
     char* b = (char*)m->ws;
     m->xseq = (float*)(b + off[0]); m->xsig = (float*)(b + off[1]);
     m->bufA = (float*)(b + off[2]); m->bufB = (float*)(b + off[3]); m->comb_in = (float*)(b + off[4]);
@@ -752,6 +759,7 @@ int32_t dsp_forward(dsp_model* m, void* stream, int64_t n, const void* kmer, int
     int prev = 0;
     HIP_TRY(hipGetDevice(&prev));
     if (prev != m->device) HIP_TRY(hipSetDevice(m->device));
+    (void)hipGetLastError();   // whatever an earlier, unrelated call of this thread left behind is not this forward's error
     int rc = ensure_ws(m, n, s);
     if (rc) { if (prev != m->device) hipSetDevice(prev); return rc; }
     // use the tile count of THIS call (padded to 16 tiles), not the capacity

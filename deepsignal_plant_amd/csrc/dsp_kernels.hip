@@ -142,6 +142,9 @@ __global__ __launch_bounds__(256) void dsp_pack_kernel(PackArgs a) {
             mean = a.means[r]; sd = a.stds[r];
             if (a.is_siglen) len = load_code(a.lens, a.ldt, r);
             if (a.is_base) code = (long)load_code(a.kmer, a.kdt, r);  // kmer.long(): truncation
+            // a code the table does not hold is the caller's error (nn.Embedding raises IndexError, models.py:186; the CLI
+            // checks its rows on the host): here the index is only kept inside the table
+            code = code < 0 ? 0 : (code >= a.V ? a.V - 1 : code);
         }
         f32x4* dst = (f32x4*)a.xseq + ((size_t)(tile * a.T + t) * (a.Fseq >> 2)) * 32 + sl;
         const int E = a.is_base ? a.E : 0;

@@ -106,7 +106,10 @@ size_t dsp_workspace_bytes(const dsp_model* m, int64_t max_sites);
 
 /* Replaces: logits, probs = model(kmer, base_means, base_stds, base_signal_lens, signals)
  * (call_modifications.py:159-162 -> models.py:178-240) and the argmax at :163.
- *   kmer    [n, seq_len]              codes 0..vocab-1, dtype kmer_dtype (DSP_DT_*)
+ *   kmer    [n, seq_len]              codes 0..vocab-1, dtype kmer_dtype (DSP_DT_*); a code outside the table is the
+ *                                     caller's error (nn.Embedding raises IndexError, models.py:186): the kernel clamps the
+ *                                     index for memory safety and does not report it -- validate on the host, as this
+ *                                     build's call_mods does
  *   means, stds [n, seq_len]          fp32
  *   lens    [n, seq_len]              dtype lens_dtype
  *   signals [n, seq_len, signal_len]  fp32

@@ -715,3 +715,45 @@ def test_the_ctypes_stub_of_integration_md_runs_as_printed(tmp_path):
     p.write_text(script)
     r = subprocess.run([sys.executable, str(p)], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "stub ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
+def test_a_base_code_beyond_n_vocab_is_an_index_error(tmp_path):
+    """--n_vocab 5 (A C G T N) and a row whose k-mer holds a W (code 5): the reference's nn.Embedding raises IndexError
+    ("index out of range in self", models.py:186); here the rows are checked on the host and the run ends with the same
+    error.  Rows inside the vocabulary are called as usual.  Through the C ABI (no host check) the index is clamped:
+    memory-safe, same result as the last table row."""
+    import torch
+    from oracle import forward_np as onp
+    cfg = onp.OracleConfig(vocab_size=5)
+    w = onp.make_weights(cfg, 33, 1.0)
+    ck = os.path.join(str(tmp_path), "v5.ckpt")
+    torch.save({k: torch.from_numpy(v) for k, v in w.items()}, ck)
+    from deepsignal_plant_amd import tsv
+    rows = [r.encode() for r in tsv.synth_rows(40, seed=3)]       # A C G T only
+    good = str(tmp_path / "good.tsv")
+    open(good, "wb").write(b"\n".join(rows) + b"\n")
+    out = str(tmp_path / "o.tsv")
+    r = _run_cli(["-i", good, "-m", ck, "-o", out, "--n_vocab", "5"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(open(out).read().splitlines()) == 40
+    w_row = rows[7].split(b"\t")
+    w_row[6] = w_row[6][:2] + b"W" + w_row[6][3:]
+    rows[7] = b"\t".join(w_row)
+    bad = str(tmp_path / "bad.tsv")
+    open(bad, "wb").write(b"\n".join(rows) + b"\n")
+    r = _run_cli(["-i", bad, "-m", ck, "-o", out, "--n_vocab", "5"])
+    assert r.returncode != 0 and "IndexError: index out of range in self" in r.stderr
+    # the C ABI itself: out-of-table codes behave like the last row of the table, whatever their value
+    from tests.test_gpu_parity import build_model, to_dev
+    m = build_model(cfg, w, init_state="zeros")
+    ins = onp.make_inputs(cfg, 64, 9)
+    ins[0][:, 3] = 4.0
+    ref = m.forward(*to_dev(ins))[1].clone()
+    for wild in (5.0, 200.0, 1e9, -3.0):
+        ins2 = [a.copy() for a in ins]
+        ins2[0][:, 3] = wild
+        got = m.forward(*to_dev(ins2))[1]
+        if wild > 0:
+            assert torch.equal(got, ref)
+        else:
+            assert bool(torch.isfinite(got).all())

@@ -478,3 +478,20 @@ def test_small_batch_tiling_does_not_change_a_bit(kw, label, monkeypatch):
     sample = [t.cpu().numpy() for t in ins[n]]
     _, po = oc.forward(cfg, w, *sample, init_mode="philox", seed=17, site_offset=10 * n)
     assert np.abs(res[None, n].cpu().numpy() - po).max() <= TOL_TIGHT
+
+
+def test_a_workspace_that_cannot_be_had_is_refused_and_leaves_the_handle_usable():
+    """dsp_model_reserve beyond the GPU's memory: DSP_ENOMEM with the size in the message -- and the next forward on the
+    same handle runs and gives the same bytes as before (the failed hipMalloc must not linger in the runtime's
+    last-error slot, where the next launch's check would find it)"""
+    torch = _torch()
+    from oracle import forward_np as onp
+    cfg = onp.OracleConfig()
+    m = build_model(cfg, onp.make_weights(cfg, 5, 1.0), init_state="zeros")
+    ins = to_dev(onp.make_inputs(cfg, 700, 6))
+    ref = m.forward(*ins)[1].clone()
+    total = torch.cuda.mem_get_info()[1]
+    too_many = int(total / 60000)          # ~73 kB of workspace per site: more sites than fit by a fifth
+    with pytest.raises(RuntimeError, match="workspace hipMalloc"):
+        m.reserve(too_many)
+    assert torch.equal(m.forward(*ins)[1], ref)
