@@ -122,6 +122,8 @@ def lib():
     L.dsp_freq_dev_encode.restype = ctypes.c_int32
     L.dsp_freq_dev_encode.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+    L.dsp_freq_dev_sort_records.restype = ctypes.c_int32
+    L.dsp_freq_dev_sort_records.argtypes = [ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 9 + [ctypes.POINTER(ctypes.c_size_t)]
     L.dsp_freq_dev_count_sites.restype = ctypes.c_int32
     L.dsp_freq_dev_count_sites.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
     L.dsp_freq_dev_reduce.restype = ctypes.c_int32

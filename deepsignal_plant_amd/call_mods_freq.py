@@ -154,7 +154,7 @@ class DeviceSiteFrequency(object):
                 a = torch.arange(1 << 21, dtype=torch.int64, device=self.dev)   # large enough for the large-input sort kernels
                 b = torch.cat([a, a])
                 b = b[b != 3]
-                k, perm = torch.sort(b, stable=True)
+                k, perm = torch.sort(b, stable=True)   # (finish() sorts its records natively; rank 0's final ordering of the sites uses this)
                 o = torch.sort(k[perm], stable=True)[1]
                 c = torch.zeros(1, dtype=torch.int64, device=self.dev)
                 d = torch.empty(4, dtype=torch.float64, device=self.dev).view(torch.int64)
@@ -314,14 +314,22 @@ class DeviceSiteFrequency(object):
         n = int(key.numel())
         torch.cuda.set_device(dev)
         s = torch.cuda.current_stream(dev)
+        def sort_records(by, a, b, c):
+            """the four columns stably sorted by `by` (csrc/dsp_freq_dev.hip: rocPRIM radix sort of (key, index) + gather)"""
+            outs = [torch.empty_like(by) for _ in range(4)]
+            need = ctypes.c_size_t(0)
+            args = [p(s.cuda_stream), n] + [p(t.data_ptr()) for t in (by, a, b, c)] + [p(t.data_ptr()) for t in outs]
+            nat.check(int(L.dsp_freq_dev_sort_records(*args, None, ctypes.byref(need))))
+            tmp = torch.empty(max(need.value, 1), dtype=torch.uint8, device=dev)
+            nat.check(int(L.dsp_freq_dev_sort_records(*args, p(tmp.data_ptr()), ctypes.byref(need))))
+            tmp.record_stream(s)
+            return outs
         if multi:
             # what arrived is ordered by source rank; ranks may own interleaved blocks of the input (a foreign .gz is dealt
             # block i -> rank i % world), so restore the global input order first: a site's sums are then taken in file
             # order -- the order `call_freq` sees on the merged per-read file -- whatever the sharding
-            o = torch.sort(row, stable=True)[1]
-            key, packed, pis, row = key[o], packed[o], pis[o], row[o]
-        key, perm = torch.sort(key, stable=True)   # file order inside a site survives
-        packed, pis, row = packed[perm], pis[perm], row[perm]
+            row, key, packed, pis = sort_records(row, key, packed, pis)
+        key, packed, pis, row = sort_records(key, packed, pis, row)   # file order inside a site survives
         mark("exchanged and sorted")
         cnt = torch.zeros(1, dtype=torch.int64, device=dev)
         nat.check(int(L.dsp_freq_dev_count_sites(p(s.cuda_stream), n, p(key.data_ptr()), p(cnt.data_ptr()))))

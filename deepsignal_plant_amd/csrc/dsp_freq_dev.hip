@@ -8,12 +8,16 @@
 //     decimal of such a float32 IS k*1e-6, and the reference's float() of it is the correctly rounded k/1e6 --
 //     tests/test_call_freq.py checks both for every k), the |p0 - p1| >= prob_cf filter in double
 //     (txt_formater.py:23-26), packed next to the label and the first-record metadata.
-//   * the caller sorts the records by site key with a STABLE sort (file order inside a site survives), then
+//   * dsp_freq_dev_sort_records: the records STABLY sorted by site key (file order inside a site survives; a radix
+//     sort of (key, index) pairs by rocPRIM, then one gather of the other three columns), then
 //   * dsp_freq_dev_reduce: one thread per site walks its records in order and adds k/1e6 in double, sequentially:
 //     the same additions in the same order as calculate_mods_frequency.
 // HBM-bound integer work: 32 B per record in, 72 B per site out; no MFMA.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include "dsp_amd.h"
 
@@ -106,6 +110,62 @@ int32_t dsp_freq_dev_encode(void* stream, int64_t n, const float* probs, int32_t
                        (long long*)packed_out);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? DSP_OK : fail_hip("dsp_freq_dev_encode", e);
+}
+
+// gather of the three payload columns by the permutation of the sort: 8 B in + 3 x (8 B in, 8 B out) per record
+__global__ __launch_bounds__(256) void freq_gather3_kernel(long long n, const unsigned* __restrict__ perm,
+                                                           const long long* __restrict__ a, const long long* __restrict__ b,
+                                                           const long long* __restrict__ c, long long* __restrict__ ao,
+                                                           long long* __restrict__ bo, long long* __restrict__ co) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned j = perm[i];
+    ao[i] = a[j]; bo[i] = b[j]; co[i] = c[j];
+}
+__global__ __launch_bounds__(256) void freq_iota_kernel(long long n, unsigned* __restrict__ p) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = (unsigned)i;
+}
+
+// Records (key, a, b, c) -> the same records STABLY sorted by key, out of place.  tmp == NULL: *tmp_bytes = the scratch
+// needed for n records (device memory, any alignment of 256) and nothing runs.  Keys are non-negative int64 (site keys,
+// global row indices, INT64_MAX for unused records): all 64 bits take part.
+int32_t dsp_freq_dev_sort_records(void* stream, int64_t n, const int64_t* key, const int64_t* a, const int64_t* b,
+                                  const int64_t* c, int64_t* key_out, int64_t* a_out, int64_t* b_out, int64_t* c_out,
+                                  void* tmp, size_t* tmp_bytes) {
+    if (n < 0 || n >= (1ll << 32) || !tmp_bytes) {
+        dsp_set_error_("dsp_freq_dev_sort_records: bad argument (at most 2^32 - 1 records per call)");
+        return DSP_EINVAL;
+    }
+    const size_t idx_bytes = ((size_t)n * sizeof(unsigned) + 255) / 256 * 256;
+    size_t sort_bytes = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, sort_bytes, (const long long*)nullptr, (long long*)nullptr,
+                                             (const unsigned*)nullptr, (unsigned*)nullptr, (size_t)n, 0, 64, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip("dsp_freq_dev_sort_records (size query)", e);
+    const size_t need = 2 * idx_bytes + (sort_bytes + 255) / 256 * 256;
+    if (!tmp) { *tmp_bytes = need; return DSP_OK; }
+    if (*tmp_bytes < need) {
+        dsp_set_error_("dsp_freq_dev_sort_records: scratch too small");
+        return DSP_ENOMEM;
+    }
+    if (n == 0) return DSP_OK;
+    if (!key || !a || !b || !c || !key_out || !a_out || !b_out || !c_out) {
+        dsp_set_error_("dsp_freq_dev_sort_records: NULL column");
+        return DSP_EINVAL;
+    }
+    unsigned* idx_in = (unsigned*)tmp;
+    unsigned* idx_out = (unsigned*)((char*)tmp + idx_bytes);
+    void* sort_tmp = (char*)tmp + 2 * idx_bytes;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(freq_iota_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long long)n, idx_in);
+    e = rocprim::radix_sort_pairs(sort_tmp, sort_bytes, (const long long*)key, (long long*)key_out, (const unsigned*)idx_in,
+                                  idx_out, (size_t)n, 0, 64, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip("dsp_freq_dev_sort_records", e);
+    hipLaunchKernelGGL(freq_gather3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long long)n, idx_out,
+                       (const long long*)a, (const long long*)b, (const long long*)c, (long long*)a_out, (long long*)b_out,
+                       (long long*)c_out);
+    e = hipGetLastError();
+    return e == hipSuccess ? DSP_OK : fail_hip("dsp_freq_dev_sort_records", e);
 }
 
 int32_t dsp_freq_dev_count_sites(void* stream, int64_t n, const int64_t* key_sorted, int64_t* n_sites) {

@@ -337,6 +337,10 @@ int64_t dsp_freq_format(const dsp_freq* f, int32_t is_sort, int32_t is_bed, char
  *   the caller must fall back to the host aggregator, loudly.
  * dsp_freq_dev_encode (DEVICE): probabilities + labels of the block (still in HBM after dsp_forward) -> key_out
  *   (INT64_MAX where |p0 - p1| < prob_cf, txt_formater.py:23-26) and packed_out.
+ * dsp_freq_dev_sort_records (DEVICE): the four record columns STABLY sorted by `key`, out of place (a radix sort of
+ *   (key, index) pairs, then one gather of the other columns).  Two calls: with tmp == NULL it only stores the scratch
+ *   size for n records in *tmp_bytes; n < 2^32.  Sorting by the global row first and by the site key second restores
+ *   file order inside every site whatever order the records arrived in.
  * dsp_freq_dev_count_sites / dsp_freq_dev_reduce (DEVICE): on records STABLY sorted by key: the number of sites, then
  *   per site (in no particular order; slot_counter is device scratch) its key, the global row / packed word /
  *   pos_in_strand of its first record, the double sums of p0 and p1 taken sequentially in record order, the
@@ -349,6 +353,9 @@ int64_t dsp_freq_block_keys(dsp_freq* f, const char* text, const uint64_t* row_o
 int32_t dsp_freq_dev_encode(void* stream, int64_t n, const float* probs, int32_t num_classes, const uint8_t* labels,
                             const int64_t* key_in, const uint32_t* meta_in, double prob_cf, int64_t* key_out,
                             int64_t* packed_out);
+int32_t dsp_freq_dev_sort_records(void* stream, int64_t n, const int64_t* key, const int64_t* a, const int64_t* b,
+                                  const int64_t* c, int64_t* key_out, int64_t* a_out, int64_t* b_out, int64_t* c_out,
+                                  void* tmp, size_t* tmp_bytes);
 int32_t dsp_freq_dev_count_sites(void* stream, int64_t n, const int64_t* key_sorted, int64_t* n_sites);
 int32_t dsp_freq_dev_reduce(void* stream, int64_t n, const int64_t* key_sorted, const int64_t* packed_sorted,
                             const int64_t* pis_sorted, const int64_t* row_sorted, int64_t* slot_counter, int64_t cap,

@@ -63,3 +63,34 @@ def test_device_call_freq_equals_host_aggregator_on_a_large_random_set():
     for sort in (False, True):
         for bed in (False, True):
             assert table.format(sort, bed) == host.format(sort, bed)
+
+
+@pytest.mark.parametrize("n", [0, 1, 257, 100_003, 3_000_000])
+def test_native_record_sort_is_numpys_stable_sort(n):
+    """dsp_freq_dev_sort_records (rocPRIM radix sort of (key, index) + one gather): keys with many ties, the unused-record
+    sentinel INT64_MAX and values across all 64 bits -- the four columns come out exactly as numpy's stable argsort
+    orders them"""
+    import ctypes
+    import torch
+    from deepsignal_plant_amd import _native as nat
+    rng = np.random.default_rng(n + 1)
+    key = rng.integers(0, max(2, n // 7), size=n).astype(np.int64) << rng.integers(0, 50, size=n).astype(np.int64)
+    key[rng.random(n) < 0.1] = np.iinfo(np.int64).max
+    cols = [rng.integers(-2 ** 62, 2 ** 62, size=n).astype(np.int64) for _ in range(3)]
+    order = np.argsort(key, kind="stable")
+    dev = [torch.from_numpy(x).cuda(0) for x in [key] + cols]
+    outs = [torch.empty_like(dev[0]) for _ in range(4)]
+    L, p = nat.lib(), ctypes.c_void_p
+    s = torch.cuda.current_stream()
+    need = ctypes.c_size_t(0)
+    args = [p(s.cuda_stream), n] + [p(t.data_ptr()) for t in dev] + [p(t.data_ptr()) for t in outs]
+    nat.check(int(L.dsp_freq_dev_sort_records(*args, None, ctypes.byref(need))))
+    tmp = torch.empty(max(need.value, 1), dtype=torch.uint8, device="cuda:0")
+    short = ctypes.c_size_t(max(need.value - 1, 0))
+    if n:
+        assert int(L.dsp_freq_dev_sort_records(*args, p(tmp.data_ptr()), ctypes.byref(short))) < 0   # scratch too small: refused
+    nat.check(int(L.dsp_freq_dev_sort_records(*args, p(tmp.data_ptr()), ctypes.byref(need))))
+    torch.cuda.synchronize()
+    assert np.array_equal(outs[0].cpu().numpy(), key[order])
+    for o, c in zip(outs[1:], cols):
+        assert np.array_equal(o.cpu().numpy(), c[order])
