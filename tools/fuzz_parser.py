@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Differential fuzz of the one-pass row parser against the general parser (csrc/dsp_text.cpp): golden rows with random byte replacements / deletions / insertions; arrays, sampleinfo addressing and error texts must agree.  No GPU.
-usage: fuzz_parser.py SEED SECONDS   (round 3: 4 seeds x 40 s + 2 x 300 s = 4.9 M cases, no mismatch)"""
+usage: fuzz_parser.py SEED SECONDS   (round 3: 4 seeds x 40 s + 2 x 300 s = 4.9 M cases, then 3 more seeds x 300 s at the round's last HEAD = 6.2 M cases: no mismatch)"""
 import sys, os, numpy as np, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deepsignal_plant_amd import textio, _native as nat
