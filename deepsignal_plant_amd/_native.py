@@ -138,6 +138,8 @@ def lib():
     L.dsp_freq_chrom_name.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_size_t]
     L.dsp_freq_intern_chrom.restype = ctypes.c_int32
     L.dsp_freq_intern_chrom.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    L.dsp_gz_member_rows.restype = ctypes.c_int32
+    L.dsp_gz_member_rows.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
     L.dsp_gz_index.restype = ctypes.c_int64
     L.dsp_gz_index.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
     L.dsp_gz_inflate_members.restype = ctypes.c_int64

@@ -148,10 +148,12 @@ def _call_mods_file(args, rank, local_rank, world):
     # my byte range and the global index of my first row (plain text: a byte range of the file; BGZF .gz: a member range,
     # feed.FeatureReader._run_bgzf; a foreign single-stream .gz is inflated by every rank, which then knows all indices)
     first_row, byte_range, gz_ring, interleaved = 0, None, None, False
+    counted = None   # the rows the counting pass (or the BGZF headers) promised this rank: checked against the rows parsed
     multi = dsp_dist.collective(world)   # several ranks (or DSP_FORCE_DIST=1: the same collectives with one)
     if input_path.endswith(".gz") and multi:
         mine = feed.count_rows_bgzf(input_path, world, rank, nthreads)
         if mine is not None:
+            counted = mine
             counts = dsp_dist.all_gather_ints(mine, world, coll_dev)
             first_row = dsp_dist.exclusive_prefix(counts, rank)
         elif world > 1:
@@ -173,6 +175,7 @@ def _call_mods_file(args, rank, local_rank, world):
             with open(input_path, "rb") as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as mm:
                 byte_range = dsp_dist.byte_range_for_rank(mm, size, world, rank)
             mine = feed.count_rows_in_range(input_path, *byte_range, nthreads=nthreads)
+            counted = mine
             counts = dsp_dist.all_gather_ints(mine, world, coll_dev)
             first_row = dsp_dist.exclusive_prefix(counts, rank)
 
@@ -245,6 +248,12 @@ def _call_mods_file(args, rank, local_rank, world):
         k += 1
         n_rows += n
     _tick("last forward issued")
+    if counted is not None and writer.error is None and n_rows - counted not in ((0, 1) if rank == world - 1 else (0,)):
+        # the global row indices of the later ranks were derived from this count (they key the initial states): a wrong
+        # one must not pass silently (a .gz whose headers carry counts that are not its rows, a file changed under the run)
+        raise RuntimeError("rank %d parsed %d rows where the counting pass found %d: %s changed during the run, or the row "
+                           "counts in its BGZF headers are not its own (DSP_BGZF_COUNT_BY_INFLATE=1 ignores them)"
+                           % (rank, n_rows, counted, input_path))
     writer.q.put(None)
     writer.join()
     torch.cuda.synchronize(dev)

@@ -137,6 +137,21 @@ int64_t dsp_gz_index(const uint8_t* src, size_t len, int64_t max_members, uint64
     return m;
 }
 
+// newline count of every BGZF member as its writer recorded it (dsp_bgzf_compress: MTIME under XFL = 'R'); -1 for members
+// of other writers (bgzip, older files of this build): the caller inflates those to count
+int32_t dsp_gz_member_rows(const uint8_t* src, const uint64_t* member_off, int64_t n_members, int64_t* rows) {
+    if (!src || !member_off || !rows || n_members < 0) return (int32_t)gz_fail(DSP_EINVAL, "dsp_gz_member_rows: bad argument");
+    for (int64_t m = 0; m < n_members; ++m) {
+        const uint8_t* p = src + member_off[m];
+        const uint32_t isize_at = (uint32_t)(member_off[m + 1] - member_off[m]);
+        const uint8_t* t = p + isize_at - 4;
+        const uint32_t isize = t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
+        const uint32_t nl = p[4] | (uint32_t)p[5] << 8 | (uint32_t)p[6] << 16 | (uint32_t)p[7] << 24;
+        rows[m] = isize == 0 ? 0 : ((p[8] == 'R' && nl <= isize) ? (int64_t)nl : -1);   // an empty member (end of file) has none
+    }
+    return DSP_OK;
+}
+
 int64_t dsp_gz_inflate_members(const uint8_t* src, const uint64_t* member_off, const uint32_t* member_isize, int64_t m0,
                                int64_t m1, uint8_t* out, size_t out_cap, int32_t nthreads) {
     if (!src || !member_off || !member_isize || !out || m0 < 0 || m1 < m0) return gz_fail(DSP_EINVAL, "dsp_gz_inflate_members: bad argument");
@@ -210,6 +225,14 @@ int64_t dsp_bgzf_compress(const uint8_t* in, size_t len, uint8_t* out, size_t ou
             uint8_t* o = tmp.data() + b * kMax;
             static const uint8_t hdr[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0, 0};
             memcpy(o, hdr, 18);
+            {   // the member's newline count rides in the two informational header fields no reader interprets -- MTIME
+                // (bytes 4..7) under the marker XFL = 'R' (byte 8): htslib / bgzip, zlib and Python's gzip ignore both, and a
+                // rank can then learn how many rows its member range holds from the headers alone (dsp_gz_member_rows)
+                uint32_t nl = 0;
+                for (const uint8_t* q = p; (q = (const uint8_t*)memchr(q, '\n', (size_t)(p + n - q))) != nullptr; ++q) ++nl;
+                for (int i = 0; i < 4; ++i) o[4 + i] = (uint8_t)(nl >> (8 * i));
+                o[8] = 'R';
+            }
             size_t produced = 0;
             uint32_t crc = 0;
             if (comp) {

@@ -69,6 +69,11 @@ def count_rows_bgzf(path, world, rank, nthreads=8, block_bytes=BLOCK_BYTES):
     if not bz.ok:
         return None
     m0, m1 = bz.members_for_rank(world, rank)
+    if m1 > m0 and not os.environ.get("DSP_BGZF_COUNT_BY_INFLATE") and bool((bz.rows[m0:m1] >= 0).all()):
+        # written by this build: every member's header carries its newline count (csrc/dsp_gz.cpp) -- no inflate pass
+        # before the first forward (at config 5's scale it would be a minute of every rank's parser threads); the caller
+        # checks the sum against the rows it then parses
+        return int(bz.rows[m0:m1].sum())
     mine, m = 0, m0
     while m < m1:
         e = min(m1, max(m + 1, int(np.searchsorted(bz.text_off, bz.text_off[m] + block_bytes, side="left"))))

@@ -149,6 +149,11 @@ class BgzfFile(object):
                 nat.check(int(L.dsp_gz_index(ctypes.c_void_p(self.src.ctypes.data), self.size, self.n_members,
                                              ctypes.c_void_p(self.off.ctypes.data), ctypes.c_void_p(self.isize.ctypes.data))))
             self.text_off = np.r_[0, np.cumsum(self.isize[:self.n_members].astype(np.int64))]
+            # newlines per member as the writer recorded them in the header (this build's BgzfWriter; -1: not recorded)
+            self.rows = np.full(max(self.n_members, 1), -1, np.int64)
+            if self.n_members:
+                nat.check(int(L.dsp_gz_member_rows(ctypes.c_void_p(self.src.ctypes.data), ctypes.c_void_p(self.off.ctypes.data),
+                                                   self.n_members, ctypes.c_void_p(self.rows.ctypes.data))))
 
     def inflate(self, m0, m1, out=None, out_offset=0, nthreads=8):
         """members [m0, m1) -> out[out_offset:...]; returns (array, bytes written)"""

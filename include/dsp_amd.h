@@ -380,6 +380,7 @@ typedef struct dsp_gz_stream dsp_gz_stream;
 int64_t dsp_gz_index(const uint8_t* src, size_t len, int64_t max_members, uint64_t* member_off, uint32_t* member_isize);
 int64_t dsp_gz_inflate_members(const uint8_t* src, const uint64_t* member_off, const uint32_t* member_isize, int64_t m0,
                                int64_t m1, uint8_t* out, size_t out_cap, int32_t nthreads);
+int32_t dsp_gz_member_rows(const uint8_t* src, const uint64_t* member_off, int64_t n_members, int64_t* rows);  /* newlines per member as recorded by dsp_bgzf_compress (gzip MTIME under XFL = 'R'); -1 = not recorded */
 int64_t dsp_bgzf_compress(const uint8_t* in, size_t len, uint8_t* out, size_t out_cap, int32_t level, int32_t nthreads);
 int64_t dsp_bgzf_eof(uint8_t* out, size_t cap);
 dsp_gz_stream* dsp_gz_open(const char* path);

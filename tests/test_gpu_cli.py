@@ -757,3 +757,32 @@ def test_a_base_code_beyond_n_vocab_is_an_index_error(tmp_path):
             assert torch.equal(got, ref)
         else:
             assert bool(torch.isfinite(got).all())
+
+
+def test_two_ranks_on_a_bgzf_input_use_the_row_counts_of_its_headers(tmp_path):
+    """a BGZF feature file written by this build: the ranks take their first-row indices from the counts in the member
+    headers (no inflate pass), give the bytes of one rank and of the inflate-pass variant -- and a file whose header
+    counts are not its own ends the run loudly instead of keying the later rank's sites wrongly"""
+    from deepsignal_plant_amd import gzio
+    ck = _ckpt(tmp_path)
+    data = open(os.path.join(GOLDEN, "f2_rows.tsv"), "rb").read() * 3
+    inp = str(tmp_path / "in.tsv.gz")
+    with gzio.open_write(inp, True, nthreads=2) as wf:
+        wf.write(data)
+    one = str(tmp_path / "one.tsv")
+    r = _run_cli(["-i", inp, "-m", ck, "-o", one, "--seed", "4"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    outs = []
+    for env in (None, {"DSP_BGZF_COUNT_BY_INFLATE": "1"}):
+        two = str(tmp_path / ("two%d.tsv" % len(outs)))
+        r = _two_ranks(["-i", inp, "-m", ck, "-o", two, "--seed", "4"], env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(open(two).read())
+    assert outs[0] == outs[1] == open(one).read()
+    raw = bytearray(open(inp, "rb").read())
+    off = int(gzio.BgzfFile(inp).off[1])          # the second member belongs to rank 0: claim one row more than it holds
+    raw[off + 4] += 1
+    bad = str(tmp_path / "bad.tsv.gz")
+    open(bad, "wb").write(bytes(raw))
+    r = _two_ranks(["-i", bad, "-m", ck, "-o", str(tmp_path / "x.tsv"), "--seed", "4"])
+    assert r.returncode != 0 and "row counts in its BGZF headers are not its own" in r.stderr

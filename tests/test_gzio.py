@@ -174,3 +174,36 @@ def test_reader_on_degenerate_files(tmp_path, gz):
             n += blk.rows.n
             reader.release(blk)
         assert n == want, name
+
+
+def test_bgzf_members_carry_their_row_counts_and_the_counting_pass_uses_them(tmp_path, monkeypatch):
+    """every member this build writes records its newline count in the gzip header's MTIME field under XFL = 'R' (fields no
+    reader interprets: Python's gzip and the BGZF member walk read the file as before); a rank then learns the rows of its
+    member range from the headers instead of inflating it -- same counts as the inflate pass for every world size, and a
+    BGZF file without the marks (another writer's) still takes the inflate pass"""
+    data = _text(5)
+    p = str(tmp_path / "rows.tsv.gz")
+    with gzio.open_write(p, True, nthreads=3) as wf:
+        wf.write(data[:700_001])
+        wf.write([memoryview(data[700_001:1_500_000]), data[1_500_000:]])
+    assert gzip.open(p, "rb").read() == data
+    bz = gzio.BgzfFile(p)
+    assert bz.ok and bz.n_members > 20 and int(bz.rows[bz.n_members - 1]) == 0   # the empty end-of-file member
+    for m in range(bz.n_members - 1):
+        buf, n = bz.inflate(m, m + 1)
+        assert int(bz.rows[m]) == bytes(buf[:n]).count(b"\n"), m
+    for world in (1, 2, 3, 4):
+        by_header = [feed.count_rows_bgzf(p, world, r, nthreads=2) for r in range(world)]
+        monkeypatch.setenv("DSP_BGZF_COUNT_BY_INFLATE", "1")
+        by_inflate = [feed.count_rows_bgzf(p, world, r, nthreads=2) for r in range(world)]
+        monkeypatch.delenv("DSP_BGZF_COUNT_BY_INFLATE")
+        assert by_header == by_inflate and sum(by_header) == data.count(b"\n")
+    raw = bytearray(open(p, "rb").read())                                   # the same file as another BGZF writer leaves it
+    for off in gzio.BgzfFile(p).off[:-1]:
+        raw[int(off) + 4:int(off) + 9] = bytes(5)
+    q = str(tmp_path / "foreign_bgzf.tsv.gz")
+    open(q, "wb").write(bytes(raw))
+    fz = gzio.BgzfFile(q)
+    assert fz.ok and bool((fz.rows[:fz.n_members - 1] < 0).all())
+    assert [feed.count_rows_bgzf(q, 3, r, nthreads=2) for r in range(3)] == [feed.count_rows_bgzf(p, 3, r, nthreads=2) for r in range(3)]
+    assert gzip.open(q, "rb").read() == data
