@@ -315,6 +315,7 @@ def _call_mods_reads(args, rank, local_rank, world):
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     model = load_model(args, local_rank)
+    _tick("model loaded")
     files = dsp_reads.list_read_files(os.path.abspath(args.input_path), str2bool(args.recursively))
     if rank == 0:
         print("%d read files in total.." % len(files))
@@ -364,6 +365,8 @@ def _call_mods_reads(args, rank, local_rank, world):
         batch = rq.get()
         if batch is None:
             break
+        if k == 0:
+            _tick("first batch of reads staged")
         if writer.error is not None:
             fx.discard(batch)
             continue
@@ -398,9 +401,11 @@ def _call_mods_reads(args, rank, local_rank, world):
         blk.first_row = row_base + n_rows
         writer.q.put((blk, h_probs, h_labels, ev))
         n_rows += n
+    _tick("last forward issued")
     writer.q.put(None)
     writer.join()
     loader.join()
+    _tick("writer joined")
     torch.cuda.synchronize(dev)
     if writer.error is not None:
         raise writer.error
