@@ -93,6 +93,8 @@ def lib():
     L.dsp_model_set_precision.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     L.dsp_model_destroy.restype = None
     L.dsp_model_destroy.argtypes = [ctypes.c_void_p]
+    L.dsp_find_row_end.restype = ctypes.c_int64
+    L.dsp_find_row_end.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int64]
     L.dsp_count_rows.restype = ctypes.c_int64
     L.dsp_count_rows.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
     L.dsp_parse_feature_rows.restype = ctypes.c_int64

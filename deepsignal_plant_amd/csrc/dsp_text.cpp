@@ -457,6 +457,22 @@ int64_t dsp_count_rows(const char* text, size_t len) {
     return n;
 }
 
+// bytes of the first n_rows rows of text (the offset just behind the n_rows-th newline); len when the text holds fewer.
+// The feature reader cuts its blocks with it: 32,768 rows are exactly four rounds of LSTM workgroups on 256 CUs, and a
+// block sized by bytes had to stay 2 % below that not to spill into a fifth.
+int64_t dsp_find_row_end(const char* text, size_t len, int64_t n_rows) {
+    if (!text || n_rows <= 0) return 0;
+    const char* p = text;
+    const char* e = text + len;
+    while (p < e && n_rows > 0) {
+        const char* nl = find_ch(p, e, '\n');
+        if (nl >= e) return (int64_t)len;
+        p = nl + 1;
+        --n_rows;
+    }
+    return (int64_t)(p - text);
+}
+
 int64_t dsp_parse_feature_rows(const char* text, size_t len, int32_t seq_len, int32_t signal_len, int64_t max_rows,
                                uint8_t* kmer, float* means, float* stds, int32_t* lens, float* signals,
                                int32_t* labels, uint64_t* row_off, uint32_t* info_len, uint32_t* read_off,

@@ -20,10 +20,16 @@ from . import dist as dsp_dist
 from . import featfile, textio
 
 BLOCK_BYTES = int(os.environ.get("DSP_BLOCK_BYTES", 0) or (48 << 20))  # first block: ~23k rows of ~2.08 kB
+# blocks of a foreign .gz are inflated into fixed buffers (private, or slots of the node's shared-memory ring): room for
+# EXACT_ROWS rows of the default k-mer / signal window (2.1 kB each) and some
+GZ_BLOCK_BYTES = int(os.environ.get("DSP_BLOCK_BYTES", 0) or (76 << 20))
 # Later blocks are sized to TARGET_ROWS rows from the bytes/row seen so far: 32,768 sites are exactly four full
 # rounds of the LSTM kernels' workgroups on 256 CUs (64 sites x 2 directions per workgroup pair); aiming 2 % low
 # keeps a block from spilling into a fifth round.  DSP_BLOCK_BYTES pins the size instead (tests).
 TARGET_ROWS = 0 if os.environ.get("DSP_BLOCK_BYTES") else int(32768 * 0.98)
+# Plain text is cut at EXACTLY this many rows (the byte offset behind the n-th newline, textio.find_row_end): no 2 % margin,
+# every forward but a rank's last runs whole rounds (round 3: 97.7 % -> 99 % of the forward's own rate while streaming)
+EXACT_ROWS = 0 if os.environ.get("DSP_BLOCK_BYTES") else 32768
 
 
 class Block(object):
@@ -99,6 +105,7 @@ class FeatureReader(threading.Thread):
             max_rows_per_block = max(1, self.ff.max_block_rows())
         self.rank, self.world, self.nthreads = rank, world, max(1, nthreads)
         self.block_bytes = block_bytes
+        self.gz_block_bytes = GZ_BLOCK_BYTES if block_bytes == BLOCK_BYTES else block_bytes   # an explicit size is kept
         self.first_row = first_row
         self.byte_range = byte_range
         self.gz_ring = gz_ring       # foreign .gz read by several ranks: the node's shared-memory ring (open_gz_ring)
@@ -179,13 +186,25 @@ class FeatureReader(threading.Thread):
         a, b = self.byte_range if self.byte_range is not None else dsp_dist.byte_range_for_rank(mm, size, self.world, self.rank)
         pos = a
         while pos < b:
-            end = min(b, pos + self.block_bytes)
-            if end < b:
-                nl = mm.rfind(b"\n", pos, end)
-                if nl < 0:
-                    nl = mm.find(b"\n", end)
-                    nl = b - 1 if nl < 0 else nl
-                end = min(b, nl + 1)
+            if EXACT_ROWS and self.cap >= EXACT_ROWS:
+                win = int(self.block_bytes * 1.25) + (1 << 20)   # room for EXACT_ROWS rows at the bytes/row seen so far
+                while True:
+                    top = min(b, pos + win)
+                    view = np.frombuffer(mm, dtype=np.uint8, count=top - pos, offset=pos)
+                    k = textio.find_row_end(view, EXACT_ROWS)
+                    del view
+                    if k < top - pos or top == b:
+                        break
+                    win *= 2                                     # longer rows than expected: look further
+                end = pos + k
+            else:
+                end = min(b, pos + self.block_bytes)
+                if end < b:
+                    nl = mm.rfind(b"\n", pos, end)
+                    if nl < 0:
+                        nl = mm.find(b"\n", end)
+                        nl = b - 1 if nl < 0 else nl
+                    end = min(b, nl + 1)
             data = np.frombuffer(mm, dtype=np.uint8, count=end - pos, offset=pos)
             n = self._emit(data, row)
             row += n
@@ -219,33 +238,53 @@ class FeatureReader(threading.Thread):
                 carry = np.concatenate((tail[:n], carry))
         m = m0
         last_rank = self.rank == self.world - 1
+        exact = EXACT_ROWS if self.cap >= EXACT_ROWS else 0
+        want = self.block_bytes   # text to have in hand per block; with `exact`: a little more than EXACT_ROWS rows of it
         while m < m1:
-            e = self._batch_end(bz, m, m1)
+            e = self._batch_end(bz, m, m1, max(1, want - len(carry)))
             need = int(bz.text_off[e] - bz.text_off[m])
             buf = np.empty(len(carry) + need, np.uint8)
             buf[:len(carry)] = carry
             bz.inflate(m, e, out=buf, out_offset=len(carry), nthreads=self.nthreads)
             m = e
-            nl = -1
-            if len(buf):
-                tailpos = np.flatnonzero(buf[max(0, len(buf) - (1 << 16)):] == 10)
-                if len(tailpos):
-                    nl = max(0, len(buf) - (1 << 16)) + int(tailpos[-1])
-                else:
-                    allpos = np.flatnonzero(buf == 10)
-                    nl = int(allpos[-1]) if len(allpos) else -1
+            if exact:
+                # cut at exactly EXACT_ROWS rows (whole rounds of workgroups in the forward); what is behind them -- a few
+                # hundred rows and the head of a split one -- is carried into the next block
+                k = textio.find_row_end(buf, exact)
+                if k < len(buf) or (k and buf[k - 1] == 10 and textio.count_newlines(buf) == exact):
+                    carry = buf[k:].copy()
+                    row += self._emit(buf[:k], row)
+                    want = int(k / exact * exact * 1.02) + (1 << 16)
+                    continue
+            nl = self._gz_cut(buf, len(buf)) if len(buf) else -1
+            if m >= m1 and last_rank and len(buf) and nl < len(buf) - 1 and buf[nl + 1:].tobytes().strip():
+                nl = len(buf) - 1   # the file's last block: an unterminated last row goes with it
             if nl < 0:
                 carry = buf
                 continue
             carry = buf[nl + 1:].copy()
             n = self._emit(buf[:nl + 1], row)
             row += n
-        if last_rank and len(carry) and carry.tobytes().strip():
-            row += self._emit(carry, row)  # an unterminated last row
+            if exact and n > 256:   # fewer rows than wanted (the first block's guess): size the next ones by bytes per row
+                want = int((nl + 1) / n * exact * 1.02) + (1 << 16)
+        while len(carry):   # rows behind the last cut: their ends lie inside this rank's members
+            k = textio.find_row_end(carry, exact) if exact else len(carry)
+            if exact and k < len(carry):              # still more than a block's worth
+                row += self._emit(carry[:k], row)
+                carry = carry[k:].copy()
+                continue
+            if last_rank:                             # the file's end: an unterminated last row goes with the rest
+                if carry.tobytes().strip():
+                    row += self._emit(carry, row)
+            else:                                     # the head of a row that ends in the next rank's members stays behind
+                nl = self._gz_cut(carry, len(carry))
+                if nl >= 0:
+                    row += self._emit(carry[:nl + 1], row)
+            break
         return row
 
-    def _batch_end(self, bz, m, m1):
-        e = int(np.searchsorted(bz.text_off, bz.text_off[m] + self.block_bytes, side="left"))
+    def _batch_end(self, bz, m, m1, nbytes=None):
+        e = int(np.searchsorted(bz.text_off, bz.text_off[m] + (self.block_bytes if nbytes is None else nbytes), side="left"))
         return min(m1, max(m + 1, e))
 
     # ---- foreign .gz (one deflate stream; what the reference's `extract --gzip` writes) --------------------------------
@@ -276,7 +315,7 @@ class FeatureReader(threading.Thread):
         try:
             while True:
                 buf = get_buf(i)
-                room = min(len(buf), len(carry) + self.block_bytes)
+                room = min(len(buf), len(carry) + self.gz_block_bytes)
                 if len(carry) >= room:
                     raise ValueError("a row of %s is longer than a reader block (%d bytes)" % (self.path, room))
                 buf[:len(carry)] = carry
@@ -287,6 +326,13 @@ class FeatureReader(threading.Thread):
                         put_block(i, buf, n, row, 1)
                         i, row = i + 1, row + 1
                     break
+                exact = EXACT_ROWS if self.cap >= EXACT_ROWS else 0
+                cut = textio.find_row_end(buf[:n], exact) if exact else n
+                if exact and cut < n:                     # exactly EXACT_ROWS rows: whole rounds of workgroups in the forward
+                    carry = buf[cut:n].copy()
+                    put_block(i, buf, cut, row, exact)
+                    i, row = i + 1, row + exact
+                    continue
                 nl = self._gz_cut(buf, n)
                 if nl < 0:
                     carry = buf[:n].copy()
@@ -323,7 +369,7 @@ class FeatureReader(threading.Thread):
             raise RuntimeError("reader stopped")
 
         def get_buf(i):
-            return np.empty(self.block_bytes + slack, np.uint8)
+            return np.empty(self.gz_block_bytes + slack, np.uint8)
 
         def put_block(i, buf, n, first_row, n_rows):
             if mine(i):
@@ -404,7 +450,7 @@ class FeatureReader(threading.Thread):
         return row
 
 
-def open_gz_ring(path, rank, world, local_rank, local_world, all_gather_object, block_bytes=BLOCK_BYTES):
+def open_gz_ring(path, rank, world, local_rank, local_world, all_gather_object, block_bytes=GZ_BLOCK_BYTES):
     """Collective over all ranks (call it on every rank, before the readers start): for a foreign single-stream .gz read
     by several ranks, the first rank of every node creates a shared-memory ring; returns the `gz_ring` argument of
     FeatureReader, or None when the file needs no ring (one rank) or a node could not reserve the shared memory (every

@@ -42,6 +42,13 @@ def count_rows(text):
     return int(nat.lib().dsp_count_rows(p, n))
 
 
+def find_row_end(arr, n_rows):
+    """bytes of the first n_rows rows of a uint8 array (len(arr) when it holds fewer)"""
+    if len(arr) == 0 or n_rows <= 0:
+        return 0
+    return int(nat.lib().dsp_find_row_end(_ptr(arr), len(arr), int(n_rows)))
+
+
 def count_newlines(arr):
     """newline bytes in a uint8 array (dsp_count_rows counts an unterminated tail as a row)"""
     n = len(arr)

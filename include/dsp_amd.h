@@ -171,6 +171,7 @@ void dsp_model_destroy(dsp_model* m);
  * as Python float() + torch.tensor(dtype=float) do.  Returns the row count, or DSP_EPARSE (unknown base
  * letter = the reference's KeyError, malformed number = ValueError) / DSP_EINVAL. */
 int64_t dsp_count_rows(const char* text, size_t len);
+int64_t dsp_find_row_end(const char* text, size_t len, int64_t n_rows);   /* bytes of the first n_rows rows (len if there are fewer) */
 int64_t dsp_parse_feature_rows(const char* text, size_t len, int32_t seq_len, int32_t signal_len, int64_t max_rows,
                                uint8_t* kmer, float* means, float* stds, int32_t* lens, float* signals,
                                int32_t* labels, uint64_t* row_off, uint32_t* info_len, uint32_t* read_off,
