@@ -7,7 +7,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DSP_AMD_LIB") or os.path.join(_HERE, "libdsp_amd.so")
 
-DSP_OK, DSP_EINVAL, DSP_ESHAPE, DSP_EHIP, DSP_ENOMEM, DSP_EPARSE = 0, -1, -2, -3, -4, -5
+DSP_OK, DSP_EINVAL, DSP_ESHAPE, DSP_EHIP, DSP_ENOMEM, DSP_EPARSE, DSP_EKEY = 0, -1, -2, -3, -4, -5, -6
 MODULE_CODE = {"both_bilstm": 0, "seq_bilstm": 1, "signal_bilstm": 2}
 DT_F32, DT_U8, DT_U16, DT_I32 = 0, 1, 2, 3
 INIT_ZEROS, INIT_EXPLICIT, INIT_PHILOX = 0, 1, 2
@@ -259,4 +259,8 @@ def check(rc: int):
         raise ValueError(msg)
     if rc == DSP_EPARSE:
         raise ValueError(msg)
+    if rc == DSP_EKEY:   # base2code_dna[x] of the reference's reader (call_modifications.py:84): KeyError(x)
+        err = KeyError(msg.split("'")[1] if msg.count("'") >= 2 else msg)
+        err.detail = msg
+        raise err
     raise RuntimeError(msg)

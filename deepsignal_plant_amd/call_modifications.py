@@ -183,6 +183,7 @@ def _call_mods_file(args, rank, local_rank, world):
     if args.gzip and not out_path.endswith(".gz"):
         out_path += ".gz"  # call_modifications.py:264-267
     part_path = out_path if world == 1 else "%s.part%05d" % (out_path, rank)
+    _remove_stale_parts(part_path, world)
 
     reader = feed.FeatureReader(input_path, args.seq_len, args.signal_len, rank=rank, world=world, nthreads=nthreads,
                                 nbuf=4, first_row=first_row, byte_range=byte_range, gz_ring=gz_ring)
@@ -266,7 +267,7 @@ def _call_mods_file(args, rank, local_rank, world):
         gz_ring["ring"].close()
     if interleaved:
         np.asarray(writer.block_ends, np.int64).tofile(part_path + ".blocks")
-    return n_rows, part_path, out_path
+    return n_rows, part_path, out_path, interleaved
 
 
 def _make_freq(args, dev, world, nthreads):
@@ -332,6 +333,7 @@ def _call_mods_reads(args, rank, local_rank, world):
     if args.gzip and not out_path.endswith(".gz"):
         out_path += ".gz"
     part_path = out_path if world == 1 else "%s.part%05d" % (out_path, rank)
+    _remove_stale_parts(part_path, world)
     freq, freq_dev = _make_freq(args, dev, world, nthreads)
     writer = _Writer(part_path, args.gzip, nthreads, _NoRelease(), freq)
     writer.n_vocab = int(args.n_vocab)
@@ -411,20 +413,40 @@ def _call_mods_reads(args, rank, local_rank, world):
         raise writer.error
     _finish_freq(args, freq, freq_dev, rank, world)
     print("%d of %d read files failed.." % (batches.failed, len(files)))  # :440
-    return n_rows, part_path, out_path
+    return n_rows, part_path, out_path, False
+
+
+def _remove_stale_parts(part_path, world):
+    """What an earlier, aborted run with the same -o may have left behind: this rank's part file and its piece table.  The
+    merge never looks at the disk to decide HOW to merge (the run tells it: `interleaved`), but a stale piece table next to
+    a fresh part file must not survive to be trusted by anything else either."""
+    if world == 1:
+        return
+    for p in (part_path, part_path + ".blocks"):
+        try:
+            os.remove(p)
+        except OSError:
+            pass
 
 
 _BGZF_EOF = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
 
 
-def _merge_parts(out_path, world):
+def _merge_parts(out_path, world, interleaved=False):
     """concatenate the ranks' part files in rank order (gzip / BGZF members concatenate into a valid .gz; the empty
-    end-of-file member of every part but the last is dropped so that the result is one well-formed BGZF file)"""
+    end-of-file member of every part but the last is dropped so that the result is one well-formed BGZF file).
+    interleaved: THIS run dealt the input's blocks round-robin (a foreign .gz) and every rank wrote its piece table --
+    the run says so, the disk is not asked (a stale table of an aborted run must not choose the merge)."""
     parts = ["%s.part%05d" % (out_path, r) for r in range(world)]
-    if all(os.path.exists(p + ".blocks") for p in parts):
+    if interleaved:
         # interleaved sharding (a foreign .gz): piece k of rank r is block k * world + r of the input.  Pieces of a
         # --gzip part are whole BGZF members; the parts' end-of-file members are dropped and one is written at the end
         ends = [np.fromfile(p + ".blocks", np.int64) for p in parts]
+        for p, e in zip(parts, ends):   # a piece table describes its part file up to the end-of-file member, or it is not its own
+            want = os.path.getsize(p) - (len(_BGZF_EOF) if out_path.endswith(".gz") else 0)
+            if (int(e[-1]) if len(e) else 0) != want or (len(e) > 1 and bool(np.any(np.diff(e) < 0))):
+                raise RuntimeError("%s.blocks does not describe %s (%d pieces ending at %d, file holds %d bytes of calls)"
+                                   % (p, p, len(e), int(e[-1]) if len(e) else 0, want))
         files = [open(p, "rb") for p in parts]
         with open(out_path, "wb") as wf:
             for k in range(max(len(e) for e in ends)):
@@ -486,17 +508,17 @@ def _copy_range(src_fd, dst_fd, count, dst_off):
         left -= n
 
 
-def _merge_parts_by_all_ranks(out_path, part_path, rank, world, coll_dev):
+def _merge_parts_by_all_ranks(out_path, part_path, rank, world, coll_dev, interleaved=False):
     """Collective.  The per-read calls of N ranks become one file without funnelling them through rank 0: the ranks agree
     on the sizes (one all_gather), rank 0 sizes the result, and EVERY rank copies its own part to its offset at the same
     time (config 5's shape: 1 G rows = 60 GB of calls; one process copying them was a quarter of the run, with seven GPUs
     idle behind the barrier).  --gzip: the empty end-of-file member of every part but the last is left out, so that the
     result is one well-formed BGZF file.  The interleaved pieces of a foreign .gz input keep the rank-0 merge."""
     import torch.distributed as dist
-    if os.path.exists(part_path + ".blocks"):
+    if interleaved:   # what the run did, the same on every rank -- not what lies on the disk (ADVICE r3)
         dist.barrier()
         if rank == 0:
-            _merge_parts(out_path, world)
+            _merge_parts(out_path, world, True)
         return
     size = os.path.getsize(part_path)
     keep = size
@@ -582,9 +604,11 @@ def call_mods(args):
     ndev = torch.cuda.device_count()
     local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
-    pinned = dsp_dist.pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)),
-                               getattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id", None)
-                               if os.environ.get("DSP_RANK_AFFINITY") == "numa" else None)
+    numa = os.environ.get("DSP_RANK_AFFINITY") == "numa"
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    bus = [getattr(torch.cuda.get_device_properties(r % ndev), "pci_bus_id", None) for r in range(local_world)] if numa else None
+    pinned = dsp_dist.pin_rank(local_rank, local_world, bus[local_rank % len(bus)] if bus else None,
+                               bus if bus and all(bus) else None)
     if pinned is not None and rank == 0:
         print("[main] DSP_RANK_AFFINITY: rank 0 on CPUs %s.." % ",".join(str(c) for c in pinned[:8]))
     # one process per GPU over RCCL (gloo when ranks have to share GPUs; DSP_FORCE_DIST=1: a one-rank RCCL group)
@@ -592,9 +616,9 @@ def call_mods(args):
     dist_on = dsp_dist.collective(world)
     _tick("imports, checks, process group")
     if os.path.isdir(input_path):  # reads in, calls out: extraction + forward on the GPU (:559-583)
-        n_rows, part_path, out_path = _call_mods_reads(args, rank, local_rank, world)
+        n_rows, part_path, out_path, interleaved = _call_mods_reads(args, rank, local_rank, world)
     else:
-        n_rows, part_path, out_path = _call_mods_file(args, rank, local_rank, world)
+        n_rows, part_path, out_path, interleaved = _call_mods_file(args, rank, local_rank, world)
     if dist_on:
         import torch.distributed as dist
         cdev = torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else None
@@ -602,7 +626,7 @@ def call_mods(args):
         dist.barrier()
         _tick("all ranks done")
     if world > 1:
-        _merge_parts_by_all_ranks(out_path, part_path, rank, world, cdev)
+        _merge_parts_by_all_ranks(out_path, part_path, rank, world, cdev, interleaved)
         dist.barrier()
         if rank == 0:
             if getattr(args, "freq_file", None) and (getattr(args, "freq_on", "device") == "host" or

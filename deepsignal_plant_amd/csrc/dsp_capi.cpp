@@ -312,6 +312,7 @@ struct dsp_model {
     int tiling21 = -1;       // <2 unit tiles, 1 site tile> per wave on the dense one-pass layers (dsp_lstm21_kernel): -1 = for
                              // batches whose 32-site tiles x 2 directions fit the CUs at once (small-batch latency); DSP_LSTM_TILING=21
                              // always, =0 never (A/B switch)
+    bool sync_each = false, debug_lstm = false;  // DSP_SYNC_EACH / DSP_DEBUG_LSTM: debugging aids, read when the handle is made
     int n_cus = 256;         // compute units of the handle's device
     bool split_ready = false;  // the split-precision weight pieces are on the device (ensure_split)
     bool fp16_safe = true;         // every operand of the combined stack provably inside the fp16 range (fp16x3 only then)
@@ -484,7 +485,7 @@ struct Launcher {
         const int e = f();
         if (e != 0) { rc = fail(DSP_EHIP, "launch %s failed: %s", name, hipGetErrorString((hipError_t)e)); return; }
         if (m->prof) { hipEventRecord(eb, s); m->prof_entries.push_back({name, ea, eb}); }
-        if (getenv("DSP_SYNC_EACH")) {  // debugging aid: attribute an asynchronous GPU fault to its launch
+        if (m->sync_each) {  // DSP_SYNC_EACH (read once, in dsp_model_create): attribute an asynchronous GPU fault to its launch
             fprintf(stderr, "[launch] %s ...", name);
             const hipError_t se = hipStreamSynchronize(s);
             fprintf(stderr, " %s\n", se == hipSuccess ? "ok" : hipGetErrorString(se));
@@ -551,7 +552,7 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
             a.NQ = (ly.Ipad + ly.Hp) / 16;
             a.SG = 8 / a.UT;
         }
-        if (getenv("DSP_DEBUG_LSTM"))
+        if (m->debug_lstm)   // DSP_DEBUG_LSTM (read once, in dsp_model_create)
             fprintf(stderr, "[lstm] %s k=%zu split=%d Ipad=%d H=%d Hp=%d UT=%d SG=%d NQ=%d NTp=%lld n=%lld T=%d Fout=%d x=%p out=%p\n", name, k,
                     (int)split, a.Ipad, a.H, a.Hp, a.UT, a.SG, a.NQ, a.NTp, a.n, a.T, a.Fout, (const void*)a.x, (void*)a.out);
         L.run(name, [&] { return split ? dsp_k_lstm6(&a, prec, L.s) : dsp_k_lstm(&a, L.s); });
@@ -636,6 +637,8 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
     m->cfg = *cfg; m->d = d; m->device = device;
     if (const char* v = getenv("DSP_TRACE_LAUNCH")) m->trace_launch = atoi(v);
     if (const char* v = getenv("DSP_TRACE_WAVE")) m->trace_wave = atoi(v) & 7;
+    m->sync_each = getenv("DSP_SYNC_EACH") != nullptr;   // (never per launch: a 512-site forward is 9 launches in 2-4 ms)
+    m->debug_lstm = getenv("DSP_DEBUG_LSTM") != nullptr;
     if (const char* v = getenv("DSP_LSTM_SG")) m->sg_override = atoi(v);  // A/B switch
     if (const char* v = getenv("DSP_LSTM_NP8")) m->np8 = atoi(v) == 2 ? 2 : 1;  // A/B switch
     if (const char* v = getenv("DSP_LSTM_PRIO")) m->phase_prio = atoi(v) != 0;    // A/B switch

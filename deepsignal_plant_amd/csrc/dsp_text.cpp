@@ -179,12 +179,12 @@ int parse_row(const char* text, const char* ls, const char* le, int L, int S, in
     o.info_len[r] = (uint32_t)(fe(5) - ls);
     o.read_off[r] = (uint32_t)(f[4] - ls);
     o.read_len[r] = (uint32_t)(fe(4) - f[4]);
+    // a letter outside base2code_dna is the reference's KeyError, raised by its reader before anything looks at the k-mer's
+    // length (call_modifications.py:84): code 8, the letter in the next byte
+    for (const char* p = f[6]; p < fe(6); ++p)
+        if (g_codes.t[(unsigned char)*p] < 0) return 8 | ((int)(unsigned char)*p << 8);
     if (fe(6) - f[6] != L) return 2;
-    for (int i = 0; i < L; ++i) {
-        const int8_t c = g_codes.t[(unsigned char)f[6][i]];
-        if (c < 0) return 2;
-        o.kmer[r * L + i] = (uint8_t)c;
-    }
+    for (int i = 0; i < L; ++i) o.kmer[r * L + i] = (uint8_t)g_codes.t[(unsigned char)f[6][i]];
     if (!parse_float_list(f[7], fe(7), L, o.means + r * L)) return 3;
     if (!parse_float_list(f[8], fe(8), L, o.stds + r * L)) return 4;
     {
@@ -532,8 +532,16 @@ int64_t dsp_parse_feature_rows(const char* text, size_t len, int32_t seq_len, in
         }
     });
     for (size_t t = 0; t < bad_row.size(); ++t)
-        if (bad_row[t] >= 0)
-            return text_fail(DSP_EPARSE, "malformed feature row %lld: bad %s", (long long)bad_row[t], kFieldName[bad_code[t]]);
+        if (bad_row[t] >= 0) {
+            if ((bad_code[t] & 0xff) == 8) {
+                const int ch = (bad_code[t] >> 8) & 0xff;
+                char shown[8];
+                if (ch >= 32 && ch < 127) snprintf(shown, sizeof(shown), "%c", ch); else snprintf(shown, sizeof(shown), "\\x%02x", ch);
+                return text_fail(DSP_EKEY, "'%s': base of feature row %lld is not in the alphabet (base2code_dna)", shown, (long long)bad_row[t]);
+            } else {
+                return text_fail(DSP_EPARSE, "malformed feature row %lld: bad %s", (long long)bad_row[t], kFieldName[bad_code[t]]);
+            }
+        }
     return n;
 }
 

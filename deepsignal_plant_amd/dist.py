@@ -109,17 +109,33 @@ def available_cpus():
     return max(1, n)
 
 
+_PINNED_SHARE = None   # set by pin_rank: the process affinity IS this rank's share already
+
+
 def threads_per_rank(nproc, local_world=None):
     """Host threads (parser / formatter / deflate) of ONE rank: --nproc, capped by this rank's share of the node's CPUs
     (available CPUs // ranks on the node) -- 8 ranks must not each start --nproc threads on a node that has fewer than
-    8 x --nproc cores.  DSP_THREADS_PER_RANK overrides."""
+    8 x --nproc cores.  After pin_rank has narrowed the affinity to the rank's own CPUs the share is that set, not a
+    local_world-th of it (128 CPUs and 8 pinned ranks gave 2 threads instead of 16).  DSP_THREADS_PER_RANK
+    overrides."""
     env = os.environ.get("DSP_THREADS_PER_RANK")
     if env:
         return max(1, int(env))
     if local_world is None:
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
-    share = max(1, available_cpus() // max(1, local_world))
+    if _PINNED_SHARE is not None:
+        share = max(1, min(available_cpus(), _PINNED_SHARE))
+    else:
+        share = max(1, available_cpus() // max(1, local_world))
     return max(1, min(nproc if nproc and nproc > 0 else 1, share))
+
+
+def spare_cpus(local_world):
+    """CPUs a node-wide helper of this rank (the one inflater of a foreign .gz) may use next to the node's ranks: what
+    is allowed minus one per rank -- of the NODE's CPUs when this rank is not pinned, of its own slice when it is"""
+    if _PINNED_SHARE is not None:
+        return max(1, available_cpus() - 1)
+    return max(1, available_cpus() - max(1, local_world))
 
 
 def _cpulist(text):
@@ -132,33 +148,52 @@ def _cpulist(text):
     return out
 
 
-def pin_rank(local_rank, local_world, pci_bus_id=None):
+def _numa_node_cpus(pci_bus_id):
+    """(NUMA node of a PCI device, its CPU list) or (None, None)"""
+    try:
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % pci_bus_id.lower()).read().strip())
+        if node < 0:
+            return None, None
+        return node, _cpulist(open("/sys/devices/system/node/node%d/cpulist" % node).read())
+    except (OSError, ValueError, AttributeError):
+        return None, None
+
+
+def pin_rank(local_rank, local_world, pci_bus_id=None, peer_bus_ids=None):
     """Optional CPU placement of a rank (DSP_RANK_AFFINITY = numa | slice; default: leave the scheduler alone).
-    numa: the CPUs of the NUMA node the rank's GPU hangs off (/sys/bus/pci/devices/<bdf>/numa_node), split among the ranks
-    whose GPUs share that node by the caller's slice of it; slice: the local_rank-th of local_world equal slices of the
-    allowed CPUs.  Returns the CPU list set, or None."""
+    slice: the local_rank-th of local_world equal slices of the allowed CPUs.
+    numa: the CPUs of the NUMA node the rank's GPU hangs off (/sys/bus/pci/devices/<bdf>/numa_node); when the caller
+    names the GPUs of ALL local ranks (peer_bus_ids[r] = PCI id of local rank r's GPU) the node's CPUs are split in equal
+    slices among the ranks whose GPUs share that node; without that list every rank of the node takes the whole node (and
+    threads_per_rank divides by the ranks per node as if unpinned).
+    Returns the CPU list set, or None.  A rank whose affinity became its own share records it for threads_per_rank."""
+    global _PINNED_SHARE
     mode = os.environ.get("DSP_RANK_AFFINITY", "")
     if mode not in ("numa", "slice") or not hasattr(os, "sched_setaffinity"):
         return None
     allowed = sorted(os.sched_getaffinity(0))
-    cpus = None
+    cpus, own_share = None, False
     if mode == "numa" and pci_bus_id:
-        try:
-            bdf = pci_bus_id.lower()
-            node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read().strip())
-            if node >= 0:
-                cand = [c for c in _cpulist(open("/sys/devices/system/node/node%d/cpulist" % node).read()) if c in allowed]
-                if cand:
-                    cpus = cand
-        except (OSError, ValueError):
-            cpus = None
+        node, node_cpus = _numa_node_cpus(pci_bus_id)
+        cand = [c for c in (node_cpus or []) if c in allowed]
+        if cand:
+            cpus = cand
+            if peer_bus_ids:   # my slice of the node's CPUs among the local ranks on the same node
+                peers = [r for r, b in enumerate(peer_bus_ids) if _numa_node_cpus(b)[0] == node]
+                if local_rank in peers and len(cand) >= len(peers):
+                    k = len(cand) // len(peers)
+                    i = peers.index(local_rank)
+                    cpus, own_share = cand[i * k:(i + 1) * k], True
     if cpus is None:
         k = max(1, len(allowed) // max(1, local_world))
-        cpus = allowed[local_rank * k:(local_rank + 1) * k] or allowed
+        cpus = allowed[local_rank * k:(local_rank + 1) * k]
+        own_share = bool(cpus)
+        cpus = cpus or allowed
     try:
         os.sched_setaffinity(0, cpus)
     except OSError:
         return None
+    _PINNED_SHARE = len(cpus) if own_share else None
     return cpus
 
 

@@ -185,17 +185,29 @@ class FeatureReader(threading.Thread):
             mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
         a, b = self.byte_range if self.byte_range is not None else dsp_dist.byte_range_for_rank(mm, size, self.world, self.rank)
         pos = a
+        exact_bytes = 0   # bytes the previous block of EXACT_ROWS rows took
         while pos < b:
             if EXACT_ROWS and self.cap >= EXACT_ROWS:
-                win = int(self.block_bytes * 1.25) + (1 << 20)   # room for EXACT_ROWS rows at the bytes/row seen so far
+                # the window holds EXACT_ROWS rows at the bytes/row of the PREVIOUS block (+5 %; the first block guesses from
+                # block_bytes); when it falls short the scan continues behind it with the rows still missing -- no byte is
+                # scanned twice (a fixed 64 MB window was too small for the default 68 MB blocks, every block
+                # was searched twice)
+                win = int(exact_bytes * 1.05) + (1 << 16) if exact_bytes else int(self.block_bytes * 1.25) + (1 << 20)
+                lo, left = pos, EXACT_ROWS
                 while True:
-                    top = min(b, pos + win)
-                    view = np.frombuffer(mm, dtype=np.uint8, count=top - pos, offset=pos)
-                    k = textio.find_row_end(view, EXACT_ROWS)
-                    del view
-                    if k < top - pos or top == b:
+                    top = min(b, lo + win)
+                    view = np.frombuffer(mm, dtype=np.uint8, count=top - lo, offset=lo)
+                    k = textio.find_row_end(view, left)
+                    if k < top - lo or top == b:
+                        del view
                         break
-                    win *= 2                                     # longer rows than expected: look further
+                    left -= textio.count_newlines(view)          # rows that end inside the window scanned so far
+                    del view
+                    lo = top
+                    if left <= 0:                                # (the window ended exactly behind the last wanted row)
+                        k = 0
+                        break
+                k += lo - pos
                 end = pos + k
             else:
                 end = min(b, pos + self.block_bytes)
@@ -208,6 +220,8 @@ class FeatureReader(threading.Thread):
             data = np.frombuffer(mm, dtype=np.uint8, count=end - pos, offset=pos)
             n = self._emit(data, row)
             row += n
+            if n == EXACT_ROWS:
+                exact_bytes = end - pos
             if TARGET_ROWS and n > 256:
                 self.block_bytes = int(max(1 << 20, (end - pos) / n * min(TARGET_ROWS, 0.95 * self.cap)))
             pos = end
@@ -307,7 +321,7 @@ class FeatureReader(threading.Thread):
         # node, so with a ring it takes the CPUs the ranks' parsers leave idle while they wait for it (one stays per rank)
         nt = self.nthreads
         if self.gz_ring is not None and self.gz_ring.get("producer"):
-            nt = max(nt, dsp_dist.available_cpus() - self.gz_ring["local_world"])
+            nt = max(nt, dsp_dist.spare_cpus(self.gz_ring["local_world"]))
         st = gzio.open_gz_stream(self.path, nt)
         self.gz_parallel = isinstance(st, gzio.PgzStream)
         carry = np.zeros(0, np.uint8)
@@ -321,10 +335,21 @@ class FeatureReader(threading.Thread):
                 buf[:len(carry)] = carry
                 got = st.readinto(buf[:room], len(carry))
                 n = len(carry) + got
-                if got == 0:       # end of the stream: what is left is an unterminated last row (or nothing)
-                    if len(carry) and carry.tobytes().strip():
-                        put_block(i, buf, n, row, 1)
-                        i, row = i + 1, row + 1
+                exact = EXACT_ROWS if self.cap >= EXACT_ROWS else 0
+                if got == 0:       # end of the stream: the carry holds the rows behind the last cut (with exact cutting
+                    # usually thousands of complete ones) and possibly an unterminated last row: the same cut loop, then
+                    # the remainder with its true row count (it went out as "1 row")
+                    first = True   # (the carry already sits at the head of this block's buffer)
+                    while len(carry) and carry.tobytes().strip():
+                        cut = textio.find_row_end(carry, exact) if exact else len(carry)
+                        k = exact if (exact and cut < len(carry)) else textio.count_rows(carry[:cut])
+                        if not first:
+                            buf = get_buf(i)
+                            buf[:cut] = carry[:cut]
+                        first = False
+                        put_block(i, buf, cut, row, k)
+                        i, row = i + 1, row + k
+                        carry = carry[cut:].copy()
                     break
                 exact = EXACT_ROWS if self.cap >= EXACT_ROWS else 0
                 cut = textio.find_row_end(buf[:n], exact) if exact else n

@@ -9,7 +9,7 @@
  * (e.g. torch.Tensor.data_ptr() on PyTorch-ROCm); the handle owns only repacked weights + scratch.
  *
  * Return convention: 0 on success, negative dsp_status on error; dsp_last_error() returns a
- * thread-local message.  The Python mirror maps DSP_EINVAL -> ValueError, the rest -> RuntimeError,
+ * thread-local message.  The Python mirror maps DSP_EINVAL / DSP_EPARSE -> ValueError, DSP_EKEY -> KeyError, the rest -> RuntimeError,
  * matching the exceptions the reference raises (models.py:127-128, call_modifications.py:219-223).
  */
 #ifndef DSP_AMD_H
@@ -30,7 +30,9 @@ typedef enum dsp_status {
     DSP_ESHAPE = -2,      /* weight count/shape mismatch (reference: strict load_state_dict RuntimeError) */
     DSP_EHIP = -3,        /* HIP runtime error (message carries hipGetErrorString) */
     DSP_ENOMEM = -4,      /* host or device allocation failure */
-    DSP_EPARSE = -5       /* malformed feature row (reference: KeyError/ValueError in the row parser) */
+    DSP_EPARSE = -5,      /* malformed feature row (reference: ValueError in the row parser) */
+    DSP_EKEY = -6         /* a base letter outside base2code_dna (reference: KeyError, call_modifications.py:84); the message
+                             starts with the quoted letter */
 } dsp_status;
 
 /* module codes: ModelBiLSTM(module=...) at deepsignal_plant/models.py:120-128 */
@@ -168,8 +170,8 @@ void dsp_model_destroy(dsp_model* m);
  * [r][L][S], labels i32 [r]; row_off/info_len = byte range of the first six fields (the `sampleinfo`
  * string kept verbatim, :80) inside `text`; read_off/read_len = the readname field (:77) relative to
  * row_off, for read-boundary batching (:94-109).  Tokens go decimal -> correctly rounded double -> float32,
- * as Python float() + torch.tensor(dtype=float) do.  Returns the row count, or DSP_EPARSE (unknown base
- * letter = the reference's KeyError, malformed number = ValueError) / DSP_EINVAL. */
+ * as Python float() + torch.tensor(dtype=float) do.  Returns the row count, or DSP_EKEY (unknown base
+ * letter = the reference's KeyError), DSP_EPARSE (malformed number = ValueError) / DSP_EINVAL. */
 int64_t dsp_count_rows(const char* text, size_t len);
 int64_t dsp_find_row_end(const char* text, size_t len, int64_t n_rows);   /* bytes of the first n_rows rows (len if there are fewer) */
 int64_t dsp_parse_feature_rows(const char* text, size_t len, int32_t seq_len, int32_t signal_len, int64_t max_rows,

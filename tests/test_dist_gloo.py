@@ -233,8 +233,13 @@ def test_gpu_count_and_thread_budget_without_the_hip_runtime(monkeypatch, tmp_pa
             got = dd.pin_rank(1, 2)
             allowed = sorted(before)
             assert got == allowed[len(allowed) // 2:2 * (len(allowed) // 2)] and _os.sched_getaffinity(0) == set(got)
+            # a pinned rank's affinity IS its share: not divided by the ranks of the node once more
+            assert dd.threads_per_rank(64, 2) == len(got)
+            assert dd.spare_cpus(2) == max(1, len(got) - 1)
         finally:
             _os.sched_setaffinity(0, before)
+            dd._PINNED_SHARE = None
+        assert dd.threads_per_rank(64, 2) == max(1, cpus // 2)
 
 
 def _merge_worker(rank, world, port, outdir, gz):

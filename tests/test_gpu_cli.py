@@ -102,6 +102,9 @@ def test_cli_errors(tmp_path):
     bad = tmp_path / "bad.tsv"
     bad.write_text("chr1\t1\t+\t1\tr\tt\tACGTXACGTACGT\t0\t0\t0\t0\t0\n")
     r = _run_cli(["-i", str(bad), "-m", ck, "-o", os.path.join(str(tmp_path), "o.tsv")])
+    assert r.returncode != 0 and "KeyError: 'X'" in r.stderr   # base2code_dna['X'], call_modifications.py:84
+    bad.write_text("chr1\t1\t+\t1\tr\tt\tACGTAACGTACGT\t0\t0\t0\t0\t0\n")
+    r = _run_cli(["-i", str(bad), "-m", ck, "-o", os.path.join(str(tmp_path), "o.tsv")])
     assert r.returncode != 0 and "malformed feature row" in r.stderr
 
 

@@ -193,10 +193,38 @@ def test_interleaved_part_files_merge_back_into_input_order(tmp_path, is_gzip):
             ends = list(wf.block_ends)
         assert len(ends) == len(blocks[r::world])
         np.asarray(ends, np.int64).tofile(part + ".blocks")
-    cm._merge_parts(out, world)
+    cm._merge_parts(out, world, True)
     got = gzip.open(out, "rb").read() if is_gzip else open(out, "rb").read()
     assert got == b"".join(blocks)
     assert sorted(os.listdir(str(tmp_path))) == [os.path.basename(out)]
     if is_gzip:
         bz = gzio.BgzfFile(out)
         assert bz.ok and int(bz.isize[bz.n_members - 1]) == 0 and list(bz.isize[:bz.n_members - 1]).count(0) == 0
+
+
+def test_stale_piece_tables_do_not_choose_the_merge(tmp_path):
+    """an aborted run on a foreign .gz leaves `<part>.blocks` files behind.  A later contiguous run with the same
+    -o must not interleave its part files by those stale tables: the merge is told what THIS run did, the tables of an
+    earlier one are removed when a rank starts, and a table that does not describe its part file is an error."""
+    from deepsignal_plant_amd import call_modifications as cm
+    world = 2
+    out = str(tmp_path / "calls.tsv")
+    parts = ["%s.part%05d" % (out, r) for r in range(world)]
+    for r, p in enumerate(parts):
+        open(p, "wb").write(b"stale part %d\n" % r)
+        np.asarray([3, 7], np.int64).tofile(p + ".blocks")      # what the aborted run left
+    for p in parts:                                              # every rank clears its own leftovers at start ...
+        cm._remove_stale_parts(p, world)
+    assert os.listdir(str(tmp_path)) == []
+    for r, p in enumerate(parts):                                # ... and a contiguous run writes its parts
+        open(p, "wb").write(b"rank %d rows\n" % r * 5)
+    np.asarray([3, 7], np.int64).tofile(parts[0] + ".blocks")    # (even a table that survived is not consulted)
+    np.asarray([3, 7], np.int64).tofile(parts[1] + ".blocks")
+    cm._merge_parts(out, world, False)
+    assert open(out, "rb").read() == b"rank 0 rows\n" * 5 + b"rank 1 rows\n" * 5
+    # an interleaved merge checks every table against its part file
+    for r, p in enumerate(parts):
+        open(p, "wb").write(b"rank %d rows\n" % r * 5)
+        np.asarray([3, 7], np.int64).tofile(p + ".blocks")
+    with pytest.raises(RuntimeError, match="does not describe"):
+        cm._merge_parts(out, world, True)

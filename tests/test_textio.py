@@ -40,8 +40,13 @@ def test_parser_edge_cases():
     assert ok.n == 2 and np.array_equal(ok.means[0], ok.means[1])
     extra = textio.parse_rows(("  " + row + "\textra\tcols\n").encode(), 13, 16)  # strip(); words[11] ignores extras
     assert extra.n == 1 and extra.labels[0] == int(w[11])
+    # a base outside base2code_dna: KeyError(letter), as the reference's reader raises (call_modifications.py:84) -- also
+    # when the k-mer has the wrong length (the reference's reader never looks at the length)
+    for kmer in ("ACGTXACGTACGT", "ACGX", "acgtacgtacgta"):
+        with pytest.raises(KeyError) as ei:
+            textio.parse_rows(("\t".join(w[:6] + [kmer] + w[7:]) + "\n").encode(), 13, 16)
+        assert ei.value.args[0] == {"ACGTXACGTACGT": "X", "ACGX": "X", "acgtacgtacgta": "a"}[kmer] and "row 0" in ei.value.detail
     for bad in ("\t".join(w[:11]),                                   # 11 columns
-                "\t".join(w[:6] + ["ACGTXACGTACGT"] + w[7:]),         # unknown base -> KeyError in the reference
                 "\t".join(w[:6] + ["ACGT"] + w[7:]),                  # k-mer of the wrong length
                 "\t".join(w[:7] + [w[7] + ",1.0"] + w[8:]),           # 14 means
                 "\t".join(w[:7] + [w[7].replace(",", ",x", 1)] + w[8:]),
@@ -134,8 +139,8 @@ def test_one_pass_row_parser_agrees_with_the_general_parser_on_everything():
                 r = textio.parse_rows(data, 13, 16, nthreads=2)
                 out.append(("ok", r.n, r.kmer.tobytes(), r.means.tobytes(), r.stds.tobytes(), r.lens.tobytes(), r.signals.tobytes(),
                             r.labels.tobytes(), r.row_off.tobytes(), r.info_len.tobytes(), r.read_off.tobytes(), r.read_len.tobytes()))
-            except ValueError as e:
-                out.append(("error", str(e)))
+            except (ValueError, KeyError) as e:
+                out.append(("error", type(e).__name__ + str(e)))
         L.dsp_text_set_fast_rows_(1)
         return out
     try:

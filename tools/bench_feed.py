@@ -31,7 +31,7 @@ def _worker(rank, world, port, path, nproc, affinity, q):
     from deepsignal_plant_amd import feed, textio
     dist.init_process_group("gloo", rank=rank, world_size=world)
     cpus = dd.pin_rank(rank, world)
-    nthreads = dd.threads_per_rank(nproc, world)
+    nthreads = dd.threads_per_rank(nproc, world)   # (after pin_rank: the pinned slice is the share)
     ring = None
     first_row, byte_range = 0, None
     if path.endswith(".gz"):

@@ -15,8 +15,8 @@ def both(data):
         try:
             r=textio.parse_rows(data,13,16,nthreads=1)
             out.append(("ok",r.n,r.kmer.tobytes(),r.means.tobytes(),r.stds.tobytes(),r.lens.tobytes(),r.signals.tobytes(),r.labels.tobytes(),r.row_off.tobytes(),r.info_len.tobytes(),r.read_off.tobytes(),r.read_len.tobytes()))
-        except ValueError as e:
-            out.append(("err",str(e)))
+        except (ValueError, KeyError) as e:
+            out.append(("err",type(e).__name__+str(e)))
     return out
 t0=time.time(); n=0; nerr=0
 while time.time()-t0 < float(sys.argv[2]) if len(sys.argv)>2 else 60:
