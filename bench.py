@@ -111,7 +111,9 @@ def parse_args(argv=None):
                     help="products of the combined stack: fp32 MFMA (default, what `value` is measured in) or the opt-in "
                          "split-bf16 emulation (include/dsp_amd.h DSP_PREC_*)")
     ap.add_argument("--no_alt", action="store_true", help="skip the extra split-precision measurement reported under alt_precision")
-    ap.add_argument("--gather", action="store_true", help="optional final RCCL all_gather of per-site probs")
+    ap.add_argument("--gather", action="store_true",
+                    help="optional final gather of EVERY step's per-site probabilities to rank 0 (dist.gather_probs: RCCL "
+                         "send/recv over xGMI, off-root memory O(own rows)); outside the timed region, reported under `gather`")
     return ap.parse_args(argv)
 
 
@@ -174,10 +176,16 @@ def main(argv=None):
     batches = [synth.feature_batch(B, device=str(dev), seed=1000 * rank + i) for i in range(nb)]
     site0, site1 = dsp_dist.split_range(world * K * B, world, rank)  # this rank's range of the global site index space
     outs = None
+    # --gather: every step's probabilities are kept (8 B per site, a device-to-device copy of 0.5 MB per step, on the
+    # compute stream) so that the final gather moves the whole run's calls, as BASELINE configs[3] describes it
+    kept = torch.empty((K * B, 2), dtype=torch.float32, device=dev) if args.gather and K > 0 else None
 
-    def step(i):
+    def step(i, keep=False):
         model.site_offset = site0 + i * B
-        return model(*batches[i % nb])
+        o = model(*batches[i % nb])
+        if keep and kept is not None:
+            kept[i * B:(i + 1) * B].copy_(o[1], non_blocking=True)
+        return o
 
     for i in range(W):
         step(i)
@@ -188,7 +196,7 @@ def main(argv=None):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(K):
-        outs = step(i)
+        outs = step(i, True)
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
@@ -198,6 +206,7 @@ def main(argv=None):
     model.profile(False)
 
     ranges = [[site0, site1]]
+    gather_info = None
     if multi:
         t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -205,10 +214,20 @@ def main(argv=None):
         a = dsp_dist.all_gather_ints(site0, world, cdev)
         b = dsp_dist.all_gather_ints(site1, world, cdev)
         ranges = [[x, y] for x, y in zip(a, b)]
-        if args.gather:  # optional final gather of the per-site probabilities of the last step (RCCL over xGMI)
-            src = outs[1] if backend == "nccl" else outs[1].cpu()
-            gathered = [torch.empty_like(src) for _ in range(world)]
-            dist.all_gather(gathered, src)
+        if kept is not None:  # the optional final gather of the run's per-site probabilities (a true gather to rank 0)
+            torch.cuda.synchronize()
+            dist.barrier()
+            tg = time.perf_counter()
+            got = dsp_dist.gather_probs(kept if backend == "nccl" else kept.cpu(), world)
+            torch.cuda.synchronize()
+            tg = time.perf_counter() - tg
+            if rank == 0:
+                rows = [int(g.shape[0]) for g in got]
+                assert rows == [y - x for x, y in ranges], (rows, ranges)   # rank r's rows ARE its site range
+                ok = all(bool(torch.isfinite(g).all()) and bool(((g.sum(1) - 1).abs() < 1e-5).all()) for g in got)
+                assert ok and torch.equal(got[0].to(kept.device), kept)
+                gather_info = {"sites": sum(rows), "bytes": sum(rows) * 8, "seconds": round(tg, 4), "to_rank": 0,
+                               "how": "dist.gather_probs: sizes by one all_gather of an int, then send/recv of each rank's own rows"}
     assert K == 0 or (outs is not None and bool(torch.isfinite(outs[1]).all()))
 
     # opt-in mode, reported next to the headline (never as `value`): the same steps with the LSTMs' fp32 products
@@ -305,6 +324,8 @@ def main(argv=None):
                                  "with the LSTM cell phase counted the bound of this kernel is 0.974 of the MFMA peak "
                                  "(DESIGN.md section 3)") if nprod == 1 else None},
         }
+        if gather_info:
+            line["gather"] = gather_info
         if alt:
             line["alt_precision"] = alt
         if not args.no_cpu_baseline and world == 1:

@@ -241,19 +241,29 @@ def all_gather_ints(value, world, device=None):
 
 
 def gather_probs(probs, world, dst=0):
-    """Optional final gather of per-site probabilities [n_r, C] to rank `dst` (ragged: sizes exchanged
-    first).  One collective on RCCL over xGMI; ~8 B/site."""
+    """Optional final gather of per-site probabilities [n_r, C] to rank `dst` (ragged: one integer per rank is exchanged
+    first).  A TRUE gather: every other rank sends its own rows to `dst` point to point (RCCL send/recv over xGMI on
+    GPU tensors, gloo on host tensors), `dst` receives each rank's rows into a tensor of exactly that rank's size.
+    Off-root memory stays O(n_r) -- round 3's padded all_gather made every rank hold world x max(n_r) rows that only
+    `dst` read (800 MB per rank at BASELINE configs[3]).  Returns the list of the ranks' tensors on `dst`, None elsewhere;
+    ~8 B/site."""
     if not collective(world):
         return [probs]
     import torch
     import torch.distributed as dist
     sizes = all_gather_ints(probs.shape[0], world, probs.device if probs.is_cuda else None)
-    mx = max(sizes)
-    pad = torch.zeros((mx, probs.shape[1]), dtype=probs.dtype, device=probs.device)
-    pad[:probs.shape[0]] = probs
-    out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad)
-    return [o[:s] for o, s in zip(out, sizes)] if dist.get_rank() == dst else None
+    me = dist.get_rank()
+    probs = probs.contiguous()
+    if me != dst:
+        if sizes[me]:
+            dist.send(probs, dst)
+        return None
+    out = [probs if r == me else torch.empty((sizes[r],) + tuple(probs.shape[1:]), dtype=probs.dtype, device=probs.device)
+           for r in range(world)]
+    reqs = [dist.irecv(out[r], r) for r in range(world) if r != me and sizes[r]]
+    for q in reqs:
+        q.wait()
+    return out
 
 
 def gather_columns(cols, world, device=None):

@@ -30,8 +30,18 @@ def worker(rank, world, port):
     dist.all_to_all_single(out, src, recv_counts, send_counts)
     want = torch.cat([torch.full((c,), 100 * s + rank, dtype=torch.int64, device=dev) for s, c in enumerate(recv_counts)])
     assert torch.equal(out, want)
+    # the optional final gather of per-site probabilities: ragged, point to point to rank 0 (dist.gather_probs)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from deepsignal_plant_amd import dist as dd
+    mine = torch.full((1000 * rank + (5 if rank != 1 else 0), 2), float(rank), device=dev)   # rank 1 has no rows
+    got = dd.gather_probs(mine, world)
     if rank == 0:
-        print("rccl ok: world %d, backend %s (barrier, all_reduce, all_gather, ragged all_to_all_single)" % (world, dist.get_backend()))
+        assert [int(g.shape[0]) for g in got] == [1000 * r + (5 if r != 1 else 0) for r in range(world)]
+        assert all(bool((g == float(r)).all()) for r, g in enumerate(got))
+    else:
+        assert got is None
+    if rank == 0:
+        print("rccl ok: world %d, backend %s (barrier, all_reduce, all_gather, ragged all_to_all_single, ragged gather by send/recv)" % (world, dist.get_backend()))
     dist.destroy_process_group()
 
 
