@@ -51,13 +51,65 @@ def _get_gpus():
     return list(range(dsp_dist.visible_gpu_count()))
 
 
+_STATE_KEYS = ("h_seq", "c_seq", "h_sig", "c_sig", "h_comb", "c_comb")
+
+
+def init_state_mode(args):
+    """--init_state: ("randn" | "zeros", None) or ("file", path) for file:<states.npz>"""
+    v = getattr(args, "init_state", "randn") or "randn"
+    if v in ("randn", "zeros"):
+        return v, None
+    if v.startswith("file:") and len(v) > 5:
+        return "file", v[5:]
+    raise ValueError("--init_state must be randn, zeros or file:<states.npz>")
+
+
+class FileInitStates(object):
+    """--init_state file:<npz>: the initial LSTM states of every input row, in the layout init_hidden returns them
+    (models.py:169-176): h_seq / c_seq (2*layernum2, N, hid_seq), h_sig / c_sig (2*layernum2, N, hid_signal), h_comb /
+    c_comb (2*layernum1, N, hid_rnn), row n of axis 1 = the n-th row of the input.  Lets a captured reference run -- the
+    draws of torch.randn under a known seed -- be replayed end to end through `call_mods` (the keys may carry the
+    `state_` prefix of the golden fixtures, tests/golden/f1_*.npz).  16 KiB per row: a replay facility, not a run mode."""
+
+    def __init__(self, path, model):
+        if not os.path.exists(path):
+            raise ValueError("--init_state file: %s does not exist!" % path)
+        z = np.load(path, allow_pickle=False)
+        H = model.hidden_size
+        hs, hg = (H // 2, H - H // 2) if model.module == "both_bilstm" else ((H, 0) if model.module == "seq_bilstm" else (0, H))
+        want = {"h_seq": (2 * model.num_layers2, hs), "c_seq": (2 * model.num_layers2, hs), "h_sig": (2 * model.num_layers2, hg),
+                "c_sig": (2 * model.num_layers2, hg), "h_comb": (2 * model.num_layers1, H), "c_comb": (2 * model.num_layers1, H)}
+        self.arrays, self.rows = {}, None
+        for k, (nl, hid) in want.items():
+            if hid == 0:
+                continue
+            name = k if k in z.files else "state_" + k
+            if name not in z.files:
+                raise ValueError("--init_state file: %s holds no array %s" % (path, k))
+            a = np.asarray(z[name], np.float32)
+            if a.ndim != 3 or a.shape[0] != nl or a.shape[2] != hid:
+                raise ValueError("--init_state file: %s is %s, the model needs (%d, rows, %d)" % (k, a.shape, nl, hid))
+            if self.rows is not None and a.shape[1] != self.rows:
+                raise ValueError("--init_state file: %s holds %d rows, the arrays before it %d" % (k, a.shape[1], self.rows))
+            self.rows = int(a.shape[1])
+            self.arrays[k] = a
+        self.path = path
+
+    def for_rows(self, first_row, n):
+        import torch
+        if first_row + n > self.rows:
+            raise ValueError("--init_state file: %s holds the states of %d rows, the input has more" % (self.path, self.rows))
+        return {k: torch.from_numpy(np.ascontiguousarray(a[:, first_row:first_row + n])) for k, a in self.arrays.items()}
+
+
 def load_model(args, device):
     """Replaces the head of _call_mods_q (call_modifications.py:214-228)."""
     import torch
+    mode, _ = init_state_mode(args)
     model = ModelBiLSTM(args.seq_len, args.signal_len, args.layernum1, args.layernum2, args.class_num,
                         args.dropout_rate, args.hid_rnn, args.n_vocab, args.n_embed, str2bool(args.is_base),
                         str2bool(args.is_signallen), module=args.model_type, device=device,
-                        init_state=getattr(args, "init_state", "randn"), seed=getattr(args, "seed", 0))
+                        init_state="randn" if mode == "file" else mode, seed=getattr(args, "seed", 0))
     para_dict = torch.load(args.model_path, map_location=torch.device('cpu'))
     model_dict = model.state_dict()
     model_dict.update(para_dict)
@@ -141,6 +193,8 @@ def _call_mods_file(args, rank, local_rank, world):
     # control-plane collectives run on the GPU over RCCL, or on the host when the ranks had to fall back to gloo
     coll_dev = dev if (dsp_dist.collective(world) and dist.get_backend() == "nccl") else None
     model = load_model(args, local_rank)
+    mode, states_path = init_state_mode(args)
+    file_states = FileInitStates(states_path, model) if mode == "file" else None
     _tick("model loaded")
     input_path = os.path.abspath(args.input_path)
     nthreads = dsp_dist.threads_per_rank(args.nproc)   # --nproc, capped by this rank's share of the node's CPUs
@@ -237,7 +291,8 @@ def _call_mods_file(args, rank, local_rank, world):
         for t_in in (kmer, means, stds, lens, signals):
             t_in.record_stream(stream)
         model.site_offset = block.first_row
-        _logits, probs, labels = model.forward(kmer, means, stds, lens, signals, want_labels=True)
+        _logits, probs, labels = model.forward(kmer, means, stds, lens, signals, want_labels=True,
+                                               init_states=file_states.for_rows(block.first_row, n) if file_states else None)
         if freq_dev is not None:  # the calls go into the device-side call_freq records straight from HBM
             freq_dev.add_block(rows, probs, labels, block.first_row, stream=stream)
         slot = k % nout
@@ -315,6 +370,8 @@ def _call_mods_reads(args, rank, local_rank, world):
     from .utils.process_utils import get_contig2len
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    if init_state_mode(args)[0] == "file":
+        raise ValueError("--init_state file: names the rows of a feature file; a directory of reads has no row order to replay")
     model = load_model(args, local_rank)
     _tick("model loaded")
     files = dsp_reads.list_read_files(os.path.abspath(args.input_path), str2bool(args.recursively))
@@ -591,6 +648,7 @@ def call_mods(args):
     _native.lib()  # fail loudly before any work if the HIP library is missing
     print("cuda availability: {}".format(torch.cuda.is_available()))
 
+    init_state_mode(args)   # a bad --init_state ends the run before anything is loaded
     model_path = os.path.abspath(args.model_path)
     if not os.path.exists(model_path):
         raise ValueError("--model_path is not set right!")  # :550-551
@@ -705,8 +763,10 @@ def add_call_mods_args(p):
                    help="model processes in the reference (default 2); here: GPUs to use -- started plainly on a node "
                         "with several GPUs, call_mods runs min(nproc_gpu, GPUs) ranks of itself, one per GPU")
     g = p.add_argument_group("MI355X build")
-    g.add_argument("--init_state", type=str, default="randn", choices=["randn", "zeros"],
-                   help="LSTM initial states: 'randn' = N(0,1) like the reference's init_hidden (in-kernel Philox), 'zeros'")
+    g.add_argument("--init_state", type=str, default="randn",
+                   help="LSTM initial states: 'randn' = N(0,1) like the reference's init_hidden (in-kernel Philox), 'zeros', or "
+                        "'file:<states.npz>' = explicit states of every input row in init_hidden's layout (h_seq, c_seq, h_sig, "
+                        "c_sig, h_comb, c_comb; replays a captured reference run)")
     g.add_argument("--seed", type=int, default=0, help="seed of the in-kernel initial-state generator")
     g.add_argument("--precision", type=str, default=None, choices=["fp32", "bf16x6", "bf16x9", "fp16x3"],
                    help="how the fp32 products of the combined BiLSTM stack are evaluated: fp32 matrix cores (default), or "

@@ -16,9 +16,8 @@ come out of the reference's optimiser (Adam, gradient clipping, dropout 0.5, tra
 gate biases and recurrent weights have moved away from their U(-1/sqrt(H), 1/sqrt(H)) start, probabilities saturate the
 way a trained caller's do -- and the checkpoint file is one the reference wrote, which is what `--model_path` reads
 (call_modifications.py:219-223).  hid_rnn 128 keeps the file at 4.7 MB; the default 256 would be 18.8 MB.
-`--hid_rnn 256` makes the same fixture for the reference's default architecture into tests/golden/local/ (git-ignored:
-18.8 MB; it travels with the working tree to the GPU box like the built libraries, and the tests that use it skip when it
-is absent).
+`--hid_rnn 256` makes the same fixture for the reference's default architecture (18.8 MB; committed since round 4, so that
+a fresh clone runs the default-architecture tests too).
 
 The training data are synthetic and build-defined: every base's level follows from its 3-mer (a stand-in for the pore
 model, which the sequence branch has to learn) plus noise; label 1 shifts the centre base's level, spread and dwell the
@@ -98,11 +97,11 @@ def main():
     ap.add_argument("--epochs", type=int, default=8)
     ap.add_argument("--skip_training", action="store_true", help="reuse the checkpoint already in the work directory")
     ap.add_argument("--hid_rnn", type=int, default=HID, help="128: the committed fixture.  256 (the reference's default "
-                    "architecture, an 18.8 MB checkpoint): written to tests/golden/local/, which is kept out of the history "
-                    "for its size but travels with the working tree; the tests use it when it is there")
+                    "architecture, an 18.8 MB checkpoint): committed too since round 4; any other size goes to tests/golden/local/, "
+                    "which is kept out of the history")
     args = ap.parse_args()
     hid = args.hid_rnn
-    out_dir = HERE if hid == HID else os.path.join(HERE, "local")
+    out_dir = HERE if hid in (HID, 256) else os.path.join(HERE, "local")   # 128 and 256 are committed fixtures
     os.makedirs(out_dir, exist_ok=True)
     tag = "f8_trained_h%d" % hid
     os.makedirs(args.workdir, exist_ok=True)

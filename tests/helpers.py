@@ -70,15 +70,17 @@ def f1_tolerances(name):
 
 F8_CKPT = os.path.join(GOLDEN, "f8_trained_h128.ckpt")
 F8_ROWS = os.path.join(GOLDEN, "f8_trained_rows.tsv")
-# the same for the reference's DEFAULT architecture (hid_rnn 256): an 18.8 MB checkpoint, generated in the build container
-# (make_golden_trained.py --hid_rnn 256) into tests/golden/local/, which stays out of the history for its size but travels
-# with the working tree like the built libraries; tests that want it skip when it is not there
+# the same for the reference's DEFAULT architecture (hid_rnn 256): an 18.8 MB checkpoint (make_golden_trained.py --hid_rnn
+# 256), committed since round 4 so that a fresh clone runs the default-architecture trained-weights tests instead of
+# skipping them; other sizes would be generated into tests/golden/local/ (git-ignored)
 F8_LOCAL = os.path.join(GOLDEN, "local")
 
 
 def f8_paths(hid=128):
     if hid == 128:
         return F8_CKPT, os.path.join(GOLDEN, "f8_trained_expected.npz")
+    if hid == 256:
+        return os.path.join(GOLDEN, "f8_trained_h256.ckpt"), os.path.join(GOLDEN, "f8_trained_h256_expected.npz")
     return os.path.join(F8_LOCAL, "f8_trained_h%d.ckpt" % hid), os.path.join(F8_LOCAL, "f8_trained_h%d_expected.npz" % hid)
 
 
@@ -105,3 +107,21 @@ def load_f8(hid=128):
     return dict(cfg=cfg, w=w, inputs=inputs, states=states, logits=d["logits"], probs=d["probs"],
                 logits0=d["logits_zero_states"], probs0=d["probs_zero_states"], labels=d["labels"],
                 row_labels=np.asarray(rows.labels), noise=float(d["f64_dprob"]), n=n, raw=d, ckpt=ckpt)
+
+
+def rows_to_tsv(path, kmer, means, stds, lens, signals, labels=None):
+    """feature-TSV rows (extract_features.py:381-395's grammar) whose parsed values are EXACTLY these float32 arrays: every
+    number is printed with 9 significant digits, which round-trips a float32 through the parser's decimal -> double ->
+    float32 conversion.  kmer: codes (any numeric dtype), lens: integers."""
+    from deepsignal_plant_amd.utils.process_utils import code2base_dna
+    n = len(kmer)
+    f = lambda x: "%.9g" % float(np.float32(x))
+    with open(path, "w") as wf:
+        for i in range(n):
+            cols = ["chr%d" % (i % 3 + 1), str(100 + i), "+", str(100 + i), "read_%d" % (i // 7), "t",
+                    "".join(code2base_dna[int(c)] for c in kmer[i]),
+                    ",".join(f(x) for x in means[i]), ",".join(f(x) for x in stds[i]),
+                    ",".join(str(int(x)) for x in lens[i]),
+                    ";".join(",".join(f(x) for x in row) for row in signals[i]),
+                    str(int(labels[i]) if labels is not None else i % 2)]
+            wf.write("\t".join(cols) + "\n")

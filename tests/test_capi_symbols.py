@@ -82,3 +82,44 @@ def test_a_missing_library_is_an_error_not_a_fallback(monkeypatch, tmp_path):
         ModelBiLSTM()
     with pytest.raises(RuntimeError, match="libdsp_amd.so not found"):
         textio.parse_rows(b"x\n", 13, 16)
+
+
+def test_init_state_file_is_validated_on_the_host(tmp_path):
+    """--init_state file:<npz> (round 4): explicit initial states of every input row in init_hidden's layout
+    (models.py:169-176).  Shapes, missing arrays and row counts are checked before anything runs (no GPU needed)."""
+    import argparse
+    import numpy as np
+    from deepsignal_plant_amd import call_modifications as cm
+    from deepsignal_plant_amd.models import ModelBiLSTM
+    assert cm.init_state_mode(argparse.Namespace(init_state="randn")) == ("randn", None)
+    assert cm.init_state_mode(argparse.Namespace(init_state="file:/x/y.npz")) == ("file", "/x/y.npz")
+    with pytest.raises(ValueError):
+        cm.init_state_mode(argparse.Namespace(init_state="random"))
+    model = ModelBiLSTM()    # both_bilstm, hid 256, 3 + 1 layers
+    golden = os.path.join(ROOT, "tests", "golden", "f1_randn_capture.npz")
+    st = cm.FileInitStates(golden, model)          # the fixtures' `state_` prefix is accepted
+    assert st.rows == 4 and sorted(st.arrays) == ["c_comb", "c_seq", "c_sig", "h_comb", "h_seq", "h_sig"]
+    part = st.for_rows(1, 2)
+    assert tuple(part["h_comb"].shape) == (6, 2, 256) and tuple(part["c_seq"].shape) == (2, 2, 128)
+    assert np.array_equal(part["h_sig"].numpy(), np.load(golden)["state_h_sig"][:, 1:3])
+    with pytest.raises(ValueError, match="holds the states of 4 rows"):
+        st.for_rows(3, 2)
+    d = {k: np.zeros(s, np.float32) for k, s in (("h_seq", (2, 5, 128)), ("c_seq", (2, 5, 128)), ("h_sig", (2, 5, 128)),
+                                                  ("c_sig", (2, 5, 128)), ("h_comb", (6, 5, 256)), ("c_comb", (6, 5, 256)))}
+    p = str(tmp_path / "s.npz")
+    np.savez(p, **d)
+    assert cm.FileInitStates(p, model).rows == 5
+    np.savez(p, **dict(d, h_comb=np.zeros((4, 5, 256), np.float32)))
+    with pytest.raises(ValueError, match="the model needs"):
+        cm.FileInitStates(p, model)
+    np.savez(p, **dict(d, c_sig=np.zeros((2, 6, 128), np.float32)))
+    with pytest.raises(ValueError, match="holds 6 rows"):
+        cm.FileInitStates(p, model)
+    del d["c_comb"]
+    np.savez(p, **d)
+    with pytest.raises(ValueError, match="holds no array c_comb"):
+        cm.FileInitStates(p, model)
+    seq_only = ModelBiLSTM(module="seq_bilstm", num_layers1=2)
+    np.savez(p, h_seq=np.zeros((2, 3, 256), np.float32), c_seq=np.zeros((2, 3, 256), np.float32),
+             h_comb=np.zeros((4, 3, 256), np.float32), c_comb=np.zeros((4, 3, 256), np.float32))
+    assert sorted(cm.FileInitStates(p, seq_only).arrays) == ["c_comb", "c_seq", "h_comb", "h_seq"]

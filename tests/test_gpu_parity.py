@@ -409,8 +409,8 @@ def test_hip_matches_the_reference_on_the_checkpoint_it_trained(precision, hid, 
     outputs.  The one fixture whose weight statistics are a trained model's (tests/test_trained_fixture.py)."""
     torch = _torch()
     from tests.helpers import have_f8, load_f8
-    if not have_f8(hid):   # hid_rnn 256 = the reference's default architecture: 18.8 MB, tests/golden/local/ (tests/helpers.py)
-        pytest.skip("no hid_rnn %d checkpoint in tests/golden/local/" % hid)
+    if not have_f8(hid):   # hid_rnn 256 = the reference's default architecture: 18.8 MB, committed since round 4 (tests/helpers.py)
+        pytest.skip("no hid_rnn %d checkpoint in tests/golden/" % hid)
     f = load_f8(hid)
     m = build_model(f["cfg"], f["w"])
     m.set_precision(precision)

@@ -14,8 +14,7 @@ from tests.helpers import have_f8, load_f8
 @pytest.fixture(scope="module", params=[128, 256], ids=["hid128", "hid256_default_architecture"])
 def f8(request):
     if not have_f8(request.param):
-        pytest.skip("tests/golden/local/ holds no hid_rnn %d checkpoint (18.8 MB, kept out of the history: "
-                    "make_golden_trained.py --hid_rnn %d)" % (request.param, request.param))
+        pytest.skip("tests/golden/ holds no hid_rnn %d checkpoint (make_golden_trained.py --hid_rnn %d)" % (request.param, request.param))
     return load_f8(request.param)
 
 
