@@ -97,6 +97,26 @@ def philox_normal(seed, site, stream, ngroups):
     return out
 
 
+def philox_states(cfg: onp.OracleConfig, n, seed, site_offset=0, site_keys=None):
+    """the initial states init_mode='philox' draws inside the forward, as the dict init_mode='explicit' takes
+    (forward_np.init_state_shapes): forward(..., 'explicit', philox_states(...)) == forward(..., 'philox') bit for bit"""
+    kptr = None
+    if site_keys is not None:
+        site_keys = np.ascontiguousarray(site_keys, np.uint64)
+        kptr = site_keys.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+    out = {}
+    for lstm, (name, layers, hid) in enumerate((("seq", cfg.num_layers2, cfg.nhid_seq), ("sig", cfg.num_layers2, cfg.nhid_signal),
+                                                ("comb", cfg.num_layers1, cfg.hidden_size))):
+        if (name == "seq" and cfg.module == "signal_bilstm") or (name == "sig" and cfg.module == "seq_bilstm"):
+            continue
+        h = np.empty((2 * layers, n, hid), np.float32)
+        c = np.empty((2 * layers, n, hid), np.float32)
+        lib().orc_philox_states(lstm, layers, hid, ctypes.c_int64(n), ctypes.c_uint64(seed), ctypes.c_uint64(site_offset), kptr,
+                                _fp(h), _fp(c))
+        out["h_" + name], out["c_" + name] = h, c
+    return out
+
+
 def num_threads():
     """Host threads worth using: min(OpenMP default, CPU affinity, cgroup CPU quota) -- a container with a
     16-CPU quota on a 256-thread host must not spawn 256 OpenMP threads."""

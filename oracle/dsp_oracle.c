@@ -76,6 +76,26 @@ void orc_philox_normal(uint64_t seed, uint64_t site, uint32_t stream, uint32_t n
     for (uint32_t g = 0; g < ngroups; ++g) philox_normal4(seed, site, stream, g, out + 4 * g);
 }
 
+/* exported for tests: the initial states of n sites of one LSTM (0 seq, 1 signal, 2 comb) exactly as init mode 2 draws them
+ * inside the forward (init_block below), written in the EXPLICIT layout (2 * layers, n, H) -- so that a test can perturb
+ * them (wrong keying, wrong variance) and run the forward on the perturbed states */
+void orc_philox_states(int lstm, int layers, int H, int64_t n, uint64_t seed, uint64_t site_offset, const uint64_t* site_keys,
+                       float* h, float* c) {
+    for (int layer = 0; layer < layers; ++layer)
+        for (int dir = 0; dir < 2; ++dir)
+            for (int64_t s = 0; s < n; ++s) {
+                const uint64_t site = site_keys ? site_keys[s] : site_offset + (uint64_t)s;
+                const size_t off = ((size_t)(2 * layer + dir) * (size_t)n + (size_t)s) * (size_t)H;
+                float v[4];
+                for (int g = 0; g < (H + 3) / 4; ++g) {
+                    philox_normal4(seed, site, (uint32_t)(lstm * 64 + (layer * 2 + dir) * 2 + 0), (uint32_t)g, v);
+                    for (int j = 0; j < 4 && 4 * g + j < H; ++j) h[off + 4 * g + j] = v[j];
+                    philox_normal4(seed, site, (uint32_t)(lstm * 64 + (layer * 2 + dir) * 2 + 1), (uint32_t)g, v);
+                    for (int j = 0; j < 4 && 4 * g + j < H; ++j) c[off + 4 * g + j] = v[j];
+                }
+            }
+}
+
 static inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 /* stream id: lstm (0 seq, 1 signal, 2 comb), layer, dir, which (0 h, 1 c) */
