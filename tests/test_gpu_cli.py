@@ -437,8 +437,8 @@ def _two_ranks(args, timeout=900, env=None):
 
 
 def _keep(name, text):
-    """evidence lines travel back from the GPU box under gpurun_out/ (copied into profiles/r3/ from there)"""
-    d = os.path.join(ROOT, "gpurun_out", "r3")
+    """evidence lines travel back from the GPU box under gpurun_out/ (copied into profiles/r4/ from there)"""
+    d = os.path.join(ROOT, "gpurun_out", "r4")
     try:
         os.makedirs(d, exist_ok=True)
         with open(os.path.join(d, name), "w") as f:

@@ -1,0 +1,129 @@
+"""GPU: BASELINE.json configs[3] and configs[4] at EIGHT ranks under the driver's own `pytest -m gpu`.
+
+No 8-GPU node is available to this build, so the eight ranks share the one MI355X (control plane over gloo, exactly as
+bench.py / call_mods fall back when fewer GPUs than ranks are visible); everything else is the 8-rank code path:
+
+  configs[3]  bench.py --gpus 8 --gather: the range split of the global site index space over eight ranks
+              (call_modifications.py:613-621 is the reference's replica-DP), batch 65,536, and the optional
+              final gather of every step's per-site probabilities to rank 0 (dist.gather_probs, point to point);
+  configs[4]  torchrun x8 `call_mods --freq_file` in the DEFAULT randn mode on plain text, on a BGZF .gz and on a foreign
+              single-member .gz (what the reference's `extract --gzip` writes): per-read file and frequency file
+              byte-identical to the one-rank run -- and the same with fewer rows than ranks.
+"""
+import gzip
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from tests.helpers import ROOT
+from tests.test_gpu_cli import _ckpt, _folded_rows, _keep, _run_cli
+
+pytestmark = pytest.mark.gpu
+
+WORLD = 8
+
+
+def _ranks(args, world=WORLD, timeout=1200, env=None):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), "-m", "deepsignal_plant_amd.deepsignal_plant", "call_mods"] + args
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    e.update(env or {})
+    return subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=e)
+
+
+def test_config4_bench_at_eight_ranks_tiles_the_site_space_and_gathers_every_call():
+    """`python bench.py --gpus 8 --steps 2 --gather` started plainly: eight ranks of batch 65,536 (configs[3]'s batch; its
+    100 M sites are 191 such steps per rank -- the step count is the only thing scaled down), rank_site_ranges tile
+    [0, 8 * 2 * 65,536) without gap or overlap in rank order, and the gather brings exactly those rows to rank 0"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(WORLD), "--steps", "2", "--warmup", "1",
+                        "--gather", "--no_cpu_baseline"], cwd=ROOT, capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    B = 65536
+    assert d["n_gpus"] == WORLD and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["batch"] == B
+    ranges = d["config"]["rank_site_ranges"]
+    assert len(ranges) == WORLD and ranges[0][0] == 0 and ranges[-1][1] == WORLD * 2 * B
+    assert all(ranges[i][1] == ranges[i + 1][0] for i in range(WORLD - 1))          # no gap, no overlap, rank order
+    assert all(b - a == 2 * B for a, b in ranges)
+    assert d["config"]["sites"] == WORLD * 2 * B and "configs[3]" in d["config"]["workload"]
+    assert abs(d["value"] - WORLD * 2 * B / (d["ms_per_step"] * 2e-3)) / d["value"] < 0.01
+    g = d["gather"]
+    assert g["sites"] == WORLD * 2 * B and g["bytes"] == 8 * g["sites"] and g["to_rank"] == 0
+    assert "cpu_baseline" not in d and d["vs_baseline"] is None
+    _keep("bench_8ranks_shared_gpu.json", json.dumps(d) + "\n")
+
+
+def _inputs(tmp_path, data, tag):
+    """the same rows as plain text, as BGZF (this build's own writer) and as one foreign gzip member"""
+    from deepsignal_plant_amd import gzio
+    plain = str(tmp_path / ("%s.tsv" % tag))
+    open(plain, "wb").write(data)
+    bgzf = str(tmp_path / ("%s_bgzf.tsv.gz" % tag))
+    with gzio.open_write(bgzf, True, nthreads=2) as wf:
+        wf.write(data)
+    foreign = str(tmp_path / ("%s_foreign.tsv.gz" % tag))
+    open(foreign, "wb").write(gzip.compress(data, 1))
+    assert gzio.BgzfFile(bgzf).ok and not gzio.BgzfFile(foreign).ok
+    return {"plain": plain, "bgzf": bgzf, "foreign_gz": foreign}
+
+
+def _one_rank_reference(tmp_path, inp, ck, tag, env):
+    out, fq = str(tmp_path / ("%s_one.tsv" % tag)), str(tmp_path / ("%s_one.freq" % tag))
+    r = _run_cli(["-i", inp, "-m", ck, "-o", out, "--freq_file", fq, "--prob_cf", "0.02", "--seed", "31"], env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return open(out, "rb").read(), open(fq, "rb").read()
+
+
+@pytest.mark.parametrize("fmt", ["plain", "bgzf", "foreign_gz"])
+def test_config5_eight_ranks_write_the_bytes_of_one(tmp_path, fmt):
+    """configs[4]'s pipeline (feature TSV -> per-read calls -> call_freq aggregation) with eight ranks, default randn mode:
+    2,400 rows / 23 sites.  Plain text is split by byte range, BGZF by member range (row counts from the member
+    headers), the foreign .gz is inflated once into the shared-memory ring and dealt block by block; --freq_file is reduced
+    on the device (records exchanged by site: one all_to_all over the eight ranks).  Bytes == the one-rank run on the plain
+    file."""
+    ck = _ckpt(tmp_path)
+    data = _folded_rows(n_rep=12)
+    paths = _inputs(tmp_path, data, "rows")
+    blk = {"DSP_BLOCK_BYTES": "150000"}     # many reader blocks per rank (and ~33 ring blocks for the foreign .gz)
+    ref_calls, ref_freq = _one_rank_reference(tmp_path, paths["plain"], ck, "rows", blk)
+    assert ref_calls.count(b"\n") == 2400 and len(ref_freq) > 0
+    out, fq = str(tmp_path / "eight.tsv"), str(tmp_path / "eight.freq")
+    r = _ranks(["-i", paths[fmt], "-m", ck, "-o", out, "--freq_file", fq, "--prob_cf", "0.02", "--seed", "31"], env=blk)
+    assert r.returncode == 0, r.stderr[-4000:]
+    assert "2400 sites on 8 GPU(s)" in r.stdout
+    assert open(out, "rb").read() == ref_calls, fmt
+    assert open(fq, "rb").read() == ref_freq, fmt
+    assert not [f for f in os.listdir(str(tmp_path)) if ".part" in f or f.endswith(".blocks")]
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("dsp_gz_")]
+    # and with the calls gzip-compressed on the way out (whole BGZF members per rank, one end-of-file member)
+    r = _ranks(["-i", paths[fmt], "-m", ck, "-o", out, "--freq_file", fq, "--prob_cf", "0.02", "--seed", "31", "--gzip"], env=blk)
+    assert r.returncode == 0, r.stderr[-4000:]
+    assert gzip.open(out + ".gz", "rb").read() == ref_calls and gzip.open(fq + ".gz", "rb").read() == ref_freq
+    _keep("cli_8ranks_%s.txt" % fmt, "8 ranks sharing one GPU, %s input, 2400 rows, --freq_file (device), randn mode: calls and "
+          "frequencies byte-identical to one rank, plain and --gzip output\n" % fmt)
+
+
+@pytest.mark.parametrize("n_rows", [5, 1])
+def test_config5_fewer_rows_than_ranks(tmp_path, n_rows):
+    """five rows (and one) for eight ranks, in all three input forms: ranks without rows take part in every collective
+    (row counts, the exchange of call_freq records, the merge) and the result is the one-rank file"""
+    ck = _ckpt(tmp_path)
+    data = b"".join(_folded_rows(n_rep=1).splitlines(True)[:n_rows])
+    paths = _inputs(tmp_path, data, "few")
+    ref_calls, ref_freq = _one_rank_reference(tmp_path, paths["plain"], ck, "few", None)
+    assert ref_calls.count(b"\n") == n_rows
+    for fmt, inp in paths.items():
+        out, fq = str(tmp_path / ("eight_%s.tsv" % fmt)), str(tmp_path / ("eight_%s.freq" % fmt))
+        r = _ranks(["-i", inp, "-m", ck, "-o", out, "--freq_file", fq, "--prob_cf", "0.02", "--seed", "31"])
+        assert r.returncode == 0, (fmt, r.stderr[-4000:])
+        assert open(out, "rb").read() == ref_calls, fmt
+        assert open(fq, "rb").read() == ref_freq, fmt
+        assert not [f for f in os.listdir(str(tmp_path)) if ".part" in f or f.endswith(".blocks")]
