@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 BATCH = 65536
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-CPU_BASELINE_TARGET_S = float(os.environ.get("DSP_CPU_BASELINE_S", 15.0))  # bounded sample: ~15 s of host work
+CPU_BASELINE_TARGET_S = float(os.environ.get("DSP_CPU_BASELINE_S", 25.0))  # bounded sample: at most ~25 s of host work
 # The reference itself cannot travel to the GPU box; its own numbers were measured in the survey container
 # (8 vCPU Xeon 2.1 GHz, torch CPU) and are carried next to the port's, labelled.
 REFERENCE_CPU = {"hardware": "8 vCPU Xeon 2.10 GHz (survey container, BASELINE.md section 2), not this box",
@@ -72,27 +72,61 @@ def committed_traffic(args):
 
 
 def cpu_baseline(model_cfg_kwargs, sd_numpy, seed):
-    """The oracle's C port (oracle/dsp_oracle.c, OpenMP over site blocks) timed on this box's host cores on
-    a bounded sample of the same workload (same weights, same synthetic row statistics, batch semantics are
-    irrelevant on the CPU: sites are independent)."""
+    """BASELINE.json configs[0]'s shape on this box's host cores: a 100,000-row synthetic feature
+    TSV -> row parser -> forward in 512-row chunks (the reference's --batch_size, call_modifications.py:147) -> per-read
+    call lines -> file.  The forward is the oracle's C port (oracle/dsp_oracle.c, fp32, OpenMP over site blocks -- kind
+    "port"); parsing and formatting are this build's host code (csrc/dsp_text.cpp), the same the GPU pipeline uses.
+    Bounded: rows are processed in file order until the time budget is spent (DSP_CPU_BASELINE_S, default 25 s); the
+    sample string says how many of the 100,000 were."""
+    import tempfile
+
+    import numpy as np
+
+    from deepsignal_plant_amd import textio
     from oracle import c_oracle as oc
     from oracle import forward_np as onp
     cfg = onp.OracleConfig(**model_cfg_kwargs)
     threads = oc.num_threads()
-    probe = 32 * max(1, threads)
-    ins = onp.make_inputs(cfg, probe, 7)
-    t0 = time.time()
-    oc.forward(cfg, sd_numpy, *ins, init_mode="philox", seed=seed, nthreads=threads)
-    rate = probe / max(time.time() - t0, 1e-6)
-    n = int(max(probe, min(rate * CPU_BASELINE_TARGET_S, 1 << 20)))
-    n = (n + 15) // 16 * 16
-    ins = onp.make_inputs(cfg, n, 8)
-    t0 = time.time()
-    oc.forward(cfg, sd_numpy, *ins, init_mode="philox", seed=seed, nthreads=threads)
-    dt = time.time() - t0
-    return {"value": round(n / dt, 1), "unit": "sites/s", "cores": threads, "kind": "port",
-            "sample": "%d synthetic sites (same model/weights/row statistics), oracle/dsp_oracle.c fp32 + OpenMP, %.1f s"
-                      % (n, dt),
+    n_rows, chunk = 100000, 512
+    tmp = tempfile.mkdtemp(prefix="dsp_cpu_baseline_")
+    path = os.path.join(tmp, "features_100k.tsv")
+    try:
+        # the input file is made outside the timed region (tools/make_tsv.py: one writer process per core)
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_tsv.py"), path, str(n_rows), "--seed", "5"],
+                              stdout=subprocess.DEVNULL)   # (bench.py prints ONE line)
+        size = os.path.getsize(path)
+        t0 = time.time()
+        data = np.memmap(path, dtype=np.uint8, mode="r")   # parsed in place from the page cache, as the product's reader does
+        rows = textio.parse_rows(data, cfg.seq_len, cfg.signal_len, nthreads=threads)
+        t_parse = time.time() - t0
+        assert rows.n == n_rows
+        probs = np.empty((n_rows, cfg.num_classes), np.float32)
+        done = 0
+        t1 = time.time()
+        while done < n_rows and (done == 0 or (time.time() - t0) < CPU_BASELINE_TARGET_S):
+            a, b = done, min(n_rows, done + chunk)
+            _lg, pr = oc.forward(cfg, sd_numpy, rows.kmer[a:b].astype(np.float32), rows.means[a:b], rows.stds[a:b],
+                                 rows.lens[a:b].astype(np.float32), rows.signals[a:b], init_mode="philox", seed=seed,
+                                 site_offset=a, nthreads=threads)
+            probs[a:b] = pr
+            done = b
+        t_fwd = time.time() - t1
+        t2 = time.time()
+        labels = probs[:done].argmax(1).astype(np.uint8)
+        text = textio.format_calls(rows, probs[:done], labels, nthreads=threads, start=0, stop=done)
+        with open(os.path.join(tmp, "calls.tsv"), "wb") as f:
+            f.write(text)
+        t_fmt = time.time() - t2
+        # the parse covered the whole file: charge the sample its share of it
+        dt = t_parse * done / n_rows + t_fwd + t_fmt
+    finally:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {"value": round(done / dt, 1), "unit": "sites/s", "cores": threads, "kind": "port",
+            "sample": "the first %d of a 100,000-row synthetic feature TSV (%.0f MB; BASELINE.json configs[0]'s shape): parse "
+                      "%.2f s for the file + forward in %d-row chunks %.2f s (oracle/dsp_oracle.c fp32 + OpenMP, same "
+                      "model/weights, Philox N(0,1) states) + format and write %.2f s" % (done, size / 1e6, t_parse, chunk, t_fwd, t_fmt),
+            "seconds": {"parse_whole_file": round(t_parse, 3), "forward": round(t_fwd, 3), "format_write": round(t_fmt, 3)},
             "reference_proper": REFERENCE_CPU}
 
 
