@@ -33,10 +33,15 @@ def _keyed(lines):
 
 
 def _run_cli(args, env=None):
+    import time
     cmd = [sys.executable, "-m", "deepsignal_plant_amd.deepsignal_plant", "call_mods"] + args
     e = dict(os.environ)
     e.update(env or {})
-    return subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    t0 = time.time()
+    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    if time.time() - t0 > 30:   # a CLI run on a few hundred rows takes 2-4 s: say so when one does not
+        print("[slow cli run] %.1f s: %s" % (time.time() - t0, " ".join(args)))
+    return r
 
 
 @pytest.mark.parametrize("gz_in,gz_out", [(False, False), (True, True)])
