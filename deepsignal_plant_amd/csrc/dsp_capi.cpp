@@ -313,6 +313,10 @@ struct dsp_model {
                              // batches whose 32-site tiles x 2 directions fit the CUs at once (small-batch latency); DSP_LSTM_TILING=21
                              // always, =0 never (A/B switch)
     bool sync_each = false, debug_lstm = false;  // DSP_SYNC_EACH / DSP_DEBUG_LSTM: debugging aids, read when the handle is made
+    int cluster = -1;        // dsp_lstmc_kernel (a site tile's unit tiles spread over several CUs, small batches): -1 = whenever the
+                             // whole grid fits the CUs at once; DSP_LSTM_CLUSTER=0 never, =1 / 2 / 4 that many gates per wave
+    unsigned int* cflags = nullptr;   // arrival counters of the clustered launches of ONE forward (zeroed by its pack launch)
+    int n_cflag_words = 0;
     int n_cus = 256;         // compute units of the handle's device
     bool split_ready = false;  // the split-precision weight pieces are on the device (ensure_split)
     bool fp16_safe = true;         // every operand of the combined stack provably inside the fp16 range (fp16x3 only then)
@@ -503,6 +507,30 @@ int pick_site_groups(const dsp_model* m, int UT) {
     return g;
 }
 
+// Clustered launch of a dense one-pass layer (dsp_lstmc_kernel): the 8 unit tiles x 4 gates of a (site tile, direction) spread
+// over P = 2 / 4 / 8 workgroups on as many compute units, when the batch is so small that P x (site tiles x 2 directions)
+// workgroups still fit the CUs at once (every member of a cluster resident from the start: the members wait for each
+// other).  Returns the gates per wave (8 / P), or 0 = the layer runs unclustered.
+constexpr int kClusterWordsPerLaunch = 256 * 32;   // at most 128 clusters (x 32 words apart) fit 256 CUs at P >= 2
+constexpr int kClusterLaunches = 48;               // LSTM launches of one forward (3 stacks x at most 15 layers, 45)
+int cluster_size(const dsp_model* m, long long NTp) {
+    if (m->cluster == 0) return 0;
+    int P = 1;
+    while (P < 8 && NTp * 2 * (P * 2) <= (long long)m->n_cus) P *= 2;
+    if (m->cluster > 0) {   // DSP_LSTM_CLUSTER = gates per wave: that cluster size, if it fits
+        const int want = m->cluster == 1 ? 8 : (m->cluster == 2 ? 4 : (m->cluster == 4 ? 2 : 0));
+        P = (want && NTp * 2 * want <= (long long)m->n_cus) ? want : 1;
+    }
+    return P >= 2 ? P : 0;
+}
+int pick_cluster(const dsp_model* m, const LstmArgs& a, long long NTp, bool split) {
+    const int P = cluster_size(m, NTp);
+    if (!P || split || a.UT != 8 || a.NP > 1 || NTp * 2 * 32 > kClusterWordsPerLaunch) return 0;
+    const int nqx = a.Ipad >> 3, G = 8 / P, D = G == 4 ? 4 : (G == 2 ? 8 : 16);
+    if (a.nqx_lo != 0 || a.nqx_used != nqx || a.NQ != ((a.Ipad + a.Hp) >> 3) || nqx % D || nqx < 2 * D || a.NQ % D) return 0;
+    return G;
+}
+
 // run one BiLSTM stack; returns the buffer holding the last layer's output
 float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>& layers, int lstm_id, const float* x,
                  int64_t n, const dsp_init_state* init, const float* h0, const float* c0) {
@@ -536,6 +564,7 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
         // spread over the idle CUs instead of doubling up on busy ones)
         a.flags = (m->phase_prio ? 1 : 0) | (use21 ? 2 : 0) | (use21 && m->tiling21 < 0 ? 4 : 0);
         if (m->trace_launch >= 0 && m->trace_launch == m->lstm_launch_no) a.flags |= 256 | (m->trace_wave << 9);  // DSP_TRACE builds
+        const int launch_no = m->lstm_launch_no;
         ++m->lstm_launch_no;
         if (a.init_mode == DSP_INIT_EXPLICIT) {
             a.h0 = h0 + (size_t)(2 * k) * (size_t)n * ly.H;
@@ -552,9 +581,15 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
             a.NQ = (ly.Ipad + ly.Hp) / 16;
             a.SG = 8 / a.UT;
         }
+        // batches that leave most CUs idle: the layer's unit tiles spread over a cluster of workgroups (dsp_lstmc_kernel)
+        a.CG = (launch_no < kClusterLaunches && m->cflags) ? pick_cluster(m, a, L.NTp, split) : 0;
+        if (a.CG) {
+            a.cflags = m->cflags + (size_t)launch_no * kClusterWordsPerLaunch;
+            a.flags |= 4;   // one workgroup per CU
+        }
         if (m->debug_lstm)   // DSP_DEBUG_LSTM (read once, in dsp_model_create)
-            fprintf(stderr, "[lstm] %s k=%zu split=%d Ipad=%d H=%d Hp=%d UT=%d SG=%d NQ=%d NTp=%lld n=%lld T=%d Fout=%d x=%p out=%p\n", name, k,
-                    (int)split, a.Ipad, a.H, a.Hp, a.UT, a.SG, a.NQ, a.NTp, a.n, a.T, a.Fout, (const void*)a.x, (void*)a.out);
+            fprintf(stderr, "[lstm] %s k=%zu split=%d CG=%d Ipad=%d H=%d Hp=%d UT=%d SG=%d NQ=%d NTp=%lld n=%lld T=%d Fout=%d x=%p out=%p\n", name, k,
+                    (int)split, a.CG, a.Ipad, a.H, a.Hp, a.UT, a.SG, a.NQ, a.NTp, a.n, a.T, a.Fout, (const void*)a.x, (void*)a.out);
         L.run(name, [&] { return split ? dsp_k_lstm6(&a, prec, L.s) : dsp_k_lstm(&a, L.s); });
         cur = dst;
     }
@@ -643,9 +678,18 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
     if (const char* v = getenv("DSP_LSTM_NP8")) m->np8 = atoi(v) == 2 ? 2 : 1;  // A/B switch
     if (const char* v = getenv("DSP_LSTM_PRIO")) m->phase_prio = atoi(v) != 0;    // A/B switch
     if (const char* v = getenv("DSP_LSTM_TILING")) m->tiling21 = atoi(v) == 21 ? 1 : 0;   // A/B switch
+    if (const char* v = getenv("DSP_LSTM_CLUSTER")) m->cluster = atoi(v);                  // A/B switch
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) m->n_cus = prop.multiProcessorCount;
+    }
+    {   // arrival counters of the clustered launches (zeroed by every forward's first launch; 1.5 MB)
+        void* p = nullptr;
+        const size_t bytes = (size_t)kClusterLaunches * kClusterWordsPerLaunch * sizeof(unsigned int);
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); hipSetDevice(prev); delete m; return fail(DSP_ENOMEM, "hipMalloc(%zu) failed", bytes); }
+        m->dev_allocs.push_back(p);
+        m->cflags = (unsigned int*)p;
+        m->n_cflag_words = kClusterLaunches * kClusterWordsPerLaunch;
     }
     if (const char* v = getenv("DSP_PRECISION"))
         m->precision = !strcmp(v, "bf16x6") ? DSP_PREC_BF16X6 : (!strcmp(v, "bf16x9") ? DSP_PREC_BF16X9 :
@@ -779,6 +823,11 @@ int32_t dsp_forward(dsp_model* m, void* stream, int64_t n, const void* kmer, int
     p.n = n; p.NTp = NTp; p.kdt = kmer_dtype; p.ldt = lens_dtype;
     p.T = d.T; p.S = d.S; p.E = d.E; p.V = d.V; p.is_base = d.is_base; p.is_siglen = d.is_siglen;
     p.Fseq = m->Fseq; p.Fsig = m->Fsig; p.xoff_seq = m->xoff_seq; p.xoff_sig = m->xoff_sig;
+    if (cluster_size(m, NTp)) {   // this forward may run clustered LSTM launches: their arrival counters start from zero
+        const int launches = std::min(kClusterLaunches, (d.hseq ? d.l2 : 0) + (d.hsig ? d.l2 : 0) + d.l1);
+        p.zero_words = m->cflags;
+        p.n_zero_words = launches * kClusterWordsPerLaunch;
+    }
     L.run("pack", [&] { return dsp_k_pack(&p, s); });
 
     auto linear = [&](const char* name, const DevLinear& fc, const float* x, int out_off) {

@@ -22,6 +22,8 @@ struct PackArgs {
     int is_base, is_siglen;
     int Fseq, Fsig;
     int xoff_seq, xoff_sig;  // first padded feature that carries data (the features sit at the end of a padded block)
+    unsigned int* zero_words;  // arrival counters of this forward's clustered LSTM launches (dsp_lstmc_kernel): zeroed here, by
+    int n_zero_words;          // the first launch of the forward (a kernel boundary orders it before every later launch)
 };
 
 struct LstmArgs {
@@ -46,6 +48,8 @@ struct LstmArgs {
     int NP;                // passes over the unit tiles per time step (UT / 8 above 8 unit tiles, else 1); block = 64*(UT/NP)*SG threads
     int init_mode;         // DSP_INIT_*
     int stream_base;       // philox stream of (lstm, layer, dir=0, h): lstm*64 + layer*4
+    unsigned int* cflags;  // clustered launches (CG > 0): arrival counters of this launch, one per (site tile, direction), 32 words apart
+    int CG;                // 0, or gates per wave of dsp_lstmc_kernel: 4 / 2 / 1 = a (site tile, direction) spread over UT/CG workgroups
     int flags;             // bit 0: issue priority by phase (k-loop 2, cell 0); bit 1: <2 unit tiles, 1 site tile> per wave; bit 2: ... and one such workgroup per CU; bit 8: stamp this launch, bits 9..11: its stamping wave (DSP_TRACE builds only)
 };
 

@@ -126,6 +126,10 @@ __device__ __forceinline__ float load_code(const void* p, int dt, size_t i) {
 // One thread per (tile, t, site).  HBM-bound, ~1 KB in / ~1.2 KB out per site: negligible.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dsp_pack_kernel(PackArgs a) {
+    // the arrival counters of this forward's clustered LSTM launches start from zero (first launch of the forward: the
+    // kernel boundary orders these stores before every later launch)
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < a.n_zero_words; i += 256) a.zero_words[i] = 0u;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const int sl = (int)(idx & 31);
     const long long rem = idx >> 5;
@@ -730,6 +734,238 @@ __global__ __launch_bounds__(256, 2) void dsp_lstm21_kernel(LstmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// dsp_lstmc_kernel<G, D> (round 4): the dense one-pass layers for batches that leave most of the chip idle.
+// A batch of 512 sites is 16 site tiles x 2 directions = 32 independent recurrences; dsp_lstm21_kernel gives each of them ONE
+// compute unit (4 waves, 2 unit tiles each) and a time step then costs 96 k-groups x 2,048 cycles = 82 us on that CU while
+// 224 CUs idle: 3.7 ms per forward, whatever the batch below 4,096 sites.  Here the 8 unit tiles x 4 gates of a (site tile,
+// direction) are spread over a CLUSTER of P = 8 / G workgroups on P compute units: a wave owns G gates of one unit tile
+// (G accumulator tiles), a workgroup of 4 waves owns G unit tiles:
+//      G = 4: P = 2 (2,048 sites fill 256 CUs)    G = 2: P = 4 (1,024 sites)    G = 1: P = 8 (512 sites)
+//   * SAME arithmetic: an accumulator tile still sums its k-groups in order with the same MFMAs, the cell phase is the same
+//     code on the same values -> results are bit-identical to dsp_lstm_kernel<0, 1> / dsp_lstm21_kernel.
+//   * Gates of one unit tile that sit in different waves (G < 4) meet in LDS after the k-loop: every wave writes its
+//     accumulator tiles as [unit tile][gate][row group aa][lane] float4, one workgroup barrier, every wave reads the four gates
+//     of the row groups it owns (wave (unit tile, slice s) owns row groups [s G, s G + G): cell state in registers).
+//   * h_t crosses compute units through memory.  Producer: the h stores are WRITE-THROUGH (sc1), every wave drains them
+//     (s_waitcnt vmcnt(0)), one workgroup barrier, one lane adds 1 to the cluster's arrival counter (relaxed, agent scope).
+//     Consumer: every wave polls that ONE word (relaxed agent-scope load) until P x (step + 1) arrivals are in, then reads
+//     h_{t-1} with sc1 loads (served by L2 / memory, never by a CU's L1) -- the placement-independent R1 hand-off of
+//     /opt/skills/guides/cdna_hip_programming.md, Guideline 16.  No h row is requested before the counter says it exists:
+//     the k-loop runs the x part first (k-groups [0, nqx), 2/3 of a step in layers 1+) and polls where the B ring would
+//     first reach into the h part, so the hop is hidden behind the x part of the NEXT step as long as the cluster's
+//     workgroups run in step.  The counters are zeroed by the forward's first launch (dsp_pack_kernel).
+//   * Residency: the host only picks a cluster size whose whole grid fits the compute units at once (one workgroup per CU:
+//     the launch asks for more than half a CU's LDS); members of a cluster are P consecutive workgroups of ONE XCD's
+//     dispatch list (block b runs on XCD b % 8, observed), so that with in-order dispatch the lowest unfinished cluster
+//     always has its missing members at the head of the list.  A poll that sees nothing for seconds traps (loud failure,
+//     never a hang, never silent garbage).
+//   * Rings D k-groups deep for both operands (D x 256 G cycles of MFMA work in flight: 4 / 8 / 16 for G = 4 / 2 / 1).
+// Requirements (host-checked): 8 unit tiles (hidden 193..256), no padded k-groups, nqx a multiple of D and >= 2 D.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) unsigned int gu32;
+__device__ __forceinline__ f32x4 bld16_sc1(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 16));   // aux 16 = sc1
+}
+__device__ __forceinline__ void bst16_sc1(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, (int)soff, 16);
+    store_data_guard(v);
+}
+// wait until `target` arrivals have been counted (every wave polls for itself: no workgroup barrier inside the k-loop)
+__device__ __forceinline__ void wait_arrivals(gu32* flag, unsigned target) {
+    for (unsigned spins = 0;; ++spins) {
+        const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (v >= target) return;
+        __builtin_amdgcn_s_sleep(1);
+        if (spins > (1u << 24)) __builtin_trap();   // seconds without progress: a cluster member never became resident
+    }
+}
+
+template <int G, int D>
+__global__ __launch_bounds__(256, 1) void dsp_lstmc_kernel(LstmArgs a) {
+    constexpr int WPU = 4 / G;             // waves per unit tile = gate slices; unit tiles per workgroup = G
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* b_lds = (f32x4*)smem;           // [unit tile][aa][gate][half] float4 (Hp float4)
+    f32x4* xch = b_lds + a.Hp;             // G < 4: [local unit tile][gate][aa][64 lanes] float4
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const uint32_t voff = (uint32_t)lane * 16u;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int P = a.UT / G;
+    // cluster c = (site tile, direction); its P members are consecutive entries of one XCD's dispatch list
+    const int xs = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int pi = j % P;
+    const long long c = (long long)(j / P) * 8 + xs;
+    if (c >= a.NTp * 2) return;
+    const int dir = (int)(c & 1);
+    const long long gt0 = c >> 1;
+    const int ul = w / WPU, gs = w % WPU;
+    const int u = pi * G + ul;             // this wave's unit tile
+    const int half = lane >> 5, ls = lane & 31;
+    const int HQ = a.Hp >> 2;
+    const int nqx = a.Ipad >> 3, NQ = a.NQ;
+    const int T = a.T;
+    const int F4 = a.Fout >> 2;
+    const uint32_t xrow = (uint32_t)(a.Ipad >> 2) * 512u;
+    const uint32_t orow = (uint32_t)F4 * 512u;
+    const bool prio = (a.flags & 1) != 0;
+    gu32* flag = (gu32*)a.cflags + c * 32;
+
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc((const char*)(dir ? a.wpk1 : a.wpk0) + (size_t)u * NQ * 4096);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)a.x + (size_t)gt0 * T * xrow);
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)a.out + (size_t)gt0 * T * orow + (size_t)dir * HQ * 512);
+    const __amdgpu_buffer_rsrc_t rh0 = make_rsrc((const char*)a.h0buf + (size_t)gt0 * orow + (size_t)dir * HQ * 512);
+    const f32x4* bias4 = (const f32x4*)(dir ? a.sbias1 : a.sbias0);
+    const uint32_t voffA = voff + (uint32_t)(gs * G) * 1024u;   // this wave's gates within a k-group's 4 KiB of weights
+    const uint32_t voffO = voff + (uint32_t)(gs * G) * 1024u;   // this wave's row groups within a unit tile's 4 KiB of h
+
+    for (int i = tid; i < a.Hp; i += 256) {
+        const int h = i & 1, g = (i >> 1) & 3, aa = (i >> 3) & 3, ut = i >> 5;
+        b_lds[i] = bias4[g * HQ + ut * 8 + 2 * aa + h];
+    }
+    // initial state of the row groups this wave owns: c0 -> registers, h0 -> the K4 scratch step 0 reads as "h_{-1}"
+    f32x4 creg[G];
+    {
+        const long long site = gt0 * 32 + ls;
+        const uint64_t skey = a.init_mode == 2 ? philox_site_key(a.site_keys, a.site_offset, a.n, site) : 0;
+#pragma unroll
+        for (int al = 0; al < G; ++al) {
+            const int k4 = u * 8 + 2 * (gs * G + al) + half;
+            f32x4 hv = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
+            if (a.init_mode != 0) {
+                hv = init_state4(a.h0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, skey, (uint32_t)(a.stream_base + dir * 2 + 0));
+                cv = init_state4(a.c0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, skey, (uint32_t)(a.stream_base + dir * 2 + 1));
+            }
+            bst16_sc1(rh0, voffO + al * 1024u, (uint32_t)u * 4096u, hv);
+            creg[al] = cv;
+        }
+    }
+    // publish: every wave drains its write-through stores, the workgroup meets, one lane counts the arrival
+    auto publish = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    publish();
+
+    __amdgpu_buffer_rsrc_t rhp = rh0;
+    uint32_t xo = 0, ho = 0;
+    auto set_bases = [&](int step) __attribute__((always_inline)) {
+        const int t = dir ? (T - 1 - step) : step;
+        const int tp = dir ? (t + 1) : (t - 1);
+        rhp = step == 0 ? rh0 : ro;
+        xo = (uint32_t)t * xrow;
+        ho = (step == 0 ? 0u : (uint32_t)tp * orow) - (uint32_t)nqx * 1024u;
+    };
+    f32x4 A[D][G], B[D];
+    f32x16 acc[G];
+    auto ldA = [&](int f, int q) __attribute__((always_inline)) {
+        return bld16(rw, voffA + (uint32_t)f * 1024u, (uint32_t)(q < NQ ? q : q - NQ) * 4096u);
+    };
+    // B fragments: x part (plain loads: written by an earlier launch), h part (sc1: written by the cluster during this one)
+    auto ldBx = [&](int q) __attribute__((always_inline)) { return bld16(rx, voff, xo + (uint32_t)q * 1024u); };
+    auto ldBh = [&](int q) __attribute__((always_inline)) { return bld16_sc1(rhp, voff, ho + (uint32_t)q * 1024u); };
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // one k-group: per fragment its 4 MFMAs, then the (late) refill of the fragment before it for k-group q + D; the B
+    // fragment of the slot is refilled behind the stage.  kind (compile time): 0 = the refill is an x row of THIS step's
+    // bases, 1 = an h row
+    auto stage = [&](auto qs, int q, auto first, auto kind) __attribute__((always_inline)) {
+        constexpr int S = decltype(qs)::value % D, SP = (decltype(qs)::value + D - 1) % D;
+#pragma unroll
+        for (int f = 0; f < G; ++f) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (decltype(first)::value && i == 0)
+                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[S][f][i], B[S][i], zero16, 0, 0, 0);
+                else
+                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[S][f][i], B[S][i], acc[f], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (f == 0) A[SP][G - 1] = ldA(G - 1, q + D - 1);
+            else A[S][f - 1] = ldA(f - 1, q + D);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int qn = q + D < NQ ? q + D : q + D - NQ;
+        if constexpr (decltype(kind)::value == 1) B[S] = ldBh(qn); else B[S] = ldBx(qn);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto stages = [&](int q, auto first, auto kind) __attribute__((always_inline)) {
+        stage(ic<0>{}, q, first, kind);
+        if constexpr (D > 1) stage(ic<1>{}, q + 1, std::false_type{}, kind);
+        if constexpr (D > 2) { stage(ic<2>{}, q + 2, std::false_type{}, kind); stage(ic<3>{}, q + 3, std::false_type{}, kind); }
+        if constexpr (D > 4) { stage(ic<4>{}, q + 4, std::false_type{}, kind); stage(ic<5>{}, q + 5, std::false_type{}, kind);
+                               stage(ic<6>{}, q + 6, std::false_type{}, kind); stage(ic<7>{}, q + 7, std::false_type{}, kind); }
+        if constexpr (D > 8) { stage(ic<8>{}, q + 8, std::false_type{}, kind); stage(ic<9>{}, q + 9, std::false_type{}, kind);
+                               stage(ic<10>{}, q + 10, std::false_type{}, kind); stage(ic<11>{}, q + 11, std::false_type{}, kind);
+                               stage(ic<12>{}, q + 12, std::false_type{}, kind); stage(ic<13>{}, q + 13, std::false_type{}, kind);
+                               stage(ic<14>{}, q + 14, std::false_type{}, kind); stage(ic<15>{}, q + 15, std::false_type{}, kind); }
+    };
+
+    set_bases(0);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+#pragma unroll
+        for (int f = 0; f < G; ++f) A[d][f] = ldA(f, d);
+        B[d] = ldBx(d);
+    }
+    for (int step = 0; step < T; ++step) {
+        const int t = dir ? (T - 1 - step) : step;
+        if (prio) __builtin_amdgcn_s_setprio(2);
+        // x part: nothing here depends on h_{t-1}
+        stages(0, std::true_type{}, ic<0>{});
+        for (int q = D; q < nqx - D; q += D) stages(q, std::false_type{}, ic<0>{});
+        // the B ring is about to reach into the h part: h_{t-1} (h0 at step 0) of every member of the cluster must be in memory
+        asm volatile("" ::: "memory");   // (no h load may be moved above the poll by the compiler either)
+        wait_arrivals(flag, (unsigned)(P * (step + 1)));
+        asm volatile("" ::: "memory");
+        for (int q = nqx - D; q < NQ - D; q += D) stages(q, std::false_type{}, ic<1>{});
+        set_bases(step + 1 < T ? step + 1 : step);   // the last D refills are the next step's first x rows
+        stages(NQ - D, std::false_type{}, ic<0>{});
+        if (prio) __builtin_amdgcn_s_setprio(0);
+
+        // the four gates of a row group meet: in this wave's registers (G == 4) or through LDS
+        if constexpr (G < 4) {
+#pragma unroll
+            for (int gl = 0; gl < G; ++gl)
+#pragma unroll
+                for (int aa = 0; aa < 4; ++aa)
+                    xch[((ul * 4 + gs * G + gl) * 4 + aa) * 64 + lane] =
+                        f32x4{acc[gl][4 * aa], acc[gl][4 * aa + 1], acc[gl][4 * aa + 2], acc[gl][4 * aa + 3]};
+            __syncthreads();
+        }
+        const f32x4* b_my = b_lds + (size_t)u * 32 + half;
+#pragma unroll
+        for (int al = 0; al < G; ++al) {
+            const int aa = gs * G + al;
+            const f32x4 bi = b_my[aa * 8 + 0], bf = b_my[aa * 8 + 2], bg = b_my[aa * 8 + 4], bo = b_my[aa * 8 + 6];
+            f32x4 gi, gf, gg4, go;
+            if constexpr (G < 4) {
+                gi = xch[((ul * 4 + 0) * 4 + aa) * 64 + lane]; gf = xch[((ul * 4 + 1) * 4 + aa) * 64 + lane];
+                gg4 = xch[((ul * 4 + 2) * 4 + aa) * 64 + lane]; go = xch[((ul * 4 + 3) * 4 + aa) * 64 + lane];
+            } else {
+                gi = f32x4{acc[0][4 * al], acc[0][4 * al + 1], acc[0][4 * al + 2], acc[0][4 * al + 3]};
+                gf = f32x4{acc[1 % G][4 * al], acc[1 % G][4 * al + 1], acc[1 % G][4 * al + 2], acc[1 % G][4 * al + 3]};
+                gg4 = f32x4{acc[2 % G][4 * al], acc[2 % G][4 * al + 1], acc[2 % G][4 * al + 2], acc[2 % G][4 * al + 3]};
+                go = f32x4{acc[3 % G][4 * al], acc[3 % G][4 * al + 1], acc[3 % G][4 * al + 2], acc[3 % G][4 * al + 3]};
+            }
+            f32x4 cv = creg[al], hv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float ig = sigmoid_pre(gi[i], bi[i]);
+                const float fg = sigmoid_pre(gf[i], bf[i]);
+                const float gt = tanh_pre(gg4[i], bg[i]);
+                const float og = sigmoid_pre(go[i], bo[i]);
+                const float cn = __builtin_fmaf(fg, cv[i], ig * gt);
+                cv[i] = cn;
+                hv[i] = og * fast_tanh(cn);
+            }
+            creg[al] = cv;
+            bst16_sc1(ro, voffO + al * 1024u, (uint32_t)t * orow + (uint32_t)u * 4096u, hv);
+        }
+        publish();   // (also the barrier between this step's LDS reads and the next step's LDS writes)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // dsp_lstm6_kernel<NPROD> (opt-in, DSP_PRECISION=bf16x6 | bf16x9 | fp16x3): dsp_lstm_kernel<0, 1> with every fp32 product
 // emulated on the bf16 matrix cores.  Both operands are split into three bf16 pieces (hi + mid + lo == x exactly
 // for an fp32 x); a product keeps the NPROD largest piece products (9 = all of them, exact; 6 = without ml, lm,
@@ -1190,7 +1426,8 @@ extern "C" int dsp_k_init(void) {
     const void* fns[] = {(const void*)dsp_lstm_kernel<0, 1>, (const void*)dsp_lstm_kernel<1, 1>,
                          (const void*)dsp_lstm_kernel<2, 1, 1>, (const void*)dsp_lstm_kernel<2, 1, 2>, (const void*)dsp_lstm_kernel<2, 1, 3>,
                          (const void*)dsp_lstm_kernel<0, 0>, (const void*)dsp_lstm_kernel<1, 0>, (const void*)dsp_lstm21_kernel,
-                         (const void*)dsp_lstm6_kernel<6>, (const void*)dsp_lstm6_kernel<9>, (const void*)dsp_lstm6_kernel<3>};
+                         (const void*)dsp_lstm6_kernel<6>, (const void*)dsp_lstm6_kernel<9>, (const void*)dsp_lstm6_kernel<3>,
+                         (const void*)dsp_lstmc_kernel<4, 4>, (const void*)dsp_lstmc_kernel<2, 8>, (const void*)dsp_lstmc_kernel<1, 16>};
     for (const void* f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
@@ -1207,6 +1444,24 @@ extern "C" int dsp_k_pack(const PackArgs* a, hipStream_t s) {
 
 // a wave owns one unit tile (per pass) x two site tiles; a->SG site groups (of two tiles) per workgroup; a->NP passes
 extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
+    if (a->CG > 0) {
+        // a (site tile, direction) spread over a cluster of UT / CG workgroups (dsp_lstmc_kernel); the caller has checked the
+        // shape (dense, one pass, 8 unit tiles, nqx a multiple of the ring depth and at least twice it) and the residency
+        const int G = a->CG, D = G == 4 ? 4 : (G == 2 ? 8 : 16);
+        const int nqx = a->Ipad >> 3;
+        if ((G != 1 && G != 2 && G != 4) || a->UT % G || a->NP > 1 || !a->cflags || a->NQ != ((a->Ipad + a->Hp) >> 3) ||
+            a->nqx_lo != 0 || a->nqx_used != nqx || nqx % D || nqx < 2 * D || a->NQ % D)
+            return (int)hipErrorInvalidValue;
+        const int P = a->UT / G;
+        const unsigned clusters = (unsigned)(a->NTp * 2);
+        const unsigned grid = (clusters + 7) / 8 * 8 * (unsigned)P;
+        size_t lds = (size_t)a->Hp * 16 + (G < 4 ? (size_t)G * 16384 : 0);
+        if (a->flags & 4) lds = lds < 84 * 1024 ? 84 * 1024 : lds;   // more than half a CU's LDS: one workgroup per CU
+        if (G == 4) hipLaunchKernelGGL((dsp_lstmc_kernel<4, 4>), dim3(grid), dim3(256), lds, s, *a);
+        else if (G == 2) hipLaunchKernelGGL((dsp_lstmc_kernel<2, 8>), dim3(grid), dim3(256), lds, s, *a);
+        else hipLaunchKernelGGL((dsp_lstmc_kernel<1, 16>), dim3(grid), dim3(256), lds, s, *a);
+        return (int)hipGetLastError();
+    }
     if ((a->flags & 2) && a->NP <= 1 && a->UT >= 2 && a->UT % 2 == 0 && a->nqx_lo == 0 && a->nqx_used == (a->Ipad >> 3) &&
         a->NQ == ((a->Ipad + a->Hp) >> 3) && (a->Ipad >> 3) >= 4) {
         // <2 unit tiles, 1 site tile> per wave: UT/2 waves x SG single-tile site groups per workgroup
