@@ -312,9 +312,18 @@ struct dsp_model {
     int tiling21 = -1;       // <2 unit tiles, 1 site tile> per wave on the dense one-pass layers (dsp_lstm21_kernel): -1 = for
                              // batches whose 32-site tiles x 2 directions fit the CUs at once (small-batch latency); DSP_LSTM_TILING=21
                              // always, =0 never (A/B switch)
+    bool local8 = true;      // dense 8-unit-tile layers of 2,049..4,096-site batches on dsp_lstmc_kernel's eight-wave workgroup-local
+                             // form (two waves per SIMD: 3.43 vs 3.48 ms per forward of 4,096 sites) instead of dsp_lstm21_kernel;
+                             // DSP_LSTM_LOCAL8=0 turns it off (A/B switch)
+    bool head_st4 = false;   // DSP_HEAD_ST4=1: the head kernel keeps four site tiles per workgroup at every batch size (A/B switch)
     bool sync_each = false, debug_lstm = false;  // DSP_SYNC_EACH / DSP_DEBUG_LSTM: debugging aids, read when the handle is made
     int cluster = -1;        // dsp_lstmc_kernel (a site tile's unit tiles spread over several CUs, small batches): -1 = whenever the
                              // whole grid fits the CUs at once; DSP_LSTM_CLUSTER=0 never, =1 / 2 / 4 that many gates per wave
+    int two_streams = -1;    // the signal branch on a side stream next to the seq branch (they are independent until the combined
+                             // stack): -1 = for batches that leave CUs idle (<= 4,096 sites); DSP_TWO_STREAMS=0 never, =1 always
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    float* h0buf2 = nullptr;   // the side branch's own h0 scratch
     unsigned int* cflags = nullptr;   // arrival counters of the clustered launches of ONE forward (zeroed by its pack launch)
     int n_cflag_words = 0;
     int n_cus = 256;         // compute units of the handle's device
@@ -328,6 +337,7 @@ struct dsp_model {
     float* last_out = nullptr;
     // profiling
     bool prof = false;
+    bool prof_serial = false;   // (reserved: per-launch timing wants the branches in sequence; DSP_TWO_STREAMS=0 gives that)
     std::vector<ProfEntry> prof_entries;
     std::vector<hipEvent_t> event_pool;
     size_t event_used = 0;
@@ -420,7 +430,7 @@ int ensure_split(dsp_model* m) {
     return rc;
 }
 
-size_t ws_layout(const dsp_model* m, int64_t sites, long long* NTp_out, size_t off[7]) {
+size_t ws_layout(const dsp_model* m, int64_t sites, long long* NTp_out, size_t off[8]) {
     long long nt = (sites + 31) / 32;
     long long NTp = (nt + 15) / 16 * 16;
     if (NTp == 0) NTp = 16;
@@ -439,6 +449,7 @@ size_t ws_layout(const dsp_model* m, int64_t sites, long long* NTp_out, size_t o
     // (the DSP_LSTM_NP8=2 experiment runs two passes of four waves on a hidden-256 layer: 64 KiB per workgroup as well)
     const size_t cunits = std::max<size_t>(hmax > 256 ? (size_t)(hmax / 256) : 0, m->np8 == 2 ? 1 : 0);
     off[6] = o; o += (size_t)NTp * cunits * 65536;
+    off[7] = o; o += ((size_t)NTp * m->Fwide * 32 * sizeof(float) + 255) / 256 * 256;  // h0 scratch of the side branch
     if (NTp_out) *NTp_out = NTp;
     return o;
 }
@@ -451,7 +462,7 @@ int ensure_ws(dsp_model* m, int64_t sites, hipStream_t stream) {
         HIP_TRY(hipFree(m->ws));
         m->ws = nullptr; m->ws_sites = 0;
     }
-    size_t off[7];
+    size_t off[8];
     long long NTp;
     const size_t bytes = ws_layout(m, sites, &NTp, off);
     hipError_t e = hipMalloc(&m->ws, bytes);
@@ -465,6 +476,7 @@ int ensure_ws(dsp_model* m, int64_t sites, hipStream_t stream) {
     m->bufA = (float*)(b + off[2]); m->bufB = (float*)(b + off[3]); m->comb_in = (float*)(b + off[4]);
     m->h0buf = (float*)(b + off[5]);
     m->cbuf = (float*)(b + off[6]);
+    m->h0buf2 = (float*)(b + off[7]);
     m->ws_sites = (int64_t)NTp * 32;
     return 0;
 }
@@ -474,6 +486,7 @@ struct Launcher {
     hipStream_t s;
     long long NTp;  // padded tile count of THIS call (launch geometry is per call, never stored in the handle)
     int rc = 0;
+    bool side_by_side = false;   // the seq and signal branches of this call run on two streams
     template <class F> void run(const char* name, F&& f) {
         if (rc) return;
         hipEvent_t ea = nullptr, eb = nullptr;
@@ -515,16 +528,27 @@ constexpr int kClusterWordsPerLaunch = 256 * 32;   // at most 128 clusters (x 32
 constexpr int kClusterLaunches = 48;               // LSTM launches of one forward (3 stacks x at most 15 layers, 45)
 int cluster_size(const dsp_model* m, long long NTp) {
     if (m->cluster == 0) return 0;
+    const long long slots = (long long)m->n_cus;   // workgroups resident at once: one per CU (two clustered workgroups per CU
+    // were measured in round 4: 1.236 vs 1.191 ms at 1,024 sites, 3.515 vs 3.464 ms at 4,096 -- slower; not kept)
     int P = 1;
-    while (P < 8 && NTp * 2 * (P * 2) <= (long long)m->n_cus) P *= 2;
+    while (P < 8 && NTp * 2 * (P * 2) <= slots) P *= 2;
     if (m->cluster > 0) {   // DSP_LSTM_CLUSTER = gates per wave: that cluster size, if it fits
         const int want = m->cluster == 1 ? 8 : (m->cluster == 2 ? 4 : (m->cluster == 4 ? 2 : 0));
-        P = (want && NTp * 2 * want <= (long long)m->n_cus) ? want : 1;
+        P = (want && NTp * 2 * want <= slots) ? want : 1;
     }
     return P >= 2 ? P : 0;
 }
 int pick_cluster(const dsp_model* m, const LstmArgs& a, long long NTp, bool split) {
+    // layers of 4 unit tiles (the front ends at hidden 128): one 4-wave workgroup per (site tile, direction) holds the whole
+    // layer -- a wave 1 unit tile x 1 site tile, half the work per step of the 64-site tiling -- whenever those workgroups
+    // fit the CUs at once (<= 4,096 sites); no exchange between workgroups, so nothing to wait for
+    if (m->cluster != 0 && !split && a.UT == 4 && a.NP <= 1 && NTp * 2 <= (long long)m->n_cus &&
+        a.NQ == ((a.Ipad + a.Hp) >> 3) && (a.Ipad >> 3) % 4 == 0 && (a.Ipad >> 3) >= 4 && a.NQ % 4 == 0 && a.NQ >= 8)
+        return 4;
     const int P = cluster_size(m, NTp);
+    if (!P && m->local8 && !split && a.UT == 8 && a.NP <= 1 && NTp * 2 <= (long long)m->n_cus && a.nqx_lo == 0 &&
+        a.nqx_used == (a.Ipad >> 3) && a.NQ == ((a.Ipad + a.Hp) >> 3) && (a.Ipad >> 3) % 4 == 0 && a.NQ % 4 == 0)
+        return -4;   // (negative: the workgroup-local form with eight waves)
     if (!P || split || a.UT != 8 || a.NP > 1 || NTp * 2 * 32 > kClusterWordsPerLaunch) return 0;
     const int nqx = a.Ipad >> 3, G = 8 / P, D = G == 4 ? 4 : (G == 2 ? 8 : 16);
     if (a.nqx_lo != 0 || a.nqx_used != nqx || a.NQ != ((a.Ipad + a.Hp) >> 3) || nqx % D || nqx < 2 * D || a.NQ % D) return 0;
@@ -533,13 +557,14 @@ int pick_cluster(const dsp_model* m, const LstmArgs& a, long long NTp, bool spli
 
 // run one BiLSTM stack; returns the buffer holding the last layer's output
 float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>& layers, int lstm_id, const float* x,
-                 int64_t n, const dsp_init_state* init, const float* h0, const float* c0) {
+                 int64_t n, const dsp_init_state* init, const float* h0, const float* c0, bool side = false) {
+    // side: the stack runs next to another one (one layer only): its output goes to bufB, its h0 to the second scratch
     dsp_model* m = L.m;
     const float* cur = x;
     float* dst = nullptr;
     for (size_t k = 0; k < layers.size(); ++k) {
         const DevLstmLayer& ly = layers[k];
-        dst = ((layers.size() - 1 - k) % 2 == 0) ? m->bufA : m->bufB;
+        dst = ((layers.size() - 1 - k) % 2 == 0) != side ? m->bufA : m->bufB;
         LstmArgs a{};
         a.x = cur; a.out = dst;
         a.wpk0 = ly.wpk[0]; a.wpk1 = ly.wpk[1]; a.sbias0 = ly.sbias[0]; a.sbias1 = ly.sbias[1];
@@ -547,7 +572,7 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
         a.Ipad = ly.Ipad; a.H = ly.H; a.Hp = ly.Hp; a.T = m->d.T; a.Fout = 2 * ly.Hp;
         a.NQ = rup((ly.Ipad + ly.Hp) / 8, 4);
         a.nqx_used = (ly.Iused + 7) / 8; a.nqx_lo = ly.Ilo / 8;
-        a.h0buf = m->h0buf;
+        a.h0buf = side ? m->h0buf2 : m->h0buf;
         a.cbuf = m->cbuf;
         a.UT = ly.Hp / 32;
         a.NP = a.UT > 8 ? a.UT / 8 : (a.UT == 8 && lstm_id == 2 ? m->np8 : 1);
@@ -583,9 +608,10 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
         }
         // batches that leave most CUs idle: the layer's unit tiles spread over a cluster of workgroups (dsp_lstmc_kernel)
         a.CG = (launch_no < kClusterLaunches && m->cflags) ? pick_cluster(m, a, L.NTp, split) : 0;
+        if (a.CG < 0) { a.CG = -a.CG; a.flags |= 8; }
         if (a.CG) {
             a.cflags = m->cflags + (size_t)launch_no * kClusterWordsPerLaunch;
-            a.flags |= 4;   // one workgroup per CU
+            if (!L.side_by_side) a.flags |= 4;   // one workgroup per CU (not when two branches run side by side on two streams)
         }
         if (m->debug_lstm)   // DSP_DEBUG_LSTM (read once, in dsp_model_create)
             fprintf(stderr, "[lstm] %s k=%zu split=%d CG=%d Ipad=%d H=%d Hp=%d UT=%d SG=%d NQ=%d NTp=%lld n=%lld T=%d Fout=%d x=%p out=%p\n", name, k,
@@ -674,11 +700,19 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
     if (const char* v = getenv("DSP_TRACE_WAVE")) m->trace_wave = atoi(v) & 7;
     m->sync_each = getenv("DSP_SYNC_EACH") != nullptr;   // (never per launch: a 512-site forward is 9 launches in 2-4 ms)
     m->debug_lstm = getenv("DSP_DEBUG_LSTM") != nullptr;
+    m->head_st4 = getenv("DSP_HEAD_ST4") != nullptr;
+    if (const char* v = getenv("DSP_LSTM_LOCAL8")) m->local8 = atoi(v) != 0;
     if (const char* v = getenv("DSP_LSTM_SG")) m->sg_override = atoi(v);  // A/B switch
     if (const char* v = getenv("DSP_LSTM_NP8")) m->np8 = atoi(v) == 2 ? 2 : 1;  // A/B switch
     if (const char* v = getenv("DSP_LSTM_PRIO")) m->phase_prio = atoi(v) != 0;    // A/B switch
     if (const char* v = getenv("DSP_LSTM_TILING")) m->tiling21 = atoi(v) == 21 ? 1 : 0;   // A/B switch
     if (const char* v = getenv("DSP_LSTM_CLUSTER")) m->cluster = atoi(v);                  // A/B switch
+    if (const char* v = getenv("DSP_TWO_STREAMS")) m->two_streams = atoi(v) != 0 ? 1 : 0;   // A/B switch
+    if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        m->two_streams = 0;   // no side stream to be had: the branches run in sequence
+    }
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) m->n_cus = prop.multiProcessorCount;
@@ -769,7 +803,7 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
 
 size_t dsp_workspace_bytes(const dsp_model* m, int64_t max_sites) {
     if (!m) return 0;
-    size_t off[7];
+    size_t off[8];
     return ws_layout(m, max_sites, nullptr, off);
 }
 
@@ -834,17 +868,34 @@ int32_t dsp_forward(dsp_model* m, void* stream, int64_t n, const void* kmer, int
         LinArgs a{};
         a.x = x; a.out = m->comb_in; a.wpk = fc.wpk; a.bias = fc.bias;
         a.ncols = NTp * d.T; a.Fin = fc.Fin; a.Fout = m->Fcomb; a.out_off = out_off; a.ORT = fc.ORT; a.relu = 1;
-        L.run(name, [&] { return dsp_k_linear(&a, s); });
+        L.run(name, [&] { return dsp_k_linear(&a, L.s); });
     };
+    // The seq and the signal branch are independent until the combined stack (models.py:181-217).  On batches that leave
+    // CUs idle the signal branch runs on the handle's side stream next to the seq branch (fork / join by events: 512 sites
+    // 0.81 -> 0.66 ms per forward); one layer each (the default), so that the two stacks need one output buffer each
+    const bool two = m->side && d.hseq && d.hsig && d.l2 == 1 && m->hseq_p <= 256 && m->hsig_p <= 256 && !m->prof_serial &&
+                     (m->two_streams > 0 || (m->two_streams < 0 && NTp * 4 <= (long long)m->n_cus));   // (<= 2,048 sites: at 4,096 every CU
+    // is busy with one branch already -- 3.458 vs 3.453 ms in sequence)
+    L.side_by_side = two;
+    if (two) {
+        if (hipEventRecord(m->ev_fork, s) != hipSuccess || hipStreamWaitEvent(m->side, m->ev_fork, 0) != hipSuccess)
+            L.rc = fail(DSP_EHIP, "fork to the side stream failed: %s", hipGetErrorString(hipGetLastError()));
+    }
     if (d.hseq) {
         float* o = run_stack(L, "lstm_seq", m->seq, 0, m->xseq, n, init, init ? init->h_seq : nullptr,
                              init ? init->c_seq : nullptr);
         linear("fc_seq", m->fc_seq, o, 0);
     }
     if (d.hsig) {
+        if (two) L.s = m->side;
         float* o = run_stack(L, "lstm_signal", m->sig, 1, m->xsig, n, init, init ? init->h_sig : nullptr,
-                             init ? init->c_sig : nullptr);
+                             init ? init->c_sig : nullptr, two);
         linear("fc_signal", m->fc_sig, o, m->hseq_p);
+        if (two) {
+            L.s = s;
+            if (!L.rc && (hipEventRecord(m->ev_join, m->side) != hipSuccess || hipStreamWaitEvent(s, m->ev_join, 0) != hipSuccess))
+                L.rc = fail(DSP_EHIP, "join of the side stream failed: %s", hipGetErrorString(hipGetLastError()));
+        }
     }
     float* o = run_stack(L, "lstm_comb", m->comb, 2, m->comb_in, n, init, init ? init->h_comb : nullptr,
                          init ? init->c_comb : nullptr);
@@ -852,6 +903,7 @@ int32_t dsp_forward(dsp_model* m, void* stream, int64_t n, const void* kmer, int
     HeadArgs h{};
     h.x = o; h.w1pk = m->fc1.wpk; h.b1 = m->fc1.bias; h.w2 = m->w2; h.b2 = m->b2;
     h.logits = logits; h.probs = probs; h.labels = labels; h.n = n; h.Hp = m->Hp; h.T = d.T; h.C = d.C;
+    h.flags = m->head_st4 ? 1 : 0;
     L.run("head", [&] { return dsp_k_head(&h, s); });
 
     if (prev != m->device) hipSetDevice(prev);
@@ -933,6 +985,9 @@ void dsp_model_destroy(dsp_model* m) {
     for (void* p : m->dev_allocs) hipFree(p);
     if (m->ws) hipFree(m->ws);
     for (hipEvent_t e : m->event_pool) hipEventDestroy(e);
+    if (m->ev_fork) hipEventDestroy(m->ev_fork);
+    if (m->ev_join) hipEventDestroy(m->ev_join);
+    if (m->side) hipStreamDestroy(m->side);
     hipSetDevice(prev);
     delete m;
 }

@@ -73,6 +73,7 @@ struct HeadArgs {
     uint8_t* labels;       // [n] or NULL
     long long n;
     int Hp, T, C;
+    int flags;             // bit 0: keep four site tiles per workgroup whatever the batch (A/B switch DSP_HEAD_ST4=1)
 };
 
 #ifdef __cplusplus

@@ -780,8 +780,15 @@ __device__ __forceinline__ void wait_arrivals(gu32* flag, unsigned target) {
     }
 }
 
-template <int G, int D>
-__global__ __launch_bounds__(256, 1) void dsp_lstmc_kernel(LstmArgs a) {
+template <int G, int D, bool LOCAL = false, int DEAD = 0, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 1) void dsp_lstmc_kernel(LstmArgs a) {
+    // NW = 8 (LOCAL, layers of 8 unit tiles): eight waves, two per SIMD, a wave 1 unit tile x 1 site tile -- the alternative
+    // to dsp_lstm21_kernel's four waves of 2 unit tiles for batches of 2,049..4,096 sites (A/B: DSP_LSTM_LOCAL8)
+    // DEAD (LOCAL, nqx == D: the front ends, 7 or 16 features at the end of a 32-wide block): the first DEAD k-groups of a
+    // step are pure zero padding -- their stages keep the ring turning (refills only) and issue no MFMAs
+    // LOCAL (G = 4, layers of 4 unit tiles: the front ends at hidden 128): the workgroup holds the whole hidden state, P = 1 --
+    // the h exchange is the step barrier of dsp_lstm21_kernel (plain stores, one s_barrier, plain loads), no counter; the x
+    // part may be as short as the ring (nqx == D: the h part's first requests then leave right behind the barrier)
     constexpr int WPU = 4 / G;             // waves per unit tile = gate slices; unit tiles per workgroup = G
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* b_lds = (f32x4*)smem;           // [unit tile][aa][gate][half] float4 (Hp float4)
@@ -790,7 +797,7 @@ __global__ __launch_bounds__(256, 1) void dsp_lstmc_kernel(LstmArgs a) {
     const int lane = tid & 63;
     const uint32_t voff = (uint32_t)lane * 16u;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int P = a.UT / G;
+    const int P = LOCAL ? 1 : a.UT / G;
     // cluster c = (site tile, direction); its P members are consecutive entries of one XCD's dispatch list
     const int xs = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int pi = j % P;
@@ -818,7 +825,7 @@ __global__ __launch_bounds__(256, 1) void dsp_lstmc_kernel(LstmArgs a) {
     const uint32_t voffA = voff + (uint32_t)(gs * G) * 1024u;   // this wave's gates within a k-group's 4 KiB of weights
     const uint32_t voffO = voff + (uint32_t)(gs * G) * 1024u;   // this wave's row groups within a unit tile's 4 KiB of h
 
-    for (int i = tid; i < a.Hp; i += 256) {
+    for (int i = tid; i < a.Hp; i += NW * 64) {
         const int h = i & 1, g = (i >> 1) & 3, aa = (i >> 3) & 3, ut = i >> 5;
         b_lds[i] = bias4[g * HQ + ut * 8 + 2 * aa + h];
     }
@@ -835,15 +842,20 @@ __global__ __launch_bounds__(256, 1) void dsp_lstmc_kernel(LstmArgs a) {
                 hv = init_state4(a.h0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, skey, (uint32_t)(a.stream_base + dir * 2 + 0));
                 cv = init_state4(a.c0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, skey, (uint32_t)(a.stream_base + dir * 2 + 1));
             }
-            bst16_sc1(rh0, voffO + al * 1024u, (uint32_t)u * 4096u, hv);
+            if constexpr (LOCAL) bst16(rh0, voffO + al * 1024u, (uint32_t)u * 4096u, hv);
+            else bst16_sc1(rh0, voffO + al * 1024u, (uint32_t)u * 4096u, hv);
             creg[al] = cv;
         }
     }
     // publish: every wave drains its write-through stores, the workgroup meets, one lane counts the arrival
     auto publish = [&]() __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (LOCAL) {
+            barrier_after_global_stores();   // same CU: the stores of this workgroup's waves are ahead of the loads issued after it
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     };
     publish();
 
@@ -863,17 +875,21 @@ __global__ __launch_bounds__(256, 1) void dsp_lstmc_kernel(LstmArgs a) {
     };
     // B fragments: x part (plain loads: written by an earlier launch), h part (sc1: written by the cluster during this one)
     auto ldBx = [&](int q) __attribute__((always_inline)) { return bld16(rx, voff, xo + (uint32_t)q * 1024u); };
-    auto ldBh = [&](int q) __attribute__((always_inline)) { return bld16_sc1(rhp, voff, ho + (uint32_t)q * 1024u); };
+    auto ldBh = [&](int q) __attribute__((always_inline)) {
+        if constexpr (LOCAL) return bld16(rhp, voff, ho + (uint32_t)q * 1024u);
+        else return bld16_sc1(rhp, voff, ho + (uint32_t)q * 1024u);
+    };
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // one k-group: per fragment its 4 MFMAs, then the (late) refill of the fragment before it for k-group q + D; the B
     // fragment of the slot is refilled behind the stage.  kind (compile time): 0 = the refill is an x row of THIS step's
     // bases, 1 = an h row
-    auto stage = [&](auto qs, int q, auto first, auto kind) __attribute__((always_inline)) {
+    auto stage = [&](auto qs, int q, auto first, auto kind, auto dead) __attribute__((always_inline)) {
         constexpr int S = decltype(qs)::value % D, SP = (decltype(qs)::value + D - 1) % D;
 #pragma unroll
         for (int f = 0; f < G; ++f) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                if (decltype(dead)::value) break;
                 if (decltype(first)::value && i == 0)
                     acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[S][f][i], B[S][i], zero16, 0, 0, 0);
                 else
@@ -888,16 +904,26 @@ __global__ __launch_bounds__(256, 1) void dsp_lstmc_kernel(LstmArgs a) {
         if constexpr (decltype(kind)::value == 1) B[S] = ldBh(qn); else B[S] = ldBx(qn);
         __builtin_amdgcn_sched_barrier(0);
     };
+    using live = std::false_type;
     auto stages = [&](int q, auto first, auto kind) __attribute__((always_inline)) {
-        stage(ic<0>{}, q, first, kind);
-        if constexpr (D > 1) stage(ic<1>{}, q + 1, std::false_type{}, kind);
-        if constexpr (D > 2) { stage(ic<2>{}, q + 2, std::false_type{}, kind); stage(ic<3>{}, q + 3, std::false_type{}, kind); }
-        if constexpr (D > 4) { stage(ic<4>{}, q + 4, std::false_type{}, kind); stage(ic<5>{}, q + 5, std::false_type{}, kind);
-                               stage(ic<6>{}, q + 6, std::false_type{}, kind); stage(ic<7>{}, q + 7, std::false_type{}, kind); }
-        if constexpr (D > 8) { stage(ic<8>{}, q + 8, std::false_type{}, kind); stage(ic<9>{}, q + 9, std::false_type{}, kind);
-                               stage(ic<10>{}, q + 10, std::false_type{}, kind); stage(ic<11>{}, q + 11, std::false_type{}, kind);
-                               stage(ic<12>{}, q + 12, std::false_type{}, kind); stage(ic<13>{}, q + 13, std::false_type{}, kind);
-                               stage(ic<14>{}, q + 14, std::false_type{}, kind); stage(ic<15>{}, q + 15, std::false_type{}, kind); }
+        stage(ic<0>{}, q, first, kind, live{});
+        if constexpr (D > 1) stage(ic<1>{}, q + 1, std::false_type{}, kind, live{});
+        if constexpr (D > 2) { stage(ic<2>{}, q + 2, std::false_type{}, kind, live{}); stage(ic<3>{}, q + 3, std::false_type{}, kind, live{}); }
+        if constexpr (D > 4) { stage(ic<4>{}, q + 4, std::false_type{}, kind, live{}); stage(ic<5>{}, q + 5, std::false_type{}, kind, live{});
+                               stage(ic<6>{}, q + 6, std::false_type{}, kind, live{}); stage(ic<7>{}, q + 7, std::false_type{}, kind, live{}); }
+        if constexpr (D > 8) { stage(ic<8>{}, q + 8, std::false_type{}, kind, live{}); stage(ic<9>{}, q + 9, std::false_type{}, kind, live{});
+                               stage(ic<10>{}, q + 10, std::false_type{}, kind, live{}); stage(ic<11>{}, q + 11, std::false_type{}, kind, live{});
+                               stage(ic<12>{}, q + 12, std::false_type{}, kind, live{}); stage(ic<13>{}, q + 13, std::false_type{}, kind, live{});
+                               stage(ic<14>{}, q + 14, std::false_type{}, kind, live{}); stage(ic<15>{}, q + 15, std::false_type{}, kind, live{}); }
+    };
+    // the first block of a front-end step (D == 4 == nqx): DEAD refill-only stages, then the live x-part k-groups, the first
+    // of which starts the accumulators from zero
+    auto stages_first_sparse = [&](auto kind) __attribute__((always_inline)) {
+        static_assert(DEAD == 0 || D == 4, "front-end shape");
+        stage(ic<0>{}, 0, std::integral_constant<bool, DEAD == 0>{}, kind, std::integral_constant<bool, (0 < DEAD)>{});
+        stage(ic<1>{}, 1, std::integral_constant<bool, DEAD == 1>{}, kind, std::integral_constant<bool, (1 < DEAD)>{});
+        stage(ic<2>{}, 2, std::integral_constant<bool, DEAD == 2>{}, kind, std::integral_constant<bool, (2 < DEAD)>{});
+        stage(ic<3>{}, 3, std::integral_constant<bool, DEAD == 3>{}, kind, live{});
     };
 
     set_bases(0);
@@ -910,14 +936,27 @@ __global__ __launch_bounds__(256, 1) void dsp_lstmc_kernel(LstmArgs a) {
     for (int step = 0; step < T; ++step) {
         const int t = dir ? (T - 1 - step) : step;
         if (prio) __builtin_amdgcn_s_setprio(2);
-        // x part: nothing here depends on h_{t-1}
-        stages(0, std::true_type{}, ic<0>{});
-        for (int q = D; q < nqx - D; q += D) stages(q, std::false_type{}, ic<0>{});
-        // the B ring is about to reach into the h part: h_{t-1} (h0 at step 0) of every member of the cluster must be in memory
-        asm volatile("" ::: "memory");   // (no h load may be moved above the poll by the compiler either)
-        wait_arrivals(flag, (unsigned)(P * (step + 1)));
-        asm volatile("" ::: "memory");
-        for (int q = nqx - D; q < NQ - D; q += D) stages(q, std::false_type{}, ic<1>{});
+        if constexpr (LOCAL) {
+            // (the barrier behind the previous step's -- or the prologue's -- h stores has been passed: every request may go out)
+            if (nqx > D) {
+                stages(0, std::true_type{}, ic<0>{});
+                for (int q = D; q < nqx - D; q += D) stages(q, std::false_type{}, ic<0>{});
+                for (int q = nqx - D; q < NQ - D; q += D) stages(q, std::false_type{}, ic<1>{});
+            } else {
+                if constexpr (DEAD > 0) stages_first_sparse(ic<1>{});
+                else stages(0, std::true_type{}, ic<1>{});
+                for (int q = D; q < NQ - D; q += D) stages(q, std::false_type{}, ic<1>{});
+            }
+        } else {
+            // x part: nothing here depends on h_{t-1}
+            stages(0, std::true_type{}, ic<0>{});
+            for (int q = D; q < nqx - D; q += D) stages(q, std::false_type{}, ic<0>{});
+            // the B ring is about to reach into the h part: h_{t-1} (h0 at step 0) of every member of the cluster must be in memory
+            asm volatile("" ::: "memory");   // (no h load may be moved above the poll by the compiler either)
+            wait_arrivals(flag, (unsigned)(P * (step + 1)));
+            asm volatile("" ::: "memory");
+            for (int q = nqx - D; q < NQ - D; q += D) stages(q, std::false_type{}, ic<1>{});
+        }
         set_bases(step + 1 < T ? step + 1 : step);   // the last D refills are the next step's first x rows
         stages(NQ - D, std::false_type{}, ic<0>{});
         if (prio) __builtin_amdgcn_s_setprio(0);
@@ -959,7 +998,8 @@ __global__ __launch_bounds__(256, 1) void dsp_lstmc_kernel(LstmArgs a) {
                 hv[i] = og * fast_tanh(cn);
             }
             creg[al] = cv;
-            bst16_sc1(ro, voffO + al * 1024u, (uint32_t)t * orow + (uint32_t)u * 4096u, hv);
+            if constexpr (LOCAL) bst16(ro, voffO + al * 1024u, (uint32_t)t * orow + (uint32_t)u * 4096u, hv);
+            else bst16_sc1(ro, voffO + al * 1024u, (uint32_t)t * orow + (uint32_t)u * 4096u, hv);
         }
         publish();   // (also the barrier between this step's LDS reads and the next step's LDS writes)
     }
@@ -1286,7 +1326,11 @@ __global__ __launch_bounds__(256, 2) void dsp_linear_kernel(LinArgs a) {
 // cross-lane move, the row-tile groups with a 4 KB LDS exchange; softmax on the first 128 threads.
 // Hidden sizes above 256 (more than 8 row tiles) loop over pairs of row tiles per wave.
 // ------------------------------------------------------------------------------------------------
-constexpr int kHeadST = 4;  // site tiles per workgroup
+// Round 4: kHeadST = site tiles per workgroup is a template parameter.  4 = full batches (above).  1 = batches of a few
+// thousand sites: four times the workgroups (512 sites: 16 instead of 4), and the k-loop -- two MFMAs per fragment there,
+// i.e. pure load latency -- runs on rings four k-groups deep instead of the one-deep prefetch (0.081 -> 0.03 ms per
+// forward of 512 sites; same sums in the same order: bit-identical).
+template <int kHeadST>
 __global__ __launch_bounds__(256, 2) void dsp_head_kernel(HeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* part = smem;                         // [4 waves][C][kHeadST * 32]
@@ -1332,6 +1376,30 @@ __global__ __launch_bounds__(256, 2) void dsp_head_kernel(HeadArgs a) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { acc0[st][4 * aa + i] = b0[i]; acc1[st][4 * aa + i] = b1[i]; }
             }
+            if constexpr (kHeadST == 1) {
+                constexpr int DP = 4;   // ring depth; nq = Hp / 4 is a multiple of 8
+                f32x4 A0r[DP], A1r[DP], Br[DP];
+#pragma unroll
+                for (int dq = 0; dq < DP; ++dq) {
+                    A0r[dq] = bld16(rw, voff, wo0 + (uint32_t)dq * 1024u); A1r[dq] = bld16(rw, voff, wo1 + (uint32_t)dq * 1024u);
+                    Br[dq] = bld16(rx, voff, ((dq < nqf) ? xfo[0] : xro[0]) + (uint32_t)dq * 1024u);
+                }
+                for (int q = 0; q < nq; q += DP) {
+#pragma unroll
+                    for (int dq = 0; dq < DP; ++dq) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            acc0[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0r[dq][i], Br[dq][i], acc0[0], 0, 0, 0);
+                            acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1r[dq][i], Br[dq][i], acc1[0], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int qn = q + dq + DP < nq ? q + dq + DP : nq - 1;
+                        A0r[dq] = bld16(rw, voff, wo0 + (uint32_t)qn * 1024u); A1r[dq] = bld16(rw, voff, wo1 + (uint32_t)qn * 1024u);
+                        Br[dq] = bld16(rx, voff, ((qn < nqf) ? xfo[0] : xro[0]) + (uint32_t)qn * 1024u);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else {
             f32x4 A0n = bld16(rw, voff, wo0), A1n = bld16(rw, voff, wo1), Bn[kHeadST];
 #pragma unroll
             for (int st = 0; st < kHeadST; ++st) Bn[st] = bld16(rx, voff, xfo[st]);
@@ -1351,6 +1419,7 @@ __global__ __launch_bounds__(256, 2) void dsp_head_kernel(HeadArgs a) {
                         acc0[st] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[i], B[st][i], acc0[st], 0, 0, 0);
                         acc1[st] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[i], B[st][i], acc1[st], 0, 0, 0);
                     }
+            }
             }
             // fc2 on the registers: rows 8*aa + 4*half + i of row tile rt (and rt + 4) of this lane's site
 #pragma unroll
@@ -1427,12 +1496,16 @@ extern "C" int dsp_k_init(void) {
                          (const void*)dsp_lstm_kernel<2, 1, 1>, (const void*)dsp_lstm_kernel<2, 1, 2>, (const void*)dsp_lstm_kernel<2, 1, 3>,
                          (const void*)dsp_lstm_kernel<0, 0>, (const void*)dsp_lstm_kernel<1, 0>, (const void*)dsp_lstm21_kernel,
                          (const void*)dsp_lstm6_kernel<6>, (const void*)dsp_lstm6_kernel<9>, (const void*)dsp_lstm6_kernel<3>,
-                         (const void*)dsp_lstmc_kernel<4, 4>, (const void*)dsp_lstmc_kernel<2, 8>, (const void*)dsp_lstmc_kernel<1, 16>};
+                         (const void*)dsp_lstmc_kernel<4, 4>, (const void*)dsp_lstmc_kernel<2, 8>, (const void*)dsp_lstmc_kernel<1, 16>,
+                         (const void*)dsp_lstmc_kernel<4, 4, true>, (const void*)dsp_lstmc_kernel<4, 4, true, 2>,
+                         (const void*)dsp_lstmc_kernel<4, 4, true, 3>, (const void*)dsp_lstmc_kernel<4, 4, true, 0, 8>};
     for (const void* f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
     }
-    return (int)hipFuncSetAttribute((const void*)dsp_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    const hipError_t e1 = hipFuncSetAttribute((const void*)dsp_head_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e1 != hipSuccess) return (int)e1;
+    return (int)hipFuncSetAttribute((const void*)dsp_head_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
 }
 
 extern "C" int dsp_k_pack(const PackArgs* a, hipStream_t s) {
@@ -1446,18 +1519,27 @@ extern "C" int dsp_k_pack(const PackArgs* a, hipStream_t s) {
 extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
     if (a->CG > 0) {
         // a (site tile, direction) spread over a cluster of UT / CG workgroups (dsp_lstmc_kernel); the caller has checked the
-        // shape (dense, one pass, 8 unit tiles, nqx a multiple of the ring depth and at least twice it) and the residency
+        // residency.  CG = 4 with 4 unit tiles: the workgroup holds the whole layer (the front ends at hidden 128), no counters
         const int G = a->CG, D = G == 4 ? 4 : (G == 2 ? 8 : 16);
         const int nqx = a->Ipad >> 3;
-        if ((G != 1 && G != 2 && G != 4) || a->UT % G || a->NP > 1 || !a->cflags || a->NQ != ((a->Ipad + a->Hp) >> 3) ||
-            a->nqx_lo != 0 || a->nqx_used != nqx || nqx % D || nqx < 2 * D || a->NQ % D)
+        const bool local8 = G == 4 && a->UT == 8 && (a->flags & 8);   // eight waves hold the whole layer of 8 unit tiles
+        const bool local = (G == 4 && a->UT == 4) || local8;
+        if ((G != 1 && G != 2 && G != 4) || a->UT % G || a->NP > 1 || (!local && !a->cflags) || a->NQ != ((a->Ipad + a->Hp) >> 3) ||
+            nqx % D || nqx < (local ? D : 2 * D) || a->NQ % D || a->NQ < 2 * D)
             return (int)hipErrorInvalidValue;
-        const int P = a->UT / G;
+        // (zero-padded x-part k-groups -- nqx_lo, nqx_used -- are computed like live ones here: their weights are zero)
+        const int P = local ? 1 : a->UT / G;
         const unsigned clusters = (unsigned)(a->NTp * 2);
         const unsigned grid = (clusters + 7) / 8 * 8 * (unsigned)P;
         size_t lds = (size_t)a->Hp * 16 + (G < 4 ? (size_t)G * 16384 : 0);
         if (a->flags & 4) lds = lds < 84 * 1024 ? 84 * 1024 : lds;   // more than half a CU's LDS: one workgroup per CU
-        if (G == 4) hipLaunchKernelGGL((dsp_lstmc_kernel<4, 4>), dim3(grid), dim3(256), lds, s, *a);
+        // the front ends' zero-padded leading k-groups (features at the end of the 32-wide block) issue no MFMAs
+        const int dead = (local && nqx == 4 && a->nqx_used == 4 && (a->nqx_lo == 2 || a->nqx_lo == 3)) ? a->nqx_lo : 0;
+        if (local8) hipLaunchKernelGGL((dsp_lstmc_kernel<4, 4, true, 0, 8>), dim3(grid), dim3(512), lds, s, *a);
+        else if (local && dead == 3) hipLaunchKernelGGL((dsp_lstmc_kernel<4, 4, true, 3>), dim3(grid), dim3(256), lds, s, *a);
+        else if (local && dead == 2) hipLaunchKernelGGL((dsp_lstmc_kernel<4, 4, true, 2>), dim3(grid), dim3(256), lds, s, *a);
+        else if (local) hipLaunchKernelGGL((dsp_lstmc_kernel<4, 4, true>), dim3(grid), dim3(256), lds, s, *a);
+        else if (G == 4) hipLaunchKernelGGL((dsp_lstmc_kernel<4, 4>), dim3(grid), dim3(256), lds, s, *a);
         else if (G == 2) hipLaunchKernelGGL((dsp_lstmc_kernel<2, 8>), dim3(grid), dim3(256), lds, s, *a);
         else hipLaunchKernelGGL((dsp_lstmc_kernel<1, 16>), dim3(grid), dim3(256), lds, s, *a);
         return (int)hipGetLastError();
@@ -1522,8 +1604,12 @@ extern "C" int dsp_k_linear(const LinArgs* a, hipStream_t s) {
 }
 
 extern "C" int dsp_k_head(const HeadArgs* a, hipStream_t s) {
-    const size_t lds = (size_t)(5 * a->C * kHeadST * 32) * sizeof(float);
-    const unsigned groups = (unsigned)((a->n + 32 * kHeadST - 1) / (32 * kHeadST));  // the K4 buffers are padded to 16 tiles
-    hipLaunchKernelGGL(dsp_head_kernel, dim3(groups), dim3(256), lds, s, *a);
+    // batches of a few thousand sites: one site tile per workgroup (four times the workgroups, deeper operand rings)
+    const bool small = a->n <= 4096 && !(a->flags & 1);
+    const int st = small ? 1 : 4;
+    const size_t lds = (size_t)(5 * a->C * st * 32) * sizeof(float);
+    const unsigned groups = (unsigned)((a->n + 32 * st - 1) / (32 * st));  // the K4 buffers are padded to 16 tiles
+    if (small) hipLaunchKernelGGL(dsp_head_kernel<1>, dim3(groups), dim3(256), lds, s, *a);
+    else hipLaunchKernelGGL(dsp_head_kernel<4>, dim3(groups), dim3(256), lds, s, *a);
     return (int)hipGetLastError();
 }

@@ -480,6 +480,119 @@ def test_small_batch_tiling_does_not_change_a_bit(kw, label, monkeypatch):
     assert np.abs(res[None, n].cpu().numpy() - po).max() <= TOL_TIGHT
 
 
+@pytest.mark.parametrize("kw,label", [
+    (dict(), "configs1_hidden256"),
+    (dict(module="seq_bilstm", num_layers1=2), "configs2_seq_only"),
+    (dict(hidden_size=200, num_layers1=2), "hidden200_padded_to_UT8"),
+    (dict(hidden_size=128, num_layers1=2, num_layers2=2), "hidden128_UT4_two_front_layers"),
+    (dict(module="signal_bilstm", num_layers1=1), "signal_only"),
+])
+def test_small_batch_kernels_do_not_change_a_bit(kw, label, monkeypatch):
+    """Round 4: what a batch of <= 4,096 sites runs on.  dsp_lstmc_kernel spreads a (site tile, direction)'s 8 unit tiles x 4
+    gates over a cluster of 2 / 4 / 8 workgroups on as many CUs (<= 2,048 / 1,024 / 512 sites; h crosses CUs through memory:
+    write-through stores, an arrival counter, sc1 loads), runs 4-unit-tile layers (the front ends) and -- from 2,049 sites --
+    8-unit-tile layers as one workgroup of 4 / 8 waves, the two front-end branches go down two streams, the head kernel
+    takes one site tile per workgroup.  Same MFMAs in the same order on the same values: every switch combination gives
+    the bytes of the round-3 path (everything off), at every batch size around the switches, for Philox, explicit N(0,1)
+    and zero states -- and the oracle agrees."""
+    torch = _torch()
+    from deepsignal_plant_amd import synth
+    from oracle import c_oracle as oc
+    from oracle import forward_np as onp
+    cfg = onp.OracleConfig(**kw)
+    w = onp.make_weights(cfg, 92, 2.0)
+    sizes = (1, 31, 512, 513, 1024, 1025, 2048, 2049, 3000, 4096, 4097)
+    ins = {n: synth.feature_batch(n, device="cuda:0", seed=500 + n) for n in sizes}
+    n_x = 700
+    states = {k: torch.from_numpy(v).cuda(0) for k, v in onp.make_init_states(cfg, n_x, 9).items()}
+    ins_x = synth.feature_batch(n_x, device="cuda:0", seed=77)
+    switches = ("DSP_LSTM_CLUSTER", "DSP_LSTM_LOCAL8", "DSP_TWO_STREAMS", "DSP_HEAD_ST4", "DSP_LSTM_TILING")
+    modes = {"round3": {"DSP_LSTM_CLUSTER": "0", "DSP_LSTM_LOCAL8": "0", "DSP_TWO_STREAMS": "0", "DSP_HEAD_ST4": "1"},
+             "auto": {},
+             "one_stream": {"DSP_TWO_STREAMS": "0"},
+             "two_streams_always": {"DSP_TWO_STREAMS": "1"},
+             "G4": {"DSP_LSTM_CLUSTER": "4"}, "G2": {"DSP_LSTM_CLUSTER": "2"}, "G1": {"DSP_LSTM_CLUSTER": "1"},
+             "no_local8": {"DSP_LSTM_LOCAL8": "0"},
+             "no_lstm21": {"DSP_LSTM_TILING": "0"}}
+    res = {}
+    for name, env in modes.items():
+        for k in switches:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = build_model(cfg, w, init_state="randn", seed=18)
+        for n in sizes:
+            m.site_offset = 11 * n
+            res[name, n] = m.forward(*ins[n])[1].clone()
+        res[name, "explicit"] = m.forward(*ins_x, init_states=states)[1].clone()
+        mz = build_model(cfg, w, init_state="zeros")
+        res[name, "zeros"] = mz.forward(*ins[513])[1].clone()
+        # twice in a row on one handle: the arrival counters start from zero every time
+        res[name, "again"] = m.forward(*ins_x, init_states=states)[1].clone()
+    torch.cuda.synchronize()
+    for name in modes:
+        for key in list(sizes) + ["explicit", "zeros"]:
+            assert torch.equal(res[name, key], res["round3", key]), (label, name, key)
+        assert torch.equal(res[name, "again"], res["round3", "explicit"]), (label, name)
+    for n in (513, 3000):
+        sample = [t.cpu().numpy() for t in ins[n]]
+        _, po = oc.forward(cfg, w, *sample, init_mode="philox", seed=18, site_offset=11 * n)
+        assert np.abs(res["auto", n].cpu().numpy() - po).max() <= TOL_TIGHT, (label, n)
+
+
+def test_clustered_forwards_under_uneven_load_stay_bit_identical():
+    """The members of a cluster wait for each other (arrival counters polled across compute units): the hand-off must not
+    depend on the members running in step.  Small clustered forwards are issued while ANOTHER handle keeps the chip busy
+    with full batches on its own stream -- cluster members then start late, apart from each other, and share CUs with
+    foreign workgroups -- 300 forwards of 512 / 1,024 / 2,048 sites, every output compared bit for bit with the
+    unclustered path's."""
+    torch = _torch()
+    import os
+    from deepsignal_plant_amd import synth
+    from oracle import forward_np as onp
+    cfg = onp.OracleConfig()
+    w = onp.make_weights(cfg, 93, 2.0)
+    sizes = (512, 1024, 2048)
+    ins = {n: synth.feature_batch(n, device="cuda:0", seed=600 + n) for n in sizes}
+    old = {k: os.environ.get(k) for k in ("DSP_LSTM_CLUSTER", "DSP_LSTM_LOCAL8", "DSP_TWO_STREAMS", "DSP_HEAD_ST4")}
+    try:
+        os.environ.update({"DSP_LSTM_CLUSTER": "0", "DSP_LSTM_LOCAL8": "0", "DSP_TWO_STREAMS": "0", "DSP_HEAD_ST4": "1"})
+        ref_model = build_model(cfg, w, init_state="randn", seed=19)
+        ref = {}
+        for n in sizes:
+            ref_model.site_offset = 7 * n
+            ref[n] = ref_model.forward(*ins[n])[1].clone()
+        for k in old:
+            os.environ.pop(k, None)
+        small = build_model(cfg, w, init_state="randn", seed=19)
+        big = build_model(cfg, w, init_state="randn", seed=3)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    big_in = synth.feature_batch(65536, device="cuda:0", seed=1)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    bad = 0
+    outs = []
+    for it in range(100):
+        if it % 10 == 0:
+            with torch.cuda.stream(side):     # ~53 ms of full-chip work under the next forwards
+                big.forward(*big_in)
+        for n in sizes:
+            small.site_offset = 7 * n
+            outs.append((n, small.forward(*ins[n])[1]))
+        if len(outs) >= 60:
+            torch.cuda.synchronize()
+            bad += sum(0 if torch.equal(o, ref[n]) else 1 for n, o in outs)
+            outs = []
+    torch.cuda.synchronize()
+    bad += sum(0 if torch.equal(o, ref[n]) else 1 for n, o in outs)
+    assert bad == 0, "%d of 300 clustered forwards differ from the unclustered path under load" % bad
+
+
 def test_a_workspace_that_cannot_be_had_is_refused_and_leaves_the_handle_usable():
     """dsp_model_reserve beyond the GPU's memory: DSP_ENOMEM with the size in the message -- and the next forward on the
     same handle runs and gives the same bytes as before (the failed hipMalloc must not linger in the runtime's

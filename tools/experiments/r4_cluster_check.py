@@ -16,7 +16,7 @@ from oracle import forward_np as onp
 
 
 def build(cfg, w, env):
-    for k in ("DSP_LSTM_CLUSTER", "DSP_LSTM_TILING"):
+    for k in ("DSP_LSTM_CLUSTER", "DSP_LSTM_TILING", "DSP_HEAD_ST4", "DSP_TWO_STREAMS", "DSP_LSTM_LOCAL8"):
         os.environ.pop(k, None)
     os.environ.update(env)
     m = ModelBiLSTM(cfg.seq_len, cfg.signal_len, cfg.num_layers1, cfg.num_layers2, cfg.num_classes, 0, cfg.hidden_size,
@@ -29,10 +29,10 @@ def build(cfg, w, env):
 def main():
     cfg = onp.OracleConfig()
     w = onp.make_weights(cfg, 91, 2.0)
-    sizes = (1, 33, 512, 513, 1024, 1025, 2048, 2049, 4096)
+    sizes = (1, 33, 512, 513, 1024, 1025, 2048, 2049, 4096, 4097, 8192)
     ins = {n: synth.feature_batch(n, device="cuda:0", seed=400 + n) for n in sizes}
-    modes = [("off", {"DSP_LSTM_CLUSTER": "0"}), ("auto", {}), ("G4", {"DSP_LSTM_CLUSTER": "4"}), ("G2", {"DSP_LSTM_CLUSTER": "2"}),
-             ("G1", {"DSP_LSTM_CLUSTER": "1"})]
+    modes = [("off", {"DSP_LSTM_CLUSTER": "0", "DSP_HEAD_ST4": "1", "DSP_TWO_STREAMS": "0"}), ("auto", {}), ("1stream", {"DSP_TWO_STREAMS": "0"}), ("local8", {"DSP_LSTM_LOCAL8": "1"}), ("G4", {"DSP_LSTM_CLUSTER": "4"}),
+]
     res, ms = {}, {}
     for name, env in modes:
         m = build(cfg, w, env)
