@@ -102,6 +102,14 @@ class FileInitStates(object):
         return {k: torch.from_numpy(np.ascontiguousarray(a[:, first_row:first_row + n])) for k, a in self.arrays.items()}
 
 
+def parse_on(args):
+    """--parse_on: where feature rows become numbers -- "device" (default; DSP_PARSE_ON overrides the default) or "host" """
+    v = getattr(args, "parse_on", None) or os.environ.get("DSP_PARSE_ON") or "device"
+    if v not in ("device", "host"):
+        raise ValueError("--parse_on must be device or host")
+    return v
+
+
 def load_model(args, device):
     """Replaces the head of _call_mods_q (call_modifications.py:214-228)."""
     import torch
@@ -239,8 +247,16 @@ def _call_mods_file(args, rank, local_rank, world):
     part_path = out_path if world == 1 else "%s.part%05d" % (out_path, rank)
     _remove_stale_parts(part_path, world)
 
+    # --parse_on device (default): the reader only stages the text (one copy + row-start pass), the rows are parsed on the GPU
+    # (csrc/dsp_parse_dev.hip) one block ahead of the forward; --parse_on host: this rank's parser threads, as before round 4
+    device_parse = parse_on(args) == "device"
     reader = feed.FeatureReader(input_path, args.seq_len, args.signal_len, rank=rank, world=world, nthreads=nthreads,
-                                nbuf=4, first_row=first_row, byte_range=byte_range, gz_ring=gz_ring)
+                                nbuf=5 if device_parse else 4, first_row=first_row, byte_range=byte_range, gz_ring=gz_ring,
+                                device_parse=device_parse)
+    dparse = None
+    if reader.device_parse:
+        from .parse_dev import DeviceRowParser
+        dparse = DeviceRowParser(dev, args.seq_len, args.signal_len)
     freq, freq_dev = _make_freq(args, dev, world, nthreads)
     writer = _Writer(part_path, args.gzip, nthreads, reader, freq)
     writer.mark_blocks = interleaved
@@ -260,36 +276,39 @@ def _call_mods_file(args, rank, local_rank, world):
     k = 0
     n_rows = 0
     _tick("pinned output buffers")
-    for block in reader:
-        if writer.error is not None:
-            break
-        if k == 0:
-            _tick("first block parsed")
+    def issue(block, staged):
+        """forward of one block (its inputs: uploaded from the host parser's pinned arrays, or parsed on the GPU), results
+        towards the writer"""
+        nonlocal k, n_rows, out_probs, out_labels
         rows = block.rows
         n = rows.n
-        if n == 0:
-            if interleaved:   # the piece table of the part file needs an (empty) entry for every block
-                writer.q.put((block, None, None, None))
-            else:
-                reader.release(block)
-            continue
         if n > out_probs[0].shape[0]:  # a block grew past the pinned output capacity
             out_probs = [torch.empty((n, args.class_num), dtype=torch.float32, pin_memory=True) for _ in range(nout)]
             out_labels = [torch.empty((n,), dtype=torch.uint8, pin_memory=True) for _ in range(nout)]
-        tt = block.slot.get("_torch")
+        if staged is not None:
+            b, ev = staged
+            ev.synchronize()   # (submitted a block ago: normally long done) the writer's small arrays and the flag count are here
+            if int(block.slot["_torch"]["n_flagged"][0]) != 0:
+                # rows outside the plain grammar: the host parser decides, and raises what the reference would
+                dparse.host_fallback(rows, block.n_bytes, block.slot, b, nthreads, stream)
+            else:
+                stream.wait_event(ev)
+            kmer, means, stds, lens, signals = b["kmer"][:n], b["means"][:n], b["stds"][:n], b["lens"][:n], b["signals"][:n]
+        else:
+            tt = block.slot.get("_torch")
 
-        def dev_t(name):
-            src = tt[name][:n] if tt is not None else torch.from_numpy(getattr(rows, name))
-            return src.to(dev, non_blocking=True)
-        # uploads go down their own stream so that block k+1's H2D runs under block k's forward
-        with torch.cuda.stream(copy_stream):
-            kmer, means, stds = dev_t("kmer"), dev_t("means"), dev_t("stds")
-            lens, signals = dev_t("lens"), dev_t("signals")
-            up_done = torch.cuda.Event()
-            up_done.record(copy_stream)
-        stream.wait_event(up_done)
-        for t_in in (kmer, means, stds, lens, signals):
-            t_in.record_stream(stream)
+            def dev_t(name):
+                src = tt[name][:n] if tt is not None else torch.from_numpy(getattr(rows, name))
+                return src.to(dev, non_blocking=True)
+            # uploads go down their own stream so that block k+1's H2D runs under block k's forward
+            with torch.cuda.stream(copy_stream):
+                kmer, means, stds = dev_t("kmer"), dev_t("means"), dev_t("stds")
+                lens, signals = dev_t("lens"), dev_t("signals")
+                up_done = torch.cuda.Event()
+                up_done.record(copy_stream)
+            stream.wait_event(up_done)
+            for t_in in (kmer, means, stds, lens, signals):
+                t_in.record_stream(stream)
         model.site_offset = block.first_row
         _logits, probs, labels = model.forward(kmer, means, stds, lens, signals, want_labels=True,
                                                init_states=file_states.for_rows(block.first_row, n) if file_states else None)
@@ -303,6 +322,29 @@ def _call_mods_file(args, rank, local_rank, world):
         writer.q.put((block, out_probs[slot], out_labels[slot], out_events[slot]))
         k += 1
         n_rows += n
+
+    ahead = []   # device-parsed blocks whose parse has been submitted and whose forward has not: one block of lookahead
+    for block in reader:
+        if writer.error is not None:
+            break
+        if k == 0 and not ahead:
+            _tick("first block parsed")
+        if block.rows.n == 0:
+            while ahead:
+                issue(*ahead.pop(0))
+            if interleaved:   # the piece table of the part file needs an (empty) entry for every block
+                writer.q.put((block, None, None, None))
+            else:
+                reader.release(block)
+            continue
+        if block.n_bytes is not None:      # text staged by the reader: parse it on the GPU, under the previous block's forward
+            ahead.append((block, dparse.submit(block.rows, block.n_bytes, block.slot, copy_stream)))
+            if len(ahead) > 1:
+                issue(*ahead.pop(0))
+        else:
+            issue(block, None)
+    while ahead and writer.error is None:
+        issue(*ahead.pop(0))
     _tick("last forward issued")
     if counted is not None and writer.error is None and n_rows - counted not in ((0, 1) if rank == world - 1 else (0,)):
         # the global row indices of the later ranks were derived from this count (they key the initial states): a wrong
@@ -768,6 +810,10 @@ def add_call_mods_args(p):
                         "'file:<states.npz>' = explicit states of every input row in init_hidden's layout (h_seq, c_seq, h_sig, "
                         "c_sig, h_comb, c_comb; replays a captured reference run)")
     g.add_argument("--seed", type=int, default=0, help="seed of the in-kernel initial-state generator")
+    g.add_argument("--parse_on", type=str, default=None, choices=["device", "host"],
+                   help="where the feature rows are parsed: 'device' (default) = the host only stages the text, one GPU thread per "
+                        "row parses it (rows outside the plain grammar, and every error, still go through the host parser); "
+                        "'host' = this rank's --nproc parser threads.  Same values either way")
     g.add_argument("--precision", type=str, default=None, choices=["fp32", "bf16x6", "bf16x9", "fp16x3"],
                    help="how the fp32 products of the combined BiLSTM stack are evaluated: fp32 matrix cores (default), or "
                         "split into low-precision pieces on the fast matrix pipes with fp32 accumulation (bf16x9: nine bf16 "

@@ -473,6 +473,40 @@ int64_t dsp_find_row_end(const char* text, size_t len, int64_t n_rows) {
     return (int64_t)(p - text);
 }
 
+// The host half of the device-side row parser (csrc/dsp_parse_dev.hip): ONE pass over a block of rows that copies it into a
+// (page-locked) staging buffer and notes where every row starts -- all the host still does per byte of text.  Rows are the
+// newline-separated pieces of `text` exactly as dsp_parse_feature_rows counts them (an unterminated last row is one;
+// dst gets a '\n' behind it, so dst needs len + 1 bytes).  row_off gets n + 1 entries: row r is dst[row_off[r],
+// row_off[r + 1] - 1) followed by its '\n'.  Chunked so that the scan reads what the copy just put into the cache.
+int64_t dsp_copy_rows_index(const char* text, size_t len, char* dst, uint64_t* row_off, int64_t max_rows) {
+    if ((!text && len) || !dst || !row_off || max_rows < 0) return text_fail(DSP_EINVAL, "bad argument");
+    int64_t n = 0;
+    size_t row_start = 0;
+    const size_t chunk = 256 << 10;
+    for (size_t a = 0; a < len; a += chunk) {
+        const size_t b = a + chunk < len ? a + chunk : len;
+        memcpy(dst + a, text + a, b - a);
+        const char* p = dst + a;
+        const char* e = dst + b;
+        while (p < e) {
+            const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
+            if (!nl) break;
+            if (n >= max_rows) return text_fail(DSP_ENOMEM, "buffer holds more than %lld rows", (long long)max_rows);
+            row_off[n++] = (uint64_t)row_start;
+            row_start = (size_t)(nl + 1 - dst);
+            p = nl + 1;
+        }
+    }
+    if (row_start < len) {   // an unterminated last row
+        if (n >= max_rows) return text_fail(DSP_ENOMEM, "buffer holds more than %lld rows", (long long)max_rows);
+        row_off[n++] = (uint64_t)row_start;
+        dst[len] = '\n';
+        row_start = len + 1;
+    }
+    row_off[n] = (uint64_t)row_start;
+    return n;
+}
+
 int64_t dsp_parse_feature_rows(const char* text, size_t len, int32_t seq_len, int32_t signal_len, int64_t max_rows,
                                uint8_t* kmer, float* means, float* stds, int32_t* lens, float* signals,
                                int32_t* labels, uint64_t* row_off, uint32_t* info_len, uint32_t* read_off,

@@ -33,7 +33,9 @@ EXACT_ROWS = 0 if os.environ.get("DSP_BLOCK_BYTES") else 32768
 
 
 class Block(object):
-    __slots__ = ("rows", "first_row", "slot")
+    # n_bytes: device-parsed blocks only -- the bytes staged in slot["text"] (rows.means / stds / lens / signals are None: they
+    # will exist on the GPU only, parse_dev.DeviceRowParser)
+    __slots__ = ("rows", "first_row", "slot", "n_bytes")
 
 
 def count_rows_in_range(path, a, b, nthreads=1):
@@ -93,7 +95,10 @@ class FeatureReader(threading.Thread):
     """Producer thread: yields parsed blocks of this rank's rows, in file order, through a bounded queue."""
 
     def __init__(self, path, seq_len, signal_len, rank=0, world=1, nthreads=4, nbuf=3, block_bytes=BLOCK_BYTES,
-                 first_row=0, byte_range=None, pinned=True, max_rows_per_block=None, gz_ring=None):
+                 first_row=0, byte_range=None, pinned=True, max_rows_per_block=None, gz_ring=None, device_parse=False):
+        """device_parse: blocks of text rows are NOT parsed here -- they are copied into page-locked staging with their row
+        starts (one pass, parse_dev.stage_rows) and parsed on the GPU by the consumer (round 4); .dspf containers hold
+        parsed rows already and come out as before."""
         super().__init__(daemon=True)
         self.path, self.L, self.S = path, seq_len, signal_len
         self.ff = None
@@ -115,8 +120,14 @@ class FeatureReader(threading.Thread):
         self.free = queue.Queue()
         cap = max_rows_per_block or max(1024, block_bytes // 600)
         self.cap = cap
+        self.device_parse = bool(device_parse) and self.ff is None
+        self.pinned = pinned
         for s in range(nbuf):
-            self.free.put(textio.alloc_rows(cap, seq_len, signal_len, pinned=pinned))
+            if self.device_parse:
+                from . import parse_dev
+                self.free.put(parse_dev.alloc_stage(cap, int(max(block_bytes, self.gz_block_bytes) * 1.25) + (1 << 20), seq_len, pinned=pinned))
+            else:
+                self.free.put(textio.alloc_rows(cap, seq_len, signal_len, pinned=pinned))
         self.error = None
 
     # -- consumer side
@@ -133,7 +144,27 @@ class FeatureReader(threading.Thread):
         self.free.put(block.slot)
 
     # -- producer side
+    def _emit_staged(self, data, row0):
+        """device_parse: the block's text into a staging slot, its row starts noted on the way (no parsing here)"""
+        from . import parse_dev
+        slot = self.free.get()
+        if len(data) + 1 > slot["cap_bytes"]:      # longer rows than the slots were sized for: this slot grows
+            slot = parse_dev.alloc_stage(slot["cap_rows"], int(len(data) * 1.25) + (1 << 20), self.L, pinned=self.pinned)
+        try:
+            rows, n_bytes = parse_dev.stage_rows(data, slot, self.L, self.S)
+        except RuntimeError as e:                  # shorter rows than expected: more of them than the slot has room for
+            if "more than" not in str(e):
+                raise
+            slot = parse_dev.alloc_stage(textio.count_rows(data) + 1, slot["cap_bytes"], self.L, pinned=self.pinned)
+            rows, n_bytes = parse_dev.stage_rows(data, slot, self.L, self.S)
+        b = Block()
+        b.rows, b.first_row, b.slot, b.n_bytes = rows, row0, slot, n_bytes
+        self.q.put(b)
+        return rows.n
+
     def _emit(self, data, row0):
+        if self.device_parse:
+            return self._emit_staged(data, row0)
         slot = self.free.get()
         try:
             rows = textio.parse_rows(data, self.L, self.S, nthreads=self.nthreads, out=slot)
@@ -144,7 +175,7 @@ class FeatureReader(threading.Thread):
             slot = textio.alloc_rows(textio.count_rows(data), self.L, self.S, pinned=False)
             rows = textio.parse_rows(data, self.L, self.S, nthreads=self.nthreads, out=slot)
         b = Block()
-        b.rows, b.first_row, b.slot = rows, row0, slot
+        b.rows, b.first_row, b.slot, b.n_bytes = rows, row0, slot, None
         self.q.put(b)
         return rows.n
 
@@ -170,7 +201,7 @@ class FeatureReader(threading.Thread):
             rows, _out, info = self.ff.read_block(bi, out=slot, info=slot.get("_info"), nthreads=self.nthreads)
             slot["_info"] = info
             b = Block()
-            b.rows, b.first_row, b.slot = rows, int(self.ff.block_first_row[bi]), slot
+            b.rows, b.first_row, b.slot, b.n_bytes = rows, int(self.ff.block_first_row[bi]), slot, None
             self.q.put(b)
             row = b.first_row + rows.n
         return row

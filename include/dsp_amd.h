@@ -173,6 +173,23 @@ void dsp_model_destroy(dsp_model* m);
  * as Python float() + torch.tensor(dtype=float) do.  Returns the row count, or DSP_EKEY (unknown base
  * letter = the reference's KeyError), DSP_EPARSE (malformed number = ValueError) / DSP_EINVAL. */
 int64_t dsp_count_rows(const char* text, size_t len);
+/* The host half of the DEVICE-side row parser (below): one pass that copies a block of rows into a (page-locked) staging
+ * buffer of len + 1 bytes and notes where every row starts (row_off: n + 1 entries; an unterminated last row gets its
+ * '\n').  Returns the number of rows, DSP_ENOMEM when there are more than max_rows. */
+int64_t dsp_copy_rows_index(const char* text, size_t len, char* dst, uint64_t* row_off, int64_t max_rows);
+/* The row grammar of _read_features_file (call_modifications.py:76-86) parsed ON THE GPU (csrc/dsp_parse_dev.hip): one
+ * thread per row over the raw text in HBM (text_dev: the bytes dsp_copy_rows_index staged, + 64 readable bytes behind
+ * them; row_off_dev: its n + 1 offsets), into the arrays of dsp_parse_feature_rows (all DEVICE pointers; lens i32).
+ * A row is either parsed completely by the plain-row rules of the host's one-pass parser -- decimal -> integer mantissa
+ * (<= 18 digits, < 2^53) times / divided by an exact power of ten (|e| <= 22) in float64, ONE correctly rounded
+ * operation, then float32: bit-identical to the host parser -- or left alone and counted in *n_flagged_dev with
+ * status_dev[row] = 1 (anything else: blanks, '+', inf / nan, long mantissas, a wrong field count, an unknown base, ...):
+ * the caller hands blocks with flagged rows to dsp_parse_feature_rows, which also owns the error messages.
+ * Asynchronous on `stream`; *n_flagged_dev is zeroed by the launch. */
+int32_t dsp_parse_rows_device(void* stream, const char* text_dev, const uint64_t* row_off_dev, int64_t n, int32_t seq_len,
+                              int32_t signal_len, uint8_t* kmer, float* means, float* stds, int32_t* lens, float* signals,
+                              int32_t* labels, uint32_t* info_len, uint32_t* read_off, uint32_t* read_len,
+                              uint8_t* status_dev, uint32_t* n_flagged_dev);
 int64_t dsp_find_row_end(const char* text, size_t len, int64_t n_rows);   /* bytes of the first n_rows rows (len if there are fewer) */
 int64_t dsp_parse_feature_rows(const char* text, size_t len, int32_t seq_len, int32_t signal_len, int64_t max_rows,
                                uint8_t* kmer, float* means, float* stds, int32_t* lens, float* signals,

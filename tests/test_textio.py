@@ -186,3 +186,46 @@ def test_one_pass_row_parser_agrees_with_the_general_parser_on_everything():
         assert 300 < n_err < 1500
     finally:
         L.dsp_text_set_fast_rows_(1)
+
+
+def test_block_staging_of_the_device_parser_notes_every_row_start():
+    """Host half of the device-side row parser (round 4): parse_dev.stage_rows copies a block into the staging buffer and
+    notes where its rows start, in one pass (dsp_copy_rows_index) -- rows as dsp_parse_feature_rows counts them: every
+    newline-separated piece, an unterminated last row included (it gets its newline), CRLF and empty rows kept as they are."""
+    from deepsignal_plant_amd import feed, parse_dev
+    rows = open(os.path.join(GOLDEN, "f2_rows.tsv"), "rb").read().splitlines()
+    cases = {"plain": b"\n".join(rows[:50]) + b"\n", "unterminated": b"\n".join(rows[:7]), "crlf": b"\r\n".join(rows[:5]) + b"\r\n",
+             "blank_rows": rows[0] + b"\n\n" + rows[1] + b"\n", "one": rows[3] + b"\n", "empty": b"",
+             "big": b"\n".join(rows * 40) + b"\n"}   # 8,000 rows: many 256 KiB chunks, rows straddling them
+    for name, data in cases.items():
+        pieces = data.split(b"\n")
+        if pieces and pieces[-1] == b"":
+            pieces.pop()
+        stage = parse_dev.alloc_stage(len(pieces) + 1, len(data) + 1, 13, pinned=False)
+        r, n_bytes = parse_dev.stage_rows(np.frombuffer(data, np.uint8), stage, 13, 16)
+        assert r.n == len(pieces) == textio.count_rows(data), name
+        off = stage["row_off"][:r.n + 1].astype(np.int64)
+        assert n_bytes == int(off[-1]) == len(data) + (0 if data.endswith(b"\n") or not data else 1), name
+        text = bytes(stage["text"][:n_bytes])
+        assert text == data + (b"" if data.endswith(b"\n") or not data else b"\n"), name
+        assert [text[off[i]:off[i + 1] - 1] for i in range(r.n)] == pieces, name
+    small = parse_dev.alloc_stage(3, 1 << 20, 13, pinned=False)
+    with pytest.raises(RuntimeError, match="more than 3 rows"):
+        parse_dev.stage_rows(np.frombuffer(cases["plain"], np.uint8), small, 13, 16)
+    # the reader in device_parse mode hands out staged text blocks with the row indices of the parsing reader
+    path = os.path.join(GOLDEN, "f2_rows.tsv")
+    got = {}
+    for mode in (False, True):
+        rd = feed.FeatureReader(path, 13, 16, nthreads=2, nbuf=2, block_bytes=90_000, pinned=False, device_parse=mode)
+        rd.start()
+        seen = []
+        for blk in rd:
+            assert (blk.n_bytes is not None) == mode
+            t = bytes(blk.rows.text[:blk.n_bytes]) if mode else None
+            seen.append((blk.first_row, blk.rows.n, [int(x) for x in blk.rows.row_off[:3]] if not mode else None))
+            if mode:
+                o = blk.rows.row_off
+                assert all(t[int(o[i]):].startswith(rows[blk.first_row + i][:40]) for i in range(blk.rows.n))
+            rd.release(blk)
+        got[mode] = [(a, b) for a, b, _ in seen]
+    assert got[True] == got[False] and sum(b for _, b in got[True]) == 200
