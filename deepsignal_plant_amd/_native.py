@@ -99,9 +99,12 @@ def lib():
     L.dsp_count_rows.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
     L.dsp_copy_rows_index.restype = ctypes.c_int64
     L.dsp_copy_rows_index.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+    L.dsp_read_rows_index.restype = ctypes.c_int64
+    L.dsp_read_rows_index.argtypes = [ctypes.c_int32, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64,
+                                      ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     L.dsp_parse_rows_device.restype = ctypes.c_int32
     L.dsp_parse_rows_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
-                                        ctypes.c_int32] + [ctypes.c_void_p] * 11
+                                        ctypes.c_int32] + [ctypes.c_void_p] * 12 + [ctypes.c_uint64]
     L.dsp_parse_feature_rows.restype = ctypes.c_int64
     L.dsp_parse_feature_rows.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_int32,
                                          ctypes.c_int64] + [ctypes.c_void_p] * 10 + [ctypes.c_int32]

@@ -268,7 +268,7 @@ def _call_mods_file(args, rank, local_rank, world):
     reader.start()
     writer.start()
     stream = torch.cuda.current_stream(dev)
-    copy_stream = torch.cuda.Stream(dev)
+    copy_stream = torch.cuda.Stream(dev) if not os.environ.get("DSP_ONE_STREAM") else stream   # (DSP_ONE_STREAM=1: debugging aid)
     nout = 4
     out_probs = [torch.empty((cap, args.class_num), dtype=torch.float32, pin_memory=True) for _ in range(nout)]
     out_labels = [torch.empty((cap,), dtype=torch.uint8, pin_memory=True) for _ in range(nout)]
@@ -289,6 +289,12 @@ def _call_mods_file(args, rank, local_rank, world):
             b, ev = staged
             ev.synchronize()   # (submitted a block ago: normally long done) the writer's small arrays and the flag count are here
             if int(block.slot["_torch"]["n_flagged"][0]) != 0:
+                if os.environ.get("DSP_PARSE_DEBUG"):
+                    st = b["status"][:n].cpu().numpy()
+                    ro = b["row_off"][:n + 1].cpu().numpy()
+                    sys.stderr.write("[parse_dev] flagged block first_row %d n %d n_bytes %d: status counts %s; row_off dev==host %s; first bad rows %s\n" % (
+                        block.first_row, n, block.n_bytes, np.bincount(st, minlength=4).tolist(),
+                        bool((ro == block.slot["_torch"]["row_off"][:n + 1].numpy()).all()), np.flatnonzero(st)[:8].tolist()))
                 # rows outside the plain grammar: the host parser decides, and raises what the reference would
                 dparse.host_fallback(rows, block.n_bytes, block.slot, b, nthreads, stream)
             else:

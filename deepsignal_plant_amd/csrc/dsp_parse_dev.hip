@@ -14,9 +14,14 @@
 // 2^53, exponents beyond +-22, another field count, a letter outside base2code_dna, ...) is not guessed at: the row is
 // flagged and the caller gives the whole block to the host parser, which also owns the error messages.
 //
-// A row is about 2.1 kB in 13 + 13 + 13 + 208 numbers: one lane reads its row through 16-byte loads, one ahead of the
-// parse (32,768 rows = 512 waves; the kernel is latency-bound at a few hundred microseconds per block, under the
-// previous block's 26 ms forward).  HBM-bound integer work: no MFMA, no LDS.
+// A row is about 2.1 kB in 13 + 13 + 13 + 208 numbers.  The first version -- one thread per row walking all of it -- took
+// 0.67 ms per block of 32,768 rows (102 GB/s): 512 waves for 1,024 SIMDs, and a cursor whose 16-byte refills happen at a
+// different step in every lane, so that the wave waited out a memory round trip at nearly every byte (vmcnt counts
+// instructions, not lanes: reading the prefetch register waits for the refill another lane issued a step ago).  Now two
+// kernels: (1) one thread per row walks it UNIFORMLY (every lane loads its next word in the same iteration, four ahead)
+// and only looks for the delimiters -- tabs and the ';' of the signals field --, parses the short pieces (k-mer, lengths,
+// label) and writes the row's segment table; (2) one thread per (row, float list) -- 15 lists per row, 7.7 waves per SIMD:
+// the occupancy hides the divergent refills.  HBM-bound integer work: no MFMA, no LDS.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -125,77 +130,150 @@ struct ParseArgs {
     const char* text; const uint64_t* row_off; long long n; int L, S;
     uint8_t* kmer; float* means; float* stds; int* lens; float* signals; int* labels;
     uint32_t* info_len; uint32_t* read_off; uint32_t* read_len; uint8_t* status; uint32_t* n_flagged;
+    unsigned long long text_bytes;   // bytes staged at `text` (offsets beyond them are never followed)
+    uint32_t* seg;        // [n][L + 4]: row-relative starts of means, stds, signal groups 0 .. L-1; one past the '\t' behind the
+                          // signals field; one past the '\t' behind stds
 };
 
-// true = the row is a plain row and every output of it has been written
-__device__ bool parse_row(const ParseArgs& a, long long r) {
+__device__ __forceinline__ void flag_row(const ParseArgs& a, long long r) {
+    a.status[r] = 1;                 // (several threads of a row may say so: same value)
+    atomicAdd(a.n_flagged, 1u);      // only zero / non-zero is used
+}
+
+// ---- kernel 1: one thread per row.  A UNIFORM walk over the row in 16-byte words (every lane loads its next word in the
+// same iteration, four iterations ahead: no lane-divergent refills) that only looks for delimiters: the first 11 tabs and
+// the ';' of the signals field.  Then the short pieces -- k-mer, the L lengths, the label, the sampleinfo addressing -- and
+// the segment table of the float lists for kernel 2.
+__device__ __forceinline__ uint32_t eq_mask4(uint32_t w, uint32_t pat) {   // bit 7 of every byte of w that equals pat's byte
+    const uint32_t x = w ^ pat;
+    return ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);   // exact zero-byte detector
+}
+
+__global__ __launch_bounds__(64) void dsp_parse_scan_kernel(ParseArgs a) {
+    const long long r = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (r >= a.n) return;
+    a.status[r] = 0;
     const uint64_t o0 = a.row_off[r], o1 = a.row_off[r + 1];
+    if (o1 <= o0 || o1 > a.text_bytes || o1 - o0 > (1u << 28)) { flag_row(a, r); return; }   // not a row of this text: nothing is read
     const uint32_t len = (uint32_t)(o1 - o0 - 1);              // without the '\n'
-    const int L = a.L, S = a.S;
-    if (len < (uint32_t)(12 + L)) return false;
-    Reader rd;
-    rd.init(a.text + o0);
-    if (is_space(rd.cur())) return false;
-    // the six sampleinfo fields, kept verbatim: only their tabs matter
-    uint32_t tab3 = 0, tab4 = 0, tab5 = 0;
-    for (int k = 0; k < 6; ++k) {
-        while (rd.pos < len && rd.cur() != '\t') rd.adv();
-        if (rd.pos >= len) return false;
-        if (k == 3) tab3 = rd.pos; else if (k == 4) tab4 = rd.pos; else if (k == 5) tab5 = rd.pos;
-        rd.adv();
+    const int L = a.L;
+    const int NSEG = 2 + L;
+    uint32_t* seg = a.seg + (size_t)r * (NSEG + 2);
+    bool ok = len >= (uint32_t)(12 + L);
+    const char* row = a.text + o0;
+    // delimiters: tabs 0..10, and the ';' between tab 9 and tab 10 (or the row end)
+    uint32_t tab[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) tab[k] = 0xffffffffu;
+    int ntab = 0, nsemi = 0;
+    const uintptr_t base = (uintptr_t)row & ~(uintptr_t)15;
+    const int skip = (int)((uintptr_t)row & 15);
+    const uint4* wp = (const uint4*)base;
+    const uint32_t nwords = ok ? (len + (uint32_t)skip + 15u) / 16u : 0u;
+    uint4 q0 = wp[0], q1 = wp[1], q2 = wp[2], q3 = wp[3];   // (the staged text has 64 readable bytes behind its end)
+    for (uint32_t wi = 0; wi < nwords; ++wi) {
+        const uint4 w = q0;
+        q0 = q1; q1 = q2; q2 = q3;
+        q3 = wp[wi + 4 < nwords ? wi + 4 : wi];                 // uniform prefetch, clamped inside the row's words
+        const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t mt = eq_mask4(ws[j], 0x09090909u);
+            uint32_t ms = eq_mask4(ws[j], 0x3b3b3b3bu);
+            uint32_t m = mt | ms;
+            while (m) {                                         // rare: ~23 delimiters in 2.1 kB
+                const int bit = __builtin_ctz(m);
+                const int byte = bit >> 3;
+                const int32_t pos = (int32_t)(wi * 16u + (uint32_t)j * 4u + (uint32_t)byte) - skip;
+                m &= m - 1;
+                if (pos < 0 || (uint32_t)pos >= len) continue;
+                if ((mt >> bit) & 1u) {
+                    if (ntab < 11) {
+                        // (static indexing keeps tab[] in registers)
+#pragma unroll
+                        for (int k = 0; k < 11; ++k)
+                            if (k == ntab) tab[k] = (uint32_t)pos;
+                    }
+                    ++ntab;
+                } else if (ntab == 10) {                        // inside the signals field
+                    if (nsemi < L - 1) seg[3 + nsemi] = (uint32_t)pos + 1u;
+                    ++nsemi;
+                }
+            }
+        }
     }
-    if (len - rd.pos < (uint32_t)(L + 1)) return false;
+    ok = ok && ntab >= 10 && nsemi == L - 1;
+    // field 10 (signals) ends at tab 10 when there is a label column behind it -- there must be
+    ok = ok && ntab >= 11;
+    if (!ok) { flag_row(a, r); return; }
+    const unsigned c0 = (unsigned)(unsigned char)row[0];
+    if (is_space(c0)) { flag_row(a, r); return; }
+    a.info_len[r] = tab[5];
+    a.read_off[r] = tab[3] + 1;
+    a.read_len[r] = tab[4] - tab[3] - 1;
+    seg[0] = tab[6] + 1;            // means
+    seg[1] = tab[7] + 1;            // stds
+    seg[2] = tab[9] + 1;            // signal group 0 (groups 1 .. L-1 were noted at their ';')
+    seg[2 + L] = tab[10] + 1;       // one past the '\t' that ends the signals field
+    seg[3 + L] = tab[8] + 1;        // one past the '\t' that ends stds
+    // the k-mer: exactly L letters of base2code_dna between tab 5 and tab 6
+    if (tab[6] - tab[5] - 1 != (uint32_t)L) { flag_row(a, r); return; }
+    Reader rd;
+    rd.init(row + tab[5] + 1);
     uint8_t* km = a.kmer + r * L;
     for (int i = 0; i < L; ++i) {
         const int c = base_code(rd.cur());
-        if (c < 0) return false;
+        if (c < 0) { flag_row(a, r); return; }
         km[i] = (uint8_t)c;
         rd.adv();
     }
-    if (rd.cur() != '\t') return false;
-    rd.adv();
-    for (int which = 0; which < 2; ++which) {                  // means, stds: L numbers, ',' between, '\t' behind
-        float* dst = (which ? a.stds : a.means) + r * L;
-        for (int i = 0; i < L; ++i) {
-            float v;
-            if (!fast_float(rd, &v) || rd.cur() != (i == L - 1 ? '\t' : ',') || rd.pos >= len) return false;
-            dst[i] = v;
-            rd.adv();
-        }
-    }
+    // the L lengths between tab 8 and tab 9
+    rd.init(row + tab[8] + 1);
     int* ln = a.lens + r * L;
     for (int i = 0; i < L; ++i) {
         int v;
-        if (!fast_int(rd, &v) || rd.cur() != (i == L - 1 ? '\t' : ',') || rd.pos >= len) return false;
+        if (!fast_int(rd, &v) || rd.cur() != (i == L - 1 ? '\t' : ',')) { flag_row(a, r); return; }
         ln[i] = v;
         rd.adv();
     }
-    float* sg = a.signals + (size_t)r * L * S;
-    for (int i = 0; i < L; ++i)
-        for (int j = 0; j < S; ++j) {
-            float v;
-            const unsigned want = j < S - 1 ? ',' : (i == L - 1 ? '\t' : ';');
-            if (!fast_float(rd, &v) || rd.cur() != want || rd.pos >= len) return false;
-            sg[i * S + j] = v;
-            rd.adv();
-        }
+    if (rd.pos != tab[9] - tab[8]) { flag_row(a, r); return; }  // the list ended exactly at tab 9
+    // the label behind tab 10: ends at the line end (LF or CRLF) or at a tab (extra columns are ignored)
+    rd.init(row + tab[10] + 1);
     int lab;
-    if (!fast_int(rd, &lab) || rd.pos > len) return false;
-    // the 12th field ends at the line end (LF or CRLF) or at a tab (extra columns are ignored, as words[11] would be)
-    if (!(rd.pos == len || rd.cur() == '\t' || (rd.cur() == '\r' && rd.pos + 1 == len))) return false;
+    if (!fast_int(rd, &lab)) { flag_row(a, r); return; }
+    const uint32_t p = tab[10] + 1 + rd.pos;
+    if (!(p == len || rd.cur() == '\t' || (rd.cur() == '\r' && p + 1 == len)) || p > len) { flag_row(a, r); return; }
     a.labels[r] = lab;
-    a.info_len[r] = tab5;
-    a.read_off[r] = tab3 + 1;
-    a.read_len[r] = tab4 - tab3 - 1;
-    return true;
 }
 
-__global__ __launch_bounds__(64) void dsp_parse_rows_kernel(ParseArgs a) {
-    const long long r = (long long)blockIdx.x * 64 + threadIdx.x;
-    if (r >= a.n) return;
-    const bool ok = parse_row(a, r);
-    a.status[r] = ok ? 0 : 1;
-    if (!ok) atomicAdd(a.n_flagged, 1u);
+// ---- kernel 2: one thread per (row, float list): means, stds and the L signal groups, L or S numbers each, ',' between,
+// the list ending exactly one byte before the next segment's start.  15 lists per row: 7.7 waves per SIMD for a block
+// of 32,768 rows, which is what hides the lane-divergent 16-byte refills of the cursor.
+__global__ __launch_bounds__(256) void dsp_parse_lists_kernel(ParseArgs a) {
+    const int NSEG = 2 + a.L;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long r = t / NSEG;
+    const int sgi = (int)(t - r * NSEG);
+    if (r >= a.n || a.status[r]) return;     // (rows kernel 1 flagged have no segment table)
+    const uint32_t* seg = a.seg + (size_t)r * (NSEG + 2);
+    const uint32_t s0 = seg[sgi];
+    // one past the list's terminator: means -> the start of stds; stds -> seg[3 + L] (the lengths lie behind it); group i ->
+    // the start of group i + 1; the last group -> seg[2 + L]
+    const uint32_t s1 = sgi == 1 ? seg[3 + a.L] : seg[sgi + 1];
+    const uint64_t o0 = a.row_off[r], o1 = a.row_off[r + 1];
+    if (o1 <= o0 || o1 > a.text_bytes || s0 >= o1 - o0 || s1 > o1 - o0) { flag_row(a, r); return; }   // (a table kernel 1 did not write)
+    const int cnt = sgi < 2 ? a.L : a.S;
+    float* dst = sgi == 0 ? a.means + r * a.L : (sgi == 1 ? a.stds + r * a.L : a.signals + ((size_t)r * a.L + (sgi - 2)) * a.S);
+    const unsigned term = sgi < 2 ? '\t' : (sgi == NSEG - 1 ? '\t' : ';');
+    Reader rd;
+    rd.init(a.text + o0 + s0);
+    for (int i = 0; i < cnt; ++i) {
+        float v;
+        if (!fast_float(rd, &v) || rd.cur() != (i == cnt - 1 ? term : ',')) { flag_row(a, r); return; }
+        dst[i] = v;
+        rd.adv();
+    }
+    if (s0 + rd.pos != s1) flag_row(a, r);   // the list ended exactly where the table says
 }
 
 }  // namespace
@@ -205,10 +283,10 @@ extern "C" void dsp_set_error_(const char* msg);
 extern "C" int32_t dsp_parse_rows_device(void* stream, const char* text_dev, const uint64_t* row_off_dev, int64_t n, int32_t seq_len,
                                          int32_t signal_len, uint8_t* kmer, float* means, float* stds, int32_t* lens, float* signals,
                                          int32_t* labels, uint32_t* info_len, uint32_t* read_off, uint32_t* read_len,
-                                         uint8_t* status_dev, uint32_t* n_flagged_dev) {
+                                         uint8_t* status_dev, uint32_t* n_flagged_dev, uint32_t* seg_dev, uint64_t text_bytes) {
     if (n < 0 || seq_len < 1 || signal_len < 1 || !n_flagged_dev ||
         (n > 0 && (!text_dev || !row_off_dev || !kmer || !means || !stds || !lens || !signals || !labels || !info_len || !read_off ||
-                   !read_len || !status_dev))) {
+                   !read_len || !status_dev || !seg_dev))) {
         dsp_set_error_("dsp_parse_rows_device: bad argument");
         return DSP_EINVAL;
     }
@@ -216,8 +294,10 @@ extern "C" int32_t dsp_parse_rows_device(void* stream, const char* text_dev, con
     hipError_t e = hipMemsetAsync(n_flagged_dev, 0, sizeof(uint32_t), s);
     if (e == hipSuccess && n > 0) {
         ParseArgs a{text_dev, row_off_dev, (long long)n, seq_len, signal_len, kmer, means, stds, lens, signals, labels,
-                    info_len, read_off, read_len, status_dev, n_flagged_dev};
-        hipLaunchKernelGGL(dsp_parse_rows_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, a);
+                    info_len, read_off, read_len, status_dev, n_flagged_dev, (unsigned long long)text_bytes, seg_dev};
+        hipLaunchKernelGGL(dsp_parse_scan_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, a);
+        const long long lists = (long long)n * (2 + seq_len);
+        hipLaunchKernelGGL(dsp_parse_lists_kernel, dim3((unsigned)((lists + 255) / 256)), dim3(256), 0, s, a);
         e = hipGetLastError();
     }
     if (e != hipSuccess) {

@@ -11,6 +11,9 @@
 // compiled with -ffp-contract=off).
 #include "dsp_amd.h"
 
+#include <errno.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <charconv>
 #include <cmath>
@@ -504,6 +507,51 @@ int64_t dsp_copy_rows_index(const char* text, size_t len, char* dst, uint64_t* r
         row_start = len + 1;
     }
     row_off[n] = (uint64_t)row_start;
+    return n;
+}
+
+// The same for a plain file, without the mapping: the block is READ (pread: the kernel copies page cache -> staging, no page
+// tables to populate, no second pass to find where the block ends) in 1 MiB pieces, each scanned for row ends while it is
+// still in the cache, until want_rows rows are in (the reader cuts blocks of exactly 32,768 rows: whole rounds of
+// workgroups in the forward) or range_bytes / cap_bytes are used up.  *consumed = bytes of the file the rows took (what
+// lies behind the last complete row is read again with the next block).  at_eof: the range ends at the end of the file, so
+// an unterminated last row counts (and gets its '\n').  Returns the rows (0 with *consumed == 0: not even one row fits
+// cap_bytes -- the caller retries with a larger buffer), or a negative status.
+int64_t dsp_read_rows_index(int32_t fd, uint64_t file_off, uint64_t range_bytes, uint64_t cap_bytes, int64_t want_rows,
+                            int32_t at_eof, char* dst, uint64_t* row_off, uint64_t* consumed) {
+    if (fd < 0 || !dst || !row_off || !consumed || want_rows < 1) return text_fail(DSP_EINVAL, "bad argument");
+    *consumed = 0;
+    // (cap_bytes: the caller's budget for this block -- its buffer, or a smaller pinned block size; range_bytes: what is left
+    // of the rank's byte range)
+    const uint64_t limit = range_bytes < cap_bytes ? range_bytes : cap_bytes;
+    uint64_t filled = 0, row_start = 0;
+    int64_t n = 0;
+    while (n < want_rows && filled < limit) {
+        uint64_t chunk = limit - filled < (1u << 20) ? limit - filled : (1u << 20);
+        const ssize_t got = pread(fd, dst + filled, (size_t)chunk, (off_t)(file_off + filled));
+        if (got < 0) return text_fail(DSP_EPARSE, "pread failed at offset %llu: %s", (unsigned long long)(file_off + filled), strerror(errno));
+        if (got == 0) return text_fail(DSP_EPARSE, "the feature file ended %llu bytes early (it shrank during the run)",
+                                       (unsigned long long)(range_bytes - filled));
+        const char* p = dst + filled;
+        const char* e = p + got;
+        filled += (uint64_t)got;
+        while (p < e && n < want_rows) {
+            const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
+            if (!nl) break;
+            row_off[n++] = row_start;
+            row_start = (uint64_t)(nl + 1 - dst);
+            p = nl + 1;
+        }
+    }
+    if (n < want_rows && at_eof && filled == range_bytes && row_start < filled) {   // the file's unterminated last row
+        row_off[n++] = row_start;
+        dst[filled] = '\n';
+        row_start = filled + 1;
+        *consumed = filled;
+    } else {
+        *consumed = row_start;
+    }
+    row_off[n] = row_start;
     return n;
 }
 

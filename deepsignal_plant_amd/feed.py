@@ -122,6 +122,7 @@ class FeatureReader(threading.Thread):
         self.cap = cap
         self.device_parse = bool(device_parse) and self.ff is None
         self.pinned = pinned
+        self.stage_seconds = 0.0     # device_parse: time this reader spent copying blocks into staging (tools/bench_feed.py)
         for s in range(nbuf):
             if self.device_parse:
                 from . import parse_dev
@@ -150,6 +151,8 @@ class FeatureReader(threading.Thread):
         slot = self.free.get()
         if len(data) + 1 > slot["cap_bytes"]:      # longer rows than the slots were sized for: this slot grows
             slot = parse_dev.alloc_stage(slot["cap_rows"], int(len(data) * 1.25) + (1 << 20), self.L, pinned=self.pinned)
+        import time as _time
+        t0 = _time.time()
         try:
             rows, n_bytes = parse_dev.stage_rows(data, slot, self.L, self.S)
         except RuntimeError as e:                  # shorter rows than expected: more of them than the slot has room for
@@ -157,6 +160,7 @@ class FeatureReader(threading.Thread):
                 raise
             slot = parse_dev.alloc_stage(textio.count_rows(data) + 1, slot["cap_bytes"], self.L, pinned=self.pinned)
             rows, n_bytes = parse_dev.stage_rows(data, slot, self.L, self.S)
+        self.stage_seconds += _time.time() - t0
         b = Block()
         b.rows, b.first_row, b.slot, b.n_bytes = rows, row0, slot, n_bytes
         self.q.put(b)
@@ -206,7 +210,50 @@ class FeatureReader(threading.Thread):
             row = b.first_row + rows.n
         return row
 
+    def _run_plain_staged(self, row):
+        """device_parse, plain text: every block is read straight into a staging slot (parse_dev.read_rows: pread + row
+        starts in one pass; exactly EXACT_ROWS rows per block, or block_bytes when that is pinned)"""
+        import time as _time
+        from . import parse_dev
+        size = os.path.getsize(self.path)
+        if size == 0:
+            return row
+        if self.byte_range is not None:
+            a, b = self.byte_range
+        else:
+            with open(self.path, "rb") as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as mm:
+                a, b = dsp_dist.byte_range_for_rank(mm, size, self.world, self.rank)
+        fd = os.open(self.path, os.O_RDONLY)
+        try:
+            pos = a
+            while pos < b:
+                slot = self.free.get()
+                exact = EXACT_ROWS if (EXACT_ROWS and self.cap >= EXACT_ROWS) else 0
+                t0 = _time.time()
+                budget = None if exact else max(self.block_bytes, 1)     # (a pinned block size: tests)
+                while True:
+                    rows, n_bytes, used = parse_dev.read_rows(fd, pos, b - pos, exact or slot["cap_rows"], b == size, slot, self.L, self.S,
+                                                              budget_bytes=budget)
+                    if rows.n > 0 or used > 0:
+                        break
+                    if budget is not None and budget < slot["cap_bytes"]:
+                        budget = None         # a pinned block size smaller than a row: the block is what the slot holds
+                        continue
+                    # not even one row fits the slot: it grows
+                    slot = parse_dev.alloc_stage(slot["cap_rows"], slot["cap_bytes"] * 2, self.L, pinned=self.pinned)
+                self.stage_seconds += _time.time() - t0
+                blk = Block()
+                blk.rows, blk.first_row, blk.slot, blk.n_bytes = rows, row, slot, n_bytes
+                self.q.put(blk)
+                row += rows.n
+                pos += used
+        finally:
+            os.close(fd)
+        return row
+
     def _run_plain(self, row):
+        if self.device_parse:
+            return self._run_plain_staged(row)
         size = os.path.getsize(self.path)
         if size == 0:
             return row

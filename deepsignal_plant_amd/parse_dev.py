@@ -14,6 +14,8 @@ import numpy as np
 from . import _native as nat
 from . import textio
 
+import os
+_SYNC = bool(os.environ.get("DSP_PARSE_SYNC"))
 PAD = 64          # readable bytes behind the staged text (the kernel's 16-byte cursor runs two words ahead)
 
 
@@ -50,6 +52,24 @@ def stage_rows(data, stage, seq_len, signal_len):
     return r, int(stage["row_off"][n])               # (bytes staged, the '\n' given to an unterminated last row included)
 
 
+def read_rows(fd, file_off, range_bytes, want_rows, at_eof, stage, seq_len, signal_len, budget_bytes=None):
+    """a plain file's next block straight into the staging buffer (pread + row starts, dsp_read_rows_index): rows until
+    want_rows are in or budget_bytes (default: the buffer) / range_bytes (what is left of the rank's range) are used up.
+    -> (ParsedRows, bytes staged, bytes of the file consumed); rows.n == 0 and consumed == 0: the budget is too small for a row"""
+    consumed = ctypes.c_uint64(0)
+    want = min(int(want_rows), stage["cap_rows"])
+    budget = stage["cap_bytes"] if budget_bytes is None else min(int(budget_bytes), stage["cap_bytes"])
+    n = nat.check(int(nat.lib().dsp_read_rows_index(int(fd), int(file_off), int(range_bytes), budget, want, int(bool(at_eof)),
+                                                  textio._ptr(stage["text"]), textio._ptr(stage["row_off"]), ctypes.byref(consumed))))
+    r = textio.ParsedRows()
+    r.text, r.n, r.seq_len, r.signal_len = stage["text"], n, seq_len, signal_len
+    r.row_off = stage["row_off"][:n]
+    for k in ("info_len", "read_off", "read_len", "kmer", "labels"):
+        setattr(r, k, stage[k][:n])
+    r.means = r.stds = r.lens = r.signals = None
+    return r, int(stage["row_off"][n]), int(consumed.value)
+
+
 class DeviceRowParser(object):
     """device buffers of the reader's slots + the launches of one block"""
 
@@ -58,25 +78,36 @@ class DeviceRowParser(object):
         self.torch, self.dev, self.L, self.S = torch, dev, seq_len, signal_len
         self.bufs = {}
 
-    def _bufs(self, stage):
+    def _bufs(self, stage, stream):
+        """the device buffers of a staging slot.  Allocated UNDER `stream` (the stream the parse runs on): torch's caching
+        allocator hands a block freed on one stream to the next allocation on that stream while kernels queued on it may still
+        be writing it -- the forward's logits, dropped by Python right after the launch -- which is only safe for work on the
+        SAME stream.  (Allocated under the compute stream and used on the copy stream, a new slot's row offsets and segment
+        tables were overwritten by the head kernel of a forward still in the queue: garbage offsets, a GPU fault.)"""
         torch = self.torch
         key = id(stage["_torch"]["text"])
         b = self.bufs.get(key)
         if b is None or b["cap_rows"] < stage["cap_rows"] or b["cap_bytes"] < stage["cap_bytes"]:
             cr, cb, L, S = stage["cap_rows"], stage["cap_bytes"], self.L, self.S
-            mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=self.dev)
-            b = dict(cap_rows=cr, cap_bytes=cb, text=mk((cb + PAD,), torch.uint8), row_off=mk((cr + 1,), torch.int64),
-                     kmer=mk((cr, L), torch.uint8), means=mk((cr, L), torch.float32), stds=mk((cr, L), torch.float32),
-                     lens=mk((cr, L), torch.int32), signals=mk((cr, L, S), torch.float32), labels=mk((cr,), torch.int32),
-                     info_len=mk((cr,), torch.int32), read_off=mk((cr,), torch.int32), read_len=mk((cr,), torch.int32),
-                     status=mk((cr,), torch.uint8), n_flagged=mk((1,), torch.int32))
-            self.bufs[key] = b
+            with torch.cuda.stream(stream):
+                return self._alloc(key, cr, cb, L, S)
+        return b
+
+    def _alloc(self, key, cr, cb, L, S):
+        torch = self.torch
+        mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=self.dev)
+        b = dict(cap_rows=cr, cap_bytes=cb, text=mk((cb + PAD,), torch.uint8), row_off=mk((cr + 1,), torch.int64),
+                 kmer=mk((cr, L), torch.uint8), means=mk((cr, L), torch.float32), stds=mk((cr, L), torch.float32),
+                 lens=mk((cr, L), torch.int32), signals=mk((cr, L, S), torch.float32), labels=mk((cr,), torch.int32),
+                 info_len=mk((cr,), torch.int32), read_off=mk((cr,), torch.int32), read_len=mk((cr,), torch.int32),
+                 status=mk((cr,), torch.uint8), n_flagged=mk((1,), torch.int32), seg=mk((cr, L + 4), torch.int32))
+        self.bufs[key] = b
         return b
 
     def submit(self, rows, n_bytes, stage, stream):
         """text up, parse, the writer's small arrays back: all asynchronous on `stream`.  Returns (device arrays, event)."""
         torch = self.torch
-        b = self._bufs(stage)
+        b = self._bufs(stage, stream)
         t, n = stage["_torch"], rows.n
         with torch.cuda.stream(stream):
             b["text"][:n_bytes + PAD].copy_(t["text"][:n_bytes + PAD], non_blocking=True)
@@ -85,12 +116,17 @@ class DeviceRowParser(object):
             nat.check(int(nat.lib().dsp_parse_rows_device(
                 ctypes.c_void_p(stream.cuda_stream), p(b["text"]), p(b["row_off"]), n, self.L, self.S, p(b["kmer"]), p(b["means"]),
                 p(b["stds"]), p(b["lens"]), p(b["signals"]), p(b["labels"]), p(b["info_len"]), p(b["read_off"]), p(b["read_len"]),
-                p(b["status"]), p(b["n_flagged"]))))
+                p(b["status"]), p(b["n_flagged"]), p(b["seg"]), int(n_bytes))))
             for k in ("kmer", "labels", "info_len", "read_off", "read_len"):
                 t[k][:n].copy_(b[k][:n], non_blocking=True)
             t["n_flagged"].copy_(b["n_flagged"], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(stream)
+        if _SYNC:   # DSP_PARSE_SYNC=1 (debugging aid): attribute an asynchronous GPU fault to this block's parse
+            import sys
+            sys.stderr.write("[parse_dev] block of %d rows, %d bytes ..." % (n, n_bytes))
+            stream.synchronize()
+            sys.stderr.write(" ok, %d flag events\n" % int(t["n_flagged"][0]))
         return b, ev
 
     def host_fallback(self, rows, n_bytes, stage, b, nthreads, stream):

@@ -27,7 +27,7 @@ def _device_parse(data, L=13, S=16):
     b, ev = dp.submit(rows, n_bytes, stage, torch.cuda.current_stream())
     ev.synchronize()
     out = {k: b[k][:rows.n].cpu().numpy() for k in ("kmer", "means", "stds", "lens", "signals", "labels", "info_len", "read_off", "read_len", "status")}
-    assert int(stage["_torch"]["n_flagged"][0]) == int(out["status"].sum())
+    assert (int(stage["_torch"]["n_flagged"][0]) != 0) == bool(out["status"].any())   # (flag events: zero = every row was plain)
     return out, rows, stage
 
 

@@ -212,20 +212,36 @@ def test_block_staging_of_the_device_parser_notes_every_row_start():
     small = parse_dev.alloc_stage(3, 1 << 20, 13, pinned=False)
     with pytest.raises(RuntimeError, match="more than 3 rows"):
         parse_dev.stage_rows(np.frombuffer(cases["plain"], np.uint8), small, 13, 16)
-    # the reader in device_parse mode hands out staged text blocks with the row indices of the parsing reader
-    path = os.path.join(GOLDEN, "f2_rows.tsv")
-    got = {}
-    for mode in (False, True):
-        rd = feed.FeatureReader(path, 13, 16, nthreads=2, nbuf=2, block_bytes=90_000, pinned=False, device_parse=mode)
-        rd.start()
-        seen = []
-        for blk in rd:
-            assert (blk.n_bytes is not None) == mode
-            t = bytes(blk.rows.text[:blk.n_bytes]) if mode else None
-            seen.append((blk.first_row, blk.rows.n, [int(x) for x in blk.rows.row_off[:3]] if not mode else None))
-            if mode:
-                o = blk.rows.row_off
-                assert all(t[int(o[i]):].startswith(rows[blk.first_row + i][:40]) for i in range(blk.rows.n))
-            rd.release(blk)
-        got[mode] = [(a, b) for a, b, _ in seen]
-    assert got[True] == got[False] and sum(b for _, b in got[True]) == 200
+    # the reader in device_parse mode hands out staged text blocks (plain files: read straight into the staging slot,
+    # dsp_read_rows_index) holding the rows -- and the global row indices -- of the parsing reader: any block size (also one
+    # smaller than a row), with and without a newline behind the last row, one rank and three
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        body = b"\n".join(rows)
+        for tail in (b"\n", b""):
+            path = os.path.join(td, "rows%d.tsv" % len(tail))
+            open(path, "wb").write(body + tail)
+            for world in (1, 3):
+                for bb in (90_000, 500, 5_000_000):
+                    first = 0
+                    for rank in range(world):
+                        got = {}
+                        for mode in (False, True):
+                            rd = feed.FeatureReader(path, 13, 16, rank=rank, world=world, nthreads=2, nbuf=2, block_bytes=bb, pinned=False,
+                                                    first_row=first, device_parse=mode)
+                            rd.start()
+                            seen = []
+                            for blk in rd:
+                                assert (blk.n_bytes is not None) == mode
+                                if mode:
+                                    t, o = bytes(blk.rows.text[:blk.n_bytes]), blk.rows.row_off
+                                    ends = [int(x) for x in o[1:]] + [blk.n_bytes]
+                                    seen += [(blk.first_row + i, t[int(o[i]):ends[i] - 1]) for i in range(blk.rows.n)]
+                                else:
+                                    seen += [(blk.first_row + i, rows[blk.first_row + i]) for i in range(blk.rows.n)]
+                                rd.release(blk)
+                            got[mode] = seen
+                        assert got[True] == got[False], (tail, world, bb, rank)
+                        assert all(txt == rows[i] for i, txt in got[True])
+                        first += len(got[True])
+                    assert first == 200

@@ -65,8 +65,10 @@ def _worker(rank, world, port, path, nproc, affinity, q, parse_on="host"):
     dist.barrier()
     t0 = time.time()
     c0 = time.process_time()
+    t_count = 0.0
     if byte_range is not None and world > 1:   # the counting pass call_mods makes to learn the global row indices
         mine = feed.count_rows_in_range(path, *byte_range, nthreads=nthreads)
+        t_count = time.time() - t0
         first_row = dd.exclusive_prefix(dd.all_gather_ints(mine, world), rank)
     reader = feed.FeatureReader(path, 13, 16, rank=rank, world=world, nthreads=nthreads, nbuf=4, first_row=first_row,
                                 byte_range=byte_range, pinned=False, gz_ring=ring, device_parse=device)
@@ -93,7 +95,7 @@ def _worker(rank, world, port, path, nproc, affinity, q, parse_on="host"):
     dist.barrier()
     if ring is not None:
         ring["ring"].close()
-    q.put(dict(rank=rank, rows=rows, seconds=round(dt, 3), threads=nthreads, cpu_seconds=round(cpu, 3), format_seconds=round(t_fmt, 3), out_bytes=out_bytes,
+    q.put(dict(rank=rank, rows=rows, seconds=round(dt, 3), threads=nthreads, cpu_seconds=round(cpu, 3), count_seconds=round(t_count, 3), stage_seconds=round(reader.stage_seconds, 3), format_seconds=round(t_fmt, 3), out_bytes=out_bytes,
                cpus=len(cpus) if cpus else None, gz_bytes_in=reader.gz_bytes_in))
     dist.destroy_process_group()
 
@@ -149,6 +151,9 @@ def main():
             "rows_per_s_per_rank": round(rows / wall / args.ranks, 1),
             "format_share_of_rank_time": round(sum(r["format_seconds"] for r in res) / sum(r["seconds"] for r in res), 3),
             "one_gpu_needs_rows_per_s": 1.24e6, "ranks_fed_at_full_gpu_rate": round(rows / wall / 1.24e6, 2),
+            "count_pass_us_per_row": round(sum(r["count_seconds"] for r in res) / rows * 1e6, 3),
+            "stage_us_per_row": round(sum(r["stage_seconds"] for r in res) / rows * 1e6, 3),
+            "format_us_per_row": round(sum(r["format_seconds"] for r in res) / rows * 1e6, 3),
             "cpu_seconds_all_ranks": round(cpu, 3), "cpu_us_per_row": round(cpu / rows * 1e6, 3),
             "host_threads_per_rank_at_full_gpu_rate": round(cpu / rows * 1.24e6, 2)}
     if args.gz:

@@ -44,10 +44,13 @@ def main():
             rows = sum(1 for _ in open(out))
             assert rows == n
             print(json.dumps({"rows": n, "tsv_mb": round(os.path.getsize(tsv) / 1e6, 1), "parse_threads": nproc,
+                              "parse_on": os.environ.get("DSP_PARSE_ON", "device"),
                               "call_mods_s": secs, "process_wall_s": round(wall, 2), "sites_per_s": round(n / secs, 1),
                               "text_mb_per_s": round(os.path.getsize(tsv) / 1e6 / secs, 1), "gen_s": round(gen, 1),
                               "timeline": timeline(r.stderr)}), flush=True)
             os.remove(out)
+        if os.environ.get("DSP_BENCH_NO_DSPF"):
+            continue
         # the same rows as a binary feature container (pack_features): no parsing on the call_mods side
         packed = os.path.join(work, "feat_%d.dspf" % n)
         t0 = time.time()
