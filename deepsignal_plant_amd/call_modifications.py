@@ -102,11 +102,17 @@ class FileInitStates(object):
         return {k: torch.from_numpy(np.ascontiguousarray(a[:, first_row:first_row + n])) for k, a in self.arrays.items()}
 
 
-def parse_on(args):
-    """--parse_on: where feature rows become numbers -- "device" (default; DSP_PARSE_ON overrides the default) or "host" """
-    v = getattr(args, "parse_on", None) or os.environ.get("DSP_PARSE_ON") or "device"
-    if v not in ("device", "host"):
-        raise ValueError("--parse_on must be device or host")
+def parse_on(args, nthreads=None):
+    """--parse_on: where feature rows become numbers.  "device": one GPU thread per row / float list parses the staged text
+    (csrc/dsp_parse_dev.hip: 0.3 ms of GPU time per 32,768 rows = 1.2 % of their forward, 0.65 us of host time per row);
+    "host": this rank's parser threads (2.5-3.6 us of host time per row: four threads keep up with one GPU).  "auto" (the
+    default; DSP_PARSE_ON overrides it): the device when this rank's share of the node's CPUs is under four threads -- eight
+    ranks on sixteen cores -- else the host, whose threads are then free anyway."""
+    v = getattr(args, "parse_on", None) or os.environ.get("DSP_PARSE_ON") or "auto"
+    if v not in ("device", "host", "auto"):
+        raise ValueError("--parse_on must be device, host or auto")
+    if v == "auto":
+        v = "device" if (nthreads is not None and nthreads < 4) else "host"
     return v
 
 
@@ -249,7 +255,7 @@ def _call_mods_file(args, rank, local_rank, world):
 
     # --parse_on device (default): the reader only stages the text (one copy + row-start pass), the rows are parsed on the GPU
     # (csrc/dsp_parse_dev.hip) one block ahead of the forward; --parse_on host: this rank's parser threads, as before round 4
-    device_parse = parse_on(args) == "device"
+    device_parse = parse_on(args, nthreads) == "device"
     reader = feed.FeatureReader(input_path, args.seq_len, args.signal_len, rank=rank, world=world, nthreads=nthreads,
                                 nbuf=5 if device_parse else 4, first_row=first_row, byte_range=byte_range, gz_ring=gz_ring,
                                 device_parse=device_parse)
@@ -816,10 +822,11 @@ def add_call_mods_args(p):
                         "'file:<states.npz>' = explicit states of every input row in init_hidden's layout (h_seq, c_seq, h_sig, "
                         "c_sig, h_comb, c_comb; replays a captured reference run)")
     g.add_argument("--seed", type=int, default=0, help="seed of the in-kernel initial-state generator")
-    g.add_argument("--parse_on", type=str, default=None, choices=["device", "host"],
-                   help="where the feature rows are parsed: 'device' (default) = the host only stages the text, one GPU thread per "
-                        "row parses it (rows outside the plain grammar, and every error, still go through the host parser); "
-                        "'host' = this rank's --nproc parser threads.  Same values either way")
+    g.add_argument("--parse_on", type=str, default=None, choices=["device", "host", "auto"],
+                   help="where the feature rows are parsed: 'device' = the host only stages the text, GPU threads parse it (rows "
+                        "outside the plain grammar, and every error, still go through the host parser); 'host' = this rank's "
+                        "--nproc parser threads; 'auto' (default) = the device when this rank has fewer than four host threads "
+                        "to itself.  Same values either way")
     g.add_argument("--precision", type=str, default=None, choices=["fp32", "bf16x6", "bf16x9", "fp16x3"],
                    help="how the fp32 products of the combined BiLSTM stack are evaluated: fp32 matrix cores (default), or "
                         "split into low-precision pieces on the fast matrix pipes with fp32 accumulation (bf16x9: nine bf16 "

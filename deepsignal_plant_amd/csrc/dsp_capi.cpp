@@ -541,7 +541,9 @@ int cluster_size(const dsp_model* m, long long NTp) {
 int pick_cluster(const dsp_model* m, const LstmArgs& a, long long NTp, bool split) {
     // layers of 4 unit tiles (the front ends at hidden 128): one 4-wave workgroup per (site tile, direction) holds the whole
     // layer -- a wave 1 unit tile x 1 site tile, half the work per step of the 64-site tiling -- whenever those workgroups
-    // fit the CUs at once (<= 4,096 sites); no exchange between workgroups, so nothing to wait for
+    // fit the CUs at once (<= 4,096 sites); no exchange between workgroups, so nothing to wait for.  (On full batches this form
+    // is the slower one -- 1.99 / 2.08 ms against 1.82 / 1.93 ms of dsp_lstm_kernel<2, 1, XL> per front-end launch of 65,536
+    // sites, same-box A/B in round 4: a weight fragment feeds 4 MFMAs instead of 8.)
     if (m->cluster != 0 && !split && a.UT == 4 && a.NP <= 1 && NTp * 2 <= (long long)m->n_cus &&
         a.NQ == ((a.Ipad + a.Hp) >> 3) && (a.Ipad >> 3) % 4 == 0 && (a.Ipad >> 3) >= 4 && a.NQ % 4 == 0 && a.NQ >= 8)
         return 4;

@@ -21,7 +21,10 @@
 // kernels: (1) one thread per row walks it UNIFORMLY (every lane loads its next word in the same iteration, four ahead)
 // and only looks for the delimiters -- tabs and the ';' of the signals field --, parses the short pieces (k-mer, lengths,
 // label) and writes the row's segment table; (2) one thread per (row, float list) -- 15 lists per row, 7.7 waves per SIMD:
-// the occupancy hides the divergent refills.  HBM-bound integer work: no MFMA, no LDS.
+// the occupancy hides part of the divergent refills: 0.30 ms per block (0.13 + 0.17), 1.2 % of the block's forward.  (Measured
+// and not kept: requesting a list's lines up front so that the refills hit the cache -- 0.185 instead of 0.169 ms, the
+// kernels are bound by their ~90 instructions per byte, not by the round trips; an eight-deep instead of a four-deep
+// prefetch in the scan: no change.)  HBM-bound integer work: no MFMA, no LDS.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -32,18 +35,22 @@ namespace {
 __constant__ double kPow10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
                                   1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
 
-// a byte cursor over global memory: 16-byte words, the next one requested while the current one is consumed
+// a byte cursor over global memory: 16-byte words, the next one requested while the current one is consumed.  The pointers
+// carry the GLOBAL address space: through a generic `const char*` hipcc emits flat_load, which counts on vmcnt AND lgkmcnt
+// and made every refill wait out its own request at once (checked in the ISA)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const u32x4 guint4;
 struct Reader {
-    const uint4* next;     // address of the word after `ahead`
-    uint4 ahead;           // the word behind the current one (already loaded)
+    guint4* next;          // address of the word after `ahead`
+    u32x4 ahead;           // the word behind the current one (already loaded)
     uint64_t lo, hi;       // the unconsumed bytes of the current word, lowest byte first in `lo`
     int left;              // bytes left in lo | hi
     uint32_t pos;          // offset of the cursor from the row start
     __device__ __forceinline__ void init(const char* p) {
         const uintptr_t a = (uintptr_t)p;
-        const uint4* w = (const uint4*)(a & ~(uintptr_t)15);
+        guint4* w = (guint4*)(a & ~(uintptr_t)15);
         const int skip = (int)(a & 15);
-        const uint4 cur = w[0];
+        const u32x4 cur = w[0];
         ahead = w[1];
         next = w + 2;
         lo = (uint64_t)cur.x | ((uint64_t)cur.y << 32);
@@ -168,13 +175,16 @@ __global__ __launch_bounds__(64) void dsp_parse_scan_kernel(ParseArgs a) {
     int ntab = 0, nsemi = 0;
     const uintptr_t base = (uintptr_t)row & ~(uintptr_t)15;
     const int skip = (int)((uintptr_t)row & 15);
-    const uint4* wp = (const uint4*)base;
+    guint4* wp = (guint4*)base;
     const uint32_t nwords = ok ? (len + (uint32_t)skip + 15u) / 16u : 0u;
-    uint4 q0 = wp[0], q1 = wp[1], q2 = wp[2], q3 = wp[3];   // (the staged text has 64 readable bytes behind its end)
+    // eight words = one 128-byte line ahead (the staged text has 64 readable bytes behind its end: the first loads are
+    // clamped to the row's words as well)
+    auto wclamp = [&](uint32_t i) __attribute__((always_inline)) { return wp[i < nwords ? i : (nwords ? nwords - 1 : 0)]; };
+    u32x4 q0 = wclamp(0), q1 = wclamp(1), q2 = wclamp(2), q3 = wclamp(3), q4 = wclamp(4), q5 = wclamp(5), q6 = wclamp(6), q7 = wclamp(7);
     for (uint32_t wi = 0; wi < nwords; ++wi) {
-        const uint4 w = q0;
-        q0 = q1; q1 = q2; q2 = q3;
-        q3 = wp[wi + 4 < nwords ? wi + 4 : wi];                 // uniform prefetch, clamped inside the row's words
+        const u32x4 w = q0;
+        q0 = q1; q1 = q2; q2 = q3; q3 = q4; q4 = q5; q5 = q6; q6 = q7;
+        q7 = wclamp(wi + 8);                                    // uniform prefetch, clamped inside the row's words
         const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {

@@ -6,12 +6,14 @@ mkdir -p $out
 python tools/make_tsv.py /tmp/dsp_pipe/feat_4000000.tsv 4000000 > /dev/null 2>&1 || mkdir -p /tmp/dsp_pipe
 : > $out/pipeline_cli_parse.jsonl
 for mode in host device; do
-  DSP_PARSE_ON=$mode DSP_BENCH_THREADS=1,2,4,16 python tools/bench_pipeline.py 4000000 2>/dev/null | grep '^{' >> $out/pipeline_cli_parse.jsonl
+  DSP_PARSE_ON=$mode DSP_BENCH_THREADS=1,2,4,10 python tools/bench_pipeline.py 4000000 2>/dev/null | grep '^{' >> $out/pipeline_cli_parse.jsonl
 done
 : > $out/feed_ranks.jsonl
+python tools/make_tsv.py /tmp/dsp_pipe/feat_3200000.tsv 3200000 > /dev/null 2>&1
 for mode in host device; do
   for r in 1 2 4 8; do
-    python tools/bench_feed.py --ranks $r --rows 400000 --parse_on $mode 2>/dev/null | grep '^{' >> $out/feed_ranks.jsonl
+    # (400,000 rows per rank: a dozen blocks each, so that staging / formatting / the counting pass overlap as they do in a run)
+    python tools/bench_feed.py --ranks $r --rows 3200000 --parse_on $mode 2>/dev/null | grep '^{' >> $out/feed_ranks.jsonl
   done
 done
 python - <<'PY'
