@@ -17,6 +17,9 @@
 
 #include "dsp_amd.h"
 
+#include <fcntl.h>
+#include <unistd.h>
+
 static std::string g_err;
 extern "C" void dsp_set_error_(const char* msg) { g_err = msg ? msg : ""; }
 extern "C" const char* dsp_last_error(void) { return g_err.c_str(); }
@@ -77,7 +80,48 @@ int main(int argc, char** argv) {
         std::string m = tsv.substr(0, 200 + rnd() % (tsv.size() - 200));
         for (int k = 0; k < 1 + (int)(rnd() % 4); k++) m[rnd() % m.size()] = "\t,;\n-e.0A \r\x00\xff"[rnd() % 14];
         const int64_t r = rows.parse(m, 1 + (int)(rnd() % 4));
-        CHECK(r >= 0 || r == DSP_EPARSE || r == DSP_ENOMEM);
+        CHECK(r >= 0 || r == DSP_EPARSE || r == DSP_ENOMEM || r == DSP_EKEY);
+    }
+    // ---- the host half of the device-side row parser: one pass copy + row starts (memory: exactly len + 1 / n + 1 entries),
+    // and the same through pread on a file, block by block, with and without a newline behind the last row
+    for (int variant = 0; variant < 2; variant++) {
+        const std::string text = variant ? tsv.substr(0, tsv.size() - 1) : tsv;
+        std::vector<char> dst(text.size() + 1);
+        std::vector<uint64_t> off(nrows + 1);
+        CHECK(dsp_copy_rows_index(text.data(), text.size(), dst.data(), off.data(), nrows) == nrows);
+        CHECK(off[nrows] == text.size() + (variant ? 1 : 0) && memcmp(dst.data(), text.data(), text.size()) == 0 && dst[off[nrows] - 1] == '\n');
+        CHECK(dsp_copy_rows_index(text.data(), text.size(), dst.data(), off.data(), nrows - 1) == DSP_ENOMEM);
+        const std::string path = tmp + "/rows_index.tsv";
+        FILE* f = fopen(path.c_str(), "wb");
+        CHECK(f && fwrite(text.data(), 1, text.size(), f) == text.size());
+        fclose(f);
+        const int fd = open(path.c_str(), O_RDONLY);
+        CHECK(fd >= 0);
+        for (uint64_t budget : {(uint64_t)700, (uint64_t)5000, (uint64_t)90000, (uint64_t)text.size() + 64}) {
+            for (int64_t want : {(int64_t)1, (int64_t)7, (int64_t)1000}) {
+                uint64_t pos = 0;
+                int64_t seen = 0;
+                while (pos < text.size()) {
+                    const uint64_t cap = budget < 4096 ? 4096 : budget;   // (a budget smaller than a row: the caller falls back to its buffer)
+                    std::vector<char> buf(cap + 1);
+                    std::vector<uint64_t> ro((size_t)want + 1);
+                    uint64_t used = 0;
+                    int64_t n = dsp_read_rows_index(fd, pos, text.size() - pos, budget, want, 1, buf.data(), ro.data(), &used);
+                    if (n == 0 && used == 0) n = dsp_read_rows_index(fd, pos, text.size() - pos, cap, want, 1, buf.data(), ro.data(), &used);
+                    CHECK(n > 0 && n <= want && used > 0);
+                    CHECK(memcmp(buf.data(), text.data() + pos, (size_t)used) == 0 && buf[ro[n] - 1] == '\n');
+                    seen += n;
+                    pos += used;
+                }
+                CHECK(seen == nrows && pos == text.size());
+            }
+        }
+        uint64_t used = 0;
+        std::vector<char> buf(128);
+        std::vector<uint64_t> ro(4);
+        CHECK(dsp_read_rows_index(fd, 0, text.size() + 1000, 100, 2, 1, buf.data(), ro.data(), &used) == 0 && used == 0);      // no row fits
+        CHECK(dsp_read_rows_index(fd, text.size() - 10, 5000, 100, 2, 1, buf.data(), ro.data(), &used) == DSP_EPARSE);         // the file ends early
+        close(fd);
     }
     Rows wrong(11, 16, nrows);
     CHECK(wrong.parse(tsv, 2) == DSP_EPARSE);
