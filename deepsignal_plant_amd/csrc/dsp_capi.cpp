@@ -324,6 +324,9 @@ struct dsp_model {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float* h0buf2 = nullptr;   // the side branch's own h0 scratch
+    unsigned long long cluster_timeout = 500000;  // s_memtime ticks (shader clock on gfx950: 0.2 ms) a cluster's members wait for each other to
+                             // become resident before they hand the cluster to the clean-up launch; DSP_CLUSTER_TIMEOUT sets it
+                             // (0: every cluster is abandoned at once -- the test of the clean-up path)
     unsigned int* cflags = nullptr;   // arrival counters of the clustered launches of ONE forward (zeroed by its pack launch)
     int n_cflag_words = 0;
     int n_cus = 256;         // compute units of the handle's device
@@ -612,6 +615,7 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
         a.CG = (launch_no < kClusterLaunches && m->cflags) ? pick_cluster(m, a, L.NTp, split) : 0;
         if (a.CG < 0) { a.CG = -a.CG; a.flags |= 8; }
         if (a.CG) {
+            a.cluster_timeout = m->cluster_timeout;
             a.cflags = m->cflags + (size_t)launch_no * kClusterWordsPerLaunch;
             if (!L.side_by_side) a.flags |= 4;   // one workgroup per CU (not when two branches run side by side on two streams)
         }
@@ -709,6 +713,7 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
     if (const char* v = getenv("DSP_LSTM_PRIO")) m->phase_prio = atoi(v) != 0;    // A/B switch
     if (const char* v = getenv("DSP_LSTM_TILING")) m->tiling21 = atoi(v) == 21 ? 1 : 0;   // A/B switch
     if (const char* v = getenv("DSP_LSTM_CLUSTER")) m->cluster = atoi(v);                  // A/B switch
+    if (const char* v = getenv("DSP_CLUSTER_TIMEOUT")) m->cluster_timeout = strtoull(v, nullptr, 10);
     if (const char* v = getenv("DSP_TWO_STREAMS")) m->two_streams = atoi(v) != 0 ? 1 : 0;   // A/B switch
     if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess) {

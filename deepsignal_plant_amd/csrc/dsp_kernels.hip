@@ -780,6 +780,34 @@ __device__ __forceinline__ void wait_arrivals(gu32* flag, unsigned target) {
     }
 }
 
+// Admission of a cluster (lane 0 of every member workgroup, before anything else): the members wait for each other at every
+// step, so ALL of them must be resident -- which the dispatcher does not promise once other launches compete for the CUs
+// (five concurrent clustered dispatches sharing an XCD's 32 slots evenly hold 6 members of 8 each: nobody ever completes).
+// Each member counts itself in and waits until all P are there; a member that has waited `limit` cycles ABANDONS the cluster
+// for all (one CAS on the word that also holds the count, so that "all arrived" and "abandoned" exclude each other): every
+// member, present or still to come, exits at once, and the clean-up launch behind this one (the workgroup-local form, no
+// waiting between workgroups) computes the abandoned clusters.  Returns true when the cluster runs.
+constexpr unsigned kClusterAbandon = 0x80000000u;
+__device__ __forceinline__ bool cluster_admit(gu32* state, unsigned P, unsigned long long limit) {
+    unsigned s = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        if (s & kClusterAbandon) return false;
+        if (__hip_atomic_compare_exchange_strong(state, &s, s + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (;;) {
+        s = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (s & kClusterAbandon) return false;
+        if ((s & 0xffffu) >= P) return true;
+        if (__builtin_amdgcn_s_memtime() - t0 > limit) {
+            if (__hip_atomic_compare_exchange_strong(state, &s, s | kClusterAbandon, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                return false;
+            continue;   // (the word moved: somebody arrived or abandoned meanwhile -- look again)
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
 template <int G, int D, bool LOCAL = false, int DEAD = 0, int NW = 4>
 __global__ __launch_bounds__(NW * 64, 1) void dsp_lstmc_kernel(LstmArgs a) {
     // NW = 8 (LOCAL, layers of 8 unit tiles): eight waves, two per SIMD, a wave 1 unit tile x 1 site tile -- the alternative
@@ -815,7 +843,20 @@ __global__ __launch_bounds__(NW * 64, 1) void dsp_lstmc_kernel(LstmArgs a) {
     const uint32_t xrow = (uint32_t)(a.Ipad >> 2) * 512u;
     const uint32_t orow = (uint32_t)F4 * 512u;
     const bool prio = (a.flags & 1) != 0;
-    gu32* flag = (gu32*)a.cflags + c * 32;
+    gu32* flag = (gu32*)a.cflags + c * 32;   // word 0: arrivals of the steps; word 1: admission (count | abandoned)
+    if constexpr (LOCAL) {
+        // the clean-up launch behind a clustered one (flags bit 4): only the clusters that were abandoned are computed here
+        if ((a.flags & 16) && !(__hip_atomic_load(flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kClusterAbandon)) return;
+    } else {
+        // (the verdict travels through the first word of the dynamic LDS -- no static LDS next to a 160 KiB dynamic limit --,
+        // which the bias table overwrites only after everybody has read it)
+        int* verdict = (int*)smem;
+        if (tid == 0) *verdict = cluster_admit(flag + 1, (unsigned)P, a.cluster_timeout) ? 1 : 0;
+        __syncthreads();
+        const int admitted = *(volatile int*)verdict;
+        __syncthreads();
+        if (!admitted) return;
+    }
 
     const __amdgpu_buffer_rsrc_t rw = make_rsrc((const char*)(dir ? a.wpk1 : a.wpk0) + (size_t)u * NQ * 4096);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)a.x + (size_t)gt0 * T * xrow);
@@ -1542,6 +1583,15 @@ extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
         else if (G == 4) hipLaunchKernelGGL((dsp_lstmc_kernel<4, 4>), dim3(grid), dim3(256), lds, s, *a);
         else if (G == 2) hipLaunchKernelGGL((dsp_lstmc_kernel<2, 8>), dim3(grid), dim3(256), lds, s, *a);
         else hipLaunchKernelGGL((dsp_lstmc_kernel<1, 16>), dim3(grid), dim3(256), lds, s, *a);
+        if (!local && a->UT == 8) {
+            // the clean-up launch: clusters whose members did not all become resident in time were abandoned by them and are
+            // computed here, one 8-wave workgroup each, nothing waiting on another workgroup (a few microseconds when none was)
+            LstmArgs b = *a;
+            b.CG = 4;
+            b.flags = (a->flags | 8 | 16) & ~4;
+            const unsigned g1 = (clusters + 7) / 8 * 8;
+            hipLaunchKernelGGL((dsp_lstmc_kernel<4, 4, true, 0, 8>), dim3(g1), dim3(512), (size_t)a->Hp * 16, s, b);
+        }
         return (int)hipGetLastError();
     }
     if ((a->flags & 2) && a->NP <= 1 && a->UT >= 2 && a->UT % 2 == 0 && a->nqx_lo == 0 && a->nqx_used == (a->Ipad >> 3) &&

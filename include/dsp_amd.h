@@ -353,7 +353,7 @@ int64_t dsp_freq_add_block(dsp_freq* f, const char* text, const uint64_t* row_of
 void dsp_freq_counts(const dsp_freq* f, int64_t* count, int64_t* used, int64_t* sites);
 int64_t dsp_freq_format(const dsp_freq* f, int32_t is_sort, int32_t is_bed, char* out, size_t cap);
 
-/* ---- `call_freq` on the device and over several ranks ----------
+/* ---- `call_freq` on the device and over several ranks (profiles/LAB_NOTEBOOK_r1_r3.md section 6c) ----------
  * Records stay in HBM as (key, packed, pos_in_strand, global row) and are reduced there.  Encoding:
  *   key    = chromosome id << 40 | pos   (ids from the handle's dictionary; INT64_MAX = record not used)
  *   meta   = strand code (0 '+', 1 '-') | 5-mer << 2 (4 bits per base, codes of process_utils.base2code_dna)

@@ -452,7 +452,7 @@ def test_small_batch_tiling_does_not_change_a_bit(kw, label, monkeypatch):
     larger ones with the shipped <1, 2> tiling.  Same fragments, same order of every sum: DSP_LSTM_TILING=0 (never) and
     =21 (always) give the bytes of the automatic choice at every size around the switch, with N(0,1) Philox states, and
     the oracle agrees.  (Round 2's build of this tiling returned wrong h0 for some lanes: the store-data hazard,
-    DESIGN.md section 3a; the guarded stores are what this test now also watches.)"""
+    profiles/LAB_NOTEBOOK_r1_r3.md section 3a; the guarded stores are what this test now also watches.)"""
     torch = _torch()
     from deepsignal_plant_amd import synth
     from oracle import c_oracle as oc
@@ -506,12 +506,13 @@ def test_small_batch_kernels_do_not_change_a_bit(kw, label, monkeypatch):
     n_x = 700
     states = {k: torch.from_numpy(v).cuda(0) for k, v in onp.make_init_states(cfg, n_x, 9).items()}
     ins_x = synth.feature_batch(n_x, device="cuda:0", seed=77)
-    switches = ("DSP_LSTM_CLUSTER", "DSP_LSTM_LOCAL8", "DSP_TWO_STREAMS", "DSP_HEAD_ST4", "DSP_LSTM_TILING")
+    switches = ("DSP_LSTM_CLUSTER", "DSP_LSTM_LOCAL8", "DSP_TWO_STREAMS", "DSP_HEAD_ST4", "DSP_LSTM_TILING", "DSP_CLUSTER_TIMEOUT")
     modes = {"round3": {"DSP_LSTM_CLUSTER": "0", "DSP_LSTM_LOCAL8": "0", "DSP_TWO_STREAMS": "0", "DSP_HEAD_ST4": "1"},
              "auto": {},
              "one_stream": {"DSP_TWO_STREAMS": "0"},
              "two_streams_always": {"DSP_TWO_STREAMS": "1"},
              "G4": {"DSP_LSTM_CLUSTER": "4"}, "G2": {"DSP_LSTM_CLUSTER": "2"}, "G1": {"DSP_LSTM_CLUSTER": "1"},
+             "every_cluster_abandoned": {"DSP_CLUSTER_TIMEOUT": "0"},   # the clean-up launch computes all of them
              "no_local8": {"DSP_LSTM_LOCAL8": "0"},
              "no_lstm21": {"DSP_LSTM_TILING": "0"}}
     res = {}

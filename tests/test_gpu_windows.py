@@ -171,3 +171,62 @@ def test_handles_on_separate_streams_run_concurrently_with_unchanged_results():
     sample = [t.cpu().numpy() for t in batches[3]]
     _, po = oc.forward(cfg, w, *sample, init_mode="philox", seed=5, site_offset=3000)
     assert float(np.abs(outs[3].cpu().numpy() - po).max()) <= TOL_TIGHT
+
+
+_STRESS = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch
+from deepsignal_plant_amd import synth
+from deepsignal_plant_amd.models import ModelBiLSTM
+from oracle import forward_np as onp
+cfg = onp.OracleConfig()
+w = onp.make_weights(cfg, 72, 2.0)
+def build():
+    m = ModelBiLSTM(13, 16, 3, 1, 2, 0, 256, 16, 4, True, True, module="both_bilstm", device=0, init_state="randn", seed=6)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    return m.cuda(0).eval()
+nh, n = 16, 500
+os.environ["DSP_LSTM_CLUSTER"] = "0"
+ref_model = build()
+del os.environ["DSP_LSTM_CLUSTER"]
+models = [build() for _ in range(nh)]
+batches = [synth.feature_batch(n, device="cuda:0", seed=700 + i) for i in range(nh)]
+alone = []
+for i in range(nh):
+    ref_model.site_offset = 1000 * i
+    alone.append(ref_model.forward(*batches[i])[1].clone())
+torch.cuda.synchronize()
+streams = [torch.cuda.Stream("cuda:0") for _ in range(nh)]
+bad = 0
+for _ in range(12):
+    outs = [None] * nh
+    for rep in range(3):          # three forwards per handle back to back: the queues stay full
+        for i in range(nh):
+            with torch.cuda.stream(streams[i]):
+                models[i].site_offset = 1000 * i
+                outs[i] = models[i].forward(*batches[i])[1]
+    torch.cuda.synchronize()
+    bad += sum(0 if torch.equal(outs[i], alone[i]) else 1 for i in range(nh))
+print("stress: %%d of %%d concurrent clustered forwards differ" %% (bad, 12 * nh))
+sys.exit(1 if bad else 0)
+"""
+
+
+@pytest.mark.parametrize("queues", ["4", "32"])
+def test_sixteen_clustered_forwards_at_once_neither_hang_nor_change_a_bit(queues):
+    """Round 4: a forward of <= 512 sites spreads every (site tile, direction) of the combined stack over a cluster of 8
+    workgroups that wait for each other (dsp_lstmc_kernel) -- which needs all 8 resident.  Sixteen handles on sixteen streams
+    ask for 16 x 256 such workgroups at once; with 32 hardware queues (GPU_MAX_HW_QUEUES, read when the runtime starts: a child
+    process) the dispatcher shares the CUs among many launches and can leave clusters incomplete (five launches sharing an
+    XCD's 32 slots hold 6 members of 8 each -- without a way out nobody would ever finish).  The members of a cluster that does
+    not assemble in time abandon it and the clean-up launch computes it (cluster_admit): every forward completes, and
+    returns exactly what the same batch gives alone on the unclustered path."""
+    import os
+    import subprocess
+    import sys
+    from tests.helpers import ROOT
+    r = subprocess.run([sys.executable, "-c", _STRESS % {"root": ROOT}], cwd=ROOT, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, GPU_MAX_HW_QUEUES=queues))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    assert "stress: 0 of 192" in r.stdout

@@ -3,7 +3,7 @@
 SoA buffers with its share of the node's CPUs (dist.threads_per_rank) and formats as many call lines as it parsed rows
 -- the two host stages that bracket the forward (reference: _read_features_file, call_modifications.py:55-127; the
 per-row strings of _call_mods, :175-188).  Prints one JSON line: per-rank and aggregate rows/s and GB/s of text, next to
-what one GPU eats (1.24 M sites/s = 2.6 GB/s of text; DESIGN.md section 7).  Also `--gz`: the same rows from a foreign
+what one GPU eats (1.24 M sites/s = 2.6 GB/s of text; DESIGN.md section 6a).  Also `--gz`: the same rows from a foreign
 single-stream .gz through the node's shared-memory ring (one inflater per node).
 `--parse_on device` (round 4): the rows are parsed on the GPU, so the host's part is what is timed here -- the reader's one
 copy + row-start pass into the staging buffer (parse_dev.stage_rows) and the formatting of the call lines, with ONE thread

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Device-side call_freq throughput: N synthetic calls already in HBM (keys / pos_in_strand / meta as the host hands them
 over, probabilities and labels as the forward leaves them) -> encode -> stable sort by site -> sequential per-site reduce.
-Prints the rate of each stage and the algorithmic HBM traffic (25 B/record into encode, 16 out; the
+Prints the rate of each stage and the algorithmic HBM traffic (profiles/LAB_NOTEBOOK_r1_r3.md section 6c: 25 B/record into encode, 16 out; the
 reduce reads 32 B/record and writes 72 B/site).  usage: bench_freq_dev.py [N records] [sites]"""
 import ctypes
 import os
