@@ -828,3 +828,32 @@ def test_cli_replays_a_captured_reference_run_from_a_states_file(tmp_path):
     assert r.returncode != 0 and "holds the states of 2 rows" in r.stderr
     r = _run_cli(["-i", inp, "-m", ck, "-o", out, "--init_state", "rand"])
     assert r.returncode != 0 and "--init_state must be" in r.stderr
+
+
+def test_cli_matches_the_references_tsv_branch_under_pinned_normal_states(tmp_path):
+    """F10: the reference's TSV branch end to end on f2_rows.tsv (200 rows, 23 reads) with N(0,1) initial states pinned per
+    row -- the states the reference really runs with, where F4 pins zeros.  This build's `call_mods` gets the same rows and
+    the same states (--init_state file:<npz>) and must print the reference's lines (6-decimal values within 2e-6: fp32
+    summation order can move the last printed digit), in input order, whichever side parses the rows."""
+    import torch
+    from oracle import forward_np as onp
+    meta = np.load(os.path.join(GOLDEN, "f10_meta.npz"))
+    cfg = onp.OracleConfig()
+    w = onp.make_weights(cfg, int(meta["wseed"]), float(meta["wscale"]))
+    ck = os.path.join(str(tmp_path), "model.ckpt")
+    torch.save({k: torch.from_numpy(v) for k, v in w.items()}, ck)
+    st = os.path.join(str(tmp_path), "states.npz")
+    np.savez(st, **onp.make_init_states(cfg, int(meta["n"]), int(meta["sseed"])))
+    want_lines = open(os.path.join(GOLDEN, "f10_expected_states.tsv")).read().splitlines()
+    for mode, blk in (("host", None), ("device", {"DSP_BLOCK_BYTES": "100000"})):   # (device: several blocks, one with the odd row 3)
+        out = os.path.join(str(tmp_path), "calls_%s.tsv" % mode)
+        r = _run_cli(["-i", os.path.join(GOLDEN, "f2_rows.tsv"), "-m", ck, "-o", out, "--init_state", "file:" + st, "--parse_on", mode], env=blk)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got_lines = open(out).read().splitlines()
+        assert len(got_lines) == len(want_lines) == 200
+        for g, wl in zip(got_lines, want_lines):
+            g, wl = g.split("\t"), wl.split("\t")
+            assert g[:6] == wl[:6] and g[9] == wl[9]
+            assert abs(float(g[6]) - float(wl[6])) <= 2e-6 and abs(float(g[7]) - float(wl[7])) <= 2e-6
+            if abs(float(wl[7]) - 0.5) >= 1e-4:
+                assert g[8] == wl[8]

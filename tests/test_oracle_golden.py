@@ -107,3 +107,25 @@ def test_flop_count_matches_survey():
     assert onp.flops_per_site(onp.OracleConfig()) == 118447104
     assert onp.flops_per_site(onp.OracleConfig(module="seq_bilstm", num_layers1=2)) == 85832704
     assert sum(int(np.prod(s)) for _, s in onp.state_dict_spec(onp.OracleConfig())) == 4694082
+
+
+def test_oracle_reproduces_the_references_tsv_branch_under_pinned_normal_states():
+    """F10 (tests/golden/make_golden_text_states.py): the reference's reader -> _call_mods on f2_rows.tsv with N(0,1) initial
+    states pinned per input row (F4 is the same capture with zero states).  Parser + oracle + the formatter's rounding
+    reproduce the printed probabilities."""
+    import os
+    from deepsignal_plant_amd import textio
+    from tests.helpers import GOLDEN
+    meta = np.load(os.path.join(GOLDEN, "f10_meta.npz"))
+    cfg = onp.OracleConfig()
+    w = onp.make_weights(cfg, int(meta["wseed"]), float(meta["wscale"]))
+    rows = textio.parse_rows(open(os.path.join(GOLDEN, "f2_rows.tsv"), "rb").read(), 13, 16)
+    states = onp.make_init_states(cfg, rows.n, int(meta["sseed"]))
+    _lg, pr = oc.forward(cfg, w, rows.kmer.astype(np.float32), rows.means, rows.stds, rows.lens.astype(np.float32), rows.signals,
+                         states=states, init_mode="explicit")
+    want = [l.rstrip("\n").split("\t") for l in open(os.path.join(GOLDEN, "f10_expected_states.tsv"))]
+    assert len(want) == rows.n == int(meta["n"]) == 200
+    p0 = pr[:, 0].astype(np.float64) / (pr[:, 0].astype(np.float64) + pr[:, 1])
+    got0 = np.array([float(x[6]) for x in want])
+    assert np.abs(p0 - got0).max() <= 2e-6
+    assert [rows.sampleinfo(i) for i in range(rows.n)] == ["\t".join(x[:6]) for x in want]
