@@ -230,3 +230,40 @@ def test_sixteen_clustered_forwards_at_once_neither_hang_nor_change_a_bit(queues
                        env=dict(os.environ, GPU_MAX_HW_QUEUES=queues))
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     assert "stress: 0 of 192" in r.stdout
+
+
+@pytest.mark.parametrize("n", [500, 2048, 4096, 9000])
+def test_forward_captures_into_a_hip_graph_and_replays_the_same_bits(n):
+    """`dsp_forward` is asynchronous on the caller's stream, allocates nothing once reserved and never synchronises: a caller
+    may capture it into a HIP graph (here: torch.cuda.CUDAGraph).  The capture takes in the handle's side stream (the signal
+    branch forked from and joined back into the captured stream), the clustered launches with their clean-up launches and the
+    counter zeroing of the first kernel; a replay on new input contents gives the bits of an eager forward.  (The Philox
+    site offset is a kernel argument: a replay keeps the one it was captured with.)"""
+    torch = _torch()
+    from deepsignal_plant_amd import synth
+    from oracle import forward_np as onp
+    cfg = onp.OracleConfig()
+    m = build_model(cfg, onp.make_weights(cfg, 81, 2.0), init_state="randn", seed=4)
+    m.reserve(n)
+    static = [t.clone() for t in synth.feature_batch(n, device="cuda:0", seed=11)]
+    other = synth.feature_batch(n, device="cuda:0", seed=12)
+    m.site_offset = 123
+    eager = [m.forward(*static)[1].clone(), m.forward(*other)[1].clone()]
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        m.forward(*static)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = m.forward(*static)[1]
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager[0])
+    for a, b in zip(static, other):
+        a.copy_(b)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager[1])
