@@ -104,7 +104,7 @@ class FileInitStates(object):
 
 def parse_on(args, nthreads=None):
     """--parse_on: where feature rows become numbers.  "device": one GPU thread per row / float list parses the staged text
-    (csrc/dsp_parse_dev.hip: 0.3 ms of GPU time per 32,768 rows = 1.2 % of their forward, 0.65 us of host time per row);
+    (csrc/dsp_parse_dev.hip: 0.17 ms of GPU time per 32,768 rows = 0.65 % of their forward, 0.4-0.7 us of host time per row);
     "host": this rank's parser threads (2.5-3.6 us of host time per row: four threads keep up with one GPU).  "auto" (the
     default; DSP_PARSE_ON overrides it): the device when this rank's share of the node's CPUs is under four threads -- eight
     ranks on sixteen cores -- else the host, whose threads are then free anyway."""

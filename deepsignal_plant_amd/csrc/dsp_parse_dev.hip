@@ -14,7 +14,8 @@
 // 2^53, exponents beyond +-22, another field count, a letter outside base2code_dna, ...) is not guessed at: the row is
 // flagged and the caller gives the whole block to the host parser, which also owns the error messages.
 //
-// A row is about 2.1 kB in 13 + 13 + 13 + 208 numbers.  The first version -- one thread per row walking all of it -- took
+// Three versions (the third runs; the second is kept for rows too long for its LDS).  A row is about 2.1 kB in 13 + 13 + 13
+// + 208 numbers.  The first version -- one thread per row walking all of it -- took
 // 0.67 ms per block of 32,768 rows (102 GB/s): 512 waves for 1,024 SIMDs, and a cursor whose 16-byte refills happen at a
 // different step in every lane, so that the wave waited out a memory round trip at nearly every byte (vmcnt counts
 // instructions, not lanes: reading the prefetch register waits for the refill another lane issued a step ago).  Now two
@@ -24,9 +25,15 @@
 // the occupancy hides part of the divergent refills: 0.30 ms per block (0.13 + 0.17), 1.2 % of the block's forward.  (Measured
 // and not kept: requesting a list's lines up front so that the refills hit the cache -- 0.185 instead of 0.169 ms, the
 // kernels are bound by their ~90 instructions per byte, not by the round trips; an eight-deep instead of a four-deep
-// prefetch in the scan: no change.)  HBM-bound integer work: no MFMA, no LDS.
+// prefetch in the scan: no change.)  Third version (dsp_parse_tokens_kernel below): a workgroup stages 4 rows in LDS with
+// coalesced loads, numbers their delimiters with one scan and parses ONE TOKEN PER THREAD, so that neighbouring lanes read
+// neighbouring bytes and store neighbouring words: 0.17 ms per block = 400 GB/s of text, 0.65 % of the block's forward
+// (4 / 8 / 16 / 2 / 1 rows per workgroup: 0.171 / 0.174-0.199 / 0.243 / 0.203 / 0.242 ms; bound by the ~250 instructions a
+// number costs -- every one with a decimal point is an IEEE float64 division).  Integer / byte work: no MFMA.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "dsp_amd.h"
 
@@ -75,7 +82,8 @@ struct Reader {
 };
 
 // [-]digits[.digits][e[+-]digits], at most 18 digits; false = not a plain number (the row goes to the host parser)
-__device__ __forceinline__ bool fast_float(Reader& r, float* dst) {
+template <class RD>
+__device__ __forceinline__ bool fast_float(RD& r, float* dst) {
     const bool neg = r.cur() == '-';
     if (neg) r.adv();
     uint64_t m = 0;
@@ -111,7 +119,8 @@ __device__ __forceinline__ bool fast_float(Reader& r, float* dst) {
     return true;
 }
 
-__device__ __forceinline__ bool fast_int(Reader& r, int* out) {
+template <class RD>
+__device__ __forceinline__ bool fast_int(RD& r, int* out) {
     const bool neg = r.cur() == '-';
     if (neg) r.adv();
     long long v = 0;
@@ -286,6 +295,223 @@ __global__ __launch_bounds__(256) void dsp_parse_lists_kernel(ParseArgs a) {
     if (s0 + rd.pos != s1) flag_row(a, r);   // the list ended exactly where the table says
 }
 
+// ---- the token-parallel parser (round 4, third version): one workgroup per RB rows, the rows' text staged in LDS.
+//   (1) the RB rows are one contiguous piece of the block: copied into LDS with coalesced 16-byte loads;
+//   (2) every thread counts the delimiters (',' ';' '\t' '\n') of its slice of that piece (SWAR on LDS words), one
+//       workgroup scan numbers them, a second pass writes their positions into a table: token j of the piece ends at
+//       delimiter j.  A plain row has EXACTLY NTOK = 7 + 3 L + L S + 1 tokens whose terminators' kinds are fixed by the
+//       grammar (a row whose sampleinfo holds a ',' or ';', or extra columns, has another count: flagged -> host parser);
+//   (3) one thread per token: lane k of a row parses token k from LDS -- 6 sampleinfo fields (addressing only), the k-mer,
+//       L + L floats, L integers, L S floats, the label -- and stores its value: neighbouring lanes write neighbouring
+//       words (the thread-per-row kernels stored with a 1 kB stride between lanes).
+// Same acceptance and the same arithmetic as the kernels above (fast_float / fast_int); whatever is not plain flags its row.
+constexpr int kTokRowBytes = 2560;     // LDS per row of a workgroup: RB x this for the text (a row of the default shape: 2.09 kB)
+constexpr int kTokMaxNtok = 2048;      // tokens per row the position table is sized for (default shape: 255)
+
+// a byte cursor over LDS: 16 bytes (four aligned words) fetched at once into two 64-bit shift registers -- a number of the
+// writer's grammar (<= 12 bytes) never refills; longer tokens fetch the next four words
+struct LdsReader {
+    const uint32_t* w;
+    uint64_t lo, hi;
+    int left;
+    uint32_t pos;
+    __device__ __forceinline__ void fetch() {
+        const u32x4 q = *(const u32x4*)w;
+        w += 4;
+        lo = (uint64_t)q.x | ((uint64_t)q.y << 32);
+        hi = (uint64_t)q.z | ((uint64_t)q.w << 32);
+        left = 16;
+    }
+    __device__ __forceinline__ void init(const uint32_t* lds32, uint32_t byte) {
+        w = lds32 + ((byte >> 2) & ~3u);           // 16-byte aligned: one ds_read_b128
+        fetch();
+        const int sk = (int)(byte & 15u);
+        if (sk >= 8) { lo = hi >> (8 * (sk - 8)); hi = 0; }
+        else if (sk) { lo = (lo >> (8 * sk)) | (hi << (64 - 8 * sk)); hi >>= 8 * sk; }
+        left = 16 - sk;
+        pos = 0;
+    }
+    __device__ __forceinline__ unsigned cur() const { return (unsigned)(lo & 0xffu); }
+    __device__ __forceinline__ void adv() {
+        lo = (lo >> 8) | (hi << 56);
+        hi >>= 8;
+        ++pos;
+        if (--left == 0) fetch();
+    }
+};
+
+__device__ __forceinline__ uint32_t delim_mask4(uint32_t w) {
+    return eq_mask4(w, 0x2c2c2c2cu) | eq_mask4(w, 0x3b3b3b3bu) | eq_mask4(w, 0x09090909u) | eq_mask4(w, 0x0a0a0a0au);
+}
+
+template <int RB>
+__global__ __launch_bounds__(256, 6) void dsp_parse_tokens_kernel(ParseArgs a) {
+    constexpr int kTokCapBytes = RB * kTokRowBytes;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int L = a.L, S = a.S, NTOK = 7 + 3 * L + L * S + 1;
+    const int kTokCapDelims = (RB * NTOK + 64 + 7) & ~7;          // (the host sized the dynamic LDS with the same formula)
+    uint32_t* buf = lds;                                          // kTokCapBytes + 48 bytes of text
+    uint16_t* dpos = (uint16_t*)(lds + (kTokCapBytes + 48) / 4);   // delimiter positions (LDS byte offsets)
+    uint32_t* misc = (uint32_t*)(dpos + kTokCapDelims);           // [0..3] wave sums, [8..8+RB) row flags, then 2 x RB row tables
+    uint32_t* rflag = misc + 8;
+    uint32_t* rstart = rflag + RB;      // LDS offset of the row's first byte
+    uint32_t* rbase = rstart + RB;      // index of the row's first delimiter
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long long r0 = (long long)blockIdx.x * RB;
+    if (r0 >= a.n) return;
+    const int nr = (int)(a.n - r0 < RB ? a.n - r0 : RB);
+    const uint64_t b0 = a.row_off[r0], b1 = a.row_off[r0 + nr];
+    const bool sane = b1 > b0 && b1 <= a.text_bytes && (b1 - b0) <= (uint64_t)kTokCapBytes;
+    if (!sane) {                                                   // longer rows than the LDS holds: the host parser's
+        if (tid < nr) flag_row(a, r0 + tid);
+        return;
+    }
+    const uint32_t nbytes = (uint32_t)(b1 - b0);
+    const uintptr_t g0 = (uintptr_t)(a.text + b0);
+    const uint32_t sk = (uint32_t)(g0 & 15);
+    guint4* src = (guint4*)(g0 - sk);
+    const uint32_t nchunks = (sk + nbytes + 15u) / 16u;
+    {   // all of a thread's loads are issued before the first store (RB x 2,560 bytes / 4 KiB per round: at most 10 rounds)
+        constexpr int NR = (kTokCapBytes + 15 + 16) / 16 / 256 + 1;
+        u32x4 tmp[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const uint32_t c = (uint32_t)tid + 256u * (uint32_t)i;
+            if (c < nchunks) tmp[i] = src[c];
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const uint32_t c = (uint32_t)tid + 256u * (uint32_t)i;
+            if (c < nchunks) ((u32x4*)buf)[c] = tmp[i];
+        }
+    }
+    if (tid < RB) rflag[tid] = 0;
+    __syncthreads();
+    // bytes outside the piece (the tail of the row before it, the head of the row behind it) must not count
+    if (tid < 16) {
+        uint8_t* bb = (uint8_t*)buf;
+        if ((uint32_t)tid < sk) bb[tid] = 0;
+        const uint32_t e = sk + nbytes + (uint32_t)tid;
+        if (e < nchunks * 16u) bb[e] = 0;
+    }
+    __syncthreads();
+    // delimiters of this thread's slice of words
+    const uint32_t nwords = nchunks * 4u;
+    const uint32_t per = (nwords + 255u) / 256u;
+    const uint32_t w0 = (uint32_t)tid * per, w1 = w0 + per < nwords ? w0 + per : nwords;
+    int cnt = 0;
+    for (uint32_t i = w0; i < w1; ++i) cnt += __builtin_popcount(delim_mask4(buf[i]));
+    int v = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int u = __shfl_up(v, d);
+        if (lane >= d) v += u;
+    }
+    if (lane == 63) misc[wv] = (uint32_t)v;
+    __syncthreads();
+    int base = v - cnt;
+    for (int k = 0; k < wv; ++k) base += (int)misc[k];
+    const int total = (int)(misc[0] + misc[1] + misc[2] + misc[3]);
+    if (total > kTokCapDelims) {                                   // not rows of numbers: the host parser's
+        if (tid < nr) flag_row(a, r0 + tid);
+        return;
+    }
+    for (uint32_t i = w0; i < w1; ++i) {
+        uint32_t m = delim_mask4(buf[i]);
+        while (m) {
+            const int bit = __builtin_ctz(m);
+            m &= m - 1;
+            dpos[base++] = (uint16_t)(i * 4u + (uint32_t)(bit >> 3));
+        }
+    }
+    __syncthreads();
+    // every row's first byte and first delimiter (binary search of the row's start in the position table)
+    if (tid < nr) {
+        const uint32_t st = sk + (uint32_t)(a.row_off[r0 + tid] - b0);
+        const uint32_t en = sk + (uint32_t)(a.row_off[r0 + tid + 1] - b0);   // one past the row's '\n'
+        int lo = 0, hi = total;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (dpos[mid] < st) lo = mid + 1; else hi = mid; }
+        int lo2 = lo, hi2 = total;
+        while (lo2 < hi2) { const int mid = (lo2 + hi2) >> 1; if (dpos[mid] < en) lo2 = mid + 1; else hi2 = mid; }
+        rstart[tid] = st;
+        rbase[tid] = (uint32_t)lo;
+        const uint32_t c0 = ((const uint8_t*)buf)[st];
+        // exactly NTOK delimiters, the last one the row's '\n'; no blank in front (line.strip() is the host parser's)
+        if (lo2 - lo != NTOK || en - st < (uint32_t)(12 + L) || is_space(c0)) rflag[tid] = 1;
+    }
+    __syncthreads();
+    const uint8_t* bb = (const uint8_t*)buf;
+    for (int r = 0; r < nr; ++r) {
+        if (rflag[r]) continue;                                     // (uniform: LDS value)
+        const long long row = r0 + r;
+        const uint32_t st = rstart[r];
+        const uint32_t db = rbase[r];
+        // the first 64 tokens of a row mix five kinds (sampleinfo, k-mer, floats, integers): the wave that gets them runs five
+        // code paths one after the other -- a different wave for every row ((tid + 64 r) mod 256: the waves do not wait for
+        // each other between rows)
+        for (int kk = 0; kk < NTOK; kk += 256) {
+            const int k = kk + ((tid + 64 * r) & 255);
+            if (k >= NTOK) continue;
+            const uint32_t ts = k == 0 ? st : (uint32_t)dpos[db + k - 1] + 1u;
+            const uint32_t te = dpos[db + k];
+            const unsigned term = bb[te];
+            bool ok = true;
+            if (k < 6) {                                            // sampleinfo: kept verbatim, only addressed
+                ok = term == '\t';
+                if (k == 4) { a.read_off[row] = ts - st; a.read_len[row] = te - ts; }
+                if (k == 5) a.info_len[row] = te - st;
+            } else if (k == 6) {                                    // the k-mer: exactly L letters of base2code_dna
+                ok = term == '\t' && te - ts == (uint32_t)L;
+                if (ok) {
+                    uint8_t* km = a.kmer + row * L;
+                    for (int i = 0; i < L; ++i) {
+                        const int c = base_code(bb[ts + i]);
+                        if (c < 0) { ok = false; break; }
+                        km[i] = (uint8_t)c;
+                    }
+                }
+            } else if (k == NTOK - 1) {                             // the label: an integer, LF or CRLF behind it
+                LdsReader rd;
+                rd.init(buf, ts);
+                int lab;
+                ok = term == '\n' && fast_int(rd, &lab) && (rd.pos == te - ts || (rd.cur() == '\r' && rd.pos + 1 == te - ts));
+                if (ok) a.labels[row] = lab;
+            } else {
+                const int q = k - 7;
+                const bool is_int = q >= 2 * L && q < 3 * L;
+                int idx, cnt1;
+                unsigned last;
+                if (q < 3 * L) { idx = q % L; cnt1 = L; last = '\t'; }
+                else { idx = (q - 3 * L) % S; cnt1 = S; last = (q - 3 * L) / S == L - 1 ? '\t' : ';'; }
+                ok = term == (idx == cnt1 - 1 ? last : (unsigned)',');
+                if (ok) {
+                    LdsReader rd;
+                    rd.init(buf, ts);
+                    if (is_int) {
+                        int val;
+                        ok = fast_int(rd, &val) && rd.pos == te - ts;
+                        if (ok) a.lens[row * L + (q - 2 * L)] = val;
+                    } else {
+                        float val;
+                        ok = fast_float(rd, &val) && rd.pos == te - ts;
+                        if (ok) {
+                            if (q < L) a.means[row * L + q] = val;
+                            else if (q < 2 * L) a.stds[row * L + (q - L)] = val;
+                            else a.signals[(size_t)row * L * S + (q - 3 * L)] = val;
+                        }
+                    }
+                }
+            }
+            if (!ok) rflag[r] = 1;                                  // (benign race: every writer writes 1)
+        }
+    }
+    __syncthreads();
+    if (tid < nr) {
+        a.status[r0 + tid] = rflag[tid] ? 1 : 0;
+        if (rflag[tid]) atomicAdd(a.n_flagged, 1u);
+    }
+}
+
 }  // namespace
 
 extern "C" void dsp_set_error_(const char* msg);
@@ -305,9 +531,26 @@ extern "C" int32_t dsp_parse_rows_device(void* stream, const char* text_dev, con
     if (e == hipSuccess && n > 0) {
         ParseArgs a{text_dev, row_off_dev, (long long)n, seq_len, signal_len, kmer, means, stds, lens, signals, labels,
                     info_len, read_off, read_len, status_dev, n_flagged_dev, (unsigned long long)text_bytes, seg_dev};
-        hipLaunchKernelGGL(dsp_parse_scan_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, a);
-        const long long lists = (long long)n * (2 + seq_len);
-        hipLaunchKernelGGL(dsp_parse_lists_kernel, dim3((unsigned)((lists + 255) / 256)), dim3(256), 0, s, a);
+        // the token-parallel kernel when a row of the block's average length (+ 20 %) fits its share of the workgroup's LDS,
+        // else the thread-per-row pair above (rows of several kilobytes: other k-mer lengths / signal windows)
+        const int ntok = 7 + 3 * seq_len + seq_len * signal_len + 1;
+        const double avg = (double)text_bytes / (double)n * 1.2;
+        static const int rb_env = getenv("DSP_PARSE_RB") ? atoi(getenv("DSP_PARSE_RB")) : 4;                         // A/B switch: 4, 8, 16
+        static const bool force_rows = getenv("DSP_PARSE_KERNEL") && !strcmp(getenv("DSP_PARSE_KERNEL"), "rows");   // A/B switch
+        const int rb = (rb_env == 1 || rb_env == 2 || rb_env == 8 || rb_env == 16) ? rb_env : 4;
+        if (avg <= kTokRowBytes && ntok <= kTokMaxNtok && !force_rows) {
+            const size_t lds = (size_t)rb * kTokRowBytes + 48 + (size_t)(((rb * ntok + 64 + 7) & ~7)) * 2 + (8 + 3 * 16) * 4;
+            const unsigned grid = (unsigned)((n + rb - 1) / rb);
+            if (rb == 16) hipLaunchKernelGGL(dsp_parse_tokens_kernel<16>, dim3(grid), dim3(256), lds, s, a);
+            else if (rb == 8) hipLaunchKernelGGL(dsp_parse_tokens_kernel<8>, dim3(grid), dim3(256), lds, s, a);
+            else if (rb == 2) hipLaunchKernelGGL(dsp_parse_tokens_kernel<2>, dim3(grid), dim3(256), lds, s, a);
+            else if (rb == 1) hipLaunchKernelGGL(dsp_parse_tokens_kernel<1>, dim3(grid), dim3(256), lds, s, a);
+            else hipLaunchKernelGGL(dsp_parse_tokens_kernel<4>, dim3(grid), dim3(256), lds, s, a);
+        } else {
+            hipLaunchKernelGGL(dsp_parse_scan_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, a);
+            const long long lists = (long long)n * (2 + seq_len);
+            hipLaunchKernelGGL(dsp_parse_lists_kernel, dim3((unsigned)((lists + 255) / 256)), dim3(256), 0, s, a);
+        }
         e = hipGetLastError();
     }
     if (e != hipSuccess) {

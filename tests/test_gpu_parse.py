@@ -60,11 +60,16 @@ def test_device_parser_reproduces_the_host_parser_on_the_golden_rows():
     # CRLF rows, an unterminated last row, extra columns: plain enough
     lines = data.splitlines()
     lines = lines[10:19]
-    for variant in (b"\r\n".join(lines) + b"\r\n", b"\n".join(lines), b"\n".join(l + b"\textra\tcols" for l in lines) + b"\n"):
+    # CRLF rows and an unterminated last row are plain enough for the device; extra columns behind the label (the reference
+    # ignores them: words[11]) give a row another token count: flagged, the host parser takes the block -- never a wrong value
+    for variant, on_device in ((b"\r\n".join(lines) + b"\r\n", True), (b"\n".join(lines), True),
+                               (b"\n".join(l + b"\textra\tcols" for l in lines) + b"\n", False)):
         dev, rows, _ = _device_parse(variant)
         host = textio.parse_rows(variant, 13, 16)
-        assert rows.n == host.n == 9 and dev["status"].sum() == 0
-        assert all(_same(dev, host, i, i) is None for i in range(9))
+        assert rows.n == host.n == 9
+        if on_device:
+            assert dev["status"].sum() == 0
+        assert all(dev["status"][i] == 1 or _same(dev, host, i, i) is None for i in range(9))
 
 
 def test_device_parser_on_the_extreme_rows_and_every_float_spelling():
@@ -151,6 +156,25 @@ def test_device_parser_never_accepts_what_the_host_parser_rejects_and_never_diff
                 n_flag += 1
             i += 1
     assert i == staged.n and n_same > 2000 and n_flag > 300
+
+
+def test_device_parser_other_row_shapes_and_the_thread_per_row_kernels():
+    """rows of other k-mer lengths / signal windows: short ones through the token-parallel kernel, rows too long for its LDS
+    (seq_len 21 x signal_len 24: 5 kB) through the thread-per-row pair -- which DSP_PARSE_KERNEL=rows also selects for the
+    default shape (a child process: the switch is read once)"""
+    from deepsignal_plant_amd import textio, tsv
+    for L, S, n in ((5, 8, 300), (9, 12, 200), (21, 24, 150)):
+        data = ("\n".join(tsv.synth_rows(n, seq_len=L, signal_len=S, seed=L)) + "\n").encode()
+        host = textio.parse_rows(data, L, S)
+        dev, rows, _ = _device_parse(data, L, S)
+        assert rows.n == host.n == n and dev["status"].sum() == 0, (L, S)
+        assert all(_same(dev, host, i, i) is None for i in range(n)), (L, S)
+    code = ("import sys; sys.path.insert(0, %r); import tests.test_gpu_parse as t; "
+            "t.test_device_parser_reproduces_the_host_parser_on_the_golden_rows(); "
+            "t.test_device_parser_never_accepts_what_the_host_parser_rejects_and_never_differs(); print('rows kernels ok')" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, DSP_PARSE_KERNEL="rows"))
+    assert r.returncode == 0 and "rows kernels ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
 
 
 def _cli(args, env=None):
