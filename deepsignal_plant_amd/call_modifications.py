@@ -103,16 +103,16 @@ class FileInitStates(object):
 
 
 def parse_on(args, nthreads=None):
-    """--parse_on: where feature rows become numbers.  "device": one GPU thread per row / float list parses the staged text
-    (csrc/dsp_parse_dev.hip: 0.17 ms of GPU time per 32,768 rows = 0.65 % of their forward, 0.4-0.7 us of host time per row);
-    "host": this rank's parser threads (2.5-3.6 us of host time per row: four threads keep up with one GPU).  "auto" (the
-    default; DSP_PARSE_ON overrides it): the device when this rank's share of the node's CPUs is under four threads -- eight
-    ranks on sixteen cores -- else the host, whose threads are then free anyway."""
-    v = getattr(args, "parse_on", None) or os.environ.get("DSP_PARSE_ON") or "auto"
-    if v not in ("device", "host", "auto"):
-        raise ValueError("--parse_on must be device, host or auto")
+    """--parse_on: where feature rows become numbers.  "device" (default; DSP_PARSE_ON overrides the default): one GPU thread
+    per token parses the staged text (csrc/dsp_parse_dev.hip: 0.17 ms of GPU time per 32,768 rows = 0.65 % of their forward,
+    0.4-0.7 us of host time per row -- one host thread per GPU); "host": this rank's parser threads (2.5-3.6 us of host time
+    per row: four threads keep up with one GPU).  Same values either way; end to end the two are equally fast on one GPU
+    (4 M rows: 3.73 s device with one host thread, 3.71 s host with four)."""
+    v = getattr(args, "parse_on", None) or os.environ.get("DSP_PARSE_ON") or "device"
     if v == "auto":
-        v = "device" if (nthreads is not None and nthreads < 4) else "host"
+        v = "device"
+    if v not in ("device", "host"):
+        raise ValueError("--parse_on must be device or host")
     return v
 
 
@@ -823,10 +823,9 @@ def add_call_mods_args(p):
                         "c_sig, h_comb, c_comb; replays a captured reference run)")
     g.add_argument("--seed", type=int, default=0, help="seed of the in-kernel initial-state generator")
     g.add_argument("--parse_on", type=str, default=None, choices=["device", "host", "auto"],
-                   help="where the feature rows are parsed: 'device' = the host only stages the text, GPU threads parse it (rows "
-                        "outside the plain grammar, and every error, still go through the host parser); 'host' = this rank's "
-                        "--nproc parser threads; 'auto' (default) = the device when this rank has fewer than four host threads "
-                        "to itself.  Same values either way")
+                   help="where the feature rows are parsed: 'device' (default) = the host only stages the text, one GPU thread per "
+                        "token parses it (rows outside the plain grammar, and every error, still go through the host parser); "
+                        "'host' = this rank's --nproc parser threads.  Same values either way")
     g.add_argument("--precision", type=str, default=None, choices=["fp32", "bf16x6", "bf16x9", "fp16x3"],
                    help="how the fp32 products of the combined BiLSTM stack are evaluated: fp32 matrix cores (default), or "
                         "split into low-precision pieces on the fast matrix pipes with fp32 accumulation (bf16x9: nine bf16 "
