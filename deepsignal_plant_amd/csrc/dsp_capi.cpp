@@ -312,6 +312,7 @@ struct dsp_model {
     int tiling21 = -1;       // <2 unit tiles, 1 site tile> per wave on the dense one-pass layers (dsp_lstm21_kernel): -1 = for
                              // batches whose 32-site tiles x 2 directions fit the CUs at once (small-batch latency); DSP_LSTM_TILING=21
                              // always, =0 never (A/B switch)
+    bool fc_fused = true;    // fc_seq + fc_signal in one launch when they have one shape (A/B switch DSP_FC_FUSED=0)
     bool local8 = true;      // dense 8-unit-tile layers of 2,049..4,096-site batches on dsp_lstmc_kernel's eight-wave workgroup-local
                              // form (two waves per SIMD: 3.43 vs 3.48 ms per forward of 4,096 sites) instead of dsp_lstm21_kernel;
                              // DSP_LSTM_LOCAL8=0 turns it off (A/B switch)
@@ -708,6 +709,7 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
     m->debug_lstm = getenv("DSP_DEBUG_LSTM") != nullptr;
     m->head_st4 = getenv("DSP_HEAD_ST4") != nullptr;
     if (const char* v = getenv("DSP_LSTM_LOCAL8")) m->local8 = atoi(v) != 0;
+    if (const char* v = getenv("DSP_FC_FUSED")) m->fc_fused = atoi(v) != 0;
     if (const char* v = getenv("DSP_LSTM_SG")) m->sg_override = atoi(v);  // A/B switch
     if (const char* v = getenv("DSP_LSTM_NP8")) m->np8 = atoi(v) == 2 ? 2 : 1;  // A/B switch
     if (const char* v = getenv("DSP_LSTM_PRIO")) m->phase_prio = atoi(v) != 0;    // A/B switch
@@ -871,10 +873,13 @@ int32_t dsp_forward(dsp_model* m, void* stream, int64_t n, const void* kmer, int
     }
     L.run("pack", [&] { return dsp_k_pack(&p, s); });
 
-    auto linear = [&](const char* name, const DevLinear& fc, const float* x, int out_off) {
+    // (fc2 != NULL: both branches' projections in ONE launch -- same shape, disjoint output columns)
+    auto linear = [&](const char* name, const DevLinear& fc, const float* x, int out_off, const DevLinear* fc2 = nullptr,
+                      const float* x2 = nullptr, int out_off2 = 0) {
         LinArgs a{};
         a.x = x; a.out = m->comb_in; a.wpk = fc.wpk; a.bias = fc.bias;
         a.ncols = NTp * d.T; a.Fin = fc.Fin; a.Fout = m->Fcomb; a.out_off = out_off; a.ORT = fc.ORT; a.relu = 1;
+        if (fc2) { a.x2 = x2; a.wpk2 = fc2->wpk; a.bias2 = fc2->bias; a.out_off2 = out_off2; }
         L.run(name, [&] { return dsp_k_linear(&a, L.s); });
     };
     // The seq and the signal branch are independent until the combined stack (models.py:181-217).  On batches that leave
@@ -888,16 +893,22 @@ int32_t dsp_forward(dsp_model* m, void* stream, int64_t n, const void* kmer, int
         if (hipEventRecord(m->ev_fork, s) != hipSuccess || hipStreamWaitEvent(m->side, m->ev_fork, 0) != hipSuccess)
             L.rc = fail(DSP_EHIP, "fork to the side stream failed: %s", hipGetErrorString(hipGetLastError()));
     }
+    // one stream: fc_seq and fc_signal of the same shape share a launch behind both stacks (the two stacks then need an
+    // output buffer each, as with two streams: one layer per stack)
+    const bool fc_fused = m->fc_fused && !two && d.hseq && d.hsig && d.l2 == 1 && m->hseq_p <= 256 && m->hsig_p <= 256 &&
+                          m->fc_seq.Fin == m->fc_sig.Fin && m->fc_seq.ORT == m->fc_sig.ORT && !m->prof_serial;
+    float* oseq = nullptr;
     if (d.hseq) {
-        float* o = run_stack(L, "lstm_seq", m->seq, 0, m->xseq, n, init, init ? init->h_seq : nullptr,
-                             init ? init->c_seq : nullptr);
-        linear("fc_seq", m->fc_seq, o, 0);
+        oseq = run_stack(L, "lstm_seq", m->seq, 0, m->xseq, n, init, init ? init->h_seq : nullptr,
+                         init ? init->c_seq : nullptr);
+        if (!fc_fused) linear("fc_seq", m->fc_seq, oseq, 0);
     }
     if (d.hsig) {
         if (two) L.s = m->side;
         float* o = run_stack(L, "lstm_signal", m->sig, 1, m->xsig, n, init, init ? init->h_sig : nullptr,
-                             init ? init->c_sig : nullptr, two);
-        linear("fc_signal", m->fc_sig, o, m->hseq_p);
+                             init ? init->c_sig : nullptr, two || fc_fused);
+        if (fc_fused) linear("fc_seq+fc_signal", m->fc_seq, oseq, 0, &m->fc_sig, o, m->hseq_p);
+        else linear("fc_signal", m->fc_sig, o, m->hseq_p);
         if (two) {
             L.s = s;
             if (!L.rc && (hipEventRecord(m->ev_join, m->side) != hipSuccess || hipStreamWaitEvent(s, m->ev_join, 0) != hipSuccess))

@@ -62,6 +62,12 @@ struct LinArgs {
     const float* bias;     // [ORT*32]
     long long ncols;       // NTp * T column blocks of 32 sites
     int Fin, Fout, out_off, ORT, relu;
+    // a second problem of the same shape in the same launch (fc_seq + fc_signal): workgroups [nbx, 2 nbx)
+    const float* x2;       // NULL: one problem
+    const float* wpk2;
+    const float* bias2;
+    int out_off2;
+    unsigned nbx;          // workgroups (of 8 column blocks) per problem (set by dsp_k_linear)
 };
 
 struct HeadArgs {

@@ -1275,17 +1275,19 @@ __global__ __launch_bounds__(256, 2) void dsp_linear_kernel(LinArgs a) {
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rt0 = blockIdx.y * 4;
     const int half = lane >> 5, ls = lane & 31;
-    const long long col0 = ((long long)blockIdx.x * 4 + w) * 2;
+    const bool second = blockIdx.x >= a.nbx;   // (workgroup-uniform: the second problem of a fused launch)
+    const long long col0 = ((long long)(blockIdx.x - (second ? a.nbx : 0u)) * 4 + w) * 2;
     if (col0 >= a.ncols) return;
     const bool two = col0 + 1 < a.ncols;
     const int nq = a.Fin >> 3;   // a multiple of 8 (Fin = 2*Hp, Hp a multiple of 32)
     const int nrt = a.ORT - rt0 < 4 ? a.ORT - rt0 : 4;
     const uint32_t xrow = (uint32_t)(a.Fin >> 2) * 512u;  // bytes of one column block of the input
-    const __amdgpu_buffer_rsrc_t rw = make_rsrc((const char*)a.wpk + (size_t)rt0 * nq * 1024);
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)a.x + (size_t)col0 * xrow);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc((const char*)(second ? a.wpk2 : a.wpk) + (size_t)rt0 * nq * 1024);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)(second ? a.x2 : a.x) + (size_t)col0 * xrow);
     const uint32_t wrow = (uint32_t)nq * 1024u;           // bytes between row tiles
     const uint32_t x1 = two ? xrow : 0u;                  // a lone last column block is computed twice, stored once
-    const f32x4* bias4 = (const f32x4*)a.bias;
+    const f32x4* bias4 = (const f32x4*)(second ? a.bias2 : a.bias);
+    const int out_off = second ? a.out_off2 : a.out_off;
     f32x16 acc[4][2];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -1305,6 +1307,8 @@ __global__ __launch_bounds__(256, 2) void dsp_linear_kernel(LinArgs a) {
         Bs[1] = bld16(rx, voff, x1 + (uint32_t)q * 1024u);
     };
 #define QC(x) ((x) < nq ? (x) : nq - 1)
+// (a compiler-level memory barrier keeps the IR passes from moving the loads, sched_barrier the machine scheduler)
+#define PIN_ORDER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
     auto stage = [&](auto qs, int q) __attribute__((always_inline)) {
         constexpr int QS = decltype(qs)::value;
         constexpr int sa = QS % 2, sp = (QS + 1) % 2, sb = QS % 4;
@@ -1323,22 +1327,27 @@ __global__ __launch_bounds__(256, 2) void dsp_linear_kernel(LinArgs a) {
         ldB(B[sb], QC(q + 4));
         __builtin_amdgcn_sched_barrier(0);
     };
+    // The ring fill in the order the stages use it, PINNED (round 4): hipcc otherwise moves fragments of the first k-group to
+    // the end of the fill, and the wait it then needs at the head of the k-loop -- taken over all ways into the loop: vmcnt(2)
+    // -- drained both rings once every four k-groups for the rest of the kernel (80.5 -> 86 % of the MFMA peak)
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
         if (d < 2) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) A[d][r] = ldA(r, d);
+            for (int r = 0; r < 4; ++r) { A[d][r] = ldA(r, d); PIN_ORDER(); }
         }
         ldB(B[d], d);
+        PIN_ORDER();
     }
     for (int q = 0; q < nq; q += 4) {
         stage(ic<0>{}, q); stage(ic<1>{}, q + 1); stage(ic<2>{}, q + 2); stage(ic<3>{}, q + 3);
     }
 #undef QC
+#undef PIN_ORDER
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         if (c == 1 && !two) break;
-        f32x4* out4 = (f32x4*)a.out + ((size_t)(col0 + c) * (a.Fout >> 2) + (a.out_off >> 2) + half) * 32 + ls;
+        f32x4* out4 = (f32x4*)a.out + ((size_t)(col0 + c) * (a.Fout >> 2) + (out_off >> 2) + half) * 32 + ls;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (r >= nrt) break;
@@ -1649,7 +1658,9 @@ extern "C" int dsp_k_lstm6(const LstmArgs* a, int nprod, hipStream_t s) {
 
 extern "C" int dsp_k_linear(const LinArgs* a, hipStream_t s) {
     const unsigned bx = (unsigned)((a->ncols + 7) / 8);  // 4 waves x 2 column blocks per workgroup
-    hipLaunchKernelGGL(dsp_linear_kernel, dim3(bx, (unsigned)((a->ORT + 3) / 4)), dim3(256), 0, s, *a);
+    LinArgs b = *a;
+    b.nbx = bx;
+    hipLaunchKernelGGL(dsp_linear_kernel, dim3(a->x2 ? 2 * bx : bx, (unsigned)((a->ORT + 3) / 4)), dim3(256), 0, s, b);
     return (int)hipGetLastError();
 }
 

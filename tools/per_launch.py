@@ -36,6 +36,7 @@ def lstm_macs(i, h, layers):
     return [2 * T * 4 * h * ((i if k == 0 else 2 * h) + h) for k in range(layers)]
 macs = {"pack": [0], "lstm_seq": lstm_macs(7, hs, a.layernum2), "fc_seq": [T * hs * 2 * hs],
         "lstm_signal": lstm_macs(16, hg, a.layernum2), "fc_signal": [T * hg * 2 * hg],
+        "fc_seq+fc_signal": [T * hs * 2 * hs + T * hg * 2 * hg],
         "lstm_comb": lstm_macs(H, H, a.layernum1), "head": [H * 2 * H + 2 * H], "front": [0]}
 seen = {}
 tot = 0.0
@@ -47,7 +48,7 @@ for i in range(n):
     mac = mac[k] if k < len(mac) else 0
     tf = (" %6.1f TFLOP/s  %5.1f %% of 157.3" % (2 * mac * B / ms / 1e9, 2 * mac * B / ms / 1e9 / 1.573)) if mac else ""
     tot += ms
-    print("%d %-12s %8.3f ms%s" % (i, name, ms, tf))
+    print("%d %-16s %8.3f ms%s" % (i, name, ms, tf))
 fl = m.flops_per_site()
 print("sum %.3f ms  -> %.4f M sites/s, %.1f TFLOP/s = %.1f %% of the fp32 MFMA peak  [DSP_LSTM_SG=%s]" % (
     tot, B / tot / 1e3, fl * B / tot / 1e9, fl * B / tot / 1e9 / 1.573, os.environ.get("DSP_LSTM_SG", "")))
