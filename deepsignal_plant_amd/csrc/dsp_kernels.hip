@@ -866,40 +866,8 @@ __global__ __launch_bounds__(NW * 64, 1) void dsp_lstmc_kernel(LstmArgs a) {
     const uint32_t voffA = voff + (uint32_t)(gs * G) * 1024u;   // this wave's gates within a k-group's 4 KiB of weights
     const uint32_t voffO = voff + (uint32_t)(gs * G) * 1024u;   // this wave's row groups within a unit tile's 4 KiB of h
 
-    for (int i = tid; i < a.Hp; i += NW * 64) {
-        const int h = i & 1, g = (i >> 1) & 3, aa = (i >> 3) & 3, ut = i >> 5;
-        b_lds[i] = bias4[g * HQ + ut * 8 + 2 * aa + h];
-    }
-    // initial state of the row groups this wave owns: c0 -> registers, h0 -> the K4 scratch step 0 reads as "h_{-1}"
-    f32x4 creg[G];
-    {
-        const long long site = gt0 * 32 + ls;
-        const uint64_t skey = a.init_mode == 2 ? philox_site_key(a.site_keys, a.site_offset, a.n, site) : 0;
-#pragma unroll
-        for (int al = 0; al < G; ++al) {
-            const int k4 = u * 8 + 2 * (gs * G + al) + half;
-            f32x4 hv = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
-            if (a.init_mode != 0) {
-                hv = init_state4(a.h0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, skey, (uint32_t)(a.stream_base + dir * 2 + 0));
-                cv = init_state4(a.c0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, skey, (uint32_t)(a.stream_base + dir * 2 + 1));
-            }
-            if constexpr (LOCAL) bst16(rh0, voffO + al * 1024u, (uint32_t)u * 4096u, hv);
-            else bst16_sc1(rh0, voffO + al * 1024u, (uint32_t)u * 4096u, hv);
-            creg[al] = cv;
-        }
-    }
-    // publish: every wave drains its write-through stores, the workgroup meets, one lane counts the arrival
-    auto publish = [&]() __attribute__((always_inline)) {
-        if constexpr (LOCAL) {
-            barrier_after_global_stores();   // same CU: the stores of this workgroup's waves are ahead of the loads issued after it
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    };
-    publish();
-
+    // (the rings are filled FIRST: weights and x rows depend on nothing computed here, and their round trip runs under the
+    // Philox / Box-Muller work of the initial states below instead of behind it)
     __amdgpu_buffer_rsrc_t rhp = rh0;
     uint32_t xo = 0, ho = 0;
     auto set_bases = [&](int step) __attribute__((always_inline)) {
@@ -974,6 +942,40 @@ __global__ __launch_bounds__(NW * 64, 1) void dsp_lstmc_kernel(LstmArgs a) {
         for (int f = 0; f < G; ++f) A[d][f] = ldA(f, d);
         B[d] = ldBx(d);
     }
+    for (int i = tid; i < a.Hp; i += NW * 64) {
+        const int h = i & 1, g = (i >> 1) & 3, aa = (i >> 3) & 3, ut = i >> 5;
+        b_lds[i] = bias4[g * HQ + ut * 8 + 2 * aa + h];
+    }
+    // initial state of the row groups this wave owns: c0 -> registers, h0 -> the K4 scratch step 0 reads as "h_{-1}"
+    f32x4 creg[G];
+    {
+        const long long site = gt0 * 32 + ls;
+        const uint64_t skey = a.init_mode == 2 ? philox_site_key(a.site_keys, a.site_offset, a.n, site) : 0;
+#pragma unroll
+        for (int al = 0; al < G; ++al) {
+            const int k4 = u * 8 + 2 * (gs * G + al) + half;
+            f32x4 hv = {0.f, 0.f, 0.f, 0.f}, cv = {0.f, 0.f, 0.f, 0.f};
+            if (a.init_mode != 0) {
+                hv = init_state4(a.h0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, skey, (uint32_t)(a.stream_base + dir * 2 + 0));
+                cv = init_state4(a.c0, a.init_mode, a.n, site, dir, a.H, k4, a.seed, skey, (uint32_t)(a.stream_base + dir * 2 + 1));
+            }
+            if constexpr (LOCAL) bst16(rh0, voffO + al * 1024u, (uint32_t)u * 4096u, hv);
+            else bst16_sc1(rh0, voffO + al * 1024u, (uint32_t)u * 4096u, hv);
+            creg[al] = cv;
+        }
+    }
+    // publish: every wave drains its write-through stores, the workgroup meets, one lane counts the arrival
+    auto publish = [&]() __attribute__((always_inline)) {
+        if constexpr (LOCAL) {
+            barrier_after_global_stores();   // same CU: the stores of this workgroup's waves are ahead of the loads issued after it
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    publish();
+
     for (int step = 0; step < T; ++step) {
         const int t = dir ? (T - 1 - step) : step;
         if (prio) __builtin_amdgcn_s_setprio(2);
