@@ -492,7 +492,7 @@ def test_small_batch_kernels_do_not_change_a_bit(kw, label, monkeypatch):
     gates over a cluster of 2 / 4 / 8 workgroups on as many CUs (<= 2,048 / 1,024 / 512 sites; h crosses CUs through memory:
     write-through stores, an arrival counter, sc1 loads), runs 4-unit-tile layers (the front ends) and -- from 2,049 sites --
     8-unit-tile layers as one workgroup of 4 / 8 waves, the two front-end branches go down two streams, the head kernel
-    takes one site tile per workgroup.  Same MFMAs in the same order on the same values: every switch combination gives
+    takes one site tile per workgroup, fc_seq and fc_signal share a launch.  Same MFMAs in the same order on the same values: every switch combination gives
     the bytes of the round-3 path (everything off), at every batch size around the switches, for Philox, explicit N(0,1)
     and zero states -- and the oracle agrees."""
     torch = _torch()
@@ -501,13 +501,16 @@ def test_small_batch_kernels_do_not_change_a_bit(kw, label, monkeypatch):
     from oracle import forward_np as onp
     cfg = onp.OracleConfig(**kw)
     w = onp.make_weights(cfg, 92, 2.0)
-    sizes = (1, 31, 512, 513, 1024, 1025, 2048, 2049, 3000, 4096, 4097)
+    sizes = (1, 31, 512, 513, 1024, 1025, 2048, 2049, 3000, 4096, 4097, 9001)
     ins = {n: synth.feature_batch(n, device="cuda:0", seed=500 + n) for n in sizes}
     n_x = 700
     states = {k: torch.from_numpy(v).cuda(0) for k, v in onp.make_init_states(cfg, n_x, 9).items()}
     ins_x = synth.feature_batch(n_x, device="cuda:0", seed=77)
-    switches = ("DSP_LSTM_CLUSTER", "DSP_LSTM_LOCAL8", "DSP_TWO_STREAMS", "DSP_HEAD_ST4", "DSP_LSTM_TILING", "DSP_CLUSTER_TIMEOUT")
-    modes = {"round3": {"DSP_LSTM_CLUSTER": "0", "DSP_LSTM_LOCAL8": "0", "DSP_TWO_STREAMS": "0", "DSP_HEAD_ST4": "1"},
+    switches = ("DSP_LSTM_CLUSTER", "DSP_LSTM_LOCAL8", "DSP_TWO_STREAMS", "DSP_HEAD_ST4", "DSP_LSTM_TILING", "DSP_CLUSTER_TIMEOUT",
+                "DSP_FC_FUSED")
+    modes = {"round3": {"DSP_LSTM_CLUSTER": "0", "DSP_LSTM_LOCAL8": "0", "DSP_TWO_STREAMS": "0", "DSP_HEAD_ST4": "1",
+                        "DSP_FC_FUSED": "0"},
+             "fc_launches_apart": {"DSP_FC_FUSED": "0"},   # (auto: fc_seq and fc_signal share a launch when the branches share a stream)
              "auto": {},
              "one_stream": {"DSP_TWO_STREAMS": "0"},
              "two_streams_always": {"DSP_TWO_STREAMS": "1"},
