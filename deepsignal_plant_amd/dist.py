@@ -267,20 +267,22 @@ def gather_probs(probs, world, dst=0):
 
 
 def gather_columns(cols, world, device=None):
-    """Ragged gather of equally long 1-D int64 columns to rank 0: sizes exchanged first, then ONE padded all_gather of
-    the columns stacked as [n, k] (RCCL when `device` is a GPU).  Returns the concatenated columns on rank 0, None
-    elsewhere."""
+    """Ragged gather of equally long 1-D int64 columns to rank 0: sizes exchanged first, then every other rank sends its
+    columns, stacked as [n, k], point to point (RCCL when `device` is a GPU) -- a true gather like gather_probs: off-root
+    memory stays O(n_r) (until round 4 a padded all_gather: world x max(n_r) rows on every rank, read by rank 0 only).
+    Returns the concatenated columns on rank 0, None elsewhere."""
     import torch
     import torch.distributed as dist
     n = int(cols[0].numel())
     sizes = all_gather_ints(n, world, device)
-    mx = max(max(sizes), 1)
-    rec = torch.stack([c if device is not None else c.cpu() for c in cols], dim=1)
-    pad = torch.zeros((mx, len(cols)), dtype=rec.dtype, device=rec.device)
-    pad[:n] = rec
-    got = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(got, pad)
-    if dist.get_rank() != 0:
+    rec = torch.stack([c if device is not None else c.cpu() for c in cols], dim=1).contiguous()
+    me = dist.get_rank()
+    if me != 0:
+        if n:
+            dist.send(rec, 0)
         return None
-    out = torch.cat([g[:k] for g, k in zip(got, sizes)])
+    got = [rec if r == 0 else torch.empty((sizes[r], len(cols)), dtype=rec.dtype, device=rec.device) for r in range(world)]
+    for q in [dist.irecv(got[r], r) for r in range(1, world) if sizes[r]]:
+        q.wait()
+    out = torch.cat(got)
     return [out[:, j].contiguous() for j in range(len(cols))]
