@@ -491,6 +491,8 @@ struct Launcher {
     long long NTp;  // padded tile count of THIS call (launch geometry is per call, never stored in the handle)
     int rc = 0;
     bool side_by_side = false;   // the seq and signal branches of this call run on two streams
+    hipEvent_t last_ev = nullptr;   // profiling: the event behind the previous launch ...
+    hipStream_t last_s = nullptr;   // ... and its stream
     template <class F> void run(const char* name, F&& f) {
         if (rc) return;
         hipEvent_t ea = nullptr, eb = nullptr;
@@ -500,12 +502,15 @@ struct Launcher {
                 if (hipEventCreate(&e) != hipSuccess) { rc = fail(DSP_EHIP, "hipEventCreate failed"); return; }
                 m->event_pool.push_back(e);
             }
-            ea = m->event_pool[m->event_used++]; eb = m->event_pool[m->event_used++];
-            hipEventRecord(ea, s);
+            // consecutive launches of one stream share their boundary event (9 records per forward instead of 16: an event
+            // record costs the stream ~4 us, 0.06 ms per forward -- 9 % of a 512-site one)
+            if (last_ev && last_s == s) ea = last_ev;
+            else { ea = m->event_pool[m->event_used++]; hipEventRecord(ea, s); }
+            eb = m->event_pool[m->event_used++];
         }
         const int e = f();
         if (e != 0) { rc = fail(DSP_EHIP, "launch %s failed: %s", name, hipGetErrorString((hipError_t)e)); return; }
-        if (m->prof) { hipEventRecord(eb, s); m->prof_entries.push_back({name, ea, eb}); }
+        if (m->prof) { hipEventRecord(eb, s); m->prof_entries.push_back({name, ea, eb}); last_ev = eb; last_s = s; }
         if (m->sync_each) {  // DSP_SYNC_EACH (read once, in dsp_model_create): attribute an asynchronous GPU fault to its launch
             fprintf(stderr, "[launch] %s ...", name);
             const hipError_t se = hipStreamSynchronize(s);
