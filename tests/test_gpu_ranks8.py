@@ -33,7 +33,20 @@ def _ranks(args, world=WORLD, timeout=1200, env=None):
            "127.0.0.1", "--master-port", str(port), "-m", "deepsignal_plant_amd.deepsignal_plant", "call_mods"] + args
     e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     e.update(env or {})
-    return subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=e)
+    e["DSP_TIMING"] = "1"      # the run's milestones on rank 0's stdout
+    import time
+    t0 = time.time()
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=e)
+    dt = time.time() - t0
+    if dt > 40:                # eight ranks on a few thousand rows take 4-5 s (cold imports: 10-15): keep what a slow run says
+        print("[slow 8-rank run] %.1f s: %s" % (dt, " ".join(args)))
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out", "r4"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "r4", "slow_8rank_runs.txt"), "a") as f:
+                f.write("%.1f s: %s\n%s\n%s\n\n" % (dt, " ".join(args), r.stdout[-3000:], r.stderr[-3000:]))
+        except OSError:
+            pass
+    return r
 
 
 def test_config4_bench_at_eight_ranks_tiles_the_site_space_and_gathers_every_call():
