@@ -182,16 +182,18 @@ int64_t dsp_copy_rows_index(const char* text, size_t len, char* dst, uint64_t* r
  * counts.  dst needs cap_bytes + 1 bytes, row_off want_rows + 1 entries.  0 rows with *consumed == 0: no row fits cap_bytes. */
 int64_t dsp_read_rows_index(int32_t fd, uint64_t file_off, uint64_t range_bytes, uint64_t cap_bytes, int64_t want_rows,
                             int32_t at_eof, char* dst, uint64_t* row_off, uint64_t* consumed);
-/* The row grammar of _read_features_file (call_modifications.py:76-86) parsed ON THE GPU (csrc/dsp_parse_dev.hip): one
- * thread per row over the raw text in HBM (text_dev: the bytes dsp_copy_rows_index staged, + 64 readable bytes behind
- * them; row_off_dev: its n + 1 offsets), into the arrays of dsp_parse_feature_rows (all DEVICE pointers; lens i32).
+/* The row grammar of _read_features_file (call_modifications.py:76-86) parsed ON THE GPU (csrc/dsp_parse_dev.hip) over the
+ * raw text in HBM -- rows that fit the LDS: a workgroup stages four rows, finds their delimiters and parses ONE TOKEN PER
+ * THREAD; longer rows: one thread per row + one per float list.  text_dev: the bytes dsp_copy_rows_index /
+ * dsp_read_rows_index staged, + 64 readable bytes behind them; row_off_dev: its n + 1 offsets; text_bytes: the bytes staged
+ * (no offset beyond them is followed); outputs: the arrays of dsp_parse_feature_rows (all DEVICE pointers; lens i32);
+ * seg_dev: scratch of n x (seq_len + 4) words.
  * A row is either parsed completely by the plain-row rules of the host's one-pass parser -- decimal -> integer mantissa
  * (<= 18 digits, < 2^53) times / divided by an exact power of ten (|e| <= 22) in float64, ONE correctly rounded
- * operation, then float32: bit-identical to the host parser -- or left alone and counted in *n_flagged_dev with
- * status_dev[row] = 1 (*n_flagged_dev counts flag events: zero = every row was plain; seg_dev: scratch of n x (seq_len + 4)
- * words for the rows' segment tables; text_bytes: the bytes staged at text_dev -- no offset beyond them is followed) (anything else: blanks, '+', inf / nan, long mantissas, a wrong field count, an unknown base, ...):
- * the caller hands blocks with flagged rows to dsp_parse_feature_rows, which also owns the error messages.
- * Asynchronous on `stream`; *n_flagged_dev is zeroed by the launch. */
+ * operation, then float32: bit-identical to the host parser -- or, for anything else (blanks, '+', inf / nan, long
+ * mantissas, a wrong field count, an unknown base, ...), left alone with status_dev[row] = 1 and counted in *n_flagged_dev
+ * (flag events: zero = every row was plain).  The caller hands blocks with flagged rows to dsp_parse_feature_rows, which
+ * also owns the error messages.  Asynchronous on `stream`; *n_flagged_dev is zeroed by the launch. */
 int32_t dsp_parse_rows_device(void* stream, const char* text_dev, const uint64_t* row_off_dev, int64_t n, int32_t seq_len,
                               int32_t signal_len, uint8_t* kmer, float* means, float* stds, int32_t* lens, float* signals,
                               int32_t* labels, uint32_t* info_len, uint32_t* read_off, uint32_t* read_len,
