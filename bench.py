@@ -122,12 +122,23 @@ def cpu_baseline(model_cfg_kwargs, sd_numpy, seed):
     finally:
         import shutil
         shutil.rmtree(tmp, ignore_errors=True)
-    return {"value": round(done / dt, 1), "unit": "sites/s", "cores": threads, "kind": "port",
+    return {"value": round(done / dt, 1), "unit": "sites/s", "cores": threads, "cpu_model": _cpu_model(), "kind": "port",
             "sample": "the first %d of a 100,000-row synthetic feature TSV (%.0f MB; BASELINE.json configs[0]'s shape): parse "
                       "%.2f s for the file + forward in %d-row chunks %.2f s (oracle/dsp_oracle.c fp32 + OpenMP, same "
                       "model/weights, Philox N(0,1) states) + format and write %.2f s" % (done, size / 1e6, t_parse, chunk, t_fwd, t_fmt),
             "seconds": {"parse_whole_file": round(t_parse, 3), "forward": round(t_fwd, 3), "format_write": round(t_fmt, 3)},
             "reference_proper": REFERENCE_CPU}
+
+
+def _cpu_model():
+    """the host CPU's name, printed next to the CPU baseline"""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
 
 
 def parse_args(argv=None):
