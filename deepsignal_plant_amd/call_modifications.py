@@ -37,6 +37,7 @@ from .models import ModelBiLSTM
 from .utils.process_utils import display_args, str2bool
 
 
+_WRITER_DELAY = float(os.environ.get("DSP_WRITER_DELAY_MS", "0")) / 1e3
 _TICKS = []   # DSP_TIMING=1: (label, seconds since call_mods started) of the run's milestones, printed by rank 0 at the end
 
 
@@ -159,7 +160,8 @@ class _Writer(threading.Thread):
                     item = self.q.get()
                     if item is None:
                         break
-                    block, probs_t, labels_t, event = item
+                    block, probs_t, labels_t, event = item[:4]
+                    done = item[4] if len(item) > 4 else None   # hands the result slot back once its contents are formatted
                     if probs_t is None:   # a block without rows
                         if self.mark_blocks:
                             if self.is_gzip:
@@ -169,6 +171,9 @@ class _Writer(threading.Thread):
                         self.reader.release(block)
                         continue
                     event.synchronize()
+                    if _WRITER_DELAY:   # DSP_WRITER_DELAY_MS (tests): a writer that cannot keep up with the GPU
+                        import time as _time
+                        _time.sleep(_WRITER_DELAY)
                     probs = probs_t.numpy()[:block.rows.n]
                     labels = labels_t.numpy()[:block.rows.n]
                     if self.n_vocab < 16 and block.rows.n and int(np.asarray(block.rows.kmer)[:block.rows.n].max()) >= self.n_vocab:
@@ -189,6 +194,8 @@ class _Writer(threading.Thread):
                         agg, side_stream = self.freq_dev
                         agg.add_block(block.rows, probs, labels, block.first_row, stream=side_stream)
                     self.rows += block.rows.n
+                    if done is not None:
+                        done()
                     self.reader.release(block)
             if self.mark_blocks and self.is_gzip:
                 self.block_ends = list(wf.block_ends)   # complete once the writer is closed
@@ -278,7 +285,13 @@ def _call_mods_file(args, rank, local_rank, world):
     nout = 4
     out_probs = [torch.empty((cap, args.class_num), dtype=torch.float32, pin_memory=True) for _ in range(nout)]
     out_labels = [torch.empty((cap,), dtype=torch.uint8, pin_memory=True) for _ in range(nout)]
-    out_events = [torch.cuda.Event() for _ in range(nout)]
+    # A result slot is refilled only after the WRITER has handed it back (it has formatted the slot's previous block) -- that
+    # the copy into it has finished says nothing about the reader of the buffer.  (Until late in round 4 the slots went round
+    # by block number, guarded by the copy's event: safe only while fewer blocks were in flight than slots, which the fifth
+    # reader slot of the device parser broke at the end of a run with a writer slower than the GPU.)
+    free_out = queue.Queue()
+    for i in range(nout):
+        free_out.put(i)
     k = 0
     n_rows = 0
     _tick("pinned output buffers")
@@ -326,12 +339,18 @@ def _call_mods_file(args, rank, local_rank, world):
                                                init_states=file_states.for_rows(block.first_row, n) if file_states else None)
         if freq_dev is not None:  # the calls go into the device-side call_freq records straight from HBM
             freq_dev.add_block(rows, probs, labels, block.first_row, stream=stream)
-        slot = k % nout
-        out_events[slot].synchronize()  # the writer is done with this slot's previous contents
+        while True:
+            try:
+                slot = free_out.get(timeout=0.2)
+                break
+            except queue.Empty:
+                if writer.error is not None:   # a dead writer hands nothing back: the main loop ends the run with its error
+                    return
+        ev_out = torch.cuda.Event()
         out_probs[slot][:n].copy_(probs, non_blocking=True)
         out_labels[slot][:n].copy_(labels, non_blocking=True)
-        out_events[slot].record(stream)
-        writer.q.put((block, out_probs[slot], out_labels[slot], out_events[slot]))
+        ev_out.record(stream)
+        writer.q.put((block, out_probs[slot], out_labels[slot], ev_out, lambda s_=slot: free_out.put(s_)))
         k += 1
         n_rows += n
 
@@ -469,7 +488,9 @@ def _call_mods_reads(args, rank, local_rank, world):
 
     stream = torch.cuda.current_stream(dev)
     n_rows, k = 0, 0
-    ring = [dict(cap=0, ev=None) for _ in range(6)]  # pinned result slots (the writer queue holds at most 4)
+    ring = [dict(cap=0, ev=None) for _ in range(6)]  # pinned result slots: SIX, because the writer holds at most five batches
+    # (four in its queue + the one it is formatting) -- the slot of batch k is the slot of batch k - 6, which the writer has
+    # finished by the time batch k - 1 went into its queue
     fwd_chunk = 65536
     model.reserve(fwd_chunk)
     row_base = rank << 44  # row numbers for the output order only (rank-major = file order); the initial states of a
@@ -490,7 +511,7 @@ def _call_mods_reads(args, rank, local_rank, world):
         slot = ring[k % len(ring)]
         k += 1
         if slot["ev"] is not None:
-            slot["ev"].synchronize()  # the writer is done with this slot's previous contents
+            slot["ev"].synchronize()  # (the copy; that the writer is done with the contents follows from the slot count above)
         if slot["cap"] < n:
             cap = n + n // 4
             slot.update(cap=cap, probs=torch.empty((cap, args.class_num), dtype=torch.float32, pin_memory=True),

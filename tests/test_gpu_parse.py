@@ -239,3 +239,24 @@ def test_cli_gives_the_same_bytes_whichever_side_parses(tmp_path):
     for mode in ("host", "device"):
         r = _cli(["-i", plain, "-m", ck, "-o", out, "--parse_on", mode], env=blk)
         assert r.returncode != 0 and "KeyError: 'X'" in r.stderr, mode
+
+
+@pytest.mark.parametrize("mode", ["device", "host"])
+def test_a_writer_that_lags_behind_the_gpu_does_not_lose_a_block(tmp_path, mode):
+    """The results of a block wait for the writer in one of a few page-locked slots.  A slot may only be refilled once the
+    writer has FORMATTED its previous contents -- not merely once the copy into it has finished: with a writer slower than the
+    GPU (a single deflate thread, a slow disk; here DSP_WRITER_DELAY_MS) the last blocks of a run used to land in slots the
+    writer was still reading (device parser: five reader slots against four result slots).  20 small blocks, the writer 40 ms
+    behind on each: the calls must be the bytes of the undelayed run."""
+    from tests.test_gpu_cli import _ckpt, _folded_rows
+    ck = _ckpt(tmp_path)
+    plain = str(tmp_path / "rows.tsv")
+    open(plain, "wb").write(_folded_rows(n_rep=6))
+    blk = {"DSP_BLOCK_BYTES": "120000"}
+    ref, out = str(tmp_path / "ref.tsv"), str(tmp_path / "slow.tsv")
+    r = _cli(["-i", plain, "-m", ck, "-o", ref, "--seed", "3", "--parse_on", mode], env=blk)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = _cli(["-i", plain, "-m", ck, "-o", out, "--seed", "3", "--parse_on", mode], env=dict(blk, DSP_WRITER_DELAY_MS="40"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    a, b = open(ref, "rb").read(), open(out, "rb").read()
+    assert a.count(b"\n") == 1200 and a == b
