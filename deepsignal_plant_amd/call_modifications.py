@@ -488,9 +488,10 @@ def _call_mods_reads(args, rank, local_rank, world):
 
     stream = torch.cuda.current_stream(dev)
     n_rows, k = 0, 0
-    ring = [dict(cap=0, ev=None) for _ in range(6)]  # pinned result slots: SIX, because the writer holds at most five batches
-    # (four in its queue + the one it is formatting) -- the slot of batch k is the slot of batch k - 6, which the writer has
-    # finished by the time batch k - 1 went into its queue
+    ring = [dict(cap=0) for _ in range(6)]  # pinned result slots; a slot is refilled once the writer has handed it back
+    free_ring = queue.Queue()
+    for i in range(len(ring)):
+        free_ring.put(i)
     fwd_chunk = 65536
     model.reserve(fwd_chunk)
     row_base = rank << 44  # row numbers for the output order only (rank-major = file order); the initial states of a
@@ -508,10 +509,17 @@ def _call_mods_reads(args, rank, local_rank, world):
         n = ext.n
         if n == 0:
             continue
-        slot = ring[k % len(ring)]
+        si = None
+        while si is None:
+            try:
+                si = free_ring.get(timeout=0.2)
+            except queue.Empty:
+                if writer.error is not None:
+                    break
+        if si is None:        # the writer died: nothing comes back (its error ends the run below)
+            continue
+        slot = ring[si]
         k += 1
-        if slot["ev"] is not None:
-            slot["ev"].synchronize()  # (the copy; that the writer is done with the contents follows from the slot count above)
         if slot["cap"] < n:
             cap = n + n // 4
             slot.update(cap=cap, probs=torch.empty((cap, args.class_num), dtype=torch.float32, pin_memory=True),
@@ -528,12 +536,11 @@ def _call_mods_reads(args, rank, local_rank, world):
         h_kmer.copy_(ext.kmer, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(stream)
-        slot["ev"] = ev
         ext.rows.kmer = h_kmer.numpy()  # valid once `ev` has passed; the writer waits on it first
         blk = _ReadsBlock()
         blk.rows = ext.rows
         blk.first_row = row_base + n_rows
-        writer.q.put((blk, h_probs, h_labels, ev))
+        writer.q.put((blk, h_probs, h_labels, ev, lambda i_=si: free_ring.put(i_)))
         n_rows += n
     _tick("last forward issued")
     writer.q.put(None)
