@@ -266,6 +266,8 @@ def check(rc: int):
     if rc == DSP_EINVAL:
         raise ValueError(msg)
     if rc == DSP_EPARSE:
+        if "bad field count" in msg:   # a row with fewer than 12 fields (a blank line too): words[k] of the reference's reader
+            raise IndexError("list index out of range (%s)" % msg)   # (call_modifications.py:84-86, :117) is an IndexError
         raise ValueError(msg)
     if rc == DSP_EKEY:   # base2code_dna[x] of the reference's reader (call_modifications.py:84): KeyError(x)
         err = KeyError(msg.split("'")[1] if msg.count("'") >= 2 else msg)

@@ -9,7 +9,7 @@
  * (e.g. torch.Tensor.data_ptr() on PyTorch-ROCm); the handle owns only repacked weights + scratch.
  *
  * Return convention: 0 on success, negative dsp_status on error; dsp_last_error() returns a
- * thread-local message.  The Python mirror maps DSP_EINVAL / DSP_EPARSE -> ValueError, DSP_EKEY -> KeyError, the rest -> RuntimeError,
+ * thread-local message.  The Python mirror maps DSP_EINVAL / DSP_EPARSE -> ValueError (a short row's DSP_EPARSE -> IndexError), DSP_EKEY -> KeyError, the rest -> RuntimeError,
  * matching the exceptions the reference raises (models.py:127-128, call_modifications.py:219-223).
  */
 #ifndef DSP_AMD_H

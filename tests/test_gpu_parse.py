@@ -144,7 +144,7 @@ def test_device_parser_never_accepts_what_the_host_parser_rejects_and_never_diff
         for piece in pieces:
             try:
                 h = textio.parse_rows(piece + b"\n", 13, 16) if piece else None
-            except (ValueError, KeyError):
+            except (ValueError, KeyError, IndexError):
                 h = None
             if h is None or h.n != 1:
                 assert dev["status"][i] == 1, piece[:80]

@@ -154,7 +154,7 @@ def test_bgzf_writer_takes_lists_of_buffers_without_copying_them_through_the_car
 def test_reader_on_degenerate_files(tmp_path, gz):
     """what a user can hand to call_mods -i: an empty file, one row without a newline, CRLF ends, extra columns (ignored
     like words[11] ignores them, call_modifications.py:75-92) -- and a blank line, which the reference dies on with an
-    IndexError in a worker (words[4]) and this reader refuses by row number"""
+    IndexError in a worker (words[4]) and this reader refuses with an IndexError that names the row"""
     rows = open(os.path.join(GOLDEN, "f2_rows.tsv"), "rb").read().split(b"\n")[:5]
     cases = {"empty": (b"", 0), "one_no_newline": (rows[0], 1), "crlf": (b"\r\n".join(rows[:3]) + b"\r\n", 3),
              "extra_col": (rows[0] + b"\textra\n" + rows[1] + b"\n", 2), "blank_line": (rows[0] + b"\n\n" + rows[1] + b"\n", None)}
@@ -165,7 +165,7 @@ def test_reader_on_degenerate_files(tmp_path, gz):
         reader.start()
         n = 0
         if want is None:
-            with pytest.raises(ValueError, match="malformed feature row 1"):
+            with pytest.raises(IndexError, match="malformed feature row 1"):   # (the reference's exception type, the row number besides)
                 for blk in reader:
                     reader.release(blk)
             continue

@@ -73,7 +73,7 @@ def main():
         assert staged.n == len(lines)
         try:
             host = textio.parse_rows(data, L, S)
-        except (ValueError, KeyError):
+        except (ValueError, KeyError, IndexError):
             host = None                                   # (an exotic token the host parser rejects: row by row then)
         for i in range(staged.n):
             if dev["status"][i]:
@@ -108,7 +108,7 @@ def main():
             for piece in blk.split(b"\n")[:-1]:
                 try:
                     h = textio.parse_rows(piece + b"\n", L, S) if piece else None
-                except (ValueError, KeyError):
+                except (ValueError, KeyError, IndexError):
                     h = None
                 if h is None or h.n != 1:
                     assert dev["status"][i] == 1, piece[:120]

@@ -15,7 +15,7 @@ def both(data):
         try:
             r=textio.parse_rows(data,13,16,nthreads=1)
             out.append(("ok",r.n,r.kmer.tobytes(),r.means.tobytes(),r.stds.tobytes(),r.lens.tobytes(),r.signals.tobytes(),r.labels.tobytes(),r.row_off.tobytes(),r.info_len.tobytes(),r.read_off.tobytes(),r.read_len.tobytes()))
-        except (ValueError, KeyError) as e:
+        except (ValueError, KeyError, IndexError) as e:
             out.append(("err",type(e).__name__+str(e)))
     return out
 t0=time.time(); n=0; nerr=0
