@@ -260,3 +260,12 @@ def test_a_writer_that_lags_behind_the_gpu_does_not_lose_a_block(tmp_path, mode)
     assert r.returncode == 0, r.stderr[-3000:]
     a, b = open(ref, "rb").read(), open(out, "rb").read()
     assert a.count(b"\n") == 1200 and a == b
+    if mode == "device":
+        # ... and with two ranks dealing the blocks of a foreign .gz between them, calls deflated on the way out
+        import gzip
+        from tests.test_gpu_cli import _two_ranks
+        fz = str(tmp_path / "rows_foreign.tsv.gz")
+        open(fz, "wb").write(gzip.compress(open(plain, "rb").read(), 1))
+        r = _two_ranks(["-i", fz, "-m", ck, "-o", out, "--seed", "3", "--gzip"], env=dict(blk, DSP_WRITER_DELAY_MS="40"))
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert gzip.open(out + ".gz", "rb").read() == a
