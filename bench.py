@@ -249,6 +249,19 @@ def main(argv=None):
     dt = time.perf_counter() - t0
     prof = model.profile_read()
     model.profile(False)
+    # the same steps once more WITHOUT the per-launch events (untimed by the contract; reported beside the line): an event record
+    # costs the stream ~4 us, 9 of them a forward -- nothing at 65,536 sites, 1 % at 4,096, 9 % at 512 (profiles/r4/profile_events_overhead.txt)
+    ms_events_off = None
+    if world == 1 and K > 0:
+        ko = min(K, 40)
+        for i in range(min(W, 5) + 3):      # (reading the events back left the GPU idle: back to its clocks first)
+            step(i)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(ko):
+            step(i)
+        torch.cuda.synchronize()
+        ms_events_off = (time.perf_counter() - t1) / ko * 1e3
 
     ranges = [[site0, site1]]
     gather_info = None
@@ -363,6 +376,9 @@ def main(argv=None):
                          "hbm_gbps_algorithmic": round(value / world * 1048 / 1e9, 3),
                          "hbm_frac_algorithmic": round(value / world * 1048 / 8e12, 6),  # of 8 TB/s: the north_star's "HBM roofline" does not bind
                          "kernel_time_frac_of_wall": round(all_ms * 1e-3 / dt, 4) if dt > 0 else None,
+                         "ms_per_step_events_off": round(ms_events_off, 4) if ms_events_off else None,
+                         "whole_forward_frac_events_off": round(B / (ms_events_off * 1e-3) * flops_site / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4)
+                         if ms_events_off else None,
                          "ms_per_step_by_launch": {k: round(sum(v) / max(K, 1), 4) for k, v in per_launch.items()},
                          "kernel_src_sha16": kernel_source_hash(),
                          "note": ("fp32 MFMA and VALU work do not overlap on gfx950 (profiles/r2/micro_mfma_cell_overlap.txt): "
