@@ -139,8 +139,10 @@ int32_t dsp_forward(dsp_model* m, void* stream, int64_t n_sites, const void* kme
 int32_t dsp_debug_read_activation(dsp_model* m, void* stream, int32_t which, int64_t n_sites, float* host_out);
 
 /* Per-kernel timing measured with HIP events on the launch stream (used by bench.py for the roofline
- * line).  While enabled, every launch of every dsp_forward is bracketed by two events; entries
- * accumulate until dsp_profile_read() drains them (call it after synchronising the stream).
+ * line).  While enabled, every launch of every dsp_forward is bracketed by two events (consecutive launches of
+ * one stream share the event between them: a launch's time then includes the gap before it; an event record costs
+ * the stream a few microseconds -- ~0.03 ms per forward); entries accumulate until dsp_profile_read() drains them
+ * (call it after synchronising the stream).
  * names: NUL-separated list written into `names`; ms[i] per launch. Returns the launch count. */
 int32_t dsp_profile_enable(dsp_model* m, int32_t on);
 int32_t dsp_profile_read(dsp_model* m, char* names, size_t names_cap, float* ms, int32_t cap);
