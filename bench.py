@@ -103,7 +103,7 @@ def cpu_baseline(model_cfg_kwargs, sd_numpy, seed):
         probs = np.empty((n_rows, cfg.num_classes), np.float32)
         done = 0
         t1 = time.time()
-        while done < n_rows and (done == 0 or (time.time() - t0) < CPU_BASELINE_TARGET_S):
+        while done < n_rows and (done == 0 or (time.time() - t0) < 0.6 * CPU_BASELINE_TARGET_S):
             a, b = done, min(n_rows, done + chunk)
             _lg, pr = oc.forward(cfg, sd_numpy, rows.kmer[a:b].astype(np.float32), rows.means[a:b], rows.stds[a:b],
                                  rows.lens[a:b].astype(np.float32), rows.signals[a:b], init_mode="philox", seed=seed,
@@ -119,6 +119,17 @@ def cpu_baseline(model_cfg_kwargs, sd_numpy, seed):
         t_fmt = time.time() - t2
         # the parse covered the whole file: charge the sample its share of it
         dt = t_parse * done / n_rows + t_fwd + t_fmt
+        # second figure, labelled: the same port fed LARGE batches -- the oracle parallelises over blocks of sites,
+        # so a 512-row chunk leaves most cores of a big host idle; this is what the host could do if the reference's batch
+        # size were not 512 (forward only, rounds 1-3's definition of the baseline)
+        big, big_done, tb = 8192, 0, time.time()
+        while big_done + big <= n_rows and (big_done == 0 or (time.time() - tb) < 0.4 * CPU_BASELINE_TARGET_S):
+            a, b = big_done, big_done + big
+            oc.forward(cfg, sd_numpy, rows.kmer[a:b].astype(np.float32), rows.means[a:b], rows.stds[a:b],
+                       rows.lens[a:b].astype(np.float32), rows.signals[a:b], init_mode="philox", seed=seed, site_offset=a,
+                       nthreads=threads)
+            big_done = b
+        t_big = time.time() - tb
     finally:
         import shutil
         shutil.rmtree(tmp, ignore_errors=True)
@@ -127,7 +138,21 @@ def cpu_baseline(model_cfg_kwargs, sd_numpy, seed):
                       "%.2f s for the file + forward in %d-row chunks %.2f s (oracle/dsp_oracle.c fp32 + OpenMP, same "
                       "model/weights, Philox N(0,1) states) + format and write %.2f s" % (done, size / 1e6, t_parse, chunk, t_fwd, t_fmt),
             "seconds": {"parse_whole_file": round(t_parse, 3), "forward": round(t_fwd, 3), "format_write": round(t_fmt, 3)},
+            "chunk_rows": chunk,
+            "port_forward_only_large_batches": {"value": round(big_done / t_big, 1) if big_done else None, "unit": "sites/s",
+                                                "chunk_rows": big, "sites": big_done, "seconds": round(t_big, 3),
+                                                "what": "the same C port, forward only, %d-row batches (every core busy): "
+                                                        "not the reference's configuration, which feeds 512" % big},
             "reference_proper": REFERENCE_CPU}
+
+
+def _rccl_version(torch):
+    """version of the RCCL library torch is linked against ("nccl" IS RCCL on ROCm), e.g. "2.26.6" """
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception as e:
+        return "unknown (%r)" % (e,)
 
 
 def _cpu_model():
@@ -156,6 +181,9 @@ def parse_args(argv=None):
                     help="products of the combined stack: fp32 MFMA (default, what `value` is measured in) or the opt-in "
                          "split-bf16 emulation (include/dsp_amd.h DSP_PREC_*)")
     ap.add_argument("--no_alt", action="store_true", help="skip the extra split-precision measurement reported under alt_precision")
+    ap.add_argument("--n1_ms", type=float, default=None,
+                    help="ms_per_step of the N=1 run of this same command: the line then carries scaling_efficiency_vs_n1 = "
+                         "n1_ms / ms_per_step (weak scaling: every rank does the N=1 run's work)")
     ap.add_argument("--gather", action="store_true",
                     help="optional final gather of EVERY step's per-site probabilities to rank 0 (dist.gather_probs: RCCL "
                          "send/recv over xGMI, off-root memory O(own rows)); outside the timed region, reported under `gather`")
@@ -196,6 +224,8 @@ def main(argv=None):
                          "with --nproc-per-node equal to --gpus)" % (args.gpus, world))
     ndev = torch.cuda.device_count()
     assert ndev > 0, "bench.py needs an MI355X"
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    my_bdf, my_cpus = dsp_dist.place_rank(rank, local_rank, local_world, ndev)   # NUMA placement by default when world > 1
     dev_index = local_rank % ndev
     # one process per GPU over RCCL; if fewer GPUs than ranks are visible (the 1-GPU dev box), the ranks share GPUs and
     # the control-plane collectives (barrier, max of the wall time) run over gloo instead.  DSP_FORCE_DIST=1 makes a lone
@@ -204,7 +234,6 @@ def main(argv=None):
     multi = dsp_dist.collective(world)
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
-    cdev = dev if backend == "nccl" else None
 
     K, W, B = args.steps, args.warmup, args.batch
     model = ModelBiLSTM(13, 16, args.layernum1, args.layernum2, 2, 0, args.hid_rnn, 16, 4, True, True, module=args.model_type,
@@ -223,7 +252,7 @@ def main(argv=None):
     outs = None
     # --gather: every step's probabilities are kept (8 B per site, a device-to-device copy of 0.5 MB per step, on the
     # compute stream) so that the final gather moves the whole run's calls, as BASELINE configs[3] describes it
-    kept = torch.empty((K * B, 2), dtype=torch.float32, device=dev) if args.gather and K > 0 else None
+    kept = torch.empty((K * B, model.num_classes), dtype=torch.float32, device=dev) if args.gather and K > 0 else None
 
     def step(i, keep=False):
         model.site_offset = site0 + i * B
@@ -265,18 +294,41 @@ def main(argv=None):
 
     ranges = [[site0, site1]]
     gather_info = None
+    devices = None
     if multi:
-        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        a = dsp_dist.all_gather_ints(site0, world, cdev)
-        b = dsp_dist.all_gather_ints(site1, world, cdev)
+        # every collective below is the same on RCCL and on gloo (dist.comm_device: tensors hop to the host under gloo)
+        dt_mine = dt
+        dt = dsp_dist.all_reduce_max_float(dt, world, dev)
+        a = dsp_dist.all_gather_ints(site0, world, dev)
+        b = dsp_dist.all_gather_ints(site1, world, dev)
         ranges = [[x, y] for x, y in zip(a, b)]
+        # proof of N GPUs: every rank names the device it ran on (PCI name and uuid from the HIP runtime, through the C ABI),
+        # its host, its CPUs and its OWN wall time; with RCCL the PCI names must be pairwise distinct per host
+        from deepsignal_plant_amd import _native
+        ident = {"rank": rank, "host": socket.gethostname(), "local_rank": local_rank, "hip_device": dev_index,
+                 "pci_bdf": my_bdf, "uuid": _native.device_uuid(dev_index), "name": torch.cuda.get_device_name(dev_index),
+                 "numa_node": dsp_dist._numa_node_cpus(my_bdf)[0],
+                 "cpus": dsp_dist.cpus_text(my_cpus if my_cpus is not None else sorted(os.sched_getaffinity(0))),
+                 "pinned": my_cpus is not None, "ms_per_step": round(dt_mine / max(K, 1) * 1e3, 3),
+                 "visible_devices": ndev}
+        devices = [None] * world
+        dist.all_gather_object(devices, ident)
+        distinct = len({(d["host"], d["pci_bdf"], d["uuid"]) for d in devices}) == world
+        must = backend == "nccl" or os.environ.get("DSP_REQUIRE_DISTINCT_GPUS") == "1"
+        if must and world > 1 and not distinct:
+            if rank == 0:
+                sys.stderr.write("bench.py: %d ranks but only %d distinct GPUs: %s -- a SCALE line from this run would not "
+                                 "measure %d GPUs; refusing to print one\n" % (
+                                     world, len({(d["host"], d["pci_bdf"], d["uuid"]) for d in devices}),
+                                     [(d["rank"], d["pci_bdf"]) for d in devices], world))
+            dist.barrier()
+            dist.destroy_process_group()
+            return 3
         if kept is not None:  # the optional final gather of the run's per-site probabilities (a true gather to rank 0)
             torch.cuda.synchronize()
             dist.barrier()
             tg = time.perf_counter()
-            got = dsp_dist.gather_probs(kept if backend == "nccl" else kept.cpu(), world)
+            got = dsp_dist.gather_probs(kept, world)   # (tensors on this GPU over RCCL, on the host over gloo: dist.comm_device)
             torch.cuda.synchronize()
             tg = time.perf_counter() - tg
             if rank == 0:
@@ -362,7 +414,10 @@ def main(argv=None):
                        "init_state": "in-kernel Philox N(0,1) (stand-in for torch.randn, models.py:169-176)",
                        "weights": "seeded random state_dict, PyTorch default-init scale", "parallelism": "range-shard x%d" % world,
                        "backend": ("rccl" if backend == "nccl" else "gloo (ranks share %d GPU)" % ndev) if multi else "none",
-                       "rank_site_ranges": ranges, "flops_per_site": flops_site},
+                       "rank_site_ranges": ranges, "flops_per_site": flops_site,
+                       **({"rccl_version": _rccl_version(torch) if backend == "nccl" else None,
+                           "distinct_gpus": len({(d["host"], d["pci_bdf"], d["uuid"]) for d in devices}),
+                           "ranks": devices} if devices else {})},
             "roofline": {"bound": "mfma", "kernel": "dsp_lstm_kernel (combined stack)" if nprod == 1 else "dsp_lstm_split_kernel<%d>" % nprod,
                          "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                          "traffic": traffic, "algorithmic_bytes_per_launch": algo_launch,
@@ -385,6 +440,9 @@ def main(argv=None):
                                  "with the LSTM cell phase counted the bound of this kernel is 0.974 of the MFMA peak "
                                  "(DESIGN.md section 3)") if nprod == 1 else None},
         }
+        if args.n1_ms:
+            line["scaling_efficiency_vs_n1"] = round(args.n1_ms / (dt / max(K, 1) * 1e3), 4)
+            line["n1_ms_per_step"] = args.n1_ms
         if gather_info:
             line["gather"] = gather_info
         if alt:

@@ -250,8 +250,24 @@ def lib():
     L.dsp_format_feature_rows_parts.argtypes = L.dsp_format_feature_rows.argtypes + [ctypes.c_void_p, ctypes.c_void_p]
     L.dsp_feature_row_bound.restype = ctypes.c_uint64
     L.dsp_feature_row_bound.argtypes = [ctypes.c_int32, ctypes.c_int32]
+    for fn in (L.dsp_device_pci_bdf, L.dsp_device_uuid):
+        fn.restype = ctypes.c_int64
+        fn.argtypes = [ctypes.c_int32, ctypes.c_char_p, ctypes.c_size_t]
     _lib = L
     return L
+
+
+def device_pci_bdf(device: int) -> str:
+    """sysfs name of HIP device `device` ("0000:c1:00.0"): /sys/bus/pci/devices/<that>/numa_node, bench.py's proof of N GPUs"""
+    buf = ctypes.create_string_buffer(64)
+    check(int(lib().dsp_device_pci_bdf(int(device), buf, 64)))
+    return buf.value.decode()
+
+
+def device_uuid(device: int) -> str:
+    buf = ctypes.create_string_buffer(40)
+    check(int(lib().dsp_device_uuid(int(device), buf, 40)))
+    return buf.value.decode()
 
 
 def last_error() -> str:

@@ -211,8 +211,9 @@ def _call_mods_file(args, rank, local_rank, world):
     import torch.distributed as dist
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    # control-plane collectives run on the GPU over RCCL, or on the host when the ranks had to fall back to gloo
-    coll_dev = dev if (dsp_dist.collective(world) and dist.get_backend() == "nccl") else None
+    # control-plane collectives: tensors on this GPU over RCCL, on the host when the ranks had to fall back to gloo --
+    # dist.comm_device decides, the collectives themselves are the same
+    coll_dev = dev
     model = load_model(args, local_rank)
     mode, states_path = init_state_mode(args)
     file_states = FileInitStates(states_path, model) if mode == "file" else None
@@ -571,18 +572,22 @@ def _remove_stale_parts(part_path, world):
 _BGZF_EOF = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
 
 
-def _merge_parts(out_path, world, interleaved=False):
+def _merge_parts(out_path, world, interleaved=False, is_gzip=None):
     """concatenate the ranks' part files in rank order (gzip / BGZF members concatenate into a valid .gz; the empty
     end-of-file member of every part but the last is dropped so that the result is one well-formed BGZF file).
     interleaved: THIS run dealt the input's blocks round-robin (a foreign .gz) and every rank wrote its piece table --
-    the run says so, the disk is not asked (a stale table of an aborted run must not choose the merge)."""
+    the run says so, the disk is not asked (a stale table of an aborted run must not choose the merge).
+    is_gzip: the run's --gzip flag -- whether the parts ARE BGZF is what the run wrote, not what -o is called (a plain-text
+    `-o calls.gz` without --gzip is plain text, as the reference writes it: ADVICE r4); None = the old guess from the name."""
+    if is_gzip is None:
+        is_gzip = out_path.endswith(".gz")
     parts = ["%s.part%05d" % (out_path, r) for r in range(world)]
     if interleaved:
         # interleaved sharding (a foreign .gz): piece k of rank r is block k * world + r of the input.  Pieces of a
         # --gzip part are whole BGZF members; the parts' end-of-file members are dropped and one is written at the end
         ends = [np.fromfile(p + ".blocks", np.int64) for p in parts]
         for p, e in zip(parts, ends):   # a piece table describes its part file up to the end-of-file member, or it is not its own
-            want = os.path.getsize(p) - (len(_BGZF_EOF) if out_path.endswith(".gz") else 0)
+            want = os.path.getsize(p) - (len(_BGZF_EOF) if is_gzip else 0)
             if (int(e[-1]) if len(e) else 0) != want or (len(e) > 1 and bool(np.any(np.diff(e) < 0))):
                 raise RuntimeError("%s.blocks does not describe %s (%d pieces ending at %d, file holds %d bytes of calls)"
                                    % (p, p, len(e), int(e[-1]) if len(e) else 0, want))
@@ -594,7 +599,7 @@ def _merge_parts(out_path, world, interleaved=False):
                         a = int(ends[r][k - 1]) if k else 0
                         files[r].seek(a)
                         wf.write(files[r].read(int(ends[r][k]) - a))
-            if out_path.endswith(".gz"):
+            if is_gzip:
                 wf.write(_BGZF_EOF)
         for f, p in zip(files, parts):
             f.close()
@@ -607,7 +612,7 @@ def _merge_parts(out_path, world, interleaved=False):
             size = os.path.getsize(part)
             with open(part, "rb") as rf:
                 keep = size
-                if out_path.endswith(".gz") and r < world - 1 and size >= 28:
+                if is_gzip and r < world - 1 and size >= 28:
                     rf.seek(size - 28)
                     if rf.read(28) == _BGZF_EOF:
                         keep = size - 28
@@ -647,21 +652,23 @@ def _copy_range(src_fd, dst_fd, count, dst_off):
         left -= n
 
 
-def _merge_parts_by_all_ranks(out_path, part_path, rank, world, coll_dev, interleaved=False):
+def _merge_parts_by_all_ranks(out_path, part_path, rank, world, coll_dev, interleaved=False, is_gzip=None):
     """Collective.  The per-read calls of N ranks become one file without funnelling them through rank 0: the ranks agree
     on the sizes (one all_gather), rank 0 sizes the result, and EVERY rank copies its own part to its offset at the same
     time (config 5's shape: 1 G rows = 60 GB of calls; one process copying them was a quarter of the run, with seven GPUs
     idle behind the barrier).  --gzip: the empty end-of-file member of every part but the last is left out, so that the
     result is one well-formed BGZF file.  The interleaved pieces of a foreign .gz input keep the rank-0 merge."""
     import torch.distributed as dist
+    if is_gzip is None:
+        is_gzip = out_path.endswith(".gz")
     if interleaved:   # what the run did, the same on every rank -- not what lies on the disk (ADVICE r3)
         dist.barrier()
         if rank == 0:
-            _merge_parts(out_path, world, True)
+            _merge_parts(out_path, world, True, is_gzip)
         return
     size = os.path.getsize(part_path)
     keep = size
-    if out_path.endswith(".gz") and rank < world - 1 and size >= 28:
+    if is_gzip and rank < world - 1 and size >= 28:
         with open(part_path, "rb") as rf:
             rf.seek(size - 28)
             if rf.read(28) == _BGZF_EOF:
@@ -742,15 +749,12 @@ def call_mods(args):
 
     rank, local_rank, world = dsp_dist.env_world()
     ndev = torch.cuda.device_count()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    # placement first: the page-locked slots and the staging / writer threads created below then sit next to this rank's
+    # GPU (numa by default with several ranks; DSP_RANK_AFFINITY=off opts out -- dist.pin_rank)
+    dsp_dist.place_rank(rank, local_rank, local_world, ndev)
     local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
-    numa = os.environ.get("DSP_RANK_AFFINITY") == "numa"
-    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-    bus = [getattr(torch.cuda.get_device_properties(r % ndev), "pci_bus_id", None) for r in range(local_world)] if numa else None
-    pinned = dsp_dist.pin_rank(local_rank, local_world, bus[local_rank % len(bus)] if bus else None,
-                               bus if bus and all(bus) else None)
-    if pinned is not None and rank == 0:
-        print("[main] DSP_RANK_AFFINITY: rank 0 on CPUs %s.." % ",".join(str(c) for c in pinned[:8]))
     # one process per GPU over RCCL (gloo when ranks have to share GPUs; DSP_FORCE_DIST=1: a one-rank RCCL group)
     dsp_dist.init_process_group(world, rank, local_rank, ndev)
     dist_on = dsp_dist.collective(world)
@@ -761,12 +765,12 @@ def call_mods(args):
         n_rows, part_path, out_path, interleaved = _call_mods_file(args, rank, local_rank, world)
     if dist_on:
         import torch.distributed as dist
-        cdev = torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else None
+        cdev = torch.device("cuda", local_rank)   # (dist.comm_device maps it to the host under gloo)
         total = sum(dsp_dist.all_gather_ints(n_rows, world, cdev))
         dist.barrier()
         _tick("all ranks done")
     if world > 1:
-        _merge_parts_by_all_ranks(out_path, part_path, rank, world, cdev, interleaved)
+        _merge_parts_by_all_ranks(out_path, part_path, rank, world, cdev, interleaved, bool(args.gzip))
         dist.barrier()
         if rank == 0:
             if getattr(args, "freq_file", None) and (getattr(args, "freq_on", "device") == "host" or

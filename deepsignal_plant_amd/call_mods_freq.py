@@ -224,31 +224,11 @@ class DeviceSiteFrequency(object):
             out.append(buf.raw[:k])
         return out
 
-    def _exchange(self, cols, dest, world, dist):
-        """deal the records (equally long int64 columns) to ranks by `dest`: the columns travel as ONE [n, k] tensor in one
-        all_to_all; what arrives is ordered by source rank, then source order"""
-        torch = self.torch
-        order = torch.sort(dest, stable=True)[1]
-        counts = torch.bincount(dest, minlength=world)
-        rec = torch.stack([c[order] for c in cols], dim=1).contiguous()
-        if dist.get_backend() == "nccl":
-            recv_counts = torch.empty_like(counts)
-            dist.all_to_all_single(recv_counts, counts)
-            ins, outs = counts.tolist(), recv_counts.tolist()
-            got = torch.empty((sum(outs), len(cols)), dtype=rec.dtype, device=rec.device)
-            dist.all_to_all_single(got, rec, outs, ins)
-            return [got[:, j].contiguous() for j in range(len(cols))]
-        # gloo has no all_to_all: every rank publishes its records, everybody keeps its own share (dev box / CPU tests)
-        rank = dist.get_rank()
-        objs = [None] * world
-        dist.all_gather_object(objs, (counts.cpu(), rec.cpu()))
-        parts = []
-        for src in range(world):
-            cnt, rr = objs[src]
-            off = int(cnt[:rank].sum())
-            parts.append(rr[off:off + int(cnt[rank])])
-        got = torch.cat(parts).to(self.dev)
-        return [got[:, j].contiguous() for j in range(len(cols))]
+    def _exchange(self, cols, dest, world, dist=None):
+        """deal the records (equally long int64 columns) to ranks by `dest`: dist.exchange_records -- ONE ragged
+        all_to_all_single on either backend; what arrives is ordered by source rank, then source order"""
+        from . import dist as dsp_dist
+        return dsp_dist.exchange_records(cols, dest, world, self.dev)
 
     def can_finish(self, world=1):
         """collective: True when every rank kept all its records and has room for finish()'s temporaries"""
@@ -260,10 +240,7 @@ class DeviceSiteFrequency(object):
             ok = self.count * 32 * 5 <= free
         from . import dist as dsp_dist
         if dsp_dist.collective(world):
-            import torch.distributed as dist
-            t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=self.dev if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            ok = bool(int(t.item()))
+            ok = bool(dsp_dist.all_reduce_int(1 if ok else 0, world, "min", self.dev))
         return ok
 
     def finish(self, rank=0, world=1):
@@ -306,10 +283,8 @@ class DeviceSiteFrequency(object):
             key = (remap[key >> 40] << 40) | (key & ((1 << 40) - 1))
             mixed = (key * -7046029254386353131) >> 24            # 0x9E3779B97F4A7C15 as int64; wraps like uint64
             dest = (mixed & 0xffffff) % world
-            key, packed, pis, row = self._exchange([key, packed, pis, row], dest, world, dist)
-            t = torch.tensor([total], dtype=torch.int64, device=dev if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(t)
-            total = int(t.item())
+            key, packed, pis, row = self._exchange([key, packed, pis, row], dest, world)
+            total = dsp_dist.all_reduce_int(total, world, "sum", dev)
             names = glob
         n = int(key.numel())
         torch.cuda.set_device(dev)
@@ -344,8 +319,7 @@ class DeviceSiteFrequency(object):
         cols = out_i + [o.view(torch.int64) for o in out_d]   # doubles travel as their bit patterns
         mark("sites reduced")
         if multi:
-            import torch.distributed as dist
-            gathered = dsp_dist.gather_columns(cols, world, dev if dist.get_backend() == "nccl" else None)
+            gathered = dsp_dist.gather_columns(cols, world, dev)
             if rank != 0:
                 return None
             cols = gathered

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cctype>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -998,6 +999,44 @@ int32_t dsp_model_set_precision(dsp_model* m, int32_t precision) {
     }
     m->precision = precision;
     return DSP_OK;
+}
+
+int64_t dsp_device_pci_bdf(int32_t device, char* out, size_t cap) {
+    char buf[64] = {0};
+    if (hipDeviceGetPCIBusId(buf, (int)sizeof buf, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(DSP_EHIP, "dsp_device_pci_bdf: the HIP runtime does not know device %d", (int)device);
+    }
+    size_t k = strlen(buf);
+    for (size_t i = 0; i < k; ++i) buf[i] = (char)tolower((unsigned char)buf[i]);
+    if (out && cap) {
+        const size_t c = k < cap - 1 ? k : cap - 1;
+        memcpy(out, buf, c);
+        out[c] = 0;
+    }
+    return (int64_t)k;
+}
+
+int64_t dsp_device_uuid(int32_t device, char* out, size_t cap) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(DSP_EHIP, "dsp_device_uuid: the HIP runtime does not know device %d", (int)device);
+    }
+    char buf[33];
+    static const char* hex = "0123456789abcdef";
+    for (int i = 0; i < 16; ++i) {
+        const unsigned char b = (unsigned char)prop.uuid.bytes[i];
+        buf[2 * i] = hex[b >> 4];
+        buf[2 * i + 1] = hex[b & 15];
+    }
+    buf[32] = 0;
+    if (out && cap) {
+        const size_t c = 32 < cap - 1 ? 32 : cap - 1;
+        memcpy(out, buf, c);
+        out[c] = 0;
+    }
+    return 32;
 }
 
 void dsp_model_destroy(dsp_model* m) {

@@ -148,32 +148,70 @@ def _cpulist(text):
     return out
 
 
-def _numa_node_cpus(pci_bus_id):
-    """(NUMA node of a PCI device, its CPU list) or (None, None)"""
+_SYSFS = os.environ.get("DSP_SYSFS_ROOT", "/sys")   # (the tests point this at a faked 2-socket 8-GPU tree)
+
+
+def pci_bdf(domain, bus, device, function=0):
+    """sysfs name of a PCI function from the integers torch's device properties carry (pci_domain_id, pci_bus_id,
+    pci_device_id -- in torch 2.10+rocm7 `pci_bus_id` is the bus NUMBER, not a string: ADVICE r4)"""
+    return "%04x:%02x:%02x.%x" % (int(domain), int(bus), int(device), int(function))
+
+
+def _numa_node_cpus(bdf):
+    """(NUMA node of the PCI device named like /sys/bus/pci/devices/<bdf>, the node's CPU list) or (None, None) when the
+    kernel reports no node for it (numa_node = -1: one memory domain) or the device is not there"""
+    if not isinstance(bdf, str) or not bdf:
+        return None, None
     try:
-        node = int(open("/sys/bus/pci/devices/%s/numa_node" % pci_bus_id.lower()).read().strip())
+        node = int(open(os.path.join(_SYSFS, "bus/pci/devices", bdf.lower(), "numa_node")).read().strip())
         if node < 0:
             return None, None
-        return node, _cpulist(open("/sys/devices/system/node/node%d/cpulist" % node).read())
-    except (OSError, ValueError, AttributeError):
+        return node, _cpulist(open(os.path.join(_SYSFS, "devices/system/node/node%d/cpulist" % node)).read())
+    except (OSError, ValueError):
         return None, None
 
 
+def affinity_mode(local_world):
+    """DSP_RANK_AFFINITY = numa | slice | off.  Default: numa when several ranks share the node (a 2-socket 8-GPU node
+    puts half the ranks' page-locked slots and staging threads on the wrong socket otherwise), off for
+    a lone rank."""
+    mode = os.environ.get("DSP_RANK_AFFINITY", "").strip().lower()
+    if mode in ("off", "none", "0", "no"):
+        return ""
+    if mode in ("numa", "slice"):
+        return mode
+    return "numa" if local_world > 1 else ""
+
+
+def local_gpu_bdfs(local_world, ndev, bdf_of):
+    """PCI names of the GPUs of ALL local ranks as this rank can see them: local rank r runs on visible device r % ndev
+    (call_modifications.py:523-529 maps processes to devices the same way).  None when the launcher narrowed this rank's
+    view to fewer devices than ranks AND ranks do not simply share them (then only the own GPU is known)."""
+    try:
+        return [bdf_of(r % ndev) for r in range(local_world)]
+    except Exception:
+        return None
+
+
 def pin_rank(local_rank, local_world, pci_bus_id=None, peer_bus_ids=None):
-    """Optional CPU placement of a rank (DSP_RANK_AFFINITY = numa | slice; default: leave the scheduler alone).
+    """CPU placement of a rank (affinity_mode: numa by default with several ranks; DSP_RANK_AFFINITY=off leaves the
+    scheduler alone).  Call it BEFORE the page-locked slots are allocated and the staging / writer threads start: both
+    then live next to the rank's GPU.
     slice: the local_rank-th of local_world equal slices of the allowed CPUs.
-    numa: the CPUs of the NUMA node the rank's GPU hangs off (/sys/bus/pci/devices/<bdf>/numa_node); when the caller
-    names the GPUs of ALL local ranks (peer_bus_ids[r] = PCI id of local rank r's GPU) the node's CPUs are split in equal
-    slices among the ranks whose GPUs share that node; without that list every rank of the node takes the whole node (and
-    threads_per_rank divides by the ranks per node as if unpinned).
+    numa: the CPUs of the NUMA node the rank's GPU hangs off (/sys/bus/pci/devices/<bdf>/numa_node; pci_bus_id is that
+    sysfs name, dist.pci_bdf / _native.device_pci_bdf); when the caller names the GPUs of ALL local ranks (peer_bus_ids[r] =
+    name of local rank r's GPU) the node's CPUs are split in equal slices among the ranks whose GPUs share that node;
+    without that list every rank of the node takes the whole node (and threads_per_rank divides by the ranks per node as
+    if unpinned).  A GPU whose node the kernel does not report (one memory domain) falls back to slice -- said on stderr
+    when numa was asked for explicitly.
     Returns the CPU list set, or None.  A rank whose affinity became its own share records it for threads_per_rank."""
     global _PINNED_SHARE
-    mode = os.environ.get("DSP_RANK_AFFINITY", "")
-    if mode not in ("numa", "slice") or not hasattr(os, "sched_setaffinity"):
+    mode = affinity_mode(local_world)
+    if not mode or not hasattr(os, "sched_setaffinity"):
         return None
     allowed = sorted(os.sched_getaffinity(0))
     cpus, own_share = None, False
-    if mode == "numa" and pci_bus_id:
+    if mode == "numa":
         node, node_cpus = _numa_node_cpus(pci_bus_id)
         cand = [c for c in (node_cpus or []) if c in allowed]
         if cand:
@@ -184,6 +222,11 @@ def pin_rank(local_rank, local_world, pci_bus_id=None, peer_bus_ids=None):
                     k = len(cand) // len(peers)
                     i = peers.index(local_rank)
                     cpus, own_share = cand[i * k:(i + 1) * k], True
+        elif os.environ.get("DSP_RANK_AFFINITY", "").strip().lower() == "numa":
+            import sys
+            sys.stderr.write("[dist] DSP_RANK_AFFINITY=numa: no NUMA node for GPU %r of local rank %d under %s "
+                             "(numa_node < 0 or unreadable): taking an equal slice of the allowed CPUs instead\n"
+                             % (pci_bus_id, local_rank, _SYSFS))
     if cpus is None:
         k = max(1, len(allowed) // max(1, local_world))
         cpus = allowed[local_rank * k:(local_rank + 1) * k]
@@ -195,6 +238,52 @@ def pin_rank(local_rank, local_world, pci_bus_id=None, peer_bus_ids=None):
         return None
     _PINNED_SHARE = len(cpus) if own_share else None
     return cpus
+
+
+_PLACED = None
+
+
+def place_rank(rank, local_rank, local_world, ndev):
+    """What a rank does before it allocates page-locked memory or starts threads: name its GPU and its local peers' GPUs
+    (the HIP runtime's PCI names through the C ABI, include/dsp_amd.h dsp_device_pci_bdf), pin itself (pin_rank) and,
+    under DSP_TIMING, say where it landed.  `local_rank` is the launcher's LOCAL_RANK (NOT reduced modulo the visible
+    GPUs: ranks sharing a GPU still get different CPU slices).  Returns (bdf of my GPU or None, CPU list or None)."""
+    global _PLACED
+    if _PLACED is not None:   # once per process: a second call_mods in the same process must not slice its slice again
+        return _PLACED
+    mode = affinity_mode(local_world)
+    bdf, cpus = None, None
+    try:
+        from . import _native
+        bdf = _native.device_pci_bdf(local_rank % ndev)
+        peers = local_gpu_bdfs(local_world, ndev, _native.device_pci_bdf) if mode == "numa" else None
+    except Exception:   # (a library without the symbol, a runtime that cannot name the device: placement is best effort)
+        peers = None
+    if mode:
+        cpus = pin_rank(local_rank, local_world, bdf, peers)
+    if os.environ.get("DSP_TIMING") or (cpus is not None and rank == 0 and os.environ.get("DSP_RANK_AFFINITY")):
+        import sys
+        node = _numa_node_cpus(bdf)[0]
+        sys.stderr.write("[dist] rank %d (local %d of %d): GPU %s, NUMA node %s, affinity %s -> CPUs %s\n" % (
+            rank, local_rank, local_world, bdf, "?" if node is None else node, mode or "off",
+            cpus_text(cpus) if cpus is not None else "(unchanged) " + cpus_text(sorted(os.sched_getaffinity(0)))))
+    _PLACED = (bdf, cpus)
+    return bdf, cpus
+
+
+def cpus_text(cpus):
+    """[0,1,2,3,8,9] -> "0-3,8-9" """
+    if not cpus:
+        return ""
+    out, a, prev = [], cpus[0], cpus[0]
+    for c in list(cpus[1:]) + [None]:
+        if c is not None and c == prev + 1:
+            prev = c
+            continue
+        out.append("%d" % a if a == prev else "%d-%d" % (a, prev))
+        if c is not None:
+            a = prev = c
+    return ",".join(out)
 
 
 def split_range(n, world, rank):
@@ -228,37 +317,96 @@ def exclusive_prefix(counts, rank):
     return int(sum(counts[:rank]))
 
 
+def comm_device(dev=None):
+    """Where the tensors of a collective must live: on this rank's GPU under RCCL ("nccl"), on the host under gloo (the
+    CPU tests; ranks that have to share a GPU).  This is the ONLY place the backend is looked at: every exchange of the
+    path runs the same collectives on both backends (all_gather / all_reduce / ragged all_to_all_single / send + irecv),
+    tensors merely hop to the host first when the group is gloo -- so that the 2- and 8-rank tests execute the production
+    bookkeeping."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+        return torch.device(dev) if dev is not None else torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
 def all_gather_ints(value, world, device=None):
     """One integer per rank -> list of all ranks' integers (torch.distributed must be initialised)."""
     if not collective(world):
         return [int(value)]
     import torch
     import torch.distributed as dist
-    t = torch.tensor([int(value)], dtype=torch.int64, device=device if device is not None else "cpu")
+    t = torch.tensor([int(value)], dtype=torch.int64, device=comm_device(device))
     out = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(out, t)
     return [int(x.item()) for x in out]
 
 
+def all_reduce_int(value, world, op="sum", device=None):
+    """One integer per rank -> its sum / min / max over the ranks"""
+    if not collective(world):
+        return int(value)
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([int(value)], dtype=torch.int64, device=comm_device(device))
+    dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX}[op])
+    return int(t.item())
+
+
+def all_reduce_max_float(value, world, device=None):
+    if not collective(world):
+        return float(value)
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(value)], dtype=torch.float64, device=comm_device(device))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def exchange_records(cols, dest, world, device=None):
+    """Deal records -- equally long 1-D int64 columns -- to ranks: record i goes to rank dest[i].  The one real exchange
+    of the call_mods path (the sharded call_freq, call_mods_freq.DeviceSiteFrequency.finish).  The columns travel as ONE
+    [n, k] tensor: all_to_all_single of the per-destination counts, then ONE ragged all_to_all_single of the records
+    (RCCL over xGMI on GPU tensors; gloo on host tensors -- the same two collectives).  What arrives is ordered by
+    SOURCE RANK, then by the source's own order (the stable sort by destination keeps it).  Returns the columns on the
+    device they came from."""
+    import torch
+    import torch.distributed as dist
+    home = cols[0].device
+    order = torch.sort(dest, stable=True)[1]
+    counts = torch.bincount(dest, minlength=world)
+    rec = torch.stack([c[order] for c in cols], dim=1).contiguous()
+    cdev = comm_device(device if device is not None else (home if home.type == "cuda" else None))
+    counts, rec = counts.to(cdev), rec.to(cdev)
+    recv_counts = torch.empty_like(counts)
+    dist.all_to_all_single(recv_counts, counts)
+    ins, outs = counts.tolist(), recv_counts.tolist()
+    got = torch.empty((sum(outs), len(cols)), dtype=rec.dtype, device=cdev)
+    dist.all_to_all_single(got, rec, outs, ins)
+    got = got.to(home)
+    return [got[:, j].contiguous() for j in range(len(cols))]
+
+
 def gather_probs(probs, world, dst=0):
     """Optional final gather of per-site probabilities [n_r, C] to rank `dst` (ragged: one integer per rank is exchanged
     first).  A TRUE gather: every other rank sends its own rows to `dst` point to point (RCCL send/recv over xGMI on
-    GPU tensors, gloo on host tensors), `dst` receives each rank's rows into a tensor of exactly that rank's size.
-    Off-root memory stays O(n_r) -- round 3's padded all_gather made every rank hold world x max(n_r) rows that only
-    `dst` read (800 MB per rank at BASELINE configs[3]).  Returns the list of the ranks' tensors on `dst`, None elsewhere;
-    ~8 B/site."""
+    GPU tensors, gloo on host tensors -- comm_device), `dst` receives each rank's rows into a tensor of exactly that
+    rank's size.  Off-root memory stays O(n_r) -- round 3's padded all_gather made every rank hold world x max(n_r) rows
+    that only `dst` read (800 MB per rank at BASELINE configs[3]).  Returns the list of the ranks' tensors on `dst`
+    (on the collective's device), None elsewhere; ~8 B/site."""
     if not collective(world):
         return [probs]
     import torch
     import torch.distributed as dist
-    sizes = all_gather_ints(probs.shape[0], world, probs.device if probs.is_cuda else None)
+    cdev = comm_device(probs.device if probs.is_cuda else None)
+    sizes = all_gather_ints(probs.shape[0], world, cdev)
     me = dist.get_rank()
-    probs = probs.contiguous()
+    probs = probs.contiguous().to(cdev)
     if me != dst:
         if sizes[me]:
             dist.send(probs, dst)
         return None
-    out = [probs if r == me else torch.empty((sizes[r],) + tuple(probs.shape[1:]), dtype=probs.dtype, device=probs.device)
+    out = [probs if r == me else torch.empty((sizes[r],) + tuple(probs.shape[1:]), dtype=probs.dtype, device=cdev)
            for r in range(world)]
     reqs = [dist.irecv(out[r], r) for r in range(world) if r != me and sizes[r]]
     for q in reqs:
@@ -268,20 +416,21 @@ def gather_probs(probs, world, dst=0):
 
 def gather_columns(cols, world, device=None):
     """Ragged gather of equally long 1-D int64 columns to rank 0: sizes exchanged first, then every other rank sends its
-    columns, stacked as [n, k], point to point (RCCL when `device` is a GPU) -- a true gather like gather_probs: off-root
-    memory stays O(n_r) (until round 4 a padded all_gather: world x max(n_r) rows on every rank, read by rank 0 only).
-    Returns the concatenated columns on rank 0, None elsewhere."""
+    columns, stacked as [n, k], point to point (RCCL on GPU tensors, gloo on host tensors -- comm_device) -- a true gather
+    like gather_probs: off-root memory stays O(n_r) (until round 4 a padded all_gather: world x max(n_r) rows on every
+    rank, read by rank 0 only).  Returns the concatenated columns on rank 0, None elsewhere."""
     import torch
     import torch.distributed as dist
     n = int(cols[0].numel())
-    sizes = all_gather_ints(n, world, device)
-    rec = torch.stack([c if device is not None else c.cpu() for c in cols], dim=1).contiguous()
+    cdev = comm_device(device if device is not None else (cols[0].device if cols[0].is_cuda else None))
+    sizes = all_gather_ints(n, world, cdev)
+    rec = torch.stack([c.to(cdev) for c in cols], dim=1).contiguous()
     me = dist.get_rank()
     if me != 0:
         if n:
             dist.send(rec, 0)
         return None
-    got = [rec if r == 0 else torch.empty((sizes[r], len(cols)), dtype=rec.dtype, device=rec.device) for r in range(world)]
+    got = [rec if r == 0 else torch.empty((sizes[r], len(cols)), dtype=rec.dtype, device=cdev) for r in range(world)]
     for q in [dist.irecv(got[r], r) for r in range(1, world) if sizes[r]]:
         q.wait()
     out = torch.cat(got)

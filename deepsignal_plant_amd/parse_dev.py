@@ -76,7 +76,6 @@ class DeviceRowParser(object):
     def __init__(self, dev, seq_len, signal_len):
         import torch
         self.torch, self.dev, self.L, self.S = torch, dev, seq_len, signal_len
-        self.bufs = {}
 
     def _bufs(self, stage, stream):
         """the device buffers of a staging slot.  Allocated UNDER `stream` (the stream the parse runs on): torch's caching
@@ -85,15 +84,20 @@ class DeviceRowParser(object):
         SAME stream.  (Allocated under the compute stream and used on the copy stream, a new slot's row offsets and segment
         tables were overwritten by the head kernel of a forward still in the queue: garbage offsets, a GPU fault.)"""
         torch = self.torch
-        key = id(stage["_torch"]["text"])
-        b = self.bufs.get(key)
+        # The device buffers live IN the slot (stage["_dev"]): when the reader replaces a slot by a larger one
+        # (feed._emit_staged, _run_plain_staged) the old slot's device arrays go with it.  (Until round 4 they sat in a
+        # dict keyed by id() of the slot's pinned tensor: a grown slot leaked ~100 MB of device arrays, and a recycled id()
+        # could alias another slot's entry -- ADVICE r4.)  A slot is only replaced after the writer released it, i.e. after
+        # the forward that read these arrays has completed.
+        b = stage.get("_dev")
         if b is None or b["cap_rows"] < stage["cap_rows"] or b["cap_bytes"] < stage["cap_bytes"]:
             cr, cb, L, S = stage["cap_rows"], stage["cap_bytes"], self.L, self.S
+            stage["_dev"] = None
             with torch.cuda.stream(stream):
-                return self._alloc(key, cr, cb, L, S)
+                stage["_dev"] = b = self._alloc(cr, cb, L, S)
         return b
 
-    def _alloc(self, key, cr, cb, L, S):
+    def _alloc(self, cr, cb, L, S):
         torch = self.torch
         mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=self.dev)
         b = dict(cap_rows=cr, cap_bytes=cb, text=mk((cb + PAD,), torch.uint8), row_off=mk((cr + 1,), torch.int64),
@@ -101,7 +105,6 @@ class DeviceRowParser(object):
                  lens=mk((cr, L), torch.int32), signals=mk((cr, L, S), torch.float32), labels=mk((cr,), torch.int32),
                  info_len=mk((cr,), torch.int32), read_off=mk((cr,), torch.int32), read_len=mk((cr,), torch.int32),
                  status=mk((cr,), torch.uint8), n_flagged=mk((1,), torch.int32), seg=mk((cr, L + 4), torch.int32))
-        self.bufs[key] = b
         return b
 
     def submit(self, rows, n_bytes, stage, stream):

@@ -488,6 +488,15 @@ int32_t dsp_fast5_load(const char* path, const char* corrected_group, const char
                        dsp_fast5_read* out);
 void dsp_fast5_free(dsp_fast5_read* r);
 
+/* ---- which GPU is this? (multi-GPU runs: rank placement and the bench line's proof of N distinct devices) -----------
+ * The reference maps its model processes to devices by index only (call_modifications.py:523-529 _get_gpus, :613-621);
+ * one process per GPU over RCCL additionally wants (a) the CPUs next to each GPU (dist.pin_rank) and (b) evidence in the
+ * output that N ranks ran on N different devices (bench.py).  dsp_device_pci_bdf writes the sysfs name of HIP device
+ * `device` ("0000:c1:00.0", lower case: /sys/bus/pci/devices/<that>/numa_node) and returns its length, DSP_EHIP when
+ * the runtime does not know the device; dsp_device_uuid writes the 16 bytes of hipDeviceProp_t::uuid as 32 hex digits. */
+int64_t dsp_device_pci_bdf(int32_t device, char* out, size_t cap);
+int64_t dsp_device_uuid(int32_t device, char* out, size_t cap);
+
 const char* dsp_last_error(void);
 int32_t dsp_abi_version(void);
 

@@ -228,7 +228,9 @@ def test_gpu_count_and_thread_budget_without_the_hip_runtime(monkeypatch, tmp_pa
     if hasattr(_os, "sched_setaffinity") and cpus >= 2:
         before = _os.sched_getaffinity(0)
         try:
-            assert dd.pin_rank(0, 2) is None                      # off unless asked for
+            assert dd.pin_rank(0, 1) is None                      # a lone rank is left alone
+            monkeypatch.setenv("DSP_RANK_AFFINITY", "off")
+            assert dd.pin_rank(0, 2) is None and _os.sched_getaffinity(0) == before   # opt-out (round 5: numa is the default with several ranks)
             monkeypatch.setenv("DSP_RANK_AFFINITY", "slice")
             got = dd.pin_rank(1, 2)
             allowed = sorted(before)
@@ -279,3 +281,205 @@ def test_every_rank_copies_its_part_into_the_result(tmp_path, gz):
         raw = open(out, "rb").read()
         assert gzio.BgzfFile(out).ok and raw.count(bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0])) == 1
     assert [f for f in os.listdir(str(tmp_path)) if ".part" in f] == []
+
+
+# ---- round 5: ONE collective code path on gloo and RCCL -------------------------------------------------
+
+def _exchange_case(case, world, rank):
+    """(number of records of `rank`, dest of record i) for the shapes the bookkeeping must survive"""
+    if case == "ragged":          # uneven counts, every destination used, order inside a source scrambled over destinations
+        n = [7, 0, 13, 5, 1, 0, 9, 4][rank % 8] + 3 * (rank // 8)
+        return n, [(i * 5 + rank) % world for i in range(n)]
+    if case == "one_holds_all":   # every record starts on the LAST rank
+        n = 4 * world + 3 if rank == world - 1 else 0
+        return n, [i % world for i in range(n)]
+    if case == "all_to_one":      # every record goes to rank 1 % world; the other receivers get nothing
+        n = 2 + rank
+        return n, [1 % world] * n
+    if case == "nothing":         # no rank holds a record
+        return 0, []
+    raise AssertionError(case)
+
+
+def _exchange_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+
+    from deepsignal_plant_amd import dist as dd
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    assert dd.comm_device(None).type == "cpu" and dd.comm_device("cuda:0").type == "cpu"   # gloo: tensors hop to the host
+    out = {}
+    for case in ("ragged", "one_holds_all", "all_to_one", "nothing"):
+        n, dest = _exchange_case(case, world, rank)
+        src = torch.full((n,), rank, dtype=torch.int64)
+        seq = torch.arange(n, dtype=torch.int64)
+        payload = (src << 32) | (seq * 7 + 1)
+        got = dd.exchange_records([src, seq, payload], torch.tensor(dest, dtype=torch.int64), world)
+        assert len(got) == 3 and all(g.dtype == torch.int64 and g.dim() == 1 for g in got)
+        out[case] = torch.stack(got, 1).numpy() if got[0].numel() else np.zeros((0, 3), np.int64)
+    # the small control-plane helpers take the same route
+    assert dd.all_reduce_int(rank + 1, world, "sum") == world * (world + 1) // 2
+    assert dd.all_reduce_int(rank + 1, world, "min") == 1 and dd.all_reduce_int(rank, world, "max") == world - 1
+    assert dd.all_reduce_max_float(0.5 + rank, world) == world - 0.5
+    np.savez(os.path.join(outdir, "x%d.npz" % rank), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_the_all_to_all_of_call_freq_records_is_one_code_path_on_gloo(tmp_path, world):
+    """dist.exchange_records = what DeviceSiteFrequency._exchange runs on RCCL: all_to_all_single of the counts, then ONE
+    ragged all_to_all_single of the records -- no backend fork (call_mods_freq.py:234-249 of round 4 took an
+    all_gather_object fallback on gloo, so no multi-rank test ever ran the production bookkeeping).  Ragged counts, empty
+    ranks, one rank holding everything, one rank receiving everything, nothing at all: every record arrives exactly once,
+    at the rank its `dest` names, ordered by SOURCE RANK, then by the source's own order."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.start_processes(_exchange_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    got = [np.load(os.path.join(str(tmp_path), "x%d.npz" % r)) for r in range(world)]
+    for case in ("ragged", "one_holds_all", "all_to_one", "nothing"):
+        for r in range(world):
+            want = []
+            for s in range(world):                       # by source rank ...
+                n, dest = _exchange_case(case, world, s)
+                want += [[s, i, (s << 32) | (i * 7 + 1)] for i in range(n) if dest[i] == r]   # ... then source order
+            assert got[r][case].tolist() == want, (case, r)
+
+
+def test_no_collective_of_the_path_forks_on_the_backend():
+    """the backend is looked at in ONE place (dist.comm_device: where the tensors of a collective live); nothing else in the
+    product or in bench.py may choose a different collective for gloo"""
+    import re
+    hits = []
+    for rel in ["bench.py"] + [os.path.join("deepsignal_plant_amd", f) for f in os.listdir(os.path.join(ROOT, "deepsignal_plant_amd"))
+                               if f.endswith(".py")]:
+        src = open(os.path.join(ROOT, rel)).read()
+        for m in re.finditer(r"get_backend\(\)|backend\s*==\s*[\"'](nccl|gloo)[\"']", src):
+            line = src[:m.start()].count("\n") + 1
+            hits.append((rel, line, src.splitlines()[line - 1].strip()))
+    allowed = [h for h in hits if h[0].endswith("dist.py") or "rccl_version" in h[2] or "\"backend\":" in h[2] or "must = " in h[2]]
+    assert hits == allowed, [h for h in hits if h not in allowed]
+    assert sum(1 for h in hits if h[0].endswith("dist.py") and "nccl" in h[2] and "==" in h[2]) == 1   # comm_device
+
+
+# ---- round 5: NUMA placement by default (VERDICT r4 item 3, ADVICE r4 medium) -------------------------------------------
+
+def _fake_two_socket_node(root, gpus_per_socket=4, cpus_per_socket=64):
+    """a /sys tree of a 2-socket 8-GPU node: GPUs 0-3 on node 0 (CPUs 0-63), 4-7 on node 1 (CPUs 64-127) -> bdfs"""
+    bdfs = []
+    for s in range(2):
+        d = root / "devices/system/node" / ("node%d" % s)
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text("%d-%d\n" % (s * cpus_per_socket, (s + 1) * cpus_per_socket - 1))
+        for g in range(gpus_per_socket):
+            bdf = "0000:%02x:00.0" % (0x05 + 0x20 * (s * gpus_per_socket + g))
+            p = root / "bus/pci/devices" / bdf
+            p.mkdir(parents=True)
+            (p / "numa_node").write_text("%d\n" % s)
+            bdfs.append(bdf)
+    return bdfs
+
+
+def test_ranks_are_placed_next_to_their_gpus_by_default(monkeypatch, tmp_path, capsys):
+    """dist.pin_rank on a faked 2-socket 8-GPU topology: with several ranks the default is `numa` -- every rank gets an
+    equal, disjoint slice of the CPUs of ITS GPU's node; a GPU on PCI bus 0 is not "no GPU"; an explicit numa request that
+    cannot be resolved says so and falls back to slices; DSP_RANK_AFFINITY=off opts out; a lone rank is left alone."""
+    import os as _os
+    from deepsignal_plant_amd import dist as dd
+    bdfs = _fake_two_socket_node(tmp_path)
+    monkeypatch.setattr(dd, "_SYSFS", str(tmp_path))
+    monkeypatch.delenv("DSP_RANK_AFFINITY", raising=False)
+    state = {"aff": set(range(128))}
+    monkeypatch.setattr(_os, "sched_getaffinity", lambda pid: set(state["aff"]))
+    monkeypatch.setattr(_os, "sched_setaffinity", lambda pid, cpus: state.update(aff=set(cpus)))
+    assert dd.pci_bdf(0, 0xc5, 0) == "0000:c5:00.0" and dd.pci_bdf(1, 0, 0) == "0001:00:00.0"   # ints of torch's properties
+    assert dd._numa_node_cpus(bdfs[5]) == (1, list(range(64, 128)))
+    assert dd._numa_node_cpus(0xc5) == (None, None) and dd._numa_node_cpus(None) == (None, None)  # an int is not a name
+    assert dd.affinity_mode(8) == "numa" and dd.affinity_mode(1) == ""
+    seen = []
+    try:
+        for r in range(8):
+            state["aff"] = set(range(128))
+            got = dd.pin_rank(r, 8, bdfs[r], bdfs)
+            node = r // 4
+            assert got == list(range(node * 64 + (r % 4) * 16, node * 64 + (r % 4 + 1) * 16)), (r, got)
+            assert state["aff"] == set(got) and dd._PINNED_SHARE == 16
+            assert dd.threads_per_rank(64, 8) == 16      # the slice IS the rank's share
+            seen += got
+        assert sorted(seen) == list(range(128))          # disjoint, nothing left idle
+        # without the peers' names every rank of a node takes the node (threads are then divided as if unpinned)
+        state["aff"] = set(range(128))
+        assert dd.pin_rank(5, 8, bdfs[5]) == list(range(64, 128)) and dd._PINNED_SHARE is None
+        # ranks sharing GPUs (fewer visible devices than ranks): the GPU's node is split among the ranks on it
+        state["aff"] = set(range(128))
+        shared = dd.local_gpu_bdfs(8, 2, lambda i: bdfs[i])           # 8 ranks on 2 GPUs, both on node 0
+        assert shared == [bdfs[0], bdfs[1]] * 4
+        assert dd.pin_rank(3, 8, shared[3], shared) == list(range(24, 32))
+        # a cgroup that allows only part of the node
+        state["aff"] = set(range(0, 128, 2))
+        assert dd.pin_rank(1, 8, bdfs[1], bdfs) == list(range(16, 32, 2))
+        # GPU on bus 0 / domain 0
+        zero = "0000:00:00.0"
+        (tmp_path / "bus/pci/devices" / zero).mkdir()
+        (tmp_path / "bus/pci/devices" / zero / "numa_node").write_text("1\n")
+        state["aff"] = set(range(128))
+        assert dd.pin_rank(0, 2, zero, [zero, bdfs[0]]) == list(range(64, 128))
+        # numa asked for, node unknown (numa_node = -1): said on stderr, equal slice instead
+        (tmp_path / "bus/pci/devices" / zero / "numa_node").write_text("-1\n")
+        state["aff"] = set(range(128))
+        monkeypatch.setenv("DSP_RANK_AFFINITY", "numa")
+        capsys.readouterr()
+        assert dd.pin_rank(1, 4, zero, [zero] * 4) == list(range(32, 64))
+        assert "no NUMA node for GPU" in capsys.readouterr().err
+        # by default (not asked for explicitly) the same fallback is silent
+        monkeypatch.delenv("DSP_RANK_AFFINITY")
+        state["aff"] = set(range(128))
+        assert dd.pin_rank(1, 4, zero, [zero] * 4) == list(range(32, 64)) and capsys.readouterr().err == ""
+        # opt-out, and a lone rank
+        monkeypatch.setenv("DSP_RANK_AFFINITY", "off")
+        state["aff"] = set(range(128))
+        assert dd.pin_rank(1, 8, bdfs[1], bdfs) is None and state["aff"] == set(range(128))
+        monkeypatch.delenv("DSP_RANK_AFFINITY")
+        assert dd.pin_rank(0, 1, bdfs[0], bdfs[:1]) is None
+        assert dd.cpus_text([0, 1, 2, 3, 8, 9, 11]) == "0-3,8-9,11" and dd.cpus_text([]) == "" and dd.cpus_text([5]) == "5"
+        # place_rank: names from the C ABI (faked here), the launcher's LOCAL_RANK not reduced modulo the visible GPUs
+        from deepsignal_plant_amd import _native
+        monkeypatch.setattr(_native, "device_pci_bdf", lambda i: bdfs[i])
+        monkeypatch.setenv("DSP_TIMING", "1")
+        state["aff"] = set(range(128))
+        bdf, cpus = dd.place_rank(6, 6, 8, 8)
+        assert bdf == bdfs[6] and cpus == list(range(96, 112))
+        assert "rank 6 (local 6 of 8): GPU %s, NUMA node 1, affinity numa -> CPUs 96-111" % bdfs[6] in capsys.readouterr().err
+        state["aff"] = set(range(128))
+        assert dd.place_rank(6, 6, 8, 8) == (bdf, cpus) and state["aff"] == set(range(128))   # once per process
+        dd._PLACED = None
+        bdf, cpus = dd.place_rank(6, 6, 8, 1)             # eight ranks sharing ONE GPU (the dev box): eight slices of its node
+        assert bdf == bdfs[0] and cpus == list(range(48, 56))
+    finally:
+        dd._PINNED_SHARE = None
+        dd._PLACED = None
+
+
+def test_a_plain_text_output_named_gz_merges_as_plain_text(tmp_path):
+    """`-o calls.gz` WITHOUT --gzip is plain text (as the reference writes it); the merges take the run's
+    --gzip flag, not the file name: the interleaved piece tables must validate and no BGZF end-of-file member is appended"""
+    from deepsignal_plant_amd import call_modifications as cm
+    out = str(tmp_path / "calls.gz")
+    world, pieces = 2, {0: [b"a0\n" * 3, b"a2\n"], 1: [b"b1\n" * 2]}
+    for r in range(world):
+        part = "%s.part%05d" % (out, r)
+        with open(part, "wb") as f:
+            ends = []
+            for p in pieces[r]:
+                f.write(p)
+                ends.append(f.tell())
+        np.array(ends, np.int64).tofile(part + ".blocks")
+    cm._merge_parts(out, world, True, is_gzip=False)
+    assert open(out, "rb").read() == b"a0\n" * 3 + b"b1\n" * 2 + b"a2\n"
+    for r in range(world):   # rank-order concatenation: a part that happens to end in the 28 bytes of an EOF member keeps them
+        with open("%s.part%05d" % (out, r), "wb") as f:
+            f.write(b"x%d\n" % r + cm._BGZF_EOF)
+    cm._merge_parts(out, world, False, is_gzip=False)
+    assert open(out, "rb").read() == b"x0\n" + cm._BGZF_EOF + b"x1\n" + cm._BGZF_EOF

@@ -71,7 +71,35 @@ def test_config4_bench_at_eight_ranks_tiles_the_site_space_and_gathers_every_cal
     g = d["gather"]
     assert g["sites"] == WORLD * 2 * B and g["bytes"] == 8 * g["sites"] and g["to_rank"] == 0
     assert "cpu_baseline" not in d and d["vs_baseline"] is None
+    # round 5: the line proves which devices ran it -- every rank's PCI name, uuid, host, CPUs and its
+    # OWN ms_per_step; here the eight ranks share ONE GPU and the line says so (backend gloo, distinct_gpus 1)
+    c = d["config"]
+    assert len(c["ranks"]) == WORLD and [x["rank"] for x in c["ranks"]] == list(range(WORLD))
+    for x in c["ranks"]:
+        assert set(x) >= {"host", "local_rank", "hip_device", "pci_bdf", "uuid", "numa_node", "cpus", "pinned", "ms_per_step", "name"}
+        assert len(x["pci_bdf"].split(":")) == 3 and len(x["uuid"]) == 32 and x["ms_per_step"] > 0
+        assert x["ms_per_step"] <= d["ms_per_step"] * 1.0001          # the line's time is the MAX over ranks
+    assert c["distinct_gpus"] == 1 and c["backend"].startswith("gloo") and c["rccl_version"] is None
+    assert max(x["ms_per_step"] for x in c["ranks"]) >= 0.9 * d["ms_per_step"]
+    assert len({x["cpus"] for x in c["ranks"]}) == WORLD or not all(x["pinned"] for x in c["ranks"])   # pinned ranks: disjoint CPU slices
     _keep("bench_8ranks_shared_gpu.json", json.dumps(d) + "\n")
+
+
+def test_a_scale_line_is_refused_when_ranks_do_not_sit_on_distinct_gpus():
+    """what RCCL runs check unconditionally, forced here on the 1-GPU box (DSP_REQUIRE_DISTINCT_GPUS=1): two ranks on one
+    device must NOT print a 2-GPU line -- non-zero exit, the reason on stderr.  And --n1_ms puts the driver's own
+    efficiency arithmetic on the line of a run that is allowed to print."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "4096",
+           "--no_cpu_baseline", "--n1_ms", "3.5"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=dict(env, DSP_REQUIRE_DISTINCT_GPUS="1"))
+    assert r.returncode != 0 and "2 ranks but only 1 distinct GPUs" in r.stderr, (r.returncode, r.stderr[-2000:])
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n1_ms_per_step"] == 3.5 and abs(d["scaling_efficiency_vs_n1"] - 3.5 / d["ms_per_step"]) < 1e-3
+    assert d["config"]["distinct_gpus"] == 1
 
 
 def _inputs(tmp_path, data, tag):
