@@ -32,12 +32,14 @@ import time
 import numpy as np
 
 from . import dist as dsp_dist
-from . import featfile, feed, gzio, textio
+from . import canary, featfile, feed, gzio, textio
 from .models import ModelBiLSTM
 from .utils.process_utils import display_args, str2bool
 
 
-_WRITER_DELAY = float(os.environ.get("DSP_WRITER_DELAY_MS", "0")) / 1e3
+def _writer_delay():
+    """DSP_WRITER_DELAY_MS (tests): a writer that cannot keep up with the GPU"""
+    return float(os.environ.get("DSP_WRITER_DELAY_MS", "0") or 0) / 1e3
 _TICKS = []   # DSP_TIMING=1: (label, seconds since call_mods started) of the run's milestones, printed by rank 0 at the end
 
 
@@ -147,9 +149,24 @@ class _Writer(threading.Thread):
         self.freq_dev = None  # optional (DeviceSiteFrequency, stream, first-row getter): the reads branch feeds it from here
         self.error = None
         self.rows = 0
+        self.delay = _writer_delay()
+        self.canary = canary.on()  # DSP_SLOT_CANARY=1 (canary.py): what the writer reads must not be a slot already given back
+        self.class_num = 2
         self.mark_blocks = False   # remember where every block's output ends in the part file (interleaved sharding)
         self.n_vocab = 16          # --n_vocab: rows whose k-mer holds a code beyond it are an error (set by the caller)
         self.block_ends = []
+
+    def _check_live(self, block, probs, labels):
+        """DSP_SLOT_CANARY: the block's input slot and result slot must still be this block's (no poison in what is read)"""
+        rows, n = block.rows, block.rows.n
+        named = [("probs (result slot)", probs), ("labels (result slot)", labels), ("kmer", np.asarray(rows.kmer)[:n]),
+                 ("info_len", np.asarray(rows.info_len)[:n]), ("row_off", np.asarray(rows.row_off)[:n])]
+        if isinstance(rows.text, np.ndarray) and n:
+            a, b = int(rows.row_off[0]), int(rows.row_off[n - 1]) + int(rows.info_len[n - 1])
+            named.append(("sampleinfo text", rows.text[a:b]))
+        canary.expect_live(named, "writer formats block of first row %d" % block.first_row)
+        if int(labels.max()) >= self.class_num:
+            raise canary.SlotCanaryError("DSP_SLOT_CANARY: a label of block %d is no class" % block.first_row)
 
     def run(self):
         try:
@@ -171,11 +188,13 @@ class _Writer(threading.Thread):
                         self.reader.release(block)
                         continue
                     event.synchronize()
-                    if _WRITER_DELAY:   # DSP_WRITER_DELAY_MS (tests): a writer that cannot keep up with the GPU
+                    if self.delay:   # DSP_WRITER_DELAY_MS (tests): a writer that cannot keep up with the GPU
                         import time as _time
-                        _time.sleep(_WRITER_DELAY)
+                        _time.sleep(self.delay)
                     probs = probs_t.numpy()[:block.rows.n]
                     labels = labels_t.numpy()[:block.rows.n]
+                    if self.canary:
+                        self._check_live(block, probs, labels)
                     if self.n_vocab < 16 and block.rows.n and int(np.asarray(block.rows.kmer)[:block.rows.n].max()) >= self.n_vocab:
                         # a base code the embedding table does not hold: the reference's nn.Embedding raises this
                         # (models.py:186); the kernel clamps the index for memory safety, the run ends here
@@ -275,6 +294,7 @@ def _call_mods_file(args, rank, local_rank, world):
     writer = _Writer(part_path, args.gzip, nthreads, reader, freq)
     writer.mark_blocks = interleaved
     writer.n_vocab = int(args.n_vocab)
+    writer.class_num = int(args.class_num)
     cap = reader.cap
     _tick("reader built")
     model.reserve(cap)
@@ -291,8 +311,28 @@ def _call_mods_file(args, rank, local_rank, world):
     # by block number, guarded by the copy's event: safe only while fewer blocks were in flight than slots, which the fifth
     # reader slot of the device parser broke at the end of a run with a writer slower than the GPU.)
     free_out = queue.Queue()
+    slot_canary = canary.on()   # DSP_SLOT_CANARY=1: result slots are poisoned when handed back and verified when taken (canary.py)
+    # DSP_TEST_RESULT_RING_BY_BLOCK=1 (tests only) re-enacts the round-4 bug: slots by block number, no hand-back awaited --
+    # what the canary must catch without any timing help
+    ring_by_block = int(os.environ.get("DSP_TEST_RESULT_RING_BY_BLOCK", "0") or 0)   # (its value: the length of that ring; round 4's was 4)
     for i in range(nout):
+        if slot_canary:
+            canary.poison([out_probs[i].numpy(), out_labels[i].numpy()])
         free_out.put(i)
+
+    def hand_back(s_):
+        if slot_canary:
+            canary.poison([out_probs[s_].numpy(), out_labels[s_].numpy()])
+        free_out.put(s_)
+
+    def take_slot():
+        """a result slot the writer has handed back; None when the writer is dead (the main loop ends the run with its error)"""
+        while True:
+            try:
+                return free_out.get(timeout=0.2)
+            except queue.Empty:
+                if writer.error is not None:
+                    return None
     k = 0
     n_rows = 0
     _tick("pinned output buffers")
@@ -302,9 +342,16 @@ def _call_mods_file(args, rank, local_rank, world):
         nonlocal k, n_rows, out_probs, out_labels
         rows = block.rows
         n = rows.n
-        if n > out_probs[0].shape[0]:  # a block grew past the pinned output capacity
+        if n > out_probs[0].shape[0]:  # a block grew past the pinned output capacity: new slots, once the writer holds none of the old
+            held = [take_slot() for _ in range(nout)]
+            if None in held:
+                return
             out_probs = [torch.empty((n, args.class_num), dtype=torch.float32, pin_memory=True) for _ in range(nout)]
             out_labels = [torch.empty((n,), dtype=torch.uint8, pin_memory=True) for _ in range(nout)]
+            for i in held:
+                if slot_canary:
+                    canary.poison([out_probs[i].numpy(), out_labels[i].numpy()])
+                free_out.put(i)
         if staged is not None:
             b, ev = staged
             ev.synchronize()   # (submitted a block ago: normally long done) the writer's small arrays and the flag count are here
@@ -340,18 +387,16 @@ def _call_mods_file(args, rank, local_rank, world):
                                                init_states=file_states.for_rows(block.first_row, n) if file_states else None)
         if freq_dev is not None:  # the calls go into the device-side call_freq records straight from HBM
             freq_dev.add_block(rows, probs, labels, block.first_row, stream=stream)
-        while True:
-            try:
-                slot = free_out.get(timeout=0.2)
-                break
-            except queue.Empty:
-                if writer.error is not None:   # a dead writer hands nothing back: the main loop ends the run with its error
-                    return
+        slot = k % min(nout, ring_by_block) if ring_by_block else take_slot()
+        if slot is None:
+            return
+        if slot_canary:
+            canary.expect_poisoned([out_probs[slot].numpy(), out_labels[slot].numpy()], "main loop takes result slot %d for block %d" % (slot, k))
         ev_out = torch.cuda.Event()
         out_probs[slot][:n].copy_(probs, non_blocking=True)
         out_labels[slot][:n].copy_(labels, non_blocking=True)
         ev_out.record(stream)
-        writer.q.put((block, out_probs[slot], out_labels[slot], ev_out, lambda s_=slot: free_out.put(s_)))
+        writer.q.put((block, out_probs[slot], out_labels[slot], ev_out, lambda s_=slot: hand_back(s_)))
         k += 1
         n_rows += n
 
@@ -732,6 +777,7 @@ def call_mods(args):
     start = time.time()
     del _TICKS[:]
     _tick("start")
+    feed.refresh_env()   # (DSP_BLOCK_BYTES: a second call_mods in one process may run under other settings)
     import torch
     from . import _native
     _native.lib()  # fail loudly before any work if the HIP library is missing
@@ -789,7 +835,7 @@ def call_mods(args):
             agg = SiteFrequency(args.prob_cf)
             agg.add_calls_file(out_path)
             agg.write(args.freq_file, args.freq_sort, args.freq_bed, args.gzip)
-    if dist_on:
+    if dist_on and not os.environ.get("DSP_KEEP_PROCESS_GROUP"):   # (the tests' job runner runs several call_mods in one launch)
         import torch.distributed as dist
         dist.destroy_process_group()
     if rank == 0:

@@ -343,18 +343,13 @@ class DeviceSiteFrequency(object):
 
 
 def _contig_names(spec):
-    """--contigs: genome fasta, a file of names, or a comma list (call_mods_freq.py:253-263)"""
+    """--contigs: genome fasta, a file of names, or a comma list (call_mods_freq.py:253-263).  A file is a fasta when it is
+    named .fa / .fasta / .fna or when ANY of its lines starts with '>' (_is_file_a_genome_fasta, :142-149, only skips the
+    lines that do not); fasta names keep the file's order (and duplicates), the first word of the header; a names file is
+    sorted(set(lines)) -- comment and blank lines included, as contigs no call has."""
     if os.path.isfile(spec):
         lines = open(spec, "r").read().splitlines()
-        is_fa = spec.endswith((".fa", ".fasta", ".fna"))
-        if not is_fa:
-            for l in lines:
-                if l.startswith("#"):
-                    continue
-                if l.startswith(">"):
-                    is_fa = True
-                break
-        if is_fa:
+        if spec.endswith((".fa", ".fasta", ".fna")) or any(l.startswith(">") for l in lines):
             return [l.strip()[1:].split(' ')[0] for l in lines if l.startswith(">")]
         return sorted(set(lines))
     return sorted(set(spec.strip().split(",")))

@@ -17,7 +17,7 @@ import threading
 import numpy as np
 
 from . import dist as dsp_dist
-from . import featfile, textio
+from . import canary, featfile, textio
 
 BLOCK_BYTES = int(os.environ.get("DSP_BLOCK_BYTES", 0) or (48 << 20))  # first block: ~23k rows of ~2.08 kB
 # blocks of a foreign .gz are inflated into fixed buffers (private, or slots of the node's shared-memory ring): room for
@@ -30,6 +30,15 @@ TARGET_ROWS = 0 if os.environ.get("DSP_BLOCK_BYTES") else int(32768 * 0.98)
 # Plain text is cut at EXACTLY this many rows (the byte offset behind the n-th newline, textio.find_row_end): no 2 % margin,
 # every forward but a rank's last runs whole rounds (round 3: 97.7 % -> 99 % of the forward's own rate while streaming)
 EXACT_ROWS = 0 if os.environ.get("DSP_BLOCK_BYTES") else 32768
+
+
+def refresh_env():
+    """re-read DSP_BLOCK_BYTES (a second call_mods in one process -- the tests' job runner -- may have changed it)"""
+    global BLOCK_BYTES, GZ_BLOCK_BYTES, TARGET_ROWS, EXACT_ROWS
+    BLOCK_BYTES = int(os.environ.get("DSP_BLOCK_BYTES", 0) or (48 << 20))
+    GZ_BLOCK_BYTES = int(os.environ.get("DSP_BLOCK_BYTES", 0) or (76 << 20))
+    TARGET_ROWS = 0 if os.environ.get("DSP_BLOCK_BYTES") else int(32768 * 0.98)
+    EXACT_ROWS = 0 if os.environ.get("DSP_BLOCK_BYTES") else 32768
 
 
 class Block(object):
@@ -68,7 +77,7 @@ def count_rows_in_range(path, a, b, nthreads=1):
     return newlines + (1 if tail_open else 0)
 
 
-def count_rows_bgzf(path, world, rank, nthreads=8, block_bytes=BLOCK_BYTES):
+def count_rows_bgzf(path, world, rank, nthreads=8, block_bytes=None):
     """Rows owned by `rank` of a BGZF feature file (= newlines inside its member range, see FeatureReader._run_bgzf), or
     None when the file is not BGZF.  One inflate pass on `nthreads` threads; the ranks then all_gather these counts to
     learn the global index of their first row."""
@@ -77,6 +86,7 @@ def count_rows_bgzf(path, world, rank, nthreads=8, block_bytes=BLOCK_BYTES):
     if not bz.ok:
         return None
     m0, m1 = bz.members_for_rank(world, rank)
+    block_bytes = BLOCK_BYTES if block_bytes is None else block_bytes
     if m1 > m0 and not os.environ.get("DSP_BGZF_COUNT_BY_INFLATE") and bool((bz.rows[m0:m1] >= 0).all()):
         # written by this build: every member's header carries its newline count (csrc/dsp_gz.cpp) -- no inflate pass
         # before the first forward (at config 5's scale it would be a minute of every rank's parser threads); the caller
@@ -94,7 +104,7 @@ def count_rows_bgzf(path, world, rank, nthreads=8, block_bytes=BLOCK_BYTES):
 class FeatureReader(threading.Thread):
     """Producer thread: yields parsed blocks of this rank's rows, in file order, through a bounded queue."""
 
-    def __init__(self, path, seq_len, signal_len, rank=0, world=1, nthreads=4, nbuf=3, block_bytes=BLOCK_BYTES,
+    def __init__(self, path, seq_len, signal_len, rank=0, world=1, nthreads=4, nbuf=3, block_bytes=None,
                  first_row=0, byte_range=None, pinned=True, max_rows_per_block=None, gz_ring=None, device_parse=False):
         """device_parse: blocks of text rows are NOT parsed here -- they are copied into page-locked staging with their row
         starts (one pass, parse_dev.stage_rows) and parsed on the GPU by the consumer (round 4); .dspf containers hold
@@ -109,6 +119,7 @@ class FeatureReader(threading.Thread):
                     path, self.ff.seq_len, self.ff.signal_len, seq_len, signal_len))
             max_rows_per_block = max(1, self.ff.max_block_rows())
         self.rank, self.world, self.nthreads = rank, world, max(1, nthreads)
+        block_bytes = BLOCK_BYTES if block_bytes is None else block_bytes
         self.block_bytes = block_bytes
         self.gz_block_bytes = GZ_BLOCK_BYTES if block_bytes == BLOCK_BYTES else block_bytes   # an explicit size is kept
         self.first_row = first_row
@@ -123,12 +134,16 @@ class FeatureReader(threading.Thread):
         self.device_parse = bool(device_parse) and self.ff is None
         self.pinned = pinned
         self.stage_seconds = 0.0     # device_parse: time this reader spent copying blocks into staging (tools/bench_feed.py)
+        self.canary = canary.on()    # DSP_SLOT_CANARY=1: slots are poisoned on release and verified on take (canary.py)
         for s in range(nbuf):
             if self.device_parse:
                 from . import parse_dev
-                self.free.put(parse_dev.alloc_stage(cap, int(max(block_bytes, self.gz_block_bytes) * 1.25) + (1 << 20), seq_len, pinned=pinned))
+                slot = parse_dev.alloc_stage(cap, int(max(block_bytes, self.gz_block_bytes) * 1.25) + (1 << 20), seq_len, pinned=pinned)
             else:
-                self.free.put(textio.alloc_rows(cap, seq_len, signal_len, pinned=pinned))
+                slot = textio.alloc_rows(cap, seq_len, signal_len, pinned=pinned)
+            if self.canary:
+                canary.poison(slot)
+            self.free.put(slot)
         self.error = None
 
     # -- consumer side
@@ -142,15 +157,30 @@ class FeatureReader(threading.Thread):
             yield item
 
     def release(self, block):
+        if self.canary:
+            canary.poison(block.slot)        # the consumer is done with it: whoever still reads it reads 0xFF
         self.free.put(block.slot)
+
+    def _take(self):
+        """the producer's next free slot"""
+        slot = self.free.get()
+        if self.canary:
+            canary.expect_poisoned(slot, "reader takes an input slot")
+        return slot
+
+    def _fresh(self, slot):
+        """a slot allocated to replace one that was too small"""
+        if self.canary:
+            canary.poison(slot)
+        return slot
 
     # -- producer side
     def _emit_staged(self, data, row0):
         """device_parse: the block's text into a staging slot, its row starts noted on the way (no parsing here)"""
         from . import parse_dev
-        slot = self.free.get()
+        slot = self._take()
         if len(data) + 1 > slot["cap_bytes"]:      # longer rows than the slots were sized for: this slot grows
-            slot = parse_dev.alloc_stage(slot["cap_rows"], int(len(data) * 1.25) + (1 << 20), self.L, pinned=self.pinned)
+            slot = self._fresh(parse_dev.alloc_stage(slot["cap_rows"], int(len(data) * 1.25) + (1 << 20), self.L, pinned=self.pinned))
         import time as _time
         t0 = _time.time()
         try:
@@ -158,7 +188,7 @@ class FeatureReader(threading.Thread):
         except RuntimeError as e:                  # shorter rows than expected: more of them than the slot has room for
             if "more than" not in str(e):
                 raise
-            slot = parse_dev.alloc_stage(textio.count_rows(data) + 1, slot["cap_bytes"], self.L, pinned=self.pinned)
+            slot = self._fresh(parse_dev.alloc_stage(textio.count_rows(data) + 1, slot["cap_bytes"], self.L, pinned=self.pinned))
             rows, n_bytes = parse_dev.stage_rows(data, slot, self.L, self.S)
         self.stage_seconds += _time.time() - t0
         b = Block()
@@ -169,14 +199,16 @@ class FeatureReader(threading.Thread):
     def _emit(self, data, row0):
         if self.device_parse:
             return self._emit_staged(data, row0)
-        slot = self.free.get()
+        slot = self._take()
         try:
             rows = textio.parse_rows(data, self.L, self.S, nthreads=self.nthreads, out=slot)
         except RuntimeError as e:  # rows much shorter than expected: this block gets its own (unpinned) buffers
             if "capacity" not in str(e):
                 raise
+            if self.canary:
+                canary.poison(slot)          # (the failed parse had begun to fill it)
             self.free.put(slot)
-            slot = textio.alloc_rows(textio.count_rows(data), self.L, self.S, pinned=False)
+            slot = self._fresh(textio.alloc_rows(textio.count_rows(data), self.L, self.S, pinned=False))
             rows = textio.parse_rows(data, self.L, self.S, nthreads=self.nthreads, out=slot)
         b = Block()
         b.rows, b.first_row, b.slot, b.n_bytes = rows, row0, slot, None
@@ -201,7 +233,7 @@ class FeatureReader(threading.Thread):
         b0, b1 = self.ff.blocks_for_rank(self.world, self.rank)
         row = 0
         for bi in range(b0, b1):
-            slot = self.free.get()
+            slot = self._take()
             rows, _out, info = self.ff.read_block(bi, out=slot, info=slot.get("_info"), nthreads=self.nthreads)
             slot["_info"] = info
             b = Block()
@@ -227,7 +259,7 @@ class FeatureReader(threading.Thread):
         try:
             pos = a
             while pos < b:
-                slot = self.free.get()
+                slot = self._take()
                 exact = EXACT_ROWS if (EXACT_ROWS and self.cap >= EXACT_ROWS) else 0
                 t0 = _time.time()
                 budget = None if exact else max(self.block_bytes, 1)     # (a pinned block size: tests)
@@ -240,7 +272,7 @@ class FeatureReader(threading.Thread):
                         budget = None         # a pinned block size smaller than a row: the block is what the slot holds
                         continue
                     # not even one row fits the slot: it grows
-                    slot = parse_dev.alloc_stage(slot["cap_rows"], slot["cap_bytes"] * 2, self.L, pinned=self.pinned)
+                    slot = self._fresh(parse_dev.alloc_stage(slot["cap_rows"], slot["cap_bytes"] * 2, self.L, pinned=self.pinned))
                 self.stage_seconds += _time.time() - t0
                 blk = Block()
                 blk.rows, blk.first_row, blk.slot, blk.n_bytes = rows, row, slot, n_bytes

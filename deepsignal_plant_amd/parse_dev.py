@@ -15,7 +15,6 @@ from . import _native as nat
 from . import textio
 
 import os
-_SYNC = bool(os.environ.get("DSP_PARSE_SYNC"))
 PAD = 64          # readable bytes behind the staged text (the kernel's 16-byte cursor runs two words ahead)
 
 
@@ -76,6 +75,7 @@ class DeviceRowParser(object):
     def __init__(self, dev, seq_len, signal_len):
         import torch
         self.torch, self.dev, self.L, self.S = torch, dev, seq_len, signal_len
+        self.sync = bool(os.environ.get("DSP_PARSE_SYNC"))
 
     def _bufs(self, stage, stream):
         """the device buffers of a staging slot.  Allocated UNDER `stream` (the stream the parse runs on): torch's caching
@@ -125,7 +125,7 @@ class DeviceRowParser(object):
             t["n_flagged"].copy_(b["n_flagged"], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(stream)
-        if _SYNC:   # DSP_PARSE_SYNC=1 (debugging aid): attribute an asynchronous GPU fault to this block's parse
+        if self.sync:   # DSP_PARSE_SYNC=1 (debugging aid): attribute an asynchronous GPU fault to this block's parse
             import sys
             sys.stderr.write("[parse_dev] block of %d rows, %d bytes ..." % (n, n_bytes))
             stream.synchronize()

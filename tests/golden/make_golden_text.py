@@ -126,7 +126,7 @@ def main():
     print("F4: %d lines, e.g. %r" % (len(out_lines), out_lines[0]))
 
 
-if __name__ == "__main__" and os.environ.get("DSP_GOLDEN_ONLY") != "f5":
+if __name__ == "__main__" and os.environ.get("DSP_GOLDEN_ONLY") not in ("f5", "f5c"):
     main()
     os.environ["DSP_GOLDEN_ONLY"] = "f5"
 
@@ -171,3 +171,62 @@ def make_f5():
 
 if __name__ == "__main__" and os.environ.get("DSP_GOLDEN_ONLY") == "f5":
     make_f5()
+
+
+def make_f5_contigs():
+    """F5c (round 5; VERDICT r4 missing 3): call_freq --contigs against the reference -- every branch of
+    call_mods_freq.py:218-296: the contig list from a comma string, from a names file and from a genome fasta (by suffix
+    and by content), the per-contig split of SEVERAL input files (one of them .gz), --nproc 1 and 2 worker processes, the
+    concatenation in sorted-result-file order, with and without --sort / --bed / --gzip.  The second call file holds contig
+    names that are prefixes of each other (chr1, chr10, chr1-x, chr1_2, chr1.1, Chr1): the reference concatenates in the
+    order of file names `<result>.<contig>.<uuid>.<ext>`, i.e. by `contig + "."`."""
+    import argparse
+    import gzip
+    from deepsignal_plant import call_mods_freq as cf
+    rng = np.random.default_rng(77)
+    names = ["chr1", "chr10", "chr1-x", "chr1_2", "chr1.1", "Chr1", "chr2"]
+    lines = []
+    for i in range(900):
+        ch = names[int(rng.integers(0, len(names)))]
+        pos = int(rng.integers(10, 40)) * 3
+        strand = "+" if pos % 2 == 0 else "-"
+        p1 = np.float32(rng.random() ** (0.3 if rng.random() < 0.5 else 3.5))
+        p0 = np.float32(1) - p1
+        z0 = round(p0 / (p0 + p1), 6)
+        z1 = round(1 - z0, 6)
+        lines.append("\t".join([ch, str(pos), strand, str(pos + 2), "rd%d" % (i // 5), "t", str(z0), str(z1), str(1 if p1 > p0 else 0),
+                                "GCCGA"[i % 5:] + "GCCG"[: i % 5]]))
+    second = os.path.join(HERE, "f5c_calls_b.tsv.gz")
+    with gzip.GzipFile(second, "wb", mtime=0) as f:
+        f.write(("\n".join(lines) + "\n").encode())
+    first = os.path.join(HERE, "f5_calls.tsv")
+    names_file = os.path.join(HERE, "f5c_contig_names.txt")
+    with open(names_file, "w") as f:   # unsorted, a duplicate, a name no call has, a comment line (becomes a contig no call has)
+        f.write("# contigs of interest\nchr10\nchrT\nchr1\nchr1-x\nchr1\nchrNone\nscaffold_10\nchr1_2\n")   # (not chr1.1 next to chr1: the reference orders those two by the first hex digit of a uuid1)
+    fasta = os.path.join(HERE, "f5c_genome.fa")
+    with open(fasta, "w") as f:        # fasta order is not sorted order; the header's first word is the name
+        f.write(">chr2 Arabidopsis-like chromosome 2\nACGTACGTAC\nGGTTAACC\n>chr1_2\nACGT\n>chr10 len=4\nTTGA\n>chrM mitochondrion\nACGT\n"
+                ">Chr1\nAC\n>chr1\nGT\n>absent_contig\nAAAA\n")
+    fasta_by_content = os.path.join(HERE, "f5c_genome_noext.txt")   # not named .fa/.fasta/.fna: recognised by its '>' lines
+    with open(fasta_by_content, "w") as f:
+        f.write("# a genome\n>chrT the tie contig\nACGT\n>chr1-x\nAC\n>scaffold_10\nACGT\n")
+    runs = (("comma_tsv", dict(contigs="chr1,chrT,chr10,chrNone,chr1-x", nproc=1, bed=False, sort=False, prob_cf=0.5, gzip=False)),
+            ("names_bed_sorted", dict(contigs=names_file, nproc=2, bed=True, sort=True, prob_cf=0.5, gzip=False)),
+            ("fasta_tsv_sorted", dict(contigs=fasta, nproc=2, bed=False, sort=True, prob_cf=0.5, gzip=False)),
+            ("fasta_content_bed_cf02", dict(contigs=fasta_by_content, nproc=1, bed=True, sort=False, prob_cf=0.2, gzip=False)),
+            ("comma_gzip_cf0", dict(contigs="chr2,Chr1,chr1_2,chr1.1", nproc=2, bed=False, sort=False, prob_cf=0.0, gzip=True)))
+    for tag, kw in runs:
+        out = os.path.join(HERE, "f5c_freq_%s.txt" % tag)
+        args = argparse.Namespace(input_path=[first, second], result_file=out, file_uid=None, **kw)
+        cf.call_mods_frequency_to_file(args)
+        if kw["gzip"]:   # keep the text: the compressed bytes are not the contract
+            data = gzip.open(out + ".gz", "rb").read()
+            os.remove(out + ".gz")
+            open(out, "wb").write(data)
+        print("F5c %s: %d sites" % (tag, sum(1 for _ in open(out))))
+    left = [f for f in os.listdir(HERE) if f.startswith("tmp.")]
+    assert not left, left
+
+
+if __name__ == "__main__" and os.environ.get("DSP_GOLDEN_ONLY") == "f5c":
+    make_f5_contigs()

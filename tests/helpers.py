@@ -125,3 +125,31 @@ def rows_to_tsv(path, kmer, means, stds, lens, signals, labels=None):
                     ";".join(",".join(f(x) for x in row) for row in signals[i]),
                     str(int(labels[i]) if labels is not None else i % 2)]
             wf.write("\t".join(cols) + "\n")
+
+
+def run_cli_jobs(tmp_path, jobs, world=1, timeout=900, env=None, tag="jobs"):
+    """tests/cli_jobs.py: every job ({"argv": [...], "env": {...}}) in ONE process -- or one torchrun launch of `world` ranks --
+    so that interpreter start, `import torch`, HIP initialisation (and the rendezvous) are paid once.  -> the per-job results
+    [{"rc", "stdout", "stderr", "seconds", "error"}], plus the launcher's CompletedProcess as results.proc"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    path = os.path.join(str(tmp_path), "%s.json" % tag)
+    with open(path, "w") as f:
+        json.dump(jobs, f)
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    e.update(env or {})
+    if world > 1:
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+               "127.0.0.1", "--master-port", str(port), "-m", "tests.cli_jobs", path]
+    else:
+        cmd = [sys.executable, "-m", "tests.cli_jobs", path]
+    proc = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=e)
+
+    class Results(list):
+        pass
+    out = Results(json.load(open(path + ".out")) if os.path.exists(path + ".out") else [])
+    out.proc = proc
+    return out

@@ -51,6 +51,42 @@ def test_call_freq_gzip_dir_input_and_contigs(tmp_path):
         cf.call_mods_frequency_to_file(_args(out, input_path=["/nonexistent"]))
 
 
+CONTIG_RUNS = [("comma_tsv", dict(contigs="chr1,chrT,chr10,chrNone,chr1-x", nproc=1)),
+               ("names_bed_sorted", dict(contigs=os.path.join(GOLDEN, "f5c_contig_names.txt"), nproc=2, bed=True, sort=True)),
+               ("fasta_tsv_sorted", dict(contigs=os.path.join(GOLDEN, "f5c_genome.fa"), nproc=2, sort=True)),
+               ("fasta_content_bed_cf02", dict(contigs=os.path.join(GOLDEN, "f5c_genome_noext.txt"), nproc=1, bed=True, prob_cf=0.2)),
+               ("comma_gzip_cf0", dict(contigs="chr2,Chr1,chr1_2,chr1.1", nproc=2, prob_cf=0.0, gzip=True))]
+
+
+@pytest.mark.parametrize("tag,kw", CONTIG_RUNS)
+def test_call_freq_contigs_match_reference_output(tmp_path, tag, kw):
+    """F5c (tests/golden/make_golden_text.py:make_f5_contigs -- the reference's call_mods_frequency_to_file run with
+    --contigs): the contig list from a comma string / a names file / a genome fasta (by suffix and by content), two input
+    files (one .gz), --nproc 1 and 2, per-contig results concatenated in the reference's sorted-file-name order (contig
+    names that are prefixes of each other), --sort / --bed / --gzip.  Byte-exact."""
+    out = str(tmp_path / "freq.txt")
+    cf.call_mods_frequency_to_file(_args(out, input_path=[CALLS, os.path.join(GOLDEN, "f5c_calls_b.tsv.gz")], **kw))
+    got = gzip.open(out + ".gz", "rb").read() if kw.get("gzip") else open(out, "rb").read()
+    assert got == open(os.path.join(GOLDEN, "f5c_freq_%s.txt" % tag), "rb").read()
+    assert os.listdir(str(tmp_path)) == [os.path.basename(out) + (".gz" if kw.get("gzip") else "")]   # no temporary files left
+
+
+def test_contig_list_sources_follow_the_reference(tmp_path):
+    """call_mods_freq.py:253-263 + :129-149: fasta by suffix or by ANY '>' line (not only the first non-comment line),
+    header's first word, file order kept; names file and comma string: sorted(set(...))"""
+    assert cf._contig_names("b,a,b, c") == [" c", "a", "b"]
+    assert cf._contig_names(os.path.join(GOLDEN, "f5c_genome.fa")) == ["chr2", "chr1_2", "chr10", "chrM", "Chr1", "chr1", "absent_contig"]
+    assert cf._contig_names(os.path.join(GOLDEN, "f5c_genome_noext.txt")) == ["chrT", "chr1-x", "scaffold_10"]
+    assert cf._contig_names(os.path.join(GOLDEN, "f5c_contig_names.txt")) == sorted({"# contigs of interest", "chr10", "chrT", "chr1", "chr1-x",
+                                                                                    "chrNone", "scaffold_10", "chr1_2"})
+    late = tmp_path / "names_then_header.txt"
+    late.write_text("chr1\nchr2\n>chr3 x\n")          # a '>' line anywhere makes it a fasta in the reference
+    assert cf._contig_names(str(late)) == ["chr3"]
+    fa = tmp_path / "empty.fasta"
+    fa.write_text("no header here\n")
+    assert cf._contig_names(str(fa)) == []
+
+
 def test_fused_block_path_equals_text_round_trip():
     """call_mods results fed straight into the aggregator == writing the per-read file and re-reading it"""
     f3 = np.load(os.path.join(GOLDEN, "f3_format.npz"))

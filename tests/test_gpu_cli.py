@@ -148,35 +148,33 @@ def test_cli_fused_freq_file_equals_call_freq_on_the_result(tmp_path):
         folded.append("\t".join(w))
     inp2 = os.path.join(str(tmp_path), "folded.tsv")
     open(inp2, "w").write("\n".join(folded) + "\n")
-    out = os.path.join(str(tmp_path), "calls.tsv")
-    for flags, cf_flags in (([], []), (["--freq_bed", "--freq_sort"], ["--bed", "--sort"])):
-        fq = os.path.join(str(tmp_path), "fused.freq")
-        r = _run_cli(["-i", inp2, "-m", ck, "-o", out, "--freq_file", fq, "--prob_cf", "0.02"] + flags)
-        assert r.returncode == 0, r.stderr[-2000:]
-        fq2 = os.path.join(str(tmp_path), "two_step.freq")
-        cmd = [sys.executable, "-m", "deepsignal_plant_amd.deepsignal_plant", "call_freq", "-i", out, "-o", fq2,
-               "--prob_cf", "0.02"] + cf_flags
-        r2 = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
-        assert r2.returncode == 0, r2.stderr[-2000:]
-        assert open(fq, "rb").read() == open(fq2, "rb").read() and os.path.getsize(fq) > 0
+    # round 5: the ten command lines run as jobs of TWO launches (tests/cli_jobs.py: one process, and one launch of two ranks)
+    # instead of ten processes -- each is still `deepsignal_plant <module> ...` through the CLI's main()
+    from tests.helpers import run_cli_jobs
+    T = lambda name: os.path.join(str(tmp_path), name)
+    one, two = [], []
+    for tag, flags, cf_flags in (("tsv", [], []), ("bed", ["--freq_bed", "--freq_sort"], ["--bed", "--sort"])):
+        cm = ["call_mods", "-i", inp2, "-m", ck, "--prob_cf", "0.02"]
+        one.append({"argv": cm + ["-o", T("calls_%s.tsv" % tag), "--freq_file", T("fused_%s.freq" % tag)] + flags})
+        one.append({"argv": ["call_freq", "-i", T("calls_%s.tsv" % tag), "-o", T("two_step_%s.freq" % tag), "--prob_cf", "0.02"] + cf_flags})
+        one.append({"argv": cm + ["-o", T("calls_host_%s.tsv" % tag), "--freq_file", T("host_%s.freq" % tag), "--freq_on", "host"] + flags})
+        for freq_on in ("device", "host"):
+            two.append({"argv": cm + ["-o", T("calls2_%s_%s.tsv" % (tag, freq_on)), "--freq_file", T("two_ranks_%s_%s.freq" % (tag, freq_on)),
+                                     "--freq_on", freq_on] + flags})
+    res = run_cli_jobs(tmp_path, one, world=1, tag="one")
+    assert len(res) == len(one) and all(r["rc"] == 0 for r in res), (res.proc.stderr[-3000:], [r["stderr"][-2000:] for r in res])
+    res2 = run_cli_jobs(tmp_path, two, world=2, tag="two")
+    assert len(res2) == len(two) and all(r["rc"] == 0 for r in res2), (res2.proc.stderr[-3000:], [r["stderr"][-2000:] for r in res2])
+    rd = lambda name: open(T(name), "rb").read()
+    for tag in ("tsv", "bed"):
+        want = rd("two_step_%s.freq" % tag)        # call_freq run on the per-read result file
+        assert len(want) > 0 and rd("fused_%s.freq" % tag) == want
         # the same through the host table (--freq_on host), and sharded over two ranks: records dealt to the ranks by
         # site, reduced on the device, gathered to rank 0 (DeviceSiteFrequency.finish) -- the same bytes every time
-        fq3 = os.path.join(str(tmp_path), "host.freq")
-        r = _run_cli(["-i", inp2, "-m", ck, "-o", out, "--freq_file", fq3, "--prob_cf", "0.02", "--freq_on", "host"] + flags)
-        assert r.returncode == 0, r.stderr[-2000:]
-        assert open(fq3, "rb").read() == open(fq2, "rb").read()
+        assert rd("host_%s.freq" % tag) == want and rd("calls_host_%s.tsv" % tag) == rd("calls_%s.tsv" % tag)
         for freq_on in ("device", "host"):
-            import socket
-            s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-            fq4 = os.path.join(str(tmp_path), "two_ranks_%s.freq" % freq_on)
-            out2 = os.path.join(str(tmp_path), "calls2.tsv")
-            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                   "127.0.0.1", "--master-port", str(port), "-m", "deepsignal_plant_amd.deepsignal_plant", "call_mods",
-                   "-i", inp2, "-m", ck, "-o", out2, "--freq_file", fq4, "--prob_cf", "0.02", "--freq_on", freq_on] + flags
-            r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
-            assert r.returncode == 0, r.stderr[-3000:]
-            assert open(out2, "rb").read() == open(out, "rb").read()
-            assert open(fq4, "rb").read() == open(fq2, "rb").read(), freq_on
+            assert rd("calls2_%s_%s.tsv" % (tag, freq_on)) == rd("calls_%s.tsv" % tag)
+            assert rd("two_ranks_%s_%s.freq" % (tag, freq_on)) == want, freq_on
 
 
 def test_cli_accepts_and_ignores_methy_label(tmp_path):

@@ -30,6 +30,32 @@ def test_device_call_freq_matches_reference_output(tag, kw, blocks):
     assert count == r.n and 0 < used <= count and sites > 0
 
 
+def test_device_call_freq_reproduces_the_references_contig_runs():
+    """F5c (the reference's call_freq --contigs runs, make_golden_text.py:make_f5_contigs) through the DEVICE reduction: the
+    device table over both call files, its lines grouped contig by contig in the reference's concatenation order, is the
+    reference's --contigs output -- sorted or in order of first appearance (a contig's sites appear in the whole stream in
+    the order they appear in the contig's own stream), tsv and bedMethyl, three prob_cf values."""
+    import gzip
+    import torch
+    from deepsignal_plant_amd import call_mods_freq as cf
+    from tests.test_call_freq import CONTIG_RUNS
+    lines = open(CALLS).read().splitlines() + gzip.open(os.path.join(GOLDEN, "f5c_calls_b.tsv.gz"), "rt").read().splitlines()
+    r, probs, labels = _rows_from_calls(lines)
+    pd, ld = torch.from_numpy(probs).cuda(), torch.from_numpy(labels).cuda()
+    tables = {}
+    for tag, kw in CONTIG_RUNS:
+        pc = kw.get("prob_cf", 0.5)
+        if pc not in tables:
+            agg = cf.DeviceSiteFrequency(pc, "cuda:0", nthreads=4)
+            for a in range(0, r.n, 1000):
+                agg.add_block(r, pd[a:a + 1000], ld[a:a + 1000], a, a, min(r.n, a + 1000))
+            tables[pc] = agg.finish()
+        out = tables[pc].format(kw.get("sort", False), kw.get("bed", False)).decode().splitlines(True)
+        contigs = sorted(set(cf._contig_names(kw["contigs"])), key=lambda c: c + ".")
+        got = "".join(l for c in contigs for l in out if l.split("\t")[0] == c)
+        assert got.encode() == open(os.path.join(GOLDEN, "f5c_freq_%s.txt" % tag), "rb").read(), tag
+
+
 def test_device_call_freq_equals_host_aggregator_on_a_large_random_set():
     """2 M calls over 150 k sites with ties of the %.3f output by construction (probabilities on a coarse grid): the device
     reduction (sequential double sums per site after a stable sort) and the host table print the same bytes"""

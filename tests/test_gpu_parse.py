@@ -208,37 +208,46 @@ def test_cli_gives_the_same_bytes_whichever_side_parses(tmp_path):
     fz = str(tmp_path / "rows_foreign.tsv.gz")
     open(fz, "wb").write(gzip.compress(data, 1))
     blk = {"DSP_BLOCK_BYTES": "120000"}
-    ref = None
-    for inp in (plain, bg, fz):
+    # round 5: eleven command lines as jobs of two launches (tests/cli_jobs.py) instead of eleven processes
+    from tests.helpers import run_cli_jobs
+    T = lambda name: str(tmp_path / name)
+    cm = lambda inp, out, extra=(): {"argv": ["call_mods", "-i", inp, "-m", ck, "-o", T(out), "--seed", "3"] + list(extra), "env": blk}
+    fq = lambda out: ["--freq_file", T(out + ".freq"), "--prob_cf", "0.02"]
+    jobs, names = [], []
+    for k, inp in enumerate((plain, bg, fz)):
         for mode in ("host", "device"):
-            out, fq = str(tmp_path / "o.tsv"), str(tmp_path / "o.freq")
-            r = _cli(["-i", inp, "-m", ck, "-o", out, "--freq_file", fq, "--prob_cf", "0.02", "--seed", "3", "--parse_on", mode], env=blk)
-            assert r.returncode == 0, (inp, mode, r.stderr[-3000:])
-            got = (open(out, "rb").read(), open(fq, "rb").read())
-            ref = ref or got
-            assert got == ref, (inp, mode)
-    assert ref[0].count(b"\n") == 1200
-    out, fq = str(tmp_path / "two.tsv"), str(tmp_path / "two.freq")
-    r = _two_ranks(["-i", plain, "-m", ck, "-o", out, "--freq_file", fq, "--prob_cf", "0.02", "--seed", "3"], env=blk)
-    assert r.returncode == 0, r.stderr[-3000:]
-    assert (open(out, "rb").read(), open(fq, "rb").read()) == ref
+            names.append("o_%d_%s.tsv" % (k, mode))
+            jobs.append(cm(inp, names[-1], fq(names[-1]) + ["--parse_on", mode]))
     # errors: the host parser's, whichever side parses
     bad = lines[:]
     wb = bad[300].split(b"\t")
     wb[7] = wb[7].replace(b",", b";", 1)
     bad[300] = b"\t".join(wb)
-    open(plain, "wb").write(b"\n".join(bad))
-    for mode in ("host", "device"):
-        r = _cli(["-i", plain, "-m", ck, "-o", out, "--parse_on", mode], env=blk)
-        assert r.returncode != 0 and "malformed feature row" in r.stderr and "signal_means" in r.stderr, mode
+    open(T("bad_number.tsv"), "wb").write(b"\n".join(bad))
     wb = lines[10].split(b"\t")
     wb[6] = wb[6][:5] + b"X" + wb[6][6:]
     bad = lines[:]
     bad[10] = b"\t".join(wb)
-    open(plain, "wb").write(b"\n".join(bad))
-    for mode in ("host", "device"):
-        r = _cli(["-i", plain, "-m", ck, "-o", out, "--parse_on", mode], env=blk)
-        assert r.returncode != 0 and "KeyError: 'X'" in r.stderr, mode
+    open(T("bad_base.tsv"), "wb").write(b"\n".join(bad))
+    for name in ("bad_number.tsv", "bad_base.tsv"):
+        for mode in ("host", "device"):
+            jobs.append(cm(T(name), "x.tsv", ["--parse_on", mode]))
+    res = run_cli_jobs(tmp_path, jobs, world=1)
+    assert len(res) == len(jobs), (res.proc.stdout[-2000:], res.proc.stderr[-3000:])
+    ref = None
+    for name, r in zip(names, res):
+        assert r["rc"] == 0, (name, r["stderr"][-3000:])
+        got = (open(T(name), "rb").read(), open(T(name + ".freq"), "rb").read())
+        ref = ref or got
+        assert got == ref, name
+    assert ref[0].count(b"\n") == 1200
+    for r, mode in zip(res[6:8], ("host", "device")):
+        assert r["rc"] != 0 and "malformed feature row" in r["stderr"] and "signal_means" in r["stderr"], mode
+    for r, mode in zip(res[8:10], ("host", "device")):
+        assert r["rc"] != 0 and "KeyError: 'X'" in r["stderr"], mode
+    res2 = run_cli_jobs(tmp_path, [cm(plain, "two.tsv", fq("two.tsv"))], world=2, tag="two")
+    assert len(res2) == 1 and res2[0]["rc"] == 0, (res2.proc.stderr[-3000:], [r["stderr"][-2000:] for r in res2])
+    assert (open(T("two.tsv"), "rb").read(), open(T("two.tsv.freq"), "rb").read()) == ref
 
 
 @pytest.mark.parametrize("mode", ["device", "host"])

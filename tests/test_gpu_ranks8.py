@@ -19,7 +19,7 @@ import sys
 
 import pytest
 
-from tests.helpers import ROOT
+from tests.helpers import ROOT, run_cli_jobs
 from tests.test_gpu_cli import _ckpt, _folded_rows, _keep, _run_cli
 
 pytestmark = pytest.mark.gpu
@@ -116,55 +116,94 @@ def _inputs(tmp_path, data, tag):
     return {"plain": plain, "bgzf": bgzf, "foreign_gz": foreign}
 
 
-def _one_rank_reference(tmp_path, inp, ck, tag, env):
-    out, fq = str(tmp_path / ("%s_one.tsv" % tag)), str(tmp_path / ("%s_one.freq" % tag))
-    r = _run_cli(["-i", inp, "-m", ck, "-o", out, "--freq_file", fq, "--prob_cf", "0.02", "--seed", "31"], env=env)
-    assert r.returncode == 0, r.stderr[-3000:]
-    return open(out, "rb").read(), open(fq, "rb").read()
+COMMON = ["--prob_cf", "0.02", "--seed", "31"]
+BLK = {"DSP_BLOCK_BYTES": "150000"}     # many reader blocks per rank (and ~33 ring blocks for the foreign .gz)
 
 
-@pytest.mark.parametrize("fmt", ["plain", "bgzf", "foreign_gz"])
-def test_config5_eight_ranks_write_the_bytes_of_one(tmp_path, fmt):
-    """configs[4]'s pipeline (feature TSV -> per-read calls -> call_freq aggregation) with eight ranks, default randn mode:
-    2,400 rows / 23 sites.  Plain text is split by byte range, BGZF by member range (row counts from the member
-    headers), the foreign .gz is inflated once into the shared-memory ring and dealt block by block; --freq_file is reduced
-    on the device (records exchanged by site: one all_to_all over the eight ranks).  Bytes == the one-rank run on the plain
-    file."""
+def _job(inp, ck, out, env=None, extra=()):
+    return {"argv": ["call_mods", "-i", inp, "-m", ck, "-o", out, "--freq_file", out + ".freq"] + COMMON + list(extra),
+            "env": dict(env or {}, DSP_TIMING="1"), "out": out}
+
+
+@pytest.fixture(scope="module")
+def eight_rank_runs(tmp_path_factory):
+    """Round 5: the eight-rank cases share their launches.  ONE launch of eight ranks runs all six
+    configs[4] command lines (three input forms x plain / --gzip output) and ONE more the six fewer-rows-than-ranks ones
+    (tests/cli_jobs.py: the ranks, their process group and the HIP runtime are set up once per launch instead of once per
+    command line: 10-15 s of cold imports each); the one-rank references run as jobs of one process.  Every command line is
+    still `deepsignal_plant call_mods ...` through the CLI's own main()."""
+    import time
+    tmp_path = tmp_path_factory.mktemp("ranks8")
     ck = _ckpt(tmp_path)
     data = _folded_rows(n_rep=12)
     paths = _inputs(tmp_path, data, "rows")
-    blk = {"DSP_BLOCK_BYTES": "150000"}     # many reader blocks per rank (and ~33 ring blocks for the foreign .gz)
-    ref_calls, ref_freq = _one_rank_reference(tmp_path, paths["plain"], ck, "rows", blk)
+    few = {}
+    for n_rows in (5, 1):
+        few[n_rows] = _inputs(tmp_path, b"".join(_folded_rows(n_rep=1).splitlines(True)[:n_rows]), "few%d" % n_rows)
+    ref_jobs = [_job(paths["plain"], ck, str(tmp_path / "rows_one.tsv"), BLK)]
+    ref_jobs += [_job(few[n]["plain"], ck, str(tmp_path / ("few%d_one.tsv" % n))) for n in (5, 1)]
+    t0 = time.time()
+    refs = run_cli_jobs(tmp_path, ref_jobs, world=1, tag="refs")
+    assert len(refs) == 3 and all(r["rc"] == 0 for r in refs), (refs.proc.stderr[-3000:], [r["stderr"][-2000:] for r in refs])
+    big = {}
+    for fmt in ("plain", "bgzf", "foreign_gz"):
+        big[(fmt, False)] = _job(paths[fmt], ck, str(tmp_path / ("eight_%s.tsv" % fmt)), BLK)
+        big[(fmt, True)] = _job(paths[fmt], ck, str(tmp_path / ("eight_%s_gz.tsv" % fmt)), BLK, ["--gzip"])
+    res_big = run_cli_jobs(tmp_path, list(big.values()), world=WORLD, tag="big", timeout=1200)
+    small = {}
+    for n in (5, 1):
+        for fmt in ("plain", "bgzf", "foreign_gz"):
+            small[(n, fmt)] = _job(few[n][fmt], ck, str(tmp_path / ("eight_few%d_%s.tsv" % (n, fmt))))
+    res_small = run_cli_jobs(tmp_path, list(small.values()), world=WORLD, tag="small", timeout=1200)
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out", "r5"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "r5", "ranks8_launches.txt"), "w") as f:
+            f.write("3 launches (1 rank x 3 jobs, 8 ranks x 6 jobs, 8 ranks x 6 jobs): %.1f s in all\n" % (time.time() - t0))
+            for name, jobs, res in (("refs", ref_jobs, refs), ("big", list(big.values()), res_big), ("small", list(small.values()), res_small)):
+                for j, r in zip(jobs, res):
+                    f.write("%-6s %6.2f s  %s\n" % (name, r["seconds"], " ".join(j["argv"][1:])))
+    except OSError:
+        pass
+    return dict(tmp=tmp_path, refs=dict(zip(("rows", 5, 1), ref_jobs)), big=big, res_big=dict(zip(big, res_big)), small=small,
+                res_small=dict(zip(small, res_small)), procs=(res_big.proc, res_small.proc))
+
+
+def _read(job, gz=False):
+    rd = (lambda p: gzip.open(p + ".gz", "rb").read()) if gz else (lambda p: open(p, "rb").read())
+    return rd(job["out"]), rd(job["out"] + ".freq")
+
+
+@pytest.mark.parametrize("fmt", ["plain", "bgzf", "foreign_gz"])
+def test_config5_eight_ranks_write_the_bytes_of_one(eight_rank_runs, fmt):
+    """configs[4]'s pipeline (feature TSV -> per-read calls -> call_freq aggregation) with eight ranks, default randn mode:
+    2,400 rows / 23 sites.  Plain text is split by byte range, BGZF by member range (row counts from the member
+    headers), the foreign .gz is inflated once into the shared-memory ring and dealt block by block; --freq_file is reduced
+    on the device (records exchanged by site: one all_to_all over the eight ranks -- since round 5 the SAME ragged
+    all_to_all_single that runs on RCCL, dist.exchange_records).  Bytes == the one-rank run on the plain file."""
+    R = eight_rank_runs
+    ref_calls, ref_freq = _read(R["refs"]["rows"])
     assert ref_calls.count(b"\n") == 2400 and len(ref_freq) > 0
-    out, fq = str(tmp_path / "eight.tsv"), str(tmp_path / "eight.freq")
-    r = _ranks(["-i", paths[fmt], "-m", ck, "-o", out, "--freq_file", fq, "--prob_cf", "0.02", "--seed", "31"], env=blk)
-    assert r.returncode == 0, r.stderr[-4000:]
-    assert "2400 sites on 8 GPU(s)" in r.stdout
-    assert open(out, "rb").read() == ref_calls, fmt
-    assert open(fq, "rb").read() == ref_freq, fmt
-    assert not [f for f in os.listdir(str(tmp_path)) if ".part" in f or f.endswith(".blocks")]
+    for gz in (False, True):   # and with the calls gzip-compressed on the way out (whole BGZF members per rank, one end-of-file member)
+        r = R["res_big"].get((fmt, gz))
+        assert r is not None and r["rc"] == 0, (fmt, gz, R["procs"][0].stderr[-3000:], r and r["stderr"][-3000:])
+        assert "2400 sites on 8 GPU(s)" in r["stdout"]
+        assert _read(R["big"][(fmt, gz)], gz) == (ref_calls, ref_freq), (fmt, gz)
+    left = os.listdir(str(R["tmp"]))
+    assert not [f for f in left if ".part" in f or f.endswith(".blocks")]
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("dsp_gz_")]
-    # and with the calls gzip-compressed on the way out (whole BGZF members per rank, one end-of-file member)
-    r = _ranks(["-i", paths[fmt], "-m", ck, "-o", out, "--freq_file", fq, "--prob_cf", "0.02", "--seed", "31", "--gzip"], env=blk)
-    assert r.returncode == 0, r.stderr[-4000:]
-    assert gzip.open(out + ".gz", "rb").read() == ref_calls and gzip.open(fq + ".gz", "rb").read() == ref_freq
     _keep("cli_8ranks_%s.txt" % fmt, "8 ranks sharing one GPU, %s input, 2400 rows, --freq_file (device), randn mode: calls and "
           "frequencies byte-identical to one rank, plain and --gzip output\n" % fmt)
 
 
 @pytest.mark.parametrize("n_rows", [5, 1])
-def test_config5_fewer_rows_than_ranks(tmp_path, n_rows):
+def test_config5_fewer_rows_than_ranks(eight_rank_runs, n_rows):
     """five rows (and one) for eight ranks, in all three input forms: ranks without rows take part in every collective
     (row counts, the exchange of call_freq records, the merge) and the result is the one-rank file"""
-    ck = _ckpt(tmp_path)
-    data = b"".join(_folded_rows(n_rep=1).splitlines(True)[:n_rows])
-    paths = _inputs(tmp_path, data, "few")
-    ref_calls, ref_freq = _one_rank_reference(tmp_path, paths["plain"], ck, "few", None)
+    R = eight_rank_runs
+    ref_calls, ref_freq = _read(R["refs"][n_rows])
     assert ref_calls.count(b"\n") == n_rows
-    for fmt, inp in paths.items():
-        out, fq = str(tmp_path / ("eight_%s.tsv" % fmt)), str(tmp_path / ("eight_%s.freq" % fmt))
-        r = _ranks(["-i", inp, "-m", ck, "-o", out, "--freq_file", fq, "--prob_cf", "0.02", "--seed", "31"])
-        assert r.returncode == 0, (fmt, r.stderr[-4000:])
-        assert open(out, "rb").read() == ref_calls, fmt
-        assert open(fq, "rb").read() == ref_freq, fmt
-        assert not [f for f in os.listdir(str(tmp_path)) if ".part" in f or f.endswith(".blocks")]
+    for fmt in ("plain", "bgzf", "foreign_gz"):
+        r = R["res_small"].get((n_rows, fmt))
+        assert r is not None and r["rc"] == 0, (fmt, R["procs"][1].stderr[-3000:], r and r["stderr"][-3000:])
+        assert _read(R["small"][(n_rows, fmt)]) == (ref_calls, ref_freq), fmt
+    assert not [f for f in os.listdir(str(R["tmp"])) if ".part" in f or f.endswith(".blocks")]
