@@ -313,12 +313,16 @@ struct dsp_model {
     int tiling21 = -1;       // <2 unit tiles, 1 site tile> per wave on the dense one-pass layers (dsp_lstm21_kernel): -1 = for
                              // batches whose 32-site tiles x 2 directions fit the CUs at once (small-batch latency); DSP_LSTM_TILING=21
                              // always, =0 never (A/B switch)
+    bool fc_small = true;    // dsp_linear1_kernel for batches <= 4,096 sites (A/B switch DSP_FC_SMALL=0)
     bool fc_fused = true;    // fc_seq + fc_signal in one launch when they have one shape (A/B switch DSP_FC_FUSED=0)
     bool local8 = true;      // dense 8-unit-tile layers of 2,049..4,096-site batches on dsp_lstmc_kernel's eight-wave workgroup-local
                              // form (two waves per SIMD: 3.43 vs 3.48 ms per forward of 4,096 sites) instead of dsp_lstm21_kernel;
                              // DSP_LSTM_LOCAL8=0 turns it off (A/B switch)
     bool head_st4 = false;   // DSP_HEAD_ST4=1: the head kernel keeps four site tiles per workgroup at every batch size (A/B switch)
     bool sync_each = false, debug_lstm = false;  // DSP_SYNC_EACH / DSP_DEBUG_LSTM: debugging aids, read when the handle is made
+    bool xcc_probe_failed = false;   // dsp_model_create's XCC_ID probe did not find block b on XCD b % 8: no clustered launches
+    int front_cluster = -1;  // the front ends (4 unit tiles) clustered too (round 5): -1 = whenever their grids fit the CUs at once;
+                             // DSP_LSTM_FRONT_CLUSTER=0 never, =1 / 2 that many gates per wave (A/B switch)
     int cluster = -1;        // dsp_lstmc_kernel (a site tile's unit tiles spread over several CUs, small batches): -1 = whenever the
                              // whole grid fits the CUs at once; DSP_LSTM_CLUSTER=0 never, =1 / 2 / 4 that many gates per wave
     int two_streams = -1;    // the signal branch on a side stream next to the seq branch (they are independent until the combined
@@ -548,7 +552,29 @@ int cluster_size(const dsp_model* m, long long NTp) {
     }
     return P >= 2 ? P : 0;
 }
-int pick_cluster(const dsp_model* m, const LstmArgs& a, long long NTp, bool split) {
+// Front ends (layers of 4 unit tiles whose x part is one ring of four k-groups: hidden 128, 7 or 16 features): gates per wave
+// of the clustered form (1: P = 4 workgroups per (site tile, direction), 2: P = 2), or 0 = workgroup-local.  `branches` = the
+// front-end launches that run side by side (2 with the signal branch on the side stream): all their workgroups must be
+// resident at once, one per CU.  Round 5: 512 sites 0.122 / 0.131 -> ~0.05 ms per front-end launch.  DSP_LSTM_FRONT_CLUSTER=0
+// turns it off (A/B switch), =1 / 2 forces that many gates per wave where it fits.
+int front_cluster_gates(const dsp_model* m, const LstmArgs& a, long long NTp, int branches) {
+    if (m->cluster == 0 || m->front_cluster == 0 || a.UT != 4 || a.NP > 1 || (a.Ipad >> 3) != 4 || a.NQ != ((a.Ipad + a.Hp) >> 3) ||
+        a.NQ % 4 || a.NQ < 8 || NTp * 2 * 32 > kClusterWordsPerLaunch)
+        return 0;
+    const long long slots = (long long)m->n_cus / std::max(1, branches);
+    int P = 1;
+    while (P < 4 && NTp * 2 * (P * 2) <= slots) P *= 2;
+    if (m->front_cluster > 0) {
+        const int want = m->front_cluster == 1 ? 4 : (m->front_cluster == 2 ? 2 : 0);
+        P = (want && NTp * 2 * want <= slots) ? want : 1;
+    }
+    return P >= 2 ? 4 / P : 0;
+}
+int pick_cluster(const dsp_model* m, const LstmArgs& a, long long NTp, bool split, int branches) {
+    if (!split) {
+        const int fg = front_cluster_gates(m, a, NTp, branches);
+        if (fg) return fg;
+    }
     // layers of 4 unit tiles (the front ends at hidden 128): one 4-wave workgroup per (site tile, direction) holds the whole
     // layer -- a wave 1 unit tile x 1 site tile, half the work per step of the 64-site tiling -- whenever those workgroups
     // fit the CUs at once (<= 4,096 sites); no exchange between workgroups, so nothing to wait for.  (On full batches this form
@@ -619,12 +645,14 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
             a.SG = 8 / a.UT;
         }
         // batches that leave most CUs idle: the layer's unit tiles spread over a cluster of workgroups (dsp_lstmc_kernel)
-        a.CG = (launch_no < kClusterLaunches && m->cflags) ? pick_cluster(m, a, L.NTp, split) : 0;
+        a.CG = (launch_no < kClusterLaunches && m->cflags) ? pick_cluster(m, a, L.NTp, split, L.side_by_side ? 2 : 1) : 0;
         if (a.CG < 0) { a.CG = -a.CG; a.flags |= 8; }
         if (a.CG) {
             a.cluster_timeout = m->cluster_timeout;
             a.cflags = m->cflags + (size_t)launch_no * kClusterWordsPerLaunch;
-            if (!L.side_by_side) a.flags |= 4;   // one workgroup per CU (not when two branches run side by side on two streams)
+            // one workgroup per CU: not for the workgroup-local forms of two branches that run side by side on two streams (they
+            // may share CUs); the CLUSTERED front ends of two branches were sized so that both grids fit the CUs together
+            if (!L.side_by_side || (a.UT == 4 && a.CG < 4)) a.flags |= 4;
         }
         if (m->debug_lstm)   // DSP_DEBUG_LSTM (read once, in dsp_model_create)
             fprintf(stderr, "[lstm] %s k=%zu split=%d CG=%d Ipad=%d H=%d Hp=%d UT=%d SG=%d NQ=%d NTp=%lld n=%lld T=%d Fout=%d x=%p out=%p\n", name, k,
@@ -716,11 +744,13 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
     m->head_st4 = getenv("DSP_HEAD_ST4") != nullptr;
     if (const char* v = getenv("DSP_LSTM_LOCAL8")) m->local8 = atoi(v) != 0;
     if (const char* v = getenv("DSP_FC_FUSED")) m->fc_fused = atoi(v) != 0;
+    if (const char* v = getenv("DSP_FC_SMALL")) m->fc_small = atoi(v) != 0;
     if (const char* v = getenv("DSP_LSTM_SG")) m->sg_override = atoi(v);  // A/B switch
     if (const char* v = getenv("DSP_LSTM_NP8")) m->np8 = atoi(v) == 2 ? 2 : 1;  // A/B switch
     if (const char* v = getenv("DSP_LSTM_PRIO")) m->phase_prio = atoi(v) != 0;    // A/B switch
     if (const char* v = getenv("DSP_LSTM_TILING")) m->tiling21 = atoi(v) == 21 ? 1 : 0;   // A/B switch
     if (const char* v = getenv("DSP_LSTM_CLUSTER")) m->cluster = atoi(v);                  // A/B switch
+    if (const char* v = getenv("DSP_LSTM_FRONT_CLUSTER")) m->front_cluster = atoi(v);      // A/B switch
     if (const char* v = getenv("DSP_CLUSTER_TIMEOUT")) m->cluster_timeout = strtoull(v, nullptr, 10);
     if (const char* v = getenv("DSP_TWO_STREAMS")) m->two_streams = atoi(v) != 0 ? 1 : 0;   // A/B switch
     if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -731,6 +761,27 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) m->n_cus = prop.multiProcessorCount;
+    }
+    if (m->cluster != 0) {
+        // The clustered launches assume block b of a launch runs on XCD b % 8 (members of a cluster = consecutive entries of
+        // one XCD's dispatch list).  Observed, not promised: ask this device once -- 64 blocks report their XCC_ID -- and keep
+        // to the workgroup-local forms when it answers anything else (CPX / partition modes, CU masks, another XCD count).
+        // DSP_LSTM_CLUSTER_PROBE=0 skips the question.
+        const char* pv = getenv("DSP_LSTM_CLUSTER_PROBE");
+        if (!(pv && atoi(pv) == 0)) {
+            unsigned* dp = nullptr;
+            unsigned host[64];
+            bool ok = hipMalloc((void**)&dp, sizeof host) == hipSuccess && dsp_k_probe_xcc(dp, 64, nullptr) == 0 &&
+                      hipMemcpy(host, dp, sizeof host, hipMemcpyDeviceToHost) == hipSuccess;
+            if (dp) hipFree(dp);
+            for (int b = 0; ok && b < 64; ++b) ok = host[b] == (unsigned)(b % 8);
+            if (!ok) {
+                (void)hipGetLastError();
+                m->cluster = 0;
+                m->xcc_probe_failed = true;
+                if (m->debug_lstm) fprintf(stderr, "[lstm] XCC probe: block b does not run on XCD b %% 8 here: clustered launches off\n");
+            }
+        }
     }
     {   // arrival counters of the clustered launches (zeroed by every forward's first launch; 1.5 MB)
         void* p = nullptr;
@@ -872,7 +923,8 @@ int32_t dsp_forward(dsp_model* m, void* stream, int64_t n, const void* kmer, int
     p.n = n; p.NTp = NTp; p.kdt = kmer_dtype; p.ldt = lens_dtype;
     p.T = d.T; p.S = d.S; p.E = d.E; p.V = d.V; p.is_base = d.is_base; p.is_siglen = d.is_siglen;
     p.Fseq = m->Fseq; p.Fsig = m->Fsig; p.xoff_seq = m->xoff_seq; p.xoff_sig = m->xoff_sig;
-    if (cluster_size(m, NTp)) {   // this forward may run clustered LSTM launches: their arrival counters start from zero
+    if (m->cluster != 0 && NTp * 4 <= (long long)m->n_cus) {   // this forward may run clustered LSTM launches (the combined stack
+        // from P = 2: <= 2,048 sites; the front ends from P = 2 as well): their arrival counters start from zero
         const int launches = std::min(kClusterLaunches, (d.hseq ? d.l2 : 0) + (d.hsig ? d.l2 : 0) + d.l1);
         p.zero_words = m->cflags;
         p.n_zero_words = launches * kClusterWordsPerLaunch;
@@ -886,6 +938,9 @@ int32_t dsp_forward(dsp_model* m, void* stream, int64_t n, const void* kmer, int
         a.x = x; a.out = m->comb_in; a.wpk = fc.wpk; a.bias = fc.bias;
         a.ncols = NTp * d.T; a.Fin = fc.Fin; a.Fout = m->Fcomb; a.out_off = out_off; a.ORT = fc.ORT; a.relu = 1;
         if (fc2) { a.x2 = x2; a.wpk2 = fc2->wpk; a.bias2 = fc2->bias; a.out_off2 = out_off2; }
+        // batches of <= 4,096 sites: one accumulator tile per wave (round 5: 512 sites 35 -> ~12 us per projection; the
+        // 8-tile wave of dsp_linear_kernel runs 28 us whatever the batch).  DSP_FC_SMALL=0 turns it off (A/B switch)
+        a.small = (m->fc_small && NTp * 2 <= (long long)m->n_cus) ? 1 : 0;
         L.run(name, [&] { return dsp_k_linear(&a, L.s); });
     };
     // The seq and the signal branch are independent until the combined stack (models.py:181-217).  On batches that leave

@@ -770,13 +770,26 @@ __device__ __forceinline__ void bst16_sc1(__amdgpu_buffer_rsrc_t r, uint32_t vof
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, (int)soff, 16);
     store_data_guard(v);
 }
-// wait until `target` arrivals have been counted (every wave polls for itself: no workgroup barrier inside the k-loop)
-__device__ __forceinline__ void wait_arrivals(gu32* flag, unsigned target) {
+constexpr unsigned kClusterAbandon = 0x80000000u;
+// wait until `target` arrivals have been counted (every wave polls for itself: no workgroup barrier inside the k-loop).
+// Returns false when the cluster was given up: a member that sees no progress for seconds (a member that never became
+// resident or died -- admission makes that all but impossible) marks the cluster abandoned in its admission word, every
+// member notices within 4,096 polls and leaves, and the clean-up launch behind this one computes the cluster from scratch
+// (it recomputes every step, so what the members had written is overwritten).  Until round 5 this was a trap: one stuck
+// poll ended the process -- with 8 ranks, the job.
+__device__ __forceinline__ bool wait_arrivals(gu32* flag, unsigned target) {
     for (unsigned spins = 0;; ++spins) {
         const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        if (v >= target) return;
+        if (v >= target) return true;
         __builtin_amdgcn_s_sleep(1);
-        if (spins > (1u << 24)) __builtin_trap();   // seconds without progress: a cluster member never became resident
+        if ((spins & 0xfffu) == 0xfffu) {
+            const unsigned st = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (st & kClusterAbandon) return false;
+            if (spins > (1u << 24)) {
+                __hip_atomic_fetch_or(flag + 1, kClusterAbandon, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
     }
 }
 
@@ -787,7 +800,6 @@ __device__ __forceinline__ void wait_arrivals(gu32* flag, unsigned target) {
 // for all (one CAS on the word that also holds the count, so that "all arrived" and "abandoned" exclude each other): every
 // member, present or still to come, exits at once, and the clean-up launch behind this one (the workgroup-local form, no
 // waiting between workgroups) computes the abandoned clusters.  Returns true when the cluster runs.
-constexpr unsigned kClusterAbandon = 0x80000000u;
 __device__ __forceinline__ bool cluster_admit(gu32* state, unsigned P, unsigned long long limit) {
     unsigned s = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (;;) {
@@ -808,15 +820,13 @@ __device__ __forceinline__ bool cluster_admit(gu32* state, unsigned P, unsigned 
     }
 }
 
-template <int G, int D, bool LOCAL = false, int DEAD = 0, int NW = 4>
-__global__ __launch_bounds__(NW * 64, 1) void dsp_lstmc_kernel(LstmArgs a) {
-    // NW = 8 (LOCAL, layers of 8 unit tiles): eight waves, two per SIMD, a wave 1 unit tile x 1 site tile -- the alternative
-    // to dsp_lstm21_kernel's four waves of 2 unit tiles for batches of 2,049..4,096 sites (A/B: DSP_LSTM_LOCAL8)
-    // DEAD (LOCAL, nqx == D: the front ends, 7 or 16 features at the end of a 32-wide block): the first DEAD k-groups of a
-    // step are pure zero padding -- their stages keep the ring turning (refills only) and issue no MFMAs
-    // LOCAL (G = 4, layers of 4 unit tiles: the front ends at hidden 128): the workgroup holds the whole hidden state, P = 1 --
-    // the h exchange is the step barrier of dsp_lstm21_kernel (plain stores, one s_barrier, plain loads), no counter; the x
-    // part may be as short as the ring (nqx == D: the h part's first requests then leave right behind the barrier)
+// One layer of one (site tile, direction) on this workgroup: prologue (ring fill, bias table, initial states, h0 hand-off)
+// and the T steps.  `pi` = this workgroup's index in the cluster (0 when LOCAL), `flag` = the cluster's counters of THIS layer.
+// Returns false when the cluster was given up on the way (wait_arrivals).  Called once by dsp_lstmc_kernel, once per layer by
+// the persistent stack kernel (dsp_lstmp_kernel) and once per (layer, direction) by its clean-up kernel: every call ends with a
+// workgroup barrier behind its last LDS read (publish), so the next call may overwrite the LDS at once.
+template <int G, int D, bool LOCAL, int DEAD, int NW, bool XSHORT>
+__device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, const long long gt0, const int pi, gu32* flag) {
     constexpr int WPU = 4 / G;             // waves per unit tile = gate slices; unit tiles per workgroup = G
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* b_lds = (f32x4*)smem;           // [unit tile][aa][gate][half] float4 (Hp float4)
@@ -826,13 +836,6 @@ __global__ __launch_bounds__(NW * 64, 1) void dsp_lstmc_kernel(LstmArgs a) {
     const uint32_t voff = (uint32_t)lane * 16u;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int P = LOCAL ? 1 : a.UT / G;
-    // cluster c = (site tile, direction); its P members are consecutive entries of one XCD's dispatch list
-    const int xs = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int pi = j % P;
-    const long long c = (long long)(j / P) * 8 + xs;
-    if (c >= a.NTp * 2) return;
-    const int dir = (int)(c & 1);
-    const long long gt0 = c >> 1;
     const int ul = w / WPU, gs = w % WPU;
     const int u = pi * G + ul;             // this wave's unit tile
     const int half = lane >> 5, ls = lane & 31;
@@ -843,20 +846,6 @@ __global__ __launch_bounds__(NW * 64, 1) void dsp_lstmc_kernel(LstmArgs a) {
     const uint32_t xrow = (uint32_t)(a.Ipad >> 2) * 512u;
     const uint32_t orow = (uint32_t)F4 * 512u;
     const bool prio = (a.flags & 1) != 0;
-    gu32* flag = (gu32*)a.cflags + c * 32;   // word 0: arrivals of the steps; word 1: admission (count | abandoned)
-    if constexpr (LOCAL) {
-        // the clean-up launch behind a clustered one (flags bit 4): only the clusters that were abandoned are computed here
-        if ((a.flags & 16) && !(__hip_atomic_load(flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kClusterAbandon)) return;
-    } else {
-        // (the verdict travels through the first word of the dynamic LDS -- no static LDS next to a 160 KiB dynamic limit --,
-        // which the bias table overwrites only after everybody has read it)
-        int* verdict = (int*)smem;
-        if (tid == 0) *verdict = cluster_admit(flag + 1, (unsigned)P, a.cluster_timeout) ? 1 : 0;
-        __syncthreads();
-        const int admitted = *(volatile int*)verdict;
-        __syncthreads();
-        if (!admitted) return;
-    }
 
     const __amdgpu_buffer_rsrc_t rw = make_rsrc((const char*)(dir ? a.wpk1 : a.wpk0) + (size_t)u * NQ * 4096);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)a.x + (size_t)gt0 * T * xrow);
@@ -990,13 +979,21 @@ __global__ __launch_bounds__(NW * 64, 1) void dsp_lstmc_kernel(LstmArgs a) {
                 else stages(0, std::true_type{}, ic<1>{});
                 for (int q = D; q < NQ - D; q += D) stages(q, std::false_type{}, ic<1>{});
             }
+        } else if constexpr (XSHORT) {
+            // every refill of this step is an h row: h_{t-1} (h0 at step 0) of every member of the cluster must be in memory
+            asm volatile("" ::: "memory");
+            if (!wait_arrivals(flag, (unsigned)(P * (step + 1)))) return false;   // (given up: the clean-up launch computes this cluster)
+            asm volatile("" ::: "memory");
+            if constexpr (DEAD > 0) stages_first_sparse(ic<1>{});
+            else stages(0, std::true_type{}, ic<1>{});
+            for (int q = D; q < NQ - D; q += D) stages(q, std::false_type{}, ic<1>{});
         } else {
             // x part: nothing here depends on h_{t-1}
             stages(0, std::true_type{}, ic<0>{});
             for (int q = D; q < nqx - D; q += D) stages(q, std::false_type{}, ic<0>{});
             // the B ring is about to reach into the h part: h_{t-1} (h0 at step 0) of every member of the cluster must be in memory
             asm volatile("" ::: "memory");   // (no h load may be moved above the poll by the compiler either)
-            wait_arrivals(flag, (unsigned)(P * (step + 1)));
+            if (!wait_arrivals(flag, (unsigned)(P * (step + 1)))) return false;   // (given up: the clean-up launch computes this cluster)
             asm volatile("" ::: "memory");
             for (int q = nqx - D; q < NQ - D; q += D) stages(q, std::false_type{}, ic<1>{});
         }
@@ -1045,6 +1042,128 @@ __global__ __launch_bounds__(NW * 64, 1) void dsp_lstmc_kernel(LstmArgs a) {
             else bst16_sc1(ro, voffO + al * 1024u, (uint32_t)t * orow + (uint32_t)u * 4096u, hv);
         }
         publish();   // (also the barrier between this step's LDS reads and the next step's LDS writes)
+    }
+    return true;
+}
+
+template <int G, int D, bool LOCAL = false, int DEAD = 0, int NW = 4, bool XSHORT = false>
+__global__ __launch_bounds__(NW * 64, 1) void dsp_lstmc_kernel(LstmArgs a) {
+    // XSHORT (round 5; clustered, layers of 4 unit tiles whose x part is exactly one ring: nqx == D == 4 -- the front ends at
+    // hidden 128): a (site tile, direction) of a front end spread over P = 4 / G workgroups.  Until round 5 the front ends of a
+    // small batch ran workgroup-local: 32 recurrences on 32 CUs at 512 sites, 13 steps x 17 k-groups x 4 gates x 256 cycles =
+    // 0.12-0.13 ms per launch whatever the batch, a fifth of a 512-site forward, with 192 CUs idle.  There is no x part to hide
+    // the hop behind (its k-groups are the ring's first fill, requested a step early): the poll comes first, then the
+    // (partly dead) x-part stages whose refills are the first h rows.
+    // NW = 8 (LOCAL, layers of 8 unit tiles): eight waves, two per SIMD, a wave 1 unit tile x 1 site tile -- the alternative
+    // to dsp_lstm21_kernel's four waves of 2 unit tiles for batches of 2,049..4,096 sites (A/B: DSP_LSTM_LOCAL8)
+    // DEAD (LOCAL, nqx == D: the front ends, 7 or 16 features at the end of a 32-wide block): the first DEAD k-groups of a
+    // step are pure zero padding -- their stages keep the ring turning (refills only) and issue no MFMAs
+    // LOCAL (G = 4, layers of 4 unit tiles: the front ends at hidden 128): the workgroup holds the whole hidden state, P = 1 --
+    // the h exchange is the step barrier of dsp_lstm21_kernel (plain stores, one s_barrier, plain loads), no counter; the x
+    // part may be as short as the ring (nqx == D: the h part's first requests then leave right behind the barrier)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int P = LOCAL ? 1 : a.UT / G;
+    // cluster c = (site tile, direction); its P members are consecutive entries of one XCD's dispatch list
+    const int xs = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int pi = j % P;
+    const long long c = (long long)(j / P) * 8 + xs;
+    if (c >= a.NTp * 2) return;
+    const int dir = (int)(c & 1);
+    const long long gt0 = c >> 1;
+    gu32* flag = (gu32*)a.cflags + c * 32;   // word 0: arrivals of the steps; word 1: admission (count | abandoned)
+    if constexpr (LOCAL) {
+        // the clean-up launch behind a clustered one (flags bit 4): only the clusters that were abandoned are computed here
+        if ((a.flags & 16) && !(__hip_atomic_load(flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kClusterAbandon)) return;
+    } else {
+        // (the verdict travels through the first word of the dynamic LDS -- no static LDS next to a 160 KiB dynamic limit --,
+        // which the bias table overwrites only after everybody has read it)
+        int* verdict = (int*)smem;
+        if (tid == 0) *verdict = cluster_admit(flag + 1, (unsigned)P, a.cluster_timeout) ? 1 : 0;
+        __syncthreads();
+        const int admitted = *(volatile int*)verdict;
+        __syncthreads();
+        if (!admitted) return;
+    }
+    lstmc_layer<G, D, LOCAL, DEAD, NW, XSHORT>(a, dir, gt0, pi, flag);
+}
+
+// ------------------------------------------------------------------------------------------------
+// dsp_lstmp_kernel<G, D> (round 5): the layers of a clustered stack in ONE launch.  A forward of 512 sites spent ~28 us per
+// clustered launch outside its step loop -- dispatch, admission, the drain at the end, the clean-up launch behind it and two
+// kernel boundaries -- three times for the combined stack.  A layer of a BiLSTM needs BOTH directions of the layer below at
+// every step, i.e. the (site tile, forward) and the (site tile, backward) cluster of the layer below, complete: that is a
+// dependency between TWO clusters, not a grid barrier.  The arrival counter of a cluster reads P x (T + 1) once its last step
+// is published, so a cluster enters layer k + 1 when its own and its partner's counter of layer k say so; one agent-scope
+// acquire (buffer_inv sc1) drops what this CU's L1 still holds of the buffer from two layers ago, then the x rows are plain
+// loads as before.  Write-after-read on the two ping-pong buffers is covered by the same wait: layer k + 1 writes the buffer
+// layer k read, and both clusters that read this tile's rows of it have finished layer k.  One admission per stack.  A
+// cluster that is given up (admission timeout; a poll without progress) leaves its abandon bit in the word of the layer it
+// happened in; whoever waits on that word leaves too, and ONE clean-up launch (dsp_lstmp_cleanup_kernel) recomputes, per site
+// tile, every layer from the first dirty one -- one workgroup, both directions in turn, nothing to wait for.
+// Same MFMAs on the same values in the same order: bit-identical to the launches it replaces.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ LstmArgs stack_layer_args(const LstmStackArgs& st, int k) {
+    LstmArgs a = st.a;
+    const LstmStackLayer& l = st.L[k];
+    a.x = l.x; a.out = l.out; a.wpk0 = l.wpk0; a.wpk1 = l.wpk1; a.sbias0 = l.sbias0; a.sbias1 = l.sbias1;
+    a.h0 = l.h0; a.c0 = l.c0; a.cflags = l.cflags;
+    a.Ipad = l.Ipad; a.NQ = l.NQ; a.nqx_lo = l.nqx_lo; a.nqx_used = l.nqx_used; a.stream_base = l.stream_base;
+    return a;
+}
+
+template <int G, int D>
+__global__ __launch_bounds__(256, 1) void dsp_lstmp_kernel(LstmStackArgs st) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int P = st.a.UT / G;
+    const int xs = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int pi = j % P;
+    const long long c = (long long)(j / P) * 8 + xs;
+    if (c >= st.a.NTp * 2) return;
+    const int dir = (int)(c & 1);
+    const long long gt0 = c >> 1;
+    {
+        gu32* flag0 = (gu32*)st.L[0].cflags + c * 32;
+        int* verdict = (int*)smem;
+        if (tid == 0) *verdict = cluster_admit(flag0 + 1, (unsigned)P, st.a.cluster_timeout) ? 1 : 0;
+        __syncthreads();
+        const int admitted = *(volatile int*)verdict;
+        __syncthreads();
+        if (!admitted) return;
+    }
+    const unsigned done = (unsigned)(P * (st.a.T + 1));
+    for (int k = 0; k < st.nl; ++k) {
+        const LstmArgs a = stack_layer_args(st, k);
+        if (k > 0) {
+            gu32* below = (gu32*)st.L[k - 1].cflags;
+            asm volatile("" ::: "memory");
+            if (!wait_arrivals(below + c * 32, done)) return;         // every member of this cluster has published its last step
+            if (!wait_arrivals(below + (c ^ 1) * 32, done)) return;   // ... and the other direction of this site tile
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("" ::: "memory");
+        }
+        if (!lstmc_layer<G, D, false, 0, 4, false>(a, dir, gt0, pi, (gu32*)a.cflags + c * 32)) return;
+    }
+}
+
+__global__ __launch_bounds__(512, 1) void dsp_lstmp_cleanup_kernel(LstmStackArgs st) {
+    const long long tile = blockIdx.x;
+    if (tile >= st.a.NTp) return;
+    int first = st.nl;
+    for (int k = st.nl - 1; k >= 0; --k)
+        for (int d = 0; d < 2; ++d)
+            if (__hip_atomic_load((gu32*)st.L[k].cflags + (tile * 2 + d) * 32 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kClusterAbandon)
+                first = k;
+    if (first >= st.nl) return;
+    for (int k = first; k < st.nl; ++k) {
+        const LstmArgs a = stack_layer_args(st, k);
+        for (int d = 0; d < 2; ++d)
+            lstmc_layer<4, 4, true, 0, 8, false>(a, d, tile, 0, (gu32*)a.cflags + (tile * 2 + d) * 32);
+        // the next layer reads what this workgroup has just written (and, in its L1, may still hold what the buffer held before)
+        __syncthreads();
+        __threadfence();
+        __syncthreads();
     }
 }
 
@@ -1367,6 +1486,65 @@ __global__ __launch_bounds__(256, 2) void dsp_linear_kernel(LinArgs a) {
     }
 }
 
+// Round 5, small batches: the same projection with ONE accumulator tile per wave (1 row tile x 1 column block).  The wave of
+// dsp_linear_kernel above runs 32 k-groups x 32 MFMAs = 65 k cycles = 28 us whatever the batch; at 512 sites that is 26
+// workgroups on 26 CUs and a fifth of the front-end phase.  Here: 4 MFMAs per k-group, 8 k cycles per wave, rings four
+// k-groups deep for both operands (pure L2 latency otherwise), 4 x as many workgroups.  An accumulator tile still starts
+// from its bias and sums its k-groups in order with the same MFMAs: bit-identical to dsp_linear_kernel.
+__global__ __launch_bounds__(256, 2) void dsp_linear1_kernel(LinArgs a) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t voff = (uint32_t)lane * 16u;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, ls = lane & 31;
+    const bool second = blockIdx.x >= a.nbx;   // (workgroup-uniform: the second problem of a fused launch)
+    const long long col = (long long)(blockIdx.x - (second ? a.nbx : 0u));
+    const int rt = blockIdx.y * 4 + w;          // a workgroup = 4 row tiles of one column block (they share the B rows in L1)
+    if (col >= a.ncols || rt >= a.ORT) return;
+    const int nq = a.Fin >> 3;   // a multiple of 8
+    const uint32_t xrow = (uint32_t)(a.Fin >> 2) * 512u;
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc((const char*)(second ? a.wpk2 : a.wpk) + (size_t)rt * nq * 1024);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)(second ? a.x2 : a.x) + (size_t)col * xrow);
+    const f32x4* bias4 = (const f32x4*)(second ? a.bias2 : a.bias);
+    const int out_off = second ? a.out_off2 : a.out_off;
+    f32x16 acc;
+#pragma unroll
+    for (int aa = 0; aa < 4; ++aa) {
+        const f32x4 b = bias4[rt * 8 + 2 * aa + half];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[4 * aa + i] = b[i];
+    }
+    f32x4 A[4], B[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        A[d] = bld16(rw, voff, (uint32_t)d * 1024u);
+        B[d] = bld16(rx, voff, (uint32_t)d * 1024u);
+    }
+    auto stage = [&](auto qs, int q) __attribute__((always_inline)) {
+        constexpr int S = decltype(qs)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[S][i], B[S][i], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int qn = q + 4 < nq ? q + 4 : nq - 1;
+        A[S] = bld16(rw, voff, (uint32_t)qn * 1024u);
+        B[S] = bld16(rx, voff, (uint32_t)qn * 1024u);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int q = 0; q < nq; q += 4) {
+        stage(ic<0>{}, q); stage(ic<1>{}, q + 1); stage(ic<2>{}, q + 2); stage(ic<3>{}, q + 3);
+    }
+    f32x4* out4 = (f32x4*)a.out + ((size_t)col * (a.Fout >> 2) + (out_off >> 2) + half) * 32 + ls;
+#pragma unroll
+    for (int aa = 0; aa < 4; ++aa) {
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float y = acc[4 * aa + i];
+            v[i] = a.relu ? fmaxf(y, 0.f) : y;
+        }
+        gst16(&out4[(size_t)(rt * 8 + aa * 2) * 32], v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // head_kernel: [h_fwd(t=T-1) | h_bwd(t=0)] -> fc1 + ReLU -> fc2 -> softmax (+argmax)
 // (models.py:229-240; dropouts are identity in eval).  One 4-wave workgroup per FOUR 32-site tiles.
@@ -1543,6 +1721,18 @@ __global__ __launch_bounds__(256, 2) void dsp_head_kernel(HeadArgs a) {
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (called from dsp_capi.cpp; keep all <<<>>> syntax in this translation unit)
 // ------------------------------------------------------------------------------------------------
+// Which XCD does block b of a launch run on?  The clustered launches place the members of a cluster on consecutive entries of
+// ONE XCD's dispatch list (block b on XCD b % 8: observed on MI355X in SPX mode, promised by nobody).  dsp_model_create asks once.
+__global__ void dsp_xcc_probe_kernel(unsigned* out) {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    if (threadIdx.x == 0) out[blockIdx.x] = x & 0xf;
+}
+extern "C" int dsp_k_probe_xcc(unsigned* dev_out, int blocks, hipStream_t s) {
+    hipLaunchKernelGGL(dsp_xcc_probe_kernel, dim3((unsigned)blocks), dim3(64), 0, s, dev_out);
+    return (int)hipGetLastError();
+}
+
 extern "C" int dsp_k_init(void) {
     const void* fns[] = {(const void*)dsp_lstm_kernel<0, 1>, (const void*)dsp_lstm_kernel<1, 1>,
                          (const void*)dsp_lstm_kernel<2, 1, 1>, (const void*)dsp_lstm_kernel<2, 1, 2>, (const void*)dsp_lstm_kernel<2, 1, 3>,
@@ -1550,7 +1740,12 @@ extern "C" int dsp_k_init(void) {
                          (const void*)dsp_lstm6_kernel<6>, (const void*)dsp_lstm6_kernel<9>, (const void*)dsp_lstm6_kernel<3>,
                          (const void*)dsp_lstmc_kernel<4, 4>, (const void*)dsp_lstmc_kernel<2, 8>, (const void*)dsp_lstmc_kernel<1, 16>,
                          (const void*)dsp_lstmc_kernel<4, 4, true>, (const void*)dsp_lstmc_kernel<4, 4, true, 2>,
-                         (const void*)dsp_lstmc_kernel<4, 4, true, 3>, (const void*)dsp_lstmc_kernel<4, 4, true, 0, 8>};
+                         (const void*)dsp_lstmc_kernel<4, 4, true, 3>, (const void*)dsp_lstmc_kernel<4, 4, true, 0, 8>,
+                         (const void*)dsp_lstmc_kernel<1, 4, false, 0, 4, true>, (const void*)dsp_lstmc_kernel<1, 4, false, 2, 4, true>,
+                         (const void*)dsp_lstmc_kernel<1, 4, false, 3, 4, true>, (const void*)dsp_lstmc_kernel<2, 4, false, 0, 4, true>,
+                         (const void*)dsp_lstmc_kernel<2, 4, false, 2, 4, true>, (const void*)dsp_lstmc_kernel<2, 4, false, 3, 4, true>,
+                         (const void*)dsp_lstmp_kernel<4, 4>, (const void*)dsp_lstmp_kernel<2, 8>, (const void*)dsp_lstmp_kernel<1, 16>,
+                         (const void*)dsp_lstmp_cleanup_kernel};
     for (const void* f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
@@ -1572,12 +1767,15 @@ extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
     if (a->CG > 0) {
         // a (site tile, direction) spread over a cluster of UT / CG workgroups (dsp_lstmc_kernel); the caller has checked the
         // residency.  CG = 4 with 4 unit tiles: the workgroup holds the whole layer (the front ends at hidden 128), no counters
-        const int G = a->CG, D = G == 4 ? 4 : (G == 2 ? 8 : 16);
+        const int G = a->CG;
         const int nqx = a->Ipad >> 3;
         const bool local8 = G == 4 && a->UT == 8 && (a->flags & 8);   // eight waves hold the whole layer of 8 unit tiles
         const bool local = (G == 4 && a->UT == 4) || local8;
+        // a front end (4 unit tiles, an x part of exactly four k-groups) spread over 4 / G workgroups: rings four deep
+        const bool xshort = !local && a->UT == 4 && nqx == 4 && (G == 1 || G == 2);
+        const int D = xshort ? 4 : (G == 4 ? 4 : (G == 2 ? 8 : 16));
         if ((G != 1 && G != 2 && G != 4) || a->UT % G || a->NP > 1 || (!local && !a->cflags) || a->NQ != ((a->Ipad + a->Hp) >> 3) ||
-            nqx % D || nqx < (local ? D : 2 * D) || a->NQ % D || a->NQ < 2 * D)
+            nqx % D || nqx < ((local || xshort) ? D : 2 * D) || a->NQ % D || a->NQ < 2 * D || (!local && !xshort && a->UT != 8))
             return (int)hipErrorInvalidValue;
         // (zero-padded x-part k-groups -- nqx_lo, nqx_used -- are computed like live ones here: their weights are zero)
         const int P = local ? 1 : a->UT / G;
@@ -1586,22 +1784,36 @@ extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
         size_t lds = (size_t)a->Hp * 16 + (G < 4 ? (size_t)G * 16384 : 0);
         if (a->flags & 4) lds = lds < 84 * 1024 ? 84 * 1024 : lds;   // more than half a CU's LDS: one workgroup per CU
         // the front ends' zero-padded leading k-groups (features at the end of the 32-wide block) issue no MFMAs
-        const int dead = (local && nqx == 4 && a->nqx_used == 4 && (a->nqx_lo == 2 || a->nqx_lo == 3)) ? a->nqx_lo : 0;
+        const int dead = ((local || xshort) && nqx == 4 && a->nqx_used == 4 && (a->nqx_lo == 2 || a->nqx_lo == 3)) ? a->nqx_lo : 0;
         if (local8) hipLaunchKernelGGL((dsp_lstmc_kernel<4, 4, true, 0, 8>), dim3(grid), dim3(512), lds, s, *a);
         else if (local && dead == 3) hipLaunchKernelGGL((dsp_lstmc_kernel<4, 4, true, 3>), dim3(grid), dim3(256), lds, s, *a);
         else if (local && dead == 2) hipLaunchKernelGGL((dsp_lstmc_kernel<4, 4, true, 2>), dim3(grid), dim3(256), lds, s, *a);
         else if (local) hipLaunchKernelGGL((dsp_lstmc_kernel<4, 4, true>), dim3(grid), dim3(256), lds, s, *a);
+        else if (xshort && G == 1 && dead == 3) hipLaunchKernelGGL((dsp_lstmc_kernel<1, 4, false, 3, 4, true>), dim3(grid), dim3(256), lds, s, *a);
+        else if (xshort && G == 1 && dead == 2) hipLaunchKernelGGL((dsp_lstmc_kernel<1, 4, false, 2, 4, true>), dim3(grid), dim3(256), lds, s, *a);
+        else if (xshort && G == 1) hipLaunchKernelGGL((dsp_lstmc_kernel<1, 4, false, 0, 4, true>), dim3(grid), dim3(256), lds, s, *a);
+        else if (xshort && dead == 3) hipLaunchKernelGGL((dsp_lstmc_kernel<2, 4, false, 3, 4, true>), dim3(grid), dim3(256), lds, s, *a);
+        else if (xshort && dead == 2) hipLaunchKernelGGL((dsp_lstmc_kernel<2, 4, false, 2, 4, true>), dim3(grid), dim3(256), lds, s, *a);
+        else if (xshort) hipLaunchKernelGGL((dsp_lstmc_kernel<2, 4, false, 0, 4, true>), dim3(grid), dim3(256), lds, s, *a);
         else if (G == 4) hipLaunchKernelGGL((dsp_lstmc_kernel<4, 4>), dim3(grid), dim3(256), lds, s, *a);
         else if (G == 2) hipLaunchKernelGGL((dsp_lstmc_kernel<2, 8>), dim3(grid), dim3(256), lds, s, *a);
         else hipLaunchKernelGGL((dsp_lstmc_kernel<1, 16>), dim3(grid), dim3(256), lds, s, *a);
-        if (!local && a->UT == 8) {
+        if (!local) {
             // the clean-up launch: clusters whose members did not all become resident in time were abandoned by them and are
-            // computed here, one 8-wave workgroup each, nothing waiting on another workgroup (a few microseconds when none was)
+            // computed here, one workgroup each (eight waves for 8 unit tiles, four for 4), nothing waiting on another
+            // workgroup (a few microseconds when none was)
             LstmArgs b = *a;
             b.CG = 4;
-            b.flags = (a->flags | 8 | 16) & ~4;
             const unsigned g1 = (clusters + 7) / 8 * 8;
-            hipLaunchKernelGGL((dsp_lstmc_kernel<4, 4, true, 0, 8>), dim3(g1), dim3(512), (size_t)a->Hp * 16, s, b);
+            if (a->UT == 8) {
+                b.flags = (a->flags | 8 | 16) & ~4;
+                hipLaunchKernelGGL((dsp_lstmc_kernel<4, 4, true, 0, 8>), dim3(g1), dim3(512), (size_t)a->Hp * 16, s, b);
+            } else {
+                b.flags = (a->flags | 16) & ~(4 | 8);
+                if (dead == 3) hipLaunchKernelGGL((dsp_lstmc_kernel<4, 4, true, 3>), dim3(g1), dim3(256), (size_t)a->Hp * 16, s, b);
+                else if (dead == 2) hipLaunchKernelGGL((dsp_lstmc_kernel<4, 4, true, 2>), dim3(g1), dim3(256), (size_t)a->Hp * 16, s, b);
+                else hipLaunchKernelGGL((dsp_lstmc_kernel<4, 4, true>), dim3(g1), dim3(256), (size_t)a->Hp * 16, s, b);
+            }
         }
         return (int)hipGetLastError();
     }
@@ -1647,6 +1859,29 @@ extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+// a whole clustered stack in one launch + its one clean-up launch (8 unit tiles; the caller has checked shapes and residency)
+extern "C" int dsp_k_lstm_stack(const LstmStackArgs* st, hipStream_t s) {
+    const LstmArgs* a = &st->a;
+    const int G = a->CG, D = G == 4 ? 4 : (G == 2 ? 8 : 16);
+    if ((G != 1 && G != 2 && G != 4) || a->UT != 8 || a->NP > 1 || st->nl < 1 || st->nl > DSP_MAX_STACK_LAYERS) return (int)hipErrorInvalidValue;
+    for (int k = 0; k < st->nl; ++k) {
+        const LstmStackLayer& l = st->L[k];
+        const int nqx = l.Ipad >> 3;
+        if (!l.cflags || l.NQ != ((l.Ipad + a->Hp) >> 3) || nqx % D || nqx < 2 * D || l.NQ % D || l.nqx_lo != 0 || l.nqx_used != nqx)
+            return (int)hipErrorInvalidValue;
+    }
+    const int P = a->UT / G;
+    const unsigned clusters = (unsigned)(a->NTp * 2);
+    const unsigned grid = (clusters + 7) / 8 * 8 * (unsigned)P;
+    size_t lds = (size_t)a->Hp * 16 + (G < 4 ? (size_t)G * 16384 : 0);
+    if (a->flags & 4) lds = lds < 84 * 1024 ? 84 * 1024 : lds;
+    if (G == 4) hipLaunchKernelGGL((dsp_lstmp_kernel<4, 4>), dim3(grid), dim3(256), lds, s, *st);
+    else if (G == 2) hipLaunchKernelGGL((dsp_lstmp_kernel<2, 8>), dim3(grid), dim3(256), lds, s, *st);
+    else hipLaunchKernelGGL((dsp_lstmp_kernel<1, 16>), dim3(grid), dim3(256), lds, s, *st);
+    hipLaunchKernelGGL(dsp_lstmp_cleanup_kernel, dim3((unsigned)a->NTp), dim3(512), (size_t)a->Hp * 16, s, *st);
+    return (int)hipGetLastError();
+}
+
 // split variants: a->wpk0/1 = split weights, a->NQ = k-stages of 16, nprod = 6 / 9 (bf16 pieces) or 3 (fp16 pieces)
 extern "C" int dsp_k_lstm6(const LstmArgs* a, int nprod, hipStream_t s) {
     const int waves = a->UT * a->SG;
@@ -1659,6 +1894,12 @@ extern "C" int dsp_k_lstm6(const LstmArgs* a, int nprod, hipStream_t s) {
 }
 
 extern "C" int dsp_k_linear(const LinArgs* a, hipStream_t s) {
+    if (a->small) {   // batches that leave CUs idle: one accumulator tile per wave (dsp_linear1_kernel)
+        LinArgs b = *a;
+        b.nbx = (unsigned)a->ncols;
+        hipLaunchKernelGGL(dsp_linear1_kernel, dim3(a->x2 ? 2 * b.nbx : b.nbx, (unsigned)((a->ORT + 3) / 4)), dim3(256), 0, s, b);
+        return (int)hipGetLastError();
+    }
     const unsigned bx = (unsigned)((a->ncols + 7) / 8);  // 4 waves x 2 column blocks per workgroup
     LinArgs b = *a;
     b.nbx = bx;

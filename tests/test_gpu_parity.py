@@ -532,9 +532,17 @@ def test_small_batch_kernels_do_not_change_a_bit(kw, label, monkeypatch):
     states = {k: torch.from_numpy(v).cuda(0) for k, v in onp.make_init_states(cfg, n_x, 9).items()}
     ins_x = synth.feature_batch(n_x, device="cuda:0", seed=77)
     switches = ("DSP_LSTM_CLUSTER", "DSP_LSTM_LOCAL8", "DSP_TWO_STREAMS", "DSP_HEAD_ST4", "DSP_LSTM_TILING", "DSP_CLUSTER_TIMEOUT",
-                "DSP_FC_FUSED")
+                "DSP_FC_FUSED", "DSP_LSTM_FRONT_CLUSTER", "DSP_FC_SMALL")
     modes = {"round3": {"DSP_LSTM_CLUSTER": "0", "DSP_LSTM_LOCAL8": "0", "DSP_TWO_STREAMS": "0", "DSP_HEAD_ST4": "1",
-                        "DSP_FC_FUSED": "0"},
+                        "DSP_FC_FUSED": "0", "DSP_FC_SMALL": "0"},
+             "round4_fc_kernel": {"DSP_FC_SMALL": "0"},   # (auto, round 5: one accumulator tile per wave in the fc projections)
+             "fc_small_one_stream": {"DSP_TWO_STREAMS": "0"},   # ... and in the shared fc_seq+fc_signal launch
+             # round 5: the front ends (4 unit tiles) clustered too -- off, 1 gate per wave (P = 4), 2 (P = 2), on one stream
+             # (a branch may then take all the CUs), with every cluster abandoned to the clean-up launch
+             "round4_front_ends_local": {"DSP_LSTM_FRONT_CLUSTER": "0"},
+             "front_G1": {"DSP_LSTM_FRONT_CLUSTER": "1"}, "front_G2": {"DSP_LSTM_FRONT_CLUSTER": "2"},
+             "front_G1_one_stream": {"DSP_LSTM_FRONT_CLUSTER": "1", "DSP_TWO_STREAMS": "0"},
+             "front_G2_one_stream_abandoned": {"DSP_LSTM_FRONT_CLUSTER": "2", "DSP_TWO_STREAMS": "0", "DSP_CLUSTER_TIMEOUT": "0"},
              "fc_launches_apart": {"DSP_FC_FUSED": "0"},   # (auto: fc_seq and fc_signal share a launch when the branches share a stream)
              "auto": {},
              "one_stream": {"DSP_TWO_STREAMS": "0"},
