@@ -250,6 +250,8 @@ def lib():
     L.dsp_format_feature_rows_parts.argtypes = L.dsp_format_feature_rows.argtypes + [ctypes.c_void_p, ctypes.c_void_p]
     L.dsp_feature_row_bound.restype = ctypes.c_uint64
     L.dsp_feature_row_bound.argtypes = [ctypes.c_int32, ctypes.c_int32]
+    L.dsp_model_query.restype = ctypes.c_int32
+    L.dsp_model_query.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     for fn in (L.dsp_device_pci_bdf, L.dsp_device_uuid):
         fn.restype = ctypes.c_int64
         fn.argtypes = [ctypes.c_int32, ctypes.c_char_p, ctypes.c_size_t]

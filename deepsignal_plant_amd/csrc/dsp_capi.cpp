@@ -313,6 +313,8 @@ struct dsp_model {
     int tiling21 = -1;       // <2 unit tiles, 1 site tile> per wave on the dense one-pass layers (dsp_lstm21_kernel): -1 = for
                              // batches whose 32-site tiles x 2 directions fit the CUs at once (small-batch latency); DSP_LSTM_TILING=21
                              // always, =0 never (A/B switch)
+    bool test_abandon_mid = false;   // DSP_TEST_ABANDON_MID=1 (tests): every third cluster of a persistent stack gives itself up before layer 1
+    bool persist = true;     // a clustered stack in one launch (dsp_lstmp_kernel, round 5); DSP_LSTM_PERSIST=0 turns it off (A/B switch)
     bool fc_small = true;    // dsp_linear1_kernel for batches <= 4,096 sites (A/B switch DSP_FC_SMALL=0)
     bool fc_fused = true;    // fc_seq + fc_signal in one launch when they have one shape (A/B switch DSP_FC_FUSED=0)
     bool local8 = true;      // dense 8-unit-tile layers of 2,049..4,096-site batches on dsp_lstmc_kernel's eight-wave workgroup-local
@@ -600,6 +602,8 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
     dsp_model* m = L.m;
     const float* cur = x;
     float* dst = nullptr;
+    struct Planned { LstmArgs a; bool split; int prec; };
+    std::vector<Planned> plan;
     for (size_t k = 0; k < layers.size(); ++k) {
         const DevLstmLayer& ly = layers[k];
         dst = ((layers.size() - 1 - k) % 2 == 0) != side ? m->bufA : m->bufB;
@@ -657,9 +661,33 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
         if (m->debug_lstm)   // DSP_DEBUG_LSTM (read once, in dsp_model_create)
             fprintf(stderr, "[lstm] %s k=%zu split=%d CG=%d Ipad=%d H=%d Hp=%d UT=%d SG=%d NQ=%d NTp=%lld n=%lld T=%d Fout=%d x=%p out=%p\n", name, k,
                     (int)split, a.CG, a.Ipad, a.H, a.Hp, a.UT, a.SG, a.NQ, a.NTp, a.n, a.T, a.Fout, (const void*)a.x, (void*)a.out);
-        L.run(name, [&] { return split ? dsp_k_lstm6(&a, prec, L.s) : dsp_k_lstm(&a, L.s); });
+        plan.push_back({a, split, prec});
         cur = dst;
     }
+    // A stack whose layers all run clustered with one cluster size (the combined stack of a batch <= 2,048 sites): ONE launch
+    // for all of them + one clean-up launch (dsp_lstmp_kernel, round 5) instead of a launch and a clean-up launch per layer.
+    // DSP_LSTM_PERSIST=0 turns it off (A/B switch).
+    bool persist = m->persist && plan.size() >= 2 && plan.size() <= DSP_MAX_STACK_LAYERS;
+    for (const Planned& p : plan)
+        persist = persist && !p.split && p.a.UT == 8 && p.a.CG > 0 && !(p.a.flags & 8) && p.a.CG == plan[0].a.CG && p.a.NP <= 1 &&
+                  p.a.nqx_lo == 0 && p.a.nqx_used == (p.a.Ipad >> 3) && p.a.Hp == plan[0].a.Hp && !(p.a.flags & 256);
+    if (persist) {
+        LstmStackArgs st{};
+        st.a = plan[0].a;
+        if (m->test_abandon_mid) st.a.flags |= 32;
+        st.nl = (int)plan.size();
+        for (size_t k = 0; k < plan.size(); ++k) {
+            const LstmArgs& a = plan[k].a;
+            LstmStackLayer& l = st.L[k];
+            l.x = a.x; l.out = a.out; l.wpk0 = a.wpk0; l.wpk1 = a.wpk1; l.sbias0 = a.sbias0; l.sbias1 = a.sbias1;
+            l.h0 = a.h0; l.c0 = a.c0; l.cflags = a.cflags;
+            l.Ipad = a.Ipad; l.NQ = a.NQ; l.nqx_lo = a.nqx_lo; l.nqx_used = a.nqx_used; l.stream_base = a.stream_base;
+        }
+        L.run(name, [&] { return dsp_k_lstm_stack(&st, L.s); });
+        return dst;
+    }
+    for (const Planned& p : plan)
+        L.run(name, [&] { return p.split ? dsp_k_lstm6(&p.a, p.prec, L.s) : dsp_k_lstm(&p.a, L.s); });
     return dst;
 }
 
@@ -745,6 +773,8 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
     if (const char* v = getenv("DSP_LSTM_LOCAL8")) m->local8 = atoi(v) != 0;
     if (const char* v = getenv("DSP_FC_FUSED")) m->fc_fused = atoi(v) != 0;
     if (const char* v = getenv("DSP_FC_SMALL")) m->fc_small = atoi(v) != 0;
+    if (const char* v = getenv("DSP_LSTM_PERSIST")) m->persist = atoi(v) != 0;
+    m->test_abandon_mid = getenv("DSP_TEST_ABANDON_MID") != nullptr;
     if (const char* v = getenv("DSP_LSTM_SG")) m->sg_override = atoi(v);  // A/B switch
     if (const char* v = getenv("DSP_LSTM_NP8")) m->np8 = atoi(v) == 2 ? 2 : 1;  // A/B switch
     if (const char* v = getenv("DSP_LSTM_PRIO")) m->phase_prio = atoi(v) != 0;    // A/B switch
@@ -771,10 +801,20 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
         if (!(pv && atoi(pv) == 0)) {
             unsigned* dp = nullptr;
             unsigned host[64];
+            (void)hipGetLastError();   // (whatever an earlier, unrelated call of this thread left behind -- torch's event queries leave
+            // hipErrorNotReady -- is not the probe's error: the launch wrapper reports the thread's last error)
             bool ok = hipMalloc((void**)&dp, sizeof host) == hipSuccess && dsp_k_probe_xcc(dp, 64, nullptr) == 0 &&
                       hipMemcpy(host, dp, sizeof host, hipMemcpyDeviceToHost) == hipSuccess;
             if (dp) hipFree(dp);
-            for (int b = 0; ok && b < 64; ++b) ok = host[b] == (unsigned)(b % 8);
+            const bool read_ok = ok;
+            // (the dispatcher's round robin carries on where the previous launch stopped: block 0 lands on ANY XCD, block b on the
+            // b-th after it -- what the clustered launches need is that blocks 8 apart share an XCD)
+            for (int b = 0; ok && b < 64; ++b) ok = host[b] < 8 && host[b] == (host[0] + (unsigned)b) % 8;
+            if (m->debug_lstm && read_ok) {
+                fprintf(stderr, "[lstm] XCC probe:");
+                for (int b = 0; b < 64; ++b) fprintf(stderr, " %u", host[b]);
+                fprintf(stderr, "\n");
+            }
             if (!ok) {
                 (void)hipGetLastError();
                 m->cluster = 0;
@@ -1054,6 +1094,16 @@ int32_t dsp_model_set_precision(dsp_model* m, int32_t precision) {
     }
     m->precision = precision;
     return DSP_OK;
+}
+
+int32_t dsp_model_query(const dsp_model* m, int32_t what) {
+    if (!m) return fail(DSP_EINVAL, "model is NULL");
+    switch (what) {
+        case DSP_QUERY_CLUSTERING: return m->cluster != 0 ? 1 : 0;
+        case DSP_QUERY_XCC_PROBE_FAILED: return m->xcc_probe_failed ? 1 : 0;
+        case DSP_QUERY_COMPUTE_UNITS: return m->n_cus;
+        default: return fail(DSP_EINVAL, "dsp_model_query: unknown item %d", (int)what);
+    }
 }
 
 int64_t dsp_device_pci_bdf(int32_t device, char* out, size_t cap) {

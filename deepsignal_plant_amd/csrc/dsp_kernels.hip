@@ -1143,6 +1143,13 @@ __global__ __launch_bounds__(256, 1) void dsp_lstmp_kernel(LstmStackArgs st) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("" ::: "memory");
         }
+        if (k == 1 && (st.a.flags & 32) && c % 3 == 1) {
+            // test hook (DSP_TEST_ABANDON_MID=1): every third cluster gives itself up in the middle of the stack, the way a poll
+            // without progress would -- its partner direction must notice and leave, the clean-up launch must recompute this
+            // site tile from layer 1 on
+            if (tid == 0) __hip_atomic_fetch_or((gu32*)a.cflags + c * 32 + 1, kClusterAbandon, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
         if (!lstmc_layer<G, D, false, 0, 4, false>(a, dir, gt0, pi, (gu32*)a.cflags + c * 32)) return;
     }
 }

@@ -247,6 +247,12 @@ class ModelBiLSTM(object):
                                                       out.ctypes.data_as(ctypes.c_void_p)))
         return out
 
+    def query(self, what):
+        """what the handle decided about its device (include/dsp_amd.h DSP_QUERY_*): "clustering", "xcc_probe_failed",
+        "compute_units" """
+        self._ensure_handle()
+        return nat.check(int(nat.lib().dsp_model_query(self._handle, {"clustering": 0, "xcc_probe_failed": 1, "compute_units": 2}[what])))
+
     def profile(self, on=True):
         self._ensure_handle()
         nat.check(nat.lib().dsp_profile_enable(self._handle, int(bool(on))))

@@ -488,6 +488,15 @@ int32_t dsp_fast5_load(const char* path, const char* corrected_group, const char
                        dsp_fast5_read* out);
 void dsp_fast5_free(dsp_fast5_read* r);
 
+/* What a handle decided about its device when it was made (diagnostics; the tests assert that the clustered small-batch
+ * launches are really on where they are expected): DSP_QUERY_CLUSTERING 1 = batches <= 2,048 sites may run clustered launches
+ * (0: DSP_LSTM_CLUSTER=0, or the XCC_ID probe of dsp_model_create did not find consecutive blocks on consecutive XCDs);
+ * DSP_QUERY_XCC_PROBE_FAILED; DSP_QUERY_COMPUTE_UNITS. */
+#define DSP_QUERY_CLUSTERING 0
+#define DSP_QUERY_XCC_PROBE_FAILED 1
+#define DSP_QUERY_COMPUTE_UNITS 2
+int32_t dsp_model_query(const dsp_model* m, int32_t what);
+
 /* ---- which GPU is this? (multi-GPU runs: rank placement and the bench line's proof of N distinct devices) -----------
  * The reference maps its model processes to devices by index only (call_modifications.py:523-529 _get_gpus, :613-621);
  * one process per GPU over RCCL additionally wants (a) the CPUs next to each GPU (dist.pin_rank) and (b) evidence in the
