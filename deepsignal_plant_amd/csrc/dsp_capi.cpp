@@ -313,8 +313,6 @@ struct dsp_model {
     int tiling21 = -1;       // <2 unit tiles, 1 site tile> per wave on the dense one-pass layers (dsp_lstm21_kernel): -1 = for
                              // batches whose 32-site tiles x 2 directions fit the CUs at once (small-batch latency); DSP_LSTM_TILING=21
                              // always, =0 never (A/B switch)
-    bool test_abandon_mid = false;   // DSP_TEST_ABANDON_MID=1 (tests): every third cluster of a persistent stack gives itself up before layer 1
-    bool persist = true;     // a clustered stack in one launch (dsp_lstmp_kernel, round 5); DSP_LSTM_PERSIST=0 turns it off (A/B switch)
     bool fc_small = true;    // dsp_linear1_kernel for batches <= 4,096 sites (A/B switch DSP_FC_SMALL=0)
     bool fc_fused = true;    // fc_seq + fc_signal in one launch when they have one shape (A/B switch DSP_FC_FUSED=0)
     bool local8 = true;      // dense 8-unit-tile layers of 2,049..4,096-site batches on dsp_lstmc_kernel's eight-wave workgroup-local
@@ -664,28 +662,6 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
         plan.push_back({a, split, prec});
         cur = dst;
     }
-    // A stack whose layers all run clustered with one cluster size (the combined stack of a batch <= 2,048 sites): ONE launch
-    // for all of them + one clean-up launch (dsp_lstmp_kernel, round 5) instead of a launch and a clean-up launch per layer.
-    // DSP_LSTM_PERSIST=0 turns it off (A/B switch).
-    bool persist = m->persist && plan.size() >= 2 && plan.size() <= DSP_MAX_STACK_LAYERS;
-    for (const Planned& p : plan)
-        persist = persist && !p.split && p.a.UT == 8 && p.a.CG > 0 && !(p.a.flags & 8) && p.a.CG == plan[0].a.CG && p.a.NP <= 1 &&
-                  p.a.nqx_lo == 0 && p.a.nqx_used == (p.a.Ipad >> 3) && p.a.Hp == plan[0].a.Hp && !(p.a.flags & 256);
-    if (persist) {
-        LstmStackArgs st{};
-        st.a = plan[0].a;
-        if (m->test_abandon_mid) st.a.flags |= 32;
-        st.nl = (int)plan.size();
-        for (size_t k = 0; k < plan.size(); ++k) {
-            const LstmArgs& a = plan[k].a;
-            LstmStackLayer& l = st.L[k];
-            l.x = a.x; l.out = a.out; l.wpk0 = a.wpk0; l.wpk1 = a.wpk1; l.sbias0 = a.sbias0; l.sbias1 = a.sbias1;
-            l.h0 = a.h0; l.c0 = a.c0; l.cflags = a.cflags;
-            l.Ipad = a.Ipad; l.NQ = a.NQ; l.nqx_lo = a.nqx_lo; l.nqx_used = a.nqx_used; l.stream_base = a.stream_base;
-        }
-        L.run(name, [&] { return dsp_k_lstm_stack(&st, L.s); });
-        return dst;
-    }
     for (const Planned& p : plan)
         L.run(name, [&] { return p.split ? dsp_k_lstm6(&p.a, p.prec, L.s) : dsp_k_lstm(&p.a, L.s); });
     return dst;
@@ -773,8 +749,6 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
     if (const char* v = getenv("DSP_LSTM_LOCAL8")) m->local8 = atoi(v) != 0;
     if (const char* v = getenv("DSP_FC_FUSED")) m->fc_fused = atoi(v) != 0;
     if (const char* v = getenv("DSP_FC_SMALL")) m->fc_small = atoi(v) != 0;
-    if (const char* v = getenv("DSP_LSTM_PERSIST")) m->persist = atoi(v) != 0;
-    m->test_abandon_mid = getenv("DSP_TEST_ABANDON_MID") != nullptr;
     if (const char* v = getenv("DSP_LSTM_SG")) m->sg_override = atoi(v);  // A/B switch
     if (const char* v = getenv("DSP_LSTM_NP8")) m->np8 = atoi(v) == 2 ? 2 : 1;  // A/B switch
     if (const char* v = getenv("DSP_LSTM_PRIO")) m->phase_prio = atoi(v) != 0;    // A/B switch

@@ -52,22 +52,7 @@ struct LstmArgs {
     unsigned long long cluster_timeout;  // s_memtime ticks a member of a cluster waits for the others to become resident before it
                            // abandons the cluster to the clean-up launch
     int CG;                // 0, or gates per wave of dsp_lstmc_kernel: 4 / 2 / 1 = a (site tile, direction) spread over UT/CG workgroups
-    int flags;             // bit 0: issue priority by phase (k-loop 2, cell 0); bit 1: <2 unit tiles, 1 site tile> per wave; bit 2: ... and one such workgroup per CU; bit 3: the workgroup-local form of dsp_lstmc_kernel with eight waves; bit 4: ... as the clean-up launch behind a clustered one (abandoned clusters only); bit 5: test hook of the persistent stack kernel (every third cluster gives itself up before layer 1); bit 8: stamp this launch, bits 9..11: its stamping wave (DSP_TRACE builds only)
-};
-
-// A whole BiLSTM stack in ONE clustered launch (dsp_lstmp_kernel, round 5): what differs from layer to layer
-#define DSP_MAX_STACK_LAYERS 8
-struct LstmStackLayer {
-    const float* x; float* out;
-    const float *wpk0, *wpk1, *sbias0, *sbias1;
-    const float *h0, *c0;      // EXPLICIT: this layer's states
-    unsigned int* cflags;      // this layer's counters (one block of words per layer, as for separate launches)
-    int Ipad, NQ, nqx_lo, nqx_used, stream_base;
-};
-struct LstmStackArgs {
-    LstmArgs a;                // everything the layers share (and layer 0's values where they differ)
-    int nl;
-    LstmStackLayer L[DSP_MAX_STACK_LAYERS];
+    int flags;             // bit 0: issue priority by phase (k-loop 2, cell 0); bit 1: <2 unit tiles, 1 site tile> per wave; bit 2: ... and one such workgroup per CU; bit 3: the workgroup-local form of dsp_lstmc_kernel with eight waves; bit 4: ... as the clean-up launch behind a clustered one (abandoned clusters only); bit 8: stamp this launch, bits 9..11: its stamping wave (DSP_TRACE builds only)
 };
 
 struct LinArgs {
@@ -107,7 +92,6 @@ int dsp_k_init(void);
 int dsp_k_pack(const PackArgs* a, hipStream_t s);
 int dsp_k_lstm(const LstmArgs* a, hipStream_t s);
 int dsp_k_lstm6(const LstmArgs* a, int nprod, hipStream_t s);
-int dsp_k_lstm_stack(const LstmStackArgs* st, hipStream_t s);   /* a.CG = gates per wave (1 / 2 / 4), 8 unit tiles */
 int dsp_k_linear(const LinArgs* a, hipStream_t s);
 int dsp_k_head(const HeadArgs* a, hipStream_t s);
 int dsp_k_probe_xcc(unsigned* dev_out, int blocks, hipStream_t s);   /* out[b] = XCC_ID block b ran on */

@@ -822,9 +822,7 @@ __device__ __forceinline__ bool cluster_admit(gu32* state, unsigned P, unsigned 
 
 // One layer of one (site tile, direction) on this workgroup: prologue (ring fill, bias table, initial states, h0 hand-off)
 // and the T steps.  `pi` = this workgroup's index in the cluster (0 when LOCAL), `flag` = the cluster's counters of THIS layer.
-// Returns false when the cluster was given up on the way (wait_arrivals).  Called once by dsp_lstmc_kernel, once per layer by
-// the persistent stack kernel (dsp_lstmp_kernel) and once per (layer, direction) by its clean-up kernel: every call ends with a
-// workgroup barrier behind its last LDS read (publish), so the next call may overwrite the LDS at once.
+// Returns false when the cluster was given up on the way (wait_arrivals).
 template <int G, int D, bool LOCAL, int DEAD, int NW, bool XSHORT>
 __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, const long long gt0, const int pi, gu32* flag) {
     constexpr int WPU = 4 / G;             // waves per unit tile = gate slices; unit tiles per workgroup = G
@@ -924,6 +922,7 @@ __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, co
         stage(ic<3>{}, 3, std::integral_constant<bool, DEAD == 3>{}, kind, live{});
     };
 
+    { const int step = 13; TSTAMP(0); }   // (DSP_TRACE builds: prologue start / ring fill issued / states stored / h0 published)
     set_bases(0);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -931,6 +930,7 @@ __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, co
         for (int f = 0; f < G; ++f) A[d][f] = ldA(f, d);
         B[d] = ldBx(d);
     }
+    { const int step = 13; TSTAMP(1); }
     for (int i = tid; i < a.Hp; i += NW * 64) {
         const int h = i & 1, g = (i >> 1) & 3, aa = (i >> 3) & 3, ut = i >> 5;
         b_lds[i] = bias4[g * HQ + ut * 8 + 2 * aa + h];
@@ -963,10 +963,13 @@ __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, co
             if (tid == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
+    { const int step = 13; TSTAMP(2); }
     publish();
+    { const int step = 13; TSTAMP(3); }
 
     for (int step = 0; step < T; ++step) {
         const int t = dir ? (T - 1 - step) : step;
+        TSTAMP(0);
         if (prio) __builtin_amdgcn_s_setprio(2);
         if constexpr (LOCAL) {
             // (the barrier behind the previous step's -- or the prologue's -- h stores has been passed: every request may go out)
@@ -982,7 +985,9 @@ __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, co
         } else if constexpr (XSHORT) {
             // every refill of this step is an h row: h_{t-1} (h0 at step 0) of every member of the cluster must be in memory
             asm volatile("" ::: "memory");
+            TSTAMP(1);
             if (!wait_arrivals(flag, (unsigned)(P * (step + 1)))) return false;   // (given up: the clean-up launch computes this cluster)
+            TSTAMP(2);
             asm volatile("" ::: "memory");
             if constexpr (DEAD > 0) stages_first_sparse(ic<1>{});
             else stages(0, std::true_type{}, ic<1>{});
@@ -993,13 +998,16 @@ __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, co
             for (int q = D; q < nqx - D; q += D) stages(q, std::false_type{}, ic<0>{});
             // the B ring is about to reach into the h part: h_{t-1} (h0 at step 0) of every member of the cluster must be in memory
             asm volatile("" ::: "memory");   // (no h load may be moved above the poll by the compiler either)
+            TSTAMP(1);
             if (!wait_arrivals(flag, (unsigned)(P * (step + 1)))) return false;   // (given up: the clean-up launch computes this cluster)
+            TSTAMP(2);
             asm volatile("" ::: "memory");
             for (int q = nqx - D; q < NQ - D; q += D) stages(q, std::false_type{}, ic<1>{});
         }
         set_bases(step + 1 < T ? step + 1 : step);   // the last D refills are the next step's first x rows
         stages(NQ - D, std::false_type{}, ic<0>{});
         if (prio) __builtin_amdgcn_s_setprio(0);
+        TSTAMP(3);
 
         // the four gates of a row group meet: in this wave's registers (G == 4) or through LDS
         if constexpr (G < 4) {
@@ -1011,6 +1019,7 @@ __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, co
                         f32x4{acc[gl][4 * aa], acc[gl][4 * aa + 1], acc[gl][4 * aa + 2], acc[gl][4 * aa + 3]};
             __syncthreads();
         }
+        TSTAMP(4);
         const f32x4* b_my = b_lds + (size_t)u * 32 + half;
 #pragma unroll
         for (int al = 0; al < G; ++al) {
@@ -1041,8 +1050,11 @@ __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, co
             if constexpr (LOCAL) bst16(ro, voffO + al * 1024u, (uint32_t)t * orow + (uint32_t)u * 4096u, hv);
             else bst16_sc1(ro, voffO + al * 1024u, (uint32_t)t * orow + (uint32_t)u * 4096u, hv);
         }
+        TSTAMP(5);
         publish();   // (also the barrier between this step's LDS reads and the next step's LDS writes)
+        TSTAMP(6);
     }
+    { const int step = 14; TSTAMP(0); }
     return true;
 }
 
@@ -1086,92 +1098,6 @@ __global__ __launch_bounds__(NW * 64, 1) void dsp_lstmc_kernel(LstmArgs a) {
         if (!admitted) return;
     }
     lstmc_layer<G, D, LOCAL, DEAD, NW, XSHORT>(a, dir, gt0, pi, flag);
-}
-
-// ------------------------------------------------------------------------------------------------
-// dsp_lstmp_kernel<G, D> (round 5): the layers of a clustered stack in ONE launch.  A forward of 512 sites spent ~28 us per
-// clustered launch outside its step loop -- dispatch, admission, the drain at the end, the clean-up launch behind it and two
-// kernel boundaries -- three times for the combined stack.  A layer of a BiLSTM needs BOTH directions of the layer below at
-// every step, i.e. the (site tile, forward) and the (site tile, backward) cluster of the layer below, complete: that is a
-// dependency between TWO clusters, not a grid barrier.  The arrival counter of a cluster reads P x (T + 1) once its last step
-// is published, so a cluster enters layer k + 1 when its own and its partner's counter of layer k say so; one agent-scope
-// acquire (buffer_inv sc1) drops what this CU's L1 still holds of the buffer from two layers ago, then the x rows are plain
-// loads as before.  Write-after-read on the two ping-pong buffers is covered by the same wait: layer k + 1 writes the buffer
-// layer k read, and both clusters that read this tile's rows of it have finished layer k.  One admission per stack.  A
-// cluster that is given up (admission timeout; a poll without progress) leaves its abandon bit in the word of the layer it
-// happened in; whoever waits on that word leaves too, and ONE clean-up launch (dsp_lstmp_cleanup_kernel) recomputes, per site
-// tile, every layer from the first dirty one -- one workgroup, both directions in turn, nothing to wait for.
-// Same MFMAs on the same values in the same order: bit-identical to the launches it replaces.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ LstmArgs stack_layer_args(const LstmStackArgs& st, int k) {
-    LstmArgs a = st.a;
-    const LstmStackLayer& l = st.L[k];
-    a.x = l.x; a.out = l.out; a.wpk0 = l.wpk0; a.wpk1 = l.wpk1; a.sbias0 = l.sbias0; a.sbias1 = l.sbias1;
-    a.h0 = l.h0; a.c0 = l.c0; a.cflags = l.cflags;
-    a.Ipad = l.Ipad; a.NQ = l.NQ; a.nqx_lo = l.nqx_lo; a.nqx_used = l.nqx_used; a.stream_base = l.stream_base;
-    return a;
-}
-
-template <int G, int D>
-__global__ __launch_bounds__(256, 1) void dsp_lstmp_kernel(LstmStackArgs st) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x;
-    const int P = st.a.UT / G;
-    const int xs = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int pi = j % P;
-    const long long c = (long long)(j / P) * 8 + xs;
-    if (c >= st.a.NTp * 2) return;
-    const int dir = (int)(c & 1);
-    const long long gt0 = c >> 1;
-    {
-        gu32* flag0 = (gu32*)st.L[0].cflags + c * 32;
-        int* verdict = (int*)smem;
-        if (tid == 0) *verdict = cluster_admit(flag0 + 1, (unsigned)P, st.a.cluster_timeout) ? 1 : 0;
-        __syncthreads();
-        const int admitted = *(volatile int*)verdict;
-        __syncthreads();
-        if (!admitted) return;
-    }
-    const unsigned done = (unsigned)(P * (st.a.T + 1));
-    for (int k = 0; k < st.nl; ++k) {
-        const LstmArgs a = stack_layer_args(st, k);
-        if (k > 0) {
-            gu32* below = (gu32*)st.L[k - 1].cflags;
-            asm volatile("" ::: "memory");
-            if (!wait_arrivals(below + c * 32, done)) return;         // every member of this cluster has published its last step
-            if (!wait_arrivals(below + (c ^ 1) * 32, done)) return;   // ... and the other direction of this site tile
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("" ::: "memory");
-        }
-        if (k == 1 && (st.a.flags & 32) && c % 3 == 1) {
-            // test hook (DSP_TEST_ABANDON_MID=1): every third cluster gives itself up in the middle of the stack, the way a poll
-            // without progress would -- its partner direction must notice and leave, the clean-up launch must recompute this
-            // site tile from layer 1 on
-            if (tid == 0) __hip_atomic_fetch_or((gu32*)a.cflags + c * 32 + 1, kClusterAbandon, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
-        if (!lstmc_layer<G, D, false, 0, 4, false>(a, dir, gt0, pi, (gu32*)a.cflags + c * 32)) return;
-    }
-}
-
-__global__ __launch_bounds__(512, 1) void dsp_lstmp_cleanup_kernel(LstmStackArgs st) {
-    const long long tile = blockIdx.x;
-    if (tile >= st.a.NTp) return;
-    int first = st.nl;
-    for (int k = st.nl - 1; k >= 0; --k)
-        for (int d = 0; d < 2; ++d)
-            if (__hip_atomic_load((gu32*)st.L[k].cflags + (tile * 2 + d) * 32 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kClusterAbandon)
-                first = k;
-    if (first >= st.nl) return;
-    for (int k = first; k < st.nl; ++k) {
-        const LstmArgs a = stack_layer_args(st, k);
-        for (int d = 0; d < 2; ++d)
-            lstmc_layer<4, 4, true, 0, 8, false>(a, d, tile, 0, (gu32*)a.cflags + (tile * 2 + d) * 32);
-        // the next layer reads what this workgroup has just written (and, in its L1, may still hold what the buffer held before)
-        __syncthreads();
-        __threadfence();
-        __syncthreads();
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1750,9 +1676,7 @@ extern "C" int dsp_k_init(void) {
                          (const void*)dsp_lstmc_kernel<4, 4, true, 3>, (const void*)dsp_lstmc_kernel<4, 4, true, 0, 8>,
                          (const void*)dsp_lstmc_kernel<1, 4, false, 0, 4, true>, (const void*)dsp_lstmc_kernel<1, 4, false, 2, 4, true>,
                          (const void*)dsp_lstmc_kernel<1, 4, false, 3, 4, true>, (const void*)dsp_lstmc_kernel<2, 4, false, 0, 4, true>,
-                         (const void*)dsp_lstmc_kernel<2, 4, false, 2, 4, true>, (const void*)dsp_lstmc_kernel<2, 4, false, 3, 4, true>,
-                         (const void*)dsp_lstmp_kernel<4, 4>, (const void*)dsp_lstmp_kernel<2, 8>, (const void*)dsp_lstmp_kernel<1, 16>,
-                         (const void*)dsp_lstmp_cleanup_kernel};
+                         (const void*)dsp_lstmc_kernel<2, 4, false, 2, 4, true>, (const void*)dsp_lstmc_kernel<2, 4, false, 3, 4, true>};
     for (const void* f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
@@ -1863,29 +1787,6 @@ extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
         if (sparse) hipLaunchKernelGGL((dsp_lstm_kernel<1, 1>), g, b, lds, s, *a);
         else hipLaunchKernelGGL((dsp_lstm_kernel<0, 1>), g, b, lds, s, *a);
     }
-    return (int)hipGetLastError();
-}
-
-// a whole clustered stack in one launch + its one clean-up launch (8 unit tiles; the caller has checked shapes and residency)
-extern "C" int dsp_k_lstm_stack(const LstmStackArgs* st, hipStream_t s) {
-    const LstmArgs* a = &st->a;
-    const int G = a->CG, D = G == 4 ? 4 : (G == 2 ? 8 : 16);
-    if ((G != 1 && G != 2 && G != 4) || a->UT != 8 || a->NP > 1 || st->nl < 1 || st->nl > DSP_MAX_STACK_LAYERS) return (int)hipErrorInvalidValue;
-    for (int k = 0; k < st->nl; ++k) {
-        const LstmStackLayer& l = st->L[k];
-        const int nqx = l.Ipad >> 3;
-        if (!l.cflags || l.NQ != ((l.Ipad + a->Hp) >> 3) || nqx % D || nqx < 2 * D || l.NQ % D || l.nqx_lo != 0 || l.nqx_used != nqx)
-            return (int)hipErrorInvalidValue;
-    }
-    const int P = a->UT / G;
-    const unsigned clusters = (unsigned)(a->NTp * 2);
-    const unsigned grid = (clusters + 7) / 8 * 8 * (unsigned)P;
-    size_t lds = (size_t)a->Hp * 16 + (G < 4 ? (size_t)G * 16384 : 0);
-    if (a->flags & 4) lds = lds < 84 * 1024 ? 84 * 1024 : lds;
-    if (G == 4) hipLaunchKernelGGL((dsp_lstmp_kernel<4, 4>), dim3(grid), dim3(256), lds, s, *st);
-    else if (G == 2) hipLaunchKernelGGL((dsp_lstmp_kernel<2, 8>), dim3(grid), dim3(256), lds, s, *st);
-    else hipLaunchKernelGGL((dsp_lstmp_kernel<1, 16>), dim3(grid), dim3(256), lds, s, *st);
-    hipLaunchKernelGGL(dsp_lstmp_cleanup_kernel, dim3((unsigned)a->NTp), dim3(512), (size_t)a->Hp * 16, s, *st);
     return (int)hipGetLastError();
 }
 

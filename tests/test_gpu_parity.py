@@ -532,15 +532,9 @@ def test_small_batch_kernels_do_not_change_a_bit(kw, label, monkeypatch):
     states = {k: torch.from_numpy(v).cuda(0) for k, v in onp.make_init_states(cfg, n_x, 9).items()}
     ins_x = synth.feature_batch(n_x, device="cuda:0", seed=77)
     switches = ("DSP_LSTM_CLUSTER", "DSP_LSTM_LOCAL8", "DSP_TWO_STREAMS", "DSP_HEAD_ST4", "DSP_LSTM_TILING", "DSP_CLUSTER_TIMEOUT",
-                "DSP_FC_FUSED", "DSP_LSTM_FRONT_CLUSTER", "DSP_FC_SMALL", "DSP_LSTM_PERSIST", "DSP_TEST_ABANDON_MID")
+                "DSP_FC_FUSED", "DSP_LSTM_FRONT_CLUSTER", "DSP_FC_SMALL")
     modes = {"round3": {"DSP_LSTM_CLUSTER": "0", "DSP_LSTM_LOCAL8": "0", "DSP_TWO_STREAMS": "0", "DSP_HEAD_ST4": "1",
                         "DSP_FC_FUSED": "0", "DSP_FC_SMALL": "0"},
-             # round 5: a clustered stack is ONE launch (dsp_lstmp_kernel) + one clean-up launch -- off; on with every third
-             # cluster giving itself up before layer 1 (the partner direction leaves, the clean-up recomputes the tile from
-             # layer 1); on at each cluster size; (every_cluster_abandoned below: the clean-up recomputes every tile from layer 0)
-             "one_launch_per_layer": {"DSP_LSTM_PERSIST": "0"},
-             "stack_abandoned_mid": {"DSP_TEST_ABANDON_MID": "1"},
-             "stack_abandoned_mid_G2": {"DSP_TEST_ABANDON_MID": "1", "DSP_LSTM_CLUSTER": "2"},
              "round4_fc_kernel": {"DSP_FC_SMALL": "0"},   # (auto, round 5: one accumulator tile per wave in the fc projections)
              "fc_small_one_stream": {"DSP_TWO_STREAMS": "0"},   # ... and in the shared fc_seq+fc_signal launch
              # round 5: the front ends (4 unit tiles) clustered too -- off, 1 gate per wave (P = 4), 2 (P = 2), on one stream
