@@ -313,6 +313,7 @@ struct dsp_model {
     int tiling21 = -1;       // <2 unit tiles, 1 site tile> per wave on the dense one-pass layers (dsp_lstm21_kernel): -1 = for
                              // batches whose 32-site tiles x 2 directions fit the CUs at once (small-batch latency); DSP_LSTM_TILING=21
                              // always, =0 never (A/B switch)
+    bool wave_handoff = true;   // per-wave, deferred arrivals in the clustered launches (round 5); DSP_LSTM_HANDOFF=0: round 4's (A/B switch)
     bool fc_small = true;    // dsp_linear1_kernel for batches <= 4,096 sites (A/B switch DSP_FC_SMALL=0)
     bool fc_fused = true;    // fc_seq + fc_signal in one launch when they have one shape (A/B switch DSP_FC_FUSED=0)
     bool local8 = true;      // dense 8-unit-tile layers of 2,049..4,096-site batches on dsp_lstmc_kernel's eight-wave workgroup-local
@@ -655,6 +656,7 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
             // one workgroup per CU: not for the workgroup-local forms of two branches that run side by side on two streams (they
             // may share CUs); the CLUSTERED front ends of two branches were sized so that both grids fit the CUs together
             if (!L.side_by_side || (a.UT == 4 && a.CG < 4)) a.flags |= 4;
+            if (m->wave_handoff) a.flags |= 64;
         }
         if (m->debug_lstm)   // DSP_DEBUG_LSTM (read once, in dsp_model_create)
             fprintf(stderr, "[lstm] %s k=%zu split=%d CG=%d Ipad=%d H=%d Hp=%d UT=%d SG=%d NQ=%d NTp=%lld n=%lld T=%d Fout=%d x=%p out=%p\n", name, k,
@@ -749,6 +751,7 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
     if (const char* v = getenv("DSP_LSTM_LOCAL8")) m->local8 = atoi(v) != 0;
     if (const char* v = getenv("DSP_FC_FUSED")) m->fc_fused = atoi(v) != 0;
     if (const char* v = getenv("DSP_FC_SMALL")) m->fc_small = atoi(v) != 0;
+    if (const char* v = getenv("DSP_LSTM_HANDOFF")) m->wave_handoff = atoi(v) != 0;
     if (const char* v = getenv("DSP_LSTM_SG")) m->sg_override = atoi(v);  // A/B switch
     if (const char* v = getenv("DSP_LSTM_NP8")) m->np8 = atoi(v) == 2 ? 2 : 1;  // A/B switch
     if (const char* v = getenv("DSP_LSTM_PRIO")) m->phase_prio = atoi(v) != 0;    // A/B switch

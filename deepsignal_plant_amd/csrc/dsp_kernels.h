@@ -52,7 +52,7 @@ struct LstmArgs {
     unsigned long long cluster_timeout;  // s_memtime ticks a member of a cluster waits for the others to become resident before it
                            // abandons the cluster to the clean-up launch
     int CG;                // 0, or gates per wave of dsp_lstmc_kernel: 4 / 2 / 1 = a (site tile, direction) spread over UT/CG workgroups
-    int flags;             // bit 0: issue priority by phase (k-loop 2, cell 0); bit 1: <2 unit tiles, 1 site tile> per wave; bit 2: ... and one such workgroup per CU; bit 3: the workgroup-local form of dsp_lstmc_kernel with eight waves; bit 4: ... as the clean-up launch behind a clustered one (abandoned clusters only); bit 8: stamp this launch, bits 9..11: its stamping wave (DSP_TRACE builds only)
+    int flags;             // bit 0: issue priority by phase (k-loop 2, cell 0); bit 1: <2 unit tiles, 1 site tile> per wave; bit 2: ... and one such workgroup per CU; bit 3: the workgroup-local form of dsp_lstmc_kernel with eight waves; bit 4: ... as the clean-up launch behind a clustered one (abandoned clusters only); bit 6: the per-wave hand-off of the clustered launches (round 5: arrivals per wave, deferred into the next step's x part; poll one block early); bit 8: stamp this launch, bits 9..11: its stamping wave (DSP_TRACE builds only)
 };
 
 struct LinArgs {

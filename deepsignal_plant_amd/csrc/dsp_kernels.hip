@@ -308,6 +308,7 @@ __device__ __forceinline__ void barrier_after_global_stores() { __syncthreads();
 __device__ unsigned long long g_trace[DSP_TRACE_WGS][16][8];
 __device__ unsigned int g_trace_hw[DSP_TRACE_WGS][4];
 #define TSTAMP(k) do { if ((a.flags & 256) && tid == ((a.flags >> 9) & 7) * 64 && blockIdx.x < DSP_TRACE_WGS && step < 16) g_trace[blockIdx.x][step][k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define TSTAMP_AT(s, k) do { const int step = (s); TSTAMP(k); } while (0)
 extern "C" int dsp_k_trace_read(unsigned long long* t, unsigned int* hw) {
     hipError_t e = hipMemcpyFromSymbol(t, HIP_SYMBOL(g_trace), sizeof(g_trace));
     if (e == hipSuccess) e = hipMemcpyFromSymbol(hw, HIP_SYMBOL(g_trace_hw), sizeof(g_trace_hw));
@@ -315,6 +316,7 @@ extern "C" int dsp_k_trace_read(unsigned long long* t, unsigned int* hw) {
 }
 #else
 #define TSTAMP(k) do { } while (0)
+#define TSTAMP_AT(s, k) do { } while (0)
 #endif
 
 template <int SPARSE, int NP, int XL = 0>
@@ -820,6 +822,11 @@ __device__ __forceinline__ bool cluster_admit(gu32* state, unsigned P, unsigned 
     }
 }
 
+template <int LO, int HI, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (LO < HI) { f(ic<LO>{}); static_for<LO + 1, HI>(f); }
+}
+
 // One layer of one (site tile, direction) on this workgroup: prologue (ring fill, bias table, initial states, h0 hand-off)
 // and the T steps.  `pi` = this workgroup's index in the cluster (0 when LOCAL), `flag` = the cluster's counters of THIS layer.
 // Returns false when the cluster was given up on the way (wait_arrivals).
@@ -879,8 +886,22 @@ __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, co
     // one k-group: per fragment its 4 MFMAs, then the (late) refill of the fragment before it for k-group q + D; the B
     // fragment of the slot is refilled behind the stage.  kind (compile time): 0 = the refill is an x row of THIS step's
     // bases, 1 = an h row
-    auto stage = [&](auto qs, int q, auto first, auto kind, auto dead) __attribute__((always_inline)) {
-        constexpr int S = decltype(qs)::value % D, SP = (decltype(qs)::value + D - 1) % D;
+    // the refills of stage qs at k-group q, in the stage's own order (f == 0: the last fragment of the slot before it)
+    auto refill_A = [&](auto qs, auto fi, int q) __attribute__((always_inline)) {
+        constexpr int S = decltype(qs)::value % D, SP = (decltype(qs)::value + D - 1) % D, f = decltype(fi)::value;
+        if constexpr (f == 0) A[SP][G - 1] = ldA(G - 1, q + D - 1);
+        else A[S][f - 1] = ldA(f - 1, q + D);
+    };
+    auto refill_B = [&](auto qs, int q, auto kind) __attribute__((always_inline)) {
+        constexpr int S = decltype(qs)::value % D;
+        const int qn = q + D < NQ ? q + D : q + D - NQ;
+        if constexpr (decltype(kind)::value == 1) B[S] = ldBh(qn); else B[S] = ldBx(qn);
+    };
+    // norefill (compile time): the stage issues NO memory request -- its refills are made up for later, in the same order,
+    // by refill_stage (the deferred arrival of the per-wave hand-off: nothing may be requested between the h stores and
+    // their drain, or the drain would wait for it too)
+    auto stage = [&](auto qs, int q, auto first, auto kind, auto dead, auto norefill) __attribute__((always_inline)) {
+        constexpr int S = decltype(qs)::value % D;
 #pragma unroll
         for (int f = 0; f < G; ++f) {
 #pragma unroll
@@ -892,37 +913,48 @@ __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, co
                     acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[S][f][i], B[S][i], acc[f], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (f == 0) A[SP][G - 1] = ldA(G - 1, q + D - 1);
-            else A[S][f - 1] = ldA(f - 1, q + D);
+            if constexpr (!decltype(norefill)::value) {
+                if (f == 0) refill_A(qs, ic<0>{}, q);
+                else if (f == 1) refill_A(qs, ic<1 % G>{}, q);
+                else if (f == 2) refill_A(qs, ic<2 % G>{}, q);
+                else refill_A(qs, ic<3 % G>{}, q);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
-        const int qn = q + D < NQ ? q + D : q + D - NQ;
-        if constexpr (decltype(kind)::value == 1) B[S] = ldBh(qn); else B[S] = ldBx(qn);
+        if constexpr (!decltype(norefill)::value) refill_B(qs, q, kind);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto refill_stage = [&](auto qs, int q, auto kind) __attribute__((always_inline)) {
+        refill_A(qs, ic<0>{}, q);
+        if constexpr (G > 1) refill_A(qs, ic<1 % G>{}, q);
+        if constexpr (G > 2) { refill_A(qs, ic<2 % G>{}, q); refill_A(qs, ic<3 % G>{}, q); }
+        refill_B(qs, q, kind);
         __builtin_amdgcn_sched_barrier(0);
     };
     using live = std::false_type;
+    using refills = std::false_type;   // (the usual stage: refills right behind the MFMAs)
     auto stages = [&](int q, auto first, auto kind) __attribute__((always_inline)) {
-        stage(ic<0>{}, q, first, kind, live{});
-        if constexpr (D > 1) stage(ic<1>{}, q + 1, std::false_type{}, kind, live{});
-        if constexpr (D > 2) { stage(ic<2>{}, q + 2, std::false_type{}, kind, live{}); stage(ic<3>{}, q + 3, std::false_type{}, kind, live{}); }
-        if constexpr (D > 4) { stage(ic<4>{}, q + 4, std::false_type{}, kind, live{}); stage(ic<5>{}, q + 5, std::false_type{}, kind, live{});
-                               stage(ic<6>{}, q + 6, std::false_type{}, kind, live{}); stage(ic<7>{}, q + 7, std::false_type{}, kind, live{}); }
-        if constexpr (D > 8) { stage(ic<8>{}, q + 8, std::false_type{}, kind, live{}); stage(ic<9>{}, q + 9, std::false_type{}, kind, live{});
-                               stage(ic<10>{}, q + 10, std::false_type{}, kind, live{}); stage(ic<11>{}, q + 11, std::false_type{}, kind, live{});
-                               stage(ic<12>{}, q + 12, std::false_type{}, kind, live{}); stage(ic<13>{}, q + 13, std::false_type{}, kind, live{});
-                               stage(ic<14>{}, q + 14, std::false_type{}, kind, live{}); stage(ic<15>{}, q + 15, std::false_type{}, kind, live{}); }
+        stage(ic<0>{}, q, first, kind, live{}, refills{});
+        if constexpr (D > 1) stage(ic<1>{}, q + 1, std::false_type{}, kind, live{}, refills{});
+        if constexpr (D > 2) { stage(ic<2>{}, q + 2, std::false_type{}, kind, live{}, refills{}); stage(ic<3>{}, q + 3, std::false_type{}, kind, live{}, refills{}); }
+        if constexpr (D > 4) { stage(ic<4>{}, q + 4, std::false_type{}, kind, live{}, refills{}); stage(ic<5>{}, q + 5, std::false_type{}, kind, live{}, refills{});
+                               stage(ic<6>{}, q + 6, std::false_type{}, kind, live{}, refills{}); stage(ic<7>{}, q + 7, std::false_type{}, kind, live{}, refills{}); }
+        if constexpr (D > 8) { stage(ic<8>{}, q + 8, std::false_type{}, kind, live{}, refills{}); stage(ic<9>{}, q + 9, std::false_type{}, kind, live{}, refills{});
+                               stage(ic<10>{}, q + 10, std::false_type{}, kind, live{}, refills{}); stage(ic<11>{}, q + 11, std::false_type{}, kind, live{}, refills{});
+                               stage(ic<12>{}, q + 12, std::false_type{}, kind, live{}, refills{}); stage(ic<13>{}, q + 13, std::false_type{}, kind, live{}, refills{});
+                               stage(ic<14>{}, q + 14, std::false_type{}, kind, live{}, refills{}); stage(ic<15>{}, q + 15, std::false_type{}, kind, live{}, refills{}); }
     };
     // the first block of a front-end step (D == 4 == nqx): DEAD refill-only stages, then the live x-part k-groups, the first
     // of which starts the accumulators from zero
     auto stages_first_sparse = [&](auto kind) __attribute__((always_inline)) {
         static_assert(DEAD == 0 || D == 4, "front-end shape");
-        stage(ic<0>{}, 0, std::integral_constant<bool, DEAD == 0>{}, kind, std::integral_constant<bool, (0 < DEAD)>{});
-        stage(ic<1>{}, 1, std::integral_constant<bool, DEAD == 1>{}, kind, std::integral_constant<bool, (1 < DEAD)>{});
-        stage(ic<2>{}, 2, std::integral_constant<bool, DEAD == 2>{}, kind, std::integral_constant<bool, (2 < DEAD)>{});
-        stage(ic<3>{}, 3, std::integral_constant<bool, DEAD == 3>{}, kind, live{});
+        stage(ic<0>{}, 0, std::integral_constant<bool, DEAD == 0>{}, kind, std::integral_constant<bool, (0 < DEAD)>{}, refills{});
+        stage(ic<1>{}, 1, std::integral_constant<bool, DEAD == 1>{}, kind, std::integral_constant<bool, (1 < DEAD)>{}, refills{});
+        stage(ic<2>{}, 2, std::integral_constant<bool, DEAD == 2>{}, kind, std::integral_constant<bool, (2 < DEAD)>{}, refills{});
+        stage(ic<3>{}, 3, std::integral_constant<bool, DEAD == 3>{}, kind, live{}, refills{});
     };
 
-    { const int step = 13; TSTAMP(0); }   // (DSP_TRACE builds: prologue start / ring fill issued / states stored / h0 published)
+    TSTAMP_AT(13, 0);   // (DSP_TRACE builds: prologue start / ring fill issued / states stored / h0 published)
     set_bases(0);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -930,7 +962,7 @@ __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, co
         for (int f = 0; f < G; ++f) A[d][f] = ldA(f, d);
         B[d] = ldBx(d);
     }
-    { const int step = 13; TSTAMP(1); }
+    TSTAMP_AT(13, 1);
     for (int i = tid; i < a.Hp; i += NW * 64) {
         const int h = i & 1, g = (i >> 1) & 3, aa = (i >> 3) & 3, ut = i >> 5;
         b_lds[i] = bias4[g * HQ + ut * 8 + 2 * aa + h];
@@ -953,6 +985,24 @@ __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, co
             creg[al] = cv;
         }
     }
+    // Hand-off, round 5 (flags bit 6; DSP_LSTM_HANDOFF=0 keeps round 4's): every WAVE counts its own arrival -- it drains its
+    // own write-through stores and adds 1; no workgroup barrier (the poll target is P x NW x (step + 1); the barrier that kept
+    // the next step's LDS writes behind this step's LDS reads is implied: nobody passes the next poll before every wave has
+    // arrived, i.e. finished its cell phase).  In the layers with a real x part the arrival is DEFERRED into the next step:
+    // the first E stages of the x part run on what the ring already holds and request nothing, so that by the time the wave
+    // drains, its h stores have long been acknowledged (round 4: 750 cycles per step in drain + barrier + atomic, every one of
+    // them with the matrix pipe idle); the E stages' refills follow in one burst -- the ring is D stages deep, E of them
+    // cover the store's round trip and D - E the refills'.  And the poll's own round trip (460 cycles with the wave stalled in
+    // front of D stages of x rows it already holds) is taken out of the way by requesting the counter one block early.
+    // (not for the front ends' XSHORT form: with no x part to defer into, 16 waves' atomics on one word lengthen the hop the
+    // step is waiting for -- 51.9 -> 53.1 us per launch at 512 sites -- so they keep one arrival per workgroup)
+    const bool wavepub = !LOCAL && !XSHORT && (a.flags & 64) != 0;
+    const unsigned per_step = wavepub ? (unsigned)(P * NW) : (unsigned)P;
+    constexpr int E = G == 1 ? 3 : (G == 2 ? 2 : 1);   // stages without requests in front of a deferred arrival
+    auto arrive = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     // publish: every wave drains its write-through stores, the workgroup meets, one lane counts the arrival
     auto publish = [&]() __attribute__((always_inline)) {
         if constexpr (LOCAL) {
@@ -963,9 +1013,12 @@ __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, co
             if (tid == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
-    { const int step = 13; TSTAMP(2); }
-    publish();
-    { const int step = 13; TSTAMP(3); }
+    TSTAMP_AT(13, 2);
+    if (!wavepub) publish();
+    else {
+        __syncthreads();              // (the bias table is complete before any wave's cell phase reads it)
+    }
+    TSTAMP_AT(13, 3);
 
     for (int step = 0; step < T; ++step) {
         const int t = dir ? (T - 1 - step) : step;
@@ -986,7 +1039,7 @@ __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, co
             // every refill of this step is an h row: h_{t-1} (h0 at step 0) of every member of the cluster must be in memory
             asm volatile("" ::: "memory");
             TSTAMP(1);
-            if (!wait_arrivals(flag, (unsigned)(P * (step + 1)))) return false;   // (given up: the clean-up launch computes this cluster)
+            if (!wait_arrivals(flag, per_step * (unsigned)(step + 1))) return false;   // (given up: the clean-up launch computes this cluster)
             TSTAMP(2);
             asm volatile("" ::: "memory");
             if constexpr (DEAD > 0) stages_first_sparse(ic<1>{});
@@ -994,12 +1047,33 @@ __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, co
             for (int q = D; q < NQ - D; q += D) stages(q, std::false_type{}, ic<1>{});
         } else {
             // x part: nothing here depends on h_{t-1}
-            stages(0, std::true_type{}, ic<0>{});
-            for (int q = D; q < nqx - D; q += D) stages(q, std::false_type{}, ic<0>{});
+            unsigned seen = 0;
+            if (!wavepub) {
+                stages(0, std::true_type{}, ic<0>{});
+                for (int q = D; q < nqx - D; q += D) stages(q, std::false_type{}, ic<0>{});
+            } else {
+                // the first block: E stages that request nothing, the deferred arrival of the previous step's (the prologue's)
+                // h stores, the E stages' refills in one burst, the rest of the block
+                static_for<0, E>([&](auto i) __attribute__((always_inline)) {
+                    stage(i, decltype(i)::value, std::integral_constant<bool, decltype(i)::value == 0>{}, ic<0>{}, live{}, std::true_type{});
+                });
+                arrive();
+                static_for<0, E>([&](auto i) __attribute__((always_inline)) { refill_stage(i, decltype(i)::value, ic<0>{}); });
+                static_for<E, D>([&](auto i) __attribute__((always_inline)) {
+                    stage(i, decltype(i)::value, std::false_type{}, ic<0>{}, live{}, refills{});
+                });
+                for (int q = D; q < nqx - 2 * D; q += D) stages(q, std::false_type{}, ic<0>{});
+                // the counter, one block early (nqx == 2 D: this was the only block -- the value may be too early to be final)
+                if (nqx > 2 * D) {
+                    seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    stages(nqx - 2 * D, std::false_type{}, ic<0>{});
+                }
+            }
             // the B ring is about to reach into the h part: h_{t-1} (h0 at step 0) of every member of the cluster must be in memory
             asm volatile("" ::: "memory");   // (no h load may be moved above the poll by the compiler either)
             TSTAMP(1);
-            if (!wait_arrivals(flag, (unsigned)(P * (step + 1)))) return false;   // (given up: the clean-up launch computes this cluster)
+            if ((unsigned)__builtin_amdgcn_readfirstlane(seen) < per_step * (unsigned)(step + 1))
+                if (!wait_arrivals(flag, per_step * (unsigned)(step + 1))) return false;   // (given up: the clean-up launch computes this cluster)
             TSTAMP(2);
             asm volatile("" ::: "memory");
             for (int q = nqx - D; q < NQ - D; q += D) stages(q, std::false_type{}, ic<1>{});
@@ -1051,10 +1125,11 @@ __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, co
             else bst16_sc1(ro, voffO + al * 1024u, (uint32_t)t * orow + (uint32_t)u * 4096u, hv);
         }
         TSTAMP(5);
-        publish();   // (also the barrier between this step's LDS reads and the next step's LDS writes)
+        if (!wavepub) publish();   // (also the barrier between this step's LDS reads and the next step's LDS writes)
+        // (wavepub: the arrival is counted E stages into the next step; the last step's is nobody's to wait for)
         TSTAMP(6);
     }
-    { const int step = 14; TSTAMP(0); }
+    TSTAMP_AT(14, 0);
     return true;
 }
 

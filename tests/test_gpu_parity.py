@@ -532,9 +532,13 @@ def test_small_batch_kernels_do_not_change_a_bit(kw, label, monkeypatch):
     states = {k: torch.from_numpy(v).cuda(0) for k, v in onp.make_init_states(cfg, n_x, 9).items()}
     ins_x = synth.feature_batch(n_x, device="cuda:0", seed=77)
     switches = ("DSP_LSTM_CLUSTER", "DSP_LSTM_LOCAL8", "DSP_TWO_STREAMS", "DSP_HEAD_ST4", "DSP_LSTM_TILING", "DSP_CLUSTER_TIMEOUT",
-                "DSP_FC_FUSED", "DSP_LSTM_FRONT_CLUSTER", "DSP_FC_SMALL")
+                "DSP_FC_FUSED", "DSP_LSTM_FRONT_CLUSTER", "DSP_FC_SMALL", "DSP_LSTM_HANDOFF")
     modes = {"round3": {"DSP_LSTM_CLUSTER": "0", "DSP_LSTM_LOCAL8": "0", "DSP_TWO_STREAMS": "0", "DSP_HEAD_ST4": "1",
                         "DSP_FC_FUSED": "0", "DSP_FC_SMALL": "0"},
+             # round 5: arrivals counted per wave and deferred into the next step's x part, the counter requested a block early
+             # (auto) -- against round 4's drain + workgroup barrier + one arrival per workgroup, at every cluster size
+             "round4_handoff": {"DSP_LSTM_HANDOFF": "0"},
+             "round4_handoff_G2_front_G2": {"DSP_LSTM_HANDOFF": "0", "DSP_LSTM_CLUSTER": "2", "DSP_LSTM_FRONT_CLUSTER": "2"},
              "round4_fc_kernel": {"DSP_FC_SMALL": "0"},   # (auto, round 5: one accumulator tile per wave in the fc projections)
              "fc_small_one_stream": {"DSP_TWO_STREAMS": "0"},   # ... and in the shared fc_seq+fc_signal launch
              # round 5: the front ends (4 unit tiles) clustered too -- off, 1 gate per wave (P = 4), 2 (P = 2), on one stream
