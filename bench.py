@@ -264,7 +264,10 @@ def main(argv=None):
     for i in range(W):
         step(i)
     torch.cuda.synchronize()
-    model.profile(True)
+    # HIP events on the launch stream around the launches of the DOMINANT kernel only (the roofline object's duration is measured
+    # live, over the timed region): 4 records per forward.  The per-launch breakdown of ALL launches is taken in the untimed
+    # steps below -- until round 5 it rode on the timed steps too: 9 records, 0.03 ms per forward whatever the batch.
+    model.profile("dominant")
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
@@ -278,9 +281,10 @@ def main(argv=None):
     dt = time.perf_counter() - t0
     prof = model.profile_read()
     model.profile(False)
-    # the same steps once more WITHOUT the per-launch events (untimed by the contract; reported beside the line): an event record
-    # costs the stream ~4 us, 9 of them a forward -- nothing at 65,536 sites, 1 % at 4,096, 9 % at 512 (profiles/r4/profile_events_overhead.txt)
+    # the same steps once more WITHOUT any events (untimed by the contract; reported beside the line): an event record costs the
+    # stream ~4 us -- nothing at 65,536 sites, 2 % at 512 with the 4 records the timed steps keep
     ms_events_off = None
+    prof_all = []
     if world == 1 and K > 0:
         ko = min(K, 40)
         for i in range(min(W, 5) + 3):      # (reading the events back left the GPU idle: back to its clocks first)
@@ -291,6 +295,13 @@ def main(argv=None):
             step(i)
         torch.cuda.synchronize()
         ms_events_off = (time.perf_counter() - t1) / ko * 1e3
+        # ... and once more with events around EVERY launch: the per-launch breakdown (ms_per_step_by_launch)
+        model.profile(True)
+        for i in range(ko):
+            step(i)
+        torch.cuda.synchronize()
+        prof_all = model.profile_read()
+        model.profile(False)
 
     ranges = [[site0, site1]]
     gather_info = None
@@ -378,7 +389,8 @@ def main(argv=None):
         # different instantiation and are listed separately by rocprofv3): algorithmic FLOPs of those launches /
         # their summed duration, durations from HIP events on the launch stream
         comb_ms = [ms for name, ms in prof if name == "lstm_comb"]
-        all_ms = sum(ms for _, ms in prof)
+        k_all = min(K, 40) if prof_all else 0
+        all_ms = sum(ms for _, ms in prof_all) / max(k_all, 1) * K if prof_all else sum(ms for _, ms in prof)
         H, T = model.hidden_size, model.seq_len
         comb_flops_site = sum(2 * (2 * T * 4 * H * ((H if k == 0 else 2 * H) + H)) for k in range(model.num_layers1))
         n_lstm = max(len(comb_ms), 1)
@@ -389,7 +401,7 @@ def main(argv=None):
         peak = FP32_MATRIX_PEAK_TFLOPS if nprod == 1 else 16 * FP32_MATRIX_PEAK_TFLOPS
         achieved = nprod * flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         per_launch = {}
-        for name, ms in prof:
+        for name, ms in (prof_all or prof):
             per_launch.setdefault(name, []).append(ms)
         # HBM-side traffic from the committed PMC passes of this command, next to the bytes the algorithm needs: per launch
         # of the dominant kernel its K4 activations (x read by both directions' workgroups + h written), per step SURVEY.md
@@ -430,11 +442,13 @@ def main(argv=None):
                          "whole_forward_frac": round(value / world * flops_site / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4),
                          "hbm_gbps_algorithmic": round(value / world * 1048 / 1e9, 3),
                          "hbm_frac_algorithmic": round(value / world * 1048 / 8e12, 6),  # of 8 TB/s: the north_star's "HBM roofline" does not bind
-                         "kernel_time_frac_of_wall": round(all_ms * 1e-3 / dt, 4) if dt > 0 else None,
+                         "kernel_time_frac_of_wall": round(all_ms * 1e-3 / dt, 4) if (dt > 0 and prof_all) else None,
                          "ms_per_step_events_off": round(ms_events_off, 4) if ms_events_off else None,
                          "whole_forward_frac_events_off": round(B / (ms_events_off * 1e-3) * flops_site / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4)
                          if ms_events_off else None,
-                         "ms_per_step_by_launch": {k: round(sum(v) / max(K, 1), 4) for k, v in per_launch.items()},
+                         "ms_per_step_by_launch": {k: round(sum(v) / max(k_all or K, 1), 4) for k, v in per_launch.items()},
+                         "events_in_timed_steps": "the dominant kernel's launches only (4 records per forward); ms_per_step_by_launch from %s" % (
+                             "%d untimed steps with events around every launch" % k_all if k_all else "the timed steps"),
                          "kernel_src_sha16": kernel_source_hash(),
                          "note": ("fp32 MFMA and VALU work do not overlap on gfx950 (profiles/r2/micro_mfma_cell_overlap.txt): "
                                  "with the LSTM cell phase counted the bound of this kernel is 0.974 of the MFMA peak "

@@ -347,6 +347,7 @@ struct dsp_model {
     float* last_out = nullptr;
     // profiling
     bool prof = false;
+    bool prof_dominant_only = false;   // dsp_profile_enable(m, 2): only the launches of the combined stack are bracketed by events
     bool prof_serial = false;   // (reserved: per-launch timing wants the branches in sequence; DSP_TWO_STREAMS=0 gives that)
     std::vector<ProfEntry> prof_entries;
     std::vector<hipEvent_t> event_pool;
@@ -502,7 +503,8 @@ struct Launcher {
     template <class F> void run(const char* name, F&& f) {
         if (rc) return;
         hipEvent_t ea = nullptr, eb = nullptr;
-        if (m->prof) {
+        const bool timed = m->prof && (!m->prof_dominant_only || !strcmp(name, "lstm_comb"));
+        if (timed) {
             while (m->event_pool.size() < m->event_used + 2) {
                 hipEvent_t e;
                 if (hipEventCreate(&e) != hipSuccess) { rc = fail(DSP_EHIP, "hipEventCreate failed"); return; }
@@ -516,7 +518,8 @@ struct Launcher {
         }
         const int e = f();
         if (e != 0) { rc = fail(DSP_EHIP, "launch %s failed: %s", name, hipGetErrorString((hipError_t)e)); return; }
-        if (m->prof) { hipEventRecord(eb, s); m->prof_entries.push_back({name, ea, eb}); last_ev = eb; last_s = s; }
+        if (timed) { hipEventRecord(eb, s); m->prof_entries.push_back({name, ea, eb}); last_ev = eb; last_s = s; }
+        else last_ev = nullptr;
         if (m->sync_each) {  // DSP_SYNC_EACH (read once, in dsp_model_create): attribute an asynchronous GPU fault to its launch
             fprintf(stderr, "[launch] %s ...", name);
             const hipError_t se = hipStreamSynchronize(s);
@@ -1036,6 +1039,7 @@ int32_t dsp_debug_read_activation(dsp_model* m, void* stream, int32_t which, int
 int32_t dsp_profile_enable(dsp_model* m, int32_t on) {
     if (!m) return fail(DSP_EINVAL, "model is NULL");
     m->prof = on != 0;
+    m->prof_dominant_only = on == 2;
     return 0;
 }
 

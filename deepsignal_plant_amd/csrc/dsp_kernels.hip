@@ -998,7 +998,11 @@ __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, co
     // step is waiting for -- 51.9 -> 53.1 us per launch at 512 sites -- so they keep one arrival per workgroup)
     const bool wavepub = !LOCAL && !XSHORT && (a.flags & 64) != 0;
     const unsigned per_step = wavepub ? (unsigned)(P * NW) : (unsigned)P;
-    constexpr int E = G == 1 ? 3 : (G == 2 ? 2 : 1);   // stages without requests in front of a deferred arrival
+    // stages without requests in front of a deferred arrival (>= 1: stage 0 starts the accumulators).  Same-box A/B of the
+    // depth (profiles/r5/handoff_ab.txt): 3 / 2 / 1 as here 0.5697 / 0.9767 / 1.7729 ms per forward of 512 / 1,024 / 2,048 sites;
+    // 1 / 1 / 1: 0.5726 / 0.9792 / 1.7716; 6 / 3 / 2: +8 / +6 / +5 us; 10 / 5 / 2: +17 / +10 / +3 us (the burst of refills
+    // behind the drain is issued with no MFMA in flight); round 4's hand-off 0.5716 / 0.9943 / 1.7962
+    constexpr int E = G == 1 ? 3 : (G == 2 ? 2 : 1);
     auto arrive = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -254,8 +254,9 @@ class ModelBiLSTM(object):
         return nat.check(int(nat.lib().dsp_model_query(self._handle, {"clustering": 0, "xcc_probe_failed": 1, "compute_units": 2}[what])))
 
     def profile(self, on=True):
+        """HIP events around every launch (True), around the dominant kernel's launches only ("dominant"), or off"""
         self._ensure_handle()
-        nat.check(nat.lib().dsp_profile_enable(self._handle, int(bool(on))))
+        nat.check(nat.lib().dsp_profile_enable(self._handle, 2 if on == "dominant" else int(bool(on))))
 
     def profile_read(self):
         """[(launch name, ms)] of every launch since profiling was enabled / last read (HIP events on the

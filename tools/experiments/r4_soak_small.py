@@ -26,7 +26,7 @@ def build(env):
     return m
 
 
-ref_m = build({"DSP_LSTM_CLUSTER": "0", "DSP_LSTM_LOCAL8": "0", "DSP_TWO_STREAMS": "0", "DSP_HEAD_ST4": "1"})
+ref_m = build({"DSP_LSTM_CLUSTER": "0", "DSP_LSTM_LOCAL8": "0", "DSP_TWO_STREAMS": "0", "DSP_HEAD_ST4": "1", "DSP_FC_SMALL": "0"})
 m = build({})
 bad = 0
 for n in (37, 512, 1000, 1024, 2048, 3000, 4096):
