@@ -314,6 +314,7 @@ struct dsp_model {
                              // batches whose 32-site tiles x 2 directions fit the CUs at once (small-batch latency); DSP_LSTM_TILING=21
                              // always, =0 never (A/B switch)
     bool wave_handoff = true;   // per-wave, deferred arrivals in the clustered launches (round 5); DSP_LSTM_HANDOFF=0: round 4's (A/B switch)
+    bool forward_split = true;  // dsp_forward cuts a call into whole rounds of 8,192 sites + a small-batch remainder (round 5); DSP_FORWARD_SPLIT=0 (A/B switch)
     bool fc_small = true;    // dsp_linear1_kernel for batches <= 4,096 sites (A/B switch DSP_FC_SMALL=0)
     bool fc_fused = true;    // fc_seq + fc_signal in one launch when they have one shape (A/B switch DSP_FC_FUSED=0)
     bool local8 = true;      // dense 8-unit-tile layers of 2,049..4,096-site batches on dsp_lstmc_kernel's eight-wave workgroup-local
@@ -345,6 +346,7 @@ struct dsp_model {
     int64_t ws_sites = 0;
     float *xseq = nullptr, *xsig = nullptr, *bufA = nullptr, *bufB = nullptr, *comb_in = nullptr, *h0buf = nullptr, *cbuf = nullptr;
     float* last_out = nullptr;
+    bool last_split = false;   // the last dsp_forward ran as several pieces: the scratch holds the last piece only
     // profiling
     bool prof = false;
     bool prof_dominant_only = false;   // dsp_profile_enable(m, 2): only the launches of the combined stack are bracketed by events
@@ -754,6 +756,7 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
     if (const char* v = getenv("DSP_LSTM_LOCAL8")) m->local8 = atoi(v) != 0;
     if (const char* v = getenv("DSP_FC_FUSED")) m->fc_fused = atoi(v) != 0;
     if (const char* v = getenv("DSP_FC_SMALL")) m->fc_small = atoi(v) != 0;
+    if (const char* v = getenv("DSP_FORWARD_SPLIT")) m->forward_split = atoi(v) != 0;
     if (const char* v = getenv("DSP_LSTM_HANDOFF")) m->wave_handoff = atoi(v) != 0;
     if (const char* v = getenv("DSP_LSTM_SG")) m->sg_override = atoi(v);  // A/B switch
     if (const char* v = getenv("DSP_LSTM_NP8")) m->np8 = atoi(v) == 2 ? 2 : 1;  // A/B switch
@@ -904,11 +907,59 @@ int32_t dsp_model_reserve(dsp_model* m, int64_t max_sites) {
     return rc;
 }
 
+static int32_t forward_chunk(dsp_model* m, void* stream, int64_t n, const void* kmer, int32_t kmer_dtype, const float* means,
+                             const float* stds, const void* lens, int32_t lens_dtype, const float* signals,
+                             const dsp_init_state* init, float* logits, float* probs, uint8_t* labels);
+
+// Sites are independent and the in-kernel initial states are keyed by the site's global index, so a call may be cut anywhere
+// without changing a bit.  Round 5: the 64-site workgroups of batches above 4,096 sites fill the chip in rounds of 8,192 sites
+// (one workgroup per CU; two per CU share its matrix pipe and gain nothing), so 10,000 sites cost two rounds = 13.3 ms -- while
+// the small-batch forms run a remainder of <= 4,096 sites in 0.6-3.4 ms.  A call whose size is not a whole number of rounds
+// runs its whole rounds first and its remainder on the small-batch forms (10,000 sites: 8.4 ms; 5,000: 4.4 instead of 6.6).
+// Not with explicit initial states (their layout has the site index in the middle dimension) and not in the split-precision
+// modes (their kernels have no small-batch forms).  DSP_FORWARD_SPLIT=0 turns it off (A/B switch).
 int32_t dsp_forward(dsp_model* m, void* stream, int64_t n, const void* kmer, int32_t kmer_dtype, const float* means,
                     const float* stds, const void* lens, int32_t lens_dtype, const float* signals,
                     const dsp_init_state* init, float* logits, float* probs, uint8_t* labels) {
     if (!m) return fail(DSP_EINVAL, "model is NULL");
     if (n < 0) return fail(DSP_EINVAL, "n_sites < 0");
+    const int mode = init ? init->mode : DSP_INIT_ZEROS;
+    const int64_t kRound = 8192, kSmall = 4096;
+    const int64_t r = n % kRound;
+    // the remainder pays when it fits the small-batch forms: <= 4,096 sites in one piece, <= 6,144 as 4,096 + the rest
+    // (two pieces of up to 4,096 cost what the round costs)
+    const bool cut = m->forward_split && n > kSmall && r != 0 && r <= kSmall + kSmall / 2 && mode != DSP_INIT_EXPLICIT &&
+                     m->precision == DSP_PREC_FP32 && m->cluster != 0 && kmer_dtype >= 0 && kmer_dtype <= 3 && lens_dtype >= 0 &&
+                     lens_dtype <= 3;
+    m->last_split = cut;
+    if (!cut) return forward_chunk(m, stream, n, kmer, kmer_dtype, means, stds, lens, lens_dtype, signals, init, logits, probs, labels);
+    static const size_t dt_size[4] = {4, 1, 2, 4};   // DSP_DT_F32, U8, U16, I32
+    const Dims& d = m->d;
+    int64_t pieces[3] = {n - r, r <= kSmall ? r : kSmall, r <= kSmall ? 0 : r - kSmall};
+    int64_t at = 0;
+    for (int64_t len : pieces) {
+        if (len <= 0) continue;
+        dsp_init_state st{};
+        if (init) {
+            st = *init;
+            st.site_offset = init->site_offset + (uint64_t)at;
+            if (init->site_keys) st.site_keys = init->site_keys + at;
+        }
+        const size_t row = (size_t)at * d.T;
+        const int32_t rc = forward_chunk(
+            m, stream, len, kmer ? (const char*)kmer + row * dt_size[kmer_dtype] : nullptr, kmer_dtype, means ? means + row : nullptr,
+            stds ? stds + row : nullptr, lens ? (const char*)lens + row * dt_size[lens_dtype] : nullptr, lens_dtype,
+            signals ? signals + row * d.S : nullptr, init ? &st : nullptr, logits ? logits + (size_t)at * d.C : nullptr,
+            probs ? probs + (size_t)at * d.C : nullptr, labels ? labels + at : nullptr);
+        if (rc) return rc;
+        at += len;
+    }
+    return 0;
+}
+
+static int32_t forward_chunk(dsp_model* m, void* stream, int64_t n, const void* kmer, int32_t kmer_dtype, const float* means,
+                             const float* stds, const void* lens, int32_t lens_dtype, const float* signals,
+                             const dsp_init_state* init, float* logits, float* probs, uint8_t* labels) {
     if (n == 0) return 0;
     const Dims& d = m->d;
     if (kmer_dtype < 0 || kmer_dtype > 3 || lens_dtype < 0 || lens_dtype > 3) return fail(DSP_EINVAL, "bad dtype code");
@@ -1012,6 +1063,8 @@ int32_t dsp_forward(dsp_model* m, void* stream, int64_t n, const void* kmer, int
 int32_t dsp_debug_read_activation(dsp_model* m, void* stream, int32_t which, int64_t n, float* host_out) {
     if (!m || !host_out) return fail(DSP_EINVAL, "NULL argument");
     if (!m->ws || !m->last_out) return fail(DSP_EINVAL, "no forward has run yet");
+    if (m->last_split) return fail(DSP_EINVAL, "the last forward ran in several pieces (more than 4,096 sites, not a whole number of rounds): "
+                                               "its activations are not in the scratch as one batch (DSP_FORWARD_SPLIT=0)");
     if (n < 1 || n > m->ws_sites) return fail(DSP_EINVAL, "n_sites out of range");
     const Dims& d = m->d;
     const float* src; int F; std::vector<int> map; int Fref;

@@ -15,7 +15,7 @@ from deepsignal_plant_amd.models import ModelBiLSTM
 from oracle import forward_np as onp
 
 SWITCHES = ("DSP_LSTM_CLUSTER", "DSP_LSTM_TILING", "DSP_HEAD_ST4", "DSP_TWO_STREAMS", "DSP_LSTM_LOCAL8", "DSP_LSTM_FRONT_CLUSTER",
-            "DSP_FC_FUSED", "DSP_CLUSTER_TIMEOUT", "DSP_LSTM_HANDOFF", "DSP_FC_SMALL")
+            "DSP_FC_FUSED", "DSP_CLUSTER_TIMEOUT", "DSP_LSTM_HANDOFF", "DSP_FC_SMALL", "DSP_FORWARD_SPLIT")
 MODES = [("round3", {"DSP_LSTM_CLUSTER": "0", "DSP_LSTM_LOCAL8": "0", "DSP_TWO_STREAMS": "0", "DSP_HEAD_ST4": "1", "DSP_FC_FUSED": "0", "DSP_FC_SMALL": "0"}),
          ("round4", {"DSP_LSTM_FRONT_CLUSTER": "0", "DSP_FC_SMALL": "0"}),
          ("fc_small", {"DSP_LSTM_FRONT_CLUSTER": "0"}),
