@@ -316,21 +316,27 @@ def main(argv=None):
         # proof of N GPUs: every rank names the device it ran on (PCI name and uuid from the HIP runtime, through the C ABI),
         # its host, its CPUs and its OWN wall time; with RCCL the PCI names must be pairwise distinct per host
         from deepsignal_plant_amd import _native
+        try:
+            my_uuid = _native.device_uuid(dev_index)
+        except Exception as e:   # (identity is evidence, not a reason to lose the measurement)
+            my_uuid = "unknown (%s)" % type(e).__name__
         ident = {"rank": rank, "host": socket.gethostname(), "local_rank": local_rank, "hip_device": dev_index,
-                 "pci_bdf": my_bdf, "uuid": _native.device_uuid(dev_index), "name": torch.cuda.get_device_name(dev_index),
+                 "pci_bdf": my_bdf, "uuid": my_uuid, "name": torch.cuda.get_device_name(dev_index),
                  "numa_node": dsp_dist._numa_node_cpus(my_bdf)[0],
                  "cpus": dsp_dist.cpus_text(my_cpus if my_cpus is not None else sorted(os.sched_getaffinity(0))),
                  "pinned": my_cpus is not None, "ms_per_step": round(dt_mine / max(K, 1) * 1e3, 3),
                  "visible_devices": ndev}
         devices = [None] * world
         dist.all_gather_object(devices, ident)
-        distinct = len({(d["host"], d["pci_bdf"], d["uuid"]) for d in devices}) == world
+        # a device the runtime could not name counts by its index on its host (the check must not refuse a good run)
+        key = lambda d: (d["host"], d["pci_bdf"], d["uuid"]) if d["pci_bdf"] else (d["host"], "hip device %d" % d["hip_device"])
+        distinct = len({key(d) for d in devices}) == world
         must = backend == "nccl" or os.environ.get("DSP_REQUIRE_DISTINCT_GPUS") == "1"
         if must and world > 1 and not distinct:
             if rank == 0:
                 sys.stderr.write("bench.py: %d ranks but only %d distinct GPUs: %s -- a SCALE line from this run would not "
                                  "measure %d GPUs; refusing to print one\n" % (
-                                     world, len({(d["host"], d["pci_bdf"], d["uuid"]) for d in devices}),
+                                     world, len({key(d) for d in devices}),
                                      [(d["rank"], d["pci_bdf"]) for d in devices], world))
             dist.barrier()
             dist.destroy_process_group()
@@ -428,7 +434,7 @@ def main(argv=None):
                        "backend": ("rccl" if backend == "nccl" else "gloo (ranks share %d GPU)" % ndev) if multi else "none",
                        "rank_site_ranges": ranges, "flops_per_site": flops_site,
                        **({"rccl_version": _rccl_version(torch) if backend == "nccl" else None,
-                           "distinct_gpus": len({(d["host"], d["pci_bdf"], d["uuid"]) for d in devices}),
+                           "distinct_gpus": len({((d["host"], d["pci_bdf"], d["uuid"]) if d["pci_bdf"] else (d["host"], d["hip_device"])) for d in devices}),
                            "ranks": devices} if devices else {})},
             "roofline": {"bound": "mfma", "kernel": "dsp_lstm_kernel (combined stack)" if nprod == 1 else "dsp_lstm_split_kernel<%d>" % nprod,
                          "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
