@@ -440,8 +440,8 @@ def _two_ranks(args, timeout=900, env=None):
 
 
 def _keep(name, text):
-    """evidence lines travel back from the GPU box under gpurun_out/ (copied into profiles/r4/ from there)"""
-    d = os.path.join(ROOT, "gpurun_out", "r4")
+    """evidence lines travel back from the GPU box under gpurun_out/ (copied into profiles/r5/ from there)"""
+    d = os.path.join(ROOT, "gpurun_out", "r5")
     try:
         os.makedirs(d, exist_ok=True)
         with open(os.path.join(d, name), "w") as f:
@@ -490,6 +490,12 @@ def test_forced_distributed_mode_takes_the_rccl_branches_with_one_rank(tmp_path)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 1 and d["config"]["backend"] == "rccl" and d["value"] > 0
+    # round 5: under RCCL the line names RCCL's version and, per rank, the device that ran it (identity gathered over RCCL itself)
+    c = d["config"]
+    assert c["rccl_version"] and c["rccl_version"][0].isdigit() and c["distinct_gpus"] == 1 and len(c["ranks"]) == 1
+    r0 = c["ranks"][0]
+    assert len(r0["pci_bdf"].split(":")) == 3 and len(r0["uuid"]) == 32 and r0["ms_per_step"] > 0 and r0["hip_device"] == 0
+    assert d["gather"]["sites"] == 2 * 8192
     _keep("bench_forced_dist_world1.json", json.dumps(d) + "\n")
 
 

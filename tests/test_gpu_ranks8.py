@@ -41,8 +41,8 @@ def _ranks(args, world=WORLD, timeout=1200, env=None):
     if dt > 40:                # eight ranks on a few thousand rows take 4-5 s (cold imports: 10-15): keep what a slow run says
         print("[slow 8-rank run] %.1f s: %s" % (dt, " ".join(args)))
         try:
-            os.makedirs(os.path.join(ROOT, "gpurun_out", "r4"), exist_ok=True)
-            with open(os.path.join(ROOT, "gpurun_out", "r4", "slow_8rank_runs.txt"), "a") as f:
+            os.makedirs(os.path.join(ROOT, "gpurun_out", "r5"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "r5", "slow_8rank_runs.txt"), "a") as f:
                 f.write("%.1f s: %s\n%s\n%s\n\n" % (dt, " ".join(args), r.stdout[-3000:], r.stderr[-3000:]))
         except OSError:
             pass
