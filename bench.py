@@ -264,9 +264,11 @@ def main(argv=None):
     for i in range(W):
         step(i)
     torch.cuda.synchronize()
-    # HIP events on the launch stream around the launches of the DOMINANT kernel only (the roofline object's duration is measured
-    # live, over the timed region): 4 records per forward.  The per-launch breakdown of ALL launches is taken in the untimed
-    # steps below -- until round 5 it rode on the timed steps too: 9 records, 0.03 ms per forward whatever the batch.
+    # HIP events on the launch stream around the run of the DOMINANT kernel's launches only (the roofline object's duration is
+    # measured live, over the timed region): ONE pair of records per forward, its time shared equally by the run's launches (the
+    # gaps and, on small batches, the clean-up launches between them included: conservative).  The per-launch breakdown of ALL
+    # launches is taken in the untimed steps below -- until round 5 it rode on the timed steps too: 9 records, 0.03 ms per
+    # forward whatever the batch.
     model.profile("dominant")
     if multi:
         dist.barrier()
@@ -282,7 +284,7 @@ def main(argv=None):
     prof = model.profile_read()
     model.profile(False)
     # the same steps once more WITHOUT any events (untimed by the contract; reported beside the line): an event record costs the
-    # stream ~4 us -- nothing at 65,536 sites, 2 % at 512 with the 4 records the timed steps keep
+    # stream ~4 us -- nothing at 65,536 sites, 1-2 % at 512 with the 2 records the timed steps keep
     ms_events_off = None
     prof_all = []
     if world == 1 and K > 0:
@@ -453,7 +455,7 @@ def main(argv=None):
                          "whole_forward_frac_events_off": round(B / (ms_events_off * 1e-3) * flops_site / 1e12 / FP32_MATRIX_PEAK_TFLOPS, 4)
                          if ms_events_off else None,
                          "ms_per_step_by_launch": {k: round(sum(v) / max(k_all or K, 1), 4) for k, v in per_launch.items()},
-                         "events_in_timed_steps": "the dominant kernel's launches only (4 records per forward); ms_per_step_by_launch from %s" % (
+                         "events_in_timed_steps": "one pair per forward around the dominant kernel's launches; ms_per_step_by_launch from %s" % (
                              "%d untimed steps with events around every launch" % k_all if k_all else "the timed steps"),
                          "kernel_src_sha16": kernel_source_hash(),
                          "note": ("fp32 MFMA and VALU work do not overlap on gfx950 (profiles/r2/micro_mfma_cell_overlap.txt): "

@@ -288,7 +288,7 @@ void pack_linear(const float* w, const float* b, int O, int Opad, int K, const s
     for (int o = 0; o < O; ++o) bias[o] = b[o];
 }
 
-struct ProfEntry { const char* name; hipEvent_t a, b; };
+struct ProfEntry { const char* name; hipEvent_t a, b; int share; };   // share: launches that divide the bracket's time
 
 }  // namespace
 
@@ -502,25 +502,49 @@ struct Launcher {
     bool side_by_side = false;   // the seq and signal branches of this call run on two streams
     hipEvent_t last_ev = nullptr;   // profiling: the event behind the previous launch ...
     hipStream_t last_s = nullptr;   // ... and its stream
+    hipEvent_t pending_a = nullptr, pending_b = nullptr;   // dominant-only profiling: the open bracket
+    int pending_n = 0;
+    const char* pending_name = nullptr;
+    // dominant-only mode (dsp_profile_enable(m, 2)): ONE pair of records brackets the run of consecutive dominant launches
+    // (2 records per forward).  The bracket is closed in front of the next other launch; every launch of the run gets an
+    // entry with an equal share of the bracket's time (gaps and clean-up launches between them included)
+    void close_bracket() {
+        if (!pending_b) return;
+        hipEventRecord(pending_b, s);
+        for (int i = 0; i < pending_n; ++i) m->prof_entries.push_back({pending_name, pending_a, pending_b, pending_n});
+        pending_a = pending_b = nullptr; pending_n = 0;
+    }
+    bool take_events(hipEvent_t* ea, hipEvent_t* eb) {
+        while (m->event_pool.size() < m->event_used + 2) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) { rc = fail(DSP_EHIP, "hipEventCreate failed"); return false; }
+            m->event_pool.push_back(e);
+        }
+        // consecutive launches of one stream share their boundary event (9 records per forward instead of 16: an event
+        // record costs the stream ~4 us, 0.06 ms per forward -- 9 % of a 512-site one)
+        if (last_ev && last_s == s) *ea = last_ev;
+        else { *ea = m->event_pool[m->event_used++]; hipEventRecord(*ea, s); }
+        *eb = m->event_pool[m->event_used++];
+        return true;
+    }
     template <class F> void run(const char* name, F&& f) {
         if (rc) return;
+        const bool dominant = !strcmp(name, "lstm_comb");
+        const bool bracket = m->prof && m->prof_dominant_only && dominant;
+        const bool timed = m->prof && !m->prof_dominant_only;
+        if (!bracket) close_bracket();
         hipEvent_t ea = nullptr, eb = nullptr;
-        const bool timed = m->prof && (!m->prof_dominant_only || !strcmp(name, "lstm_comb"));
-        if (timed) {
-            while (m->event_pool.size() < m->event_used + 2) {
-                hipEvent_t e;
-                if (hipEventCreate(&e) != hipSuccess) { rc = fail(DSP_EHIP, "hipEventCreate failed"); return; }
-                m->event_pool.push_back(e);
-            }
-            // consecutive launches of one stream share their boundary event (9 records per forward instead of 16: an event
-            // record costs the stream ~4 us, 0.06 ms per forward -- 9 % of a 512-site one)
-            if (last_ev && last_s == s) ea = last_ev;
-            else { ea = m->event_pool[m->event_used++]; hipEventRecord(ea, s); }
-            eb = m->event_pool[m->event_used++];
+        if (bracket && !pending_b) {
+            last_ev = nullptr;
+            if (!take_events(&pending_a, &pending_b)) return;
+            pending_name = name;
+        } else if (timed) {
+            if (!take_events(&ea, &eb)) return;
         }
         const int e = f();
         if (e != 0) { rc = fail(DSP_EHIP, "launch %s failed: %s", name, hipGetErrorString((hipError_t)e)); return; }
-        if (timed) { hipEventRecord(eb, s); m->prof_entries.push_back({name, ea, eb}); last_ev = eb; last_s = s; }
+        if (bracket) ++pending_n;
+        else if (timed) { hipEventRecord(eb, s); m->prof_entries.push_back({name, ea, eb, 1}); last_ev = eb; last_s = s; }
         else last_ev = nullptr;
         if (m->sync_each) {  // DSP_SYNC_EACH (read once, in dsp_model_create): attribute an asynchronous GPU fault to its launch
             fprintf(stderr, "[launch] %s ...", name);
@@ -1055,6 +1079,7 @@ static int32_t forward_chunk(dsp_model* m, void* stream, int64_t n, const void* 
     h.logits = logits; h.probs = probs; h.labels = labels; h.n = n; h.Hp = m->Hp; h.T = d.T; h.C = d.C;
     h.flags = m->head_st4 ? 1 : 0;
     L.run("head", [&] { return dsp_k_head(&h, s); });
+    L.close_bracket();
 
     if (prev != m->device) hipSetDevice(prev);
     return L.rc;
@@ -1105,7 +1130,7 @@ int32_t dsp_profile_read(dsp_model* m, char* names, size_t names_cap, float* ms,
         float t = 0.f;
         hipError_t err = hipEventElapsedTime(&t, e.a, e.b);
         if (err != hipSuccess) return fail(DSP_EHIP, "hipEventElapsedTime: %s (synchronise the stream first)", hipGetErrorString(err));
-        ms[k] = t;
+        ms[k] = t / (float)(e.share > 0 ? e.share : 1);
         const size_t len = strlen(e.name) + 1;
         if (names && pos + len <= names_cap) { memcpy(names + pos, e.name, len); pos += len; }
         ++k;

@@ -146,9 +146,10 @@ int32_t dsp_debug_read_activation(dsp_model* m, void* stream, int32_t which, int
  * line).  While enabled, every launch of every dsp_forward is bracketed by two events (consecutive launches of
  * one stream share the event between them: a launch's time then includes the gap before it; an event record costs
  * the stream a few microseconds -- ~0.03 ms per forward); entries accumulate until dsp_profile_read() drains them
- * (call it after synchronising the stream).  on = 2: only the launches of the DOMINANT kernel (the combined stack,
- * "lstm_comb") are bracketed -- what bench.py keeps on through its timed steps, 4 event records per forward instead of 9
- * (round 5: at 512 sites the full set cost 5 % of the forward it timed).
+ * (call it after synchronising the stream).  on = 2: ONE pair of records per forward brackets the run of consecutive launches of
+ * the DOMINANT kernel (the combined stack, "lstm_comb") -- what bench.py keeps on through its timed steps, 2 event records per
+ * forward instead of 9 (round 5: at 512 sites the full set cost 5 % of the forward it timed); every launch of the run is
+ * reported with an equal share of the bracket's time, the gaps and clean-up launches between them included.
  * names: NUL-separated list written into `names`; ms[i] per launch. Returns the launch count. */
 int32_t dsp_profile_enable(dsp_model* m, int32_t on);
 int32_t dsp_profile_read(dsp_model* m, char* names, size_t names_cap, float* ms, int32_t cap);
