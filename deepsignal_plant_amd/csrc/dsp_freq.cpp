@@ -164,10 +164,22 @@ bool parse_double(const char* p, const char* e, double* out) {
         }
     }
     char tmp[96];
-    const size_t n = (size_t)(e - p);
+    size_t n = (size_t)(e - p);
     if (n == 0 || n >= sizeof(tmp)) return false;
     memcpy(tmp, p, n);
     tmp[n] = 0;
+    if (memchr(tmp, '_', n)) {   // Python's float() (ModRecord, utils/txt_formater.py:8-21): one underscore between two digits
+        size_t k = 0;
+        for (size_t i = 0; i < n; ++i) {
+            if (tmp[i] == '_') {
+                if (i == 0 || i + 1 >= n || tmp[i - 1] < '0' || tmp[i - 1] > '9' || tmp[i + 1] < '0' || tmp[i + 1] > '9') return false;
+                continue;
+            }
+            tmp[k++] = tmp[i];
+        }
+        n = k;
+        tmp[n] = 0;
+    }
     if (memchr(tmp, 'x', n) || memchr(tmp, 'X', n)) return false;  // strtod takes hex floats, Python's float() does not
     char* endp = nullptr;
     *out = strtod(tmp, &endp);
