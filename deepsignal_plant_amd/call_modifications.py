@@ -538,6 +538,15 @@ def _call_mods_reads(args, rank, local_rank, world):
     free_ring = queue.Queue()
     for i in range(len(ring)):
         free_ring.put(i)
+    slot_canary = canary.on()   # DSP_SLOT_CANARY=1 (canary.py): poisoned when handed back, verified when taken
+
+    def slot_arrays(sl):
+        return [sl[k].numpy() for k in ("probs", "labels", "kmer") if k in sl]
+
+    def hand_back(i_):
+        if slot_canary:
+            canary.poison(slot_arrays(ring[i_]))
+        free_ring.put(i_)
     fwd_chunk = 65536
     model.reserve(fwd_chunk)
     row_base = rank << 44  # row numbers for the output order only (rank-major = file order); the initial states of a
@@ -566,6 +575,8 @@ def _call_mods_reads(args, rank, local_rank, world):
             continue
         slot = ring[si]
         k += 1
+        if slot_canary and slot["cap"]:
+            canary.expect_poisoned(slot_arrays(slot), "reads branch takes result slot %d for batch %d" % (si, k))
         if slot["cap"] < n:
             cap = n + n // 4
             slot.update(cap=cap, probs=torch.empty((cap, args.class_num), dtype=torch.float32, pin_memory=True),
@@ -586,7 +597,7 @@ def _call_mods_reads(args, rank, local_rank, world):
         blk = _ReadsBlock()
         blk.rows = ext.rows
         blk.first_row = row_base + n_rows
-        writer.q.put((blk, h_probs, h_labels, ev, lambda i_=si: free_ring.put(i_)))
+        writer.q.put((blk, h_probs, h_labels, ev, lambda i_=si: hand_back(i_)))
         n_rows += n
     _tick("last forward issued")
     writer.q.put(None)

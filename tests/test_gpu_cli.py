@@ -283,7 +283,9 @@ def test_cli_directory_of_reads_extracts_on_the_gpu_and_calls(tmp_path):
     outs = []
     for i, bs in enumerate(("1", "30")):
         o = str(tmp_path / ("randn%d.tsv" % i))
-        r = _run_cli(["-i", str(d), "-m", ck, "-o", o, "--seed", "4", "--reference_path", str(fa), "--f5_batch_size", bs])
+        # (the first of the two under DSP_SLOT_CANARY=1: the reads branch's result ring is poisoned / verified too, canary.py)
+        r = _run_cli(["-i", str(d), "-m", ck, "-o", o, "--seed", "4", "--reference_path", str(fa), "--f5_batch_size", bs],
+                     env={"DSP_SLOT_CANARY": "1"} if i == 0 else None)
         assert r.returncode == 0, r.stderr[-3000:]
         outs.append(open(o, "rb").read())
     assert outs[0] == outs[1] and outs[0] != got
