@@ -588,17 +588,20 @@ int cluster_size(const dsp_model* m, long long NTp) {
 // resident at once, one per CU.  Round 5: 512 sites 0.122 / 0.131 -> ~0.05 ms per front-end launch.  DSP_LSTM_FRONT_CLUSTER=0
 // turns it off (A/B switch), =1 / 2 forces that many gates per wave where it fits.
 int front_cluster_gates(const dsp_model* m, const LstmArgs& a, long long NTp, int branches) {
-    if (m->cluster == 0 || m->front_cluster == 0 || a.UT != 4 || a.NP > 1 || (a.Ipad >> 3) != 4 || a.NQ != ((a.Ipad + a.Hp) >> 3) ||
-        a.NQ % 4 || a.NQ < 8 || NTp * 2 * 32 > kClusterWordsPerLaunch)
+    // (4 unit tiles: the front ends of both_bilstm at hidden 128; 8: the seq front end of a seq-only model at hidden 193..256,
+    // BASELINE configs[2]'s shape -- clusters of 8 / 4 workgroups)
+    if (m->cluster == 0 || m->front_cluster == 0 || (a.UT != 4 && a.UT != 8) || a.NP > 1 || (a.Ipad >> 3) != 4 ||
+        a.NQ != ((a.Ipad + a.Hp) >> 3) || a.NQ % 4 || a.NQ < 8 || NTp * 2 * 32 > kClusterWordsPerLaunch)
         return 0;
     const long long slots = (long long)m->n_cus / std::max(1, branches);
     int P = 1;
-    while (P < 4 && NTp * 2 * (P * 2) <= slots) P *= 2;
+    while (P < a.UT && NTp * 2 * (P * 2) <= slots) P *= 2;
     if (m->front_cluster > 0) {
-        const int want = m->front_cluster == 1 ? 4 : (m->front_cluster == 2 ? 2 : 0);
+        const int want = m->front_cluster == 1 ? a.UT : (m->front_cluster == 2 ? a.UT / 2 : 0);
         P = (want && NTp * 2 * want <= slots) ? want : 1;
     }
-    return P >= 2 ? 4 / P : 0;
+    const int G = P >= 2 ? a.UT / P : 0;
+    return (G == 1 || G == 2) ? G : 0;   // (the clustered front-end form exists for 1 and 2 gates per wave)
 }
 int pick_cluster(const dsp_model* m, const LstmArgs& a, long long NTp, bool split, int branches) {
     if (!split) {

@@ -1782,7 +1782,8 @@ extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
         const bool local8 = G == 4 && a->UT == 8 && (a->flags & 8);   // eight waves hold the whole layer of 8 unit tiles
         const bool local = (G == 4 && a->UT == 4) || local8;
         // a front end (4 unit tiles, an x part of exactly four k-groups) spread over 4 / G workgroups: rings four deep
-        const bool xshort = !local && a->UT == 4 && nqx == 4 && (G == 1 || G == 2);
+        const bool xshort = !local && (a->UT == 4 || a->UT == 8) && nqx == 4 && (G == 1 || G == 2);   // (8 unit tiles: the seq front end of
+        // a seq-only model at hidden 193..256 -- BASELINE configs[2]'s shape)
         const int D = xshort ? 4 : (G == 4 ? 4 : (G == 2 ? 8 : 16));
         if ((G != 1 && G != 2 && G != 4) || a->UT % G || a->NP > 1 || (!local && !a->cflags) || a->NQ != ((a->Ipad + a->Hp) >> 3) ||
             nqx % D || nqx < ((local || xshort) ? D : 2 * D) || a->NQ % D || a->NQ < 2 * D || (!local && !xshort && a->UT != 8))
