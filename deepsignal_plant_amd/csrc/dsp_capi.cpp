@@ -614,8 +614,15 @@ int pick_cluster(const dsp_model* m, const LstmArgs& a, long long NTp, bool spli
     // is the slower one -- 1.99 / 2.08 ms against 1.82 / 1.93 ms of dsp_lstm_kernel<2, 1, XL> per front-end launch of 65,536
     // sites, same-box A/B in round 4: a weight fragment feeds 4 MFMAs instead of 8.)
     if (m->cluster != 0 && !split && a.UT == 4 && a.NP <= 1 && NTp * 2 <= (long long)m->n_cus &&
-        a.NQ == ((a.Ipad + a.Hp) >> 3) && (a.Ipad >> 3) % 4 == 0 && (a.Ipad >> 3) >= 4 && a.NQ % 4 == 0 && a.NQ >= 8)
+        a.NQ == ((a.Ipad + a.Hp) >> 3) && (a.Ipad >> 3) % 4 == 0 && (a.Ipad >> 3) >= 4 && a.NQ % 4 == 0 && a.NQ >= 8) {
+        // dense layers of 4 unit tiles (the combined stack of a hid_rnn-128 model: hidden 97..128) of batches that leave CUs
+        // idle: clustered like those of 8 unit tiles, 4 / 2 workgroups per (site tile, direction) (round 5)
+        const int P8 = cluster_size(m, NTp);
+        if (P8 >= 2 && m->front_cluster != 0 && a.nqx_lo == 0 && a.nqx_used == (a.Ipad >> 3) && (a.Ipad >> 3) >= 8 &&
+            NTp * 2 * 32 <= kClusterWordsPerLaunch)
+            return P8 >= 4 ? 1 : 2;
         return 4;
+    }
     const int P = cluster_size(m, NTp);
     if (!P && m->local8 && !split && a.UT == 8 && a.NP <= 1 && NTp * 2 <= (long long)m->n_cus && a.nqx_lo == 0 &&
         a.nqx_used == (a.Ipad >> 3) && a.NQ == ((a.Ipad + a.Hp) >> 3) && (a.Ipad >> 3) % 4 == 0 && a.NQ % 4 == 0)

@@ -1002,7 +1002,7 @@ __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, co
     // depth (profiles/r5/handoff_ab.txt): 3 / 2 / 1 as here 0.5697 / 0.9767 / 1.7729 ms per forward of 512 / 1,024 / 2,048 sites;
     // 1 / 1 / 1: 0.5726 / 0.9792 / 1.7716; 6 / 3 / 2: +8 / +6 / +5 us; 10 / 5 / 2: +17 / +10 / +3 us (the burst of refills
     // behind the drain is issued with no MFMA in flight); round 4's hand-off 0.5716 / 0.9943 / 1.7962
-    constexpr int E = G == 1 ? 3 : (G == 2 ? 2 : 1);
+    constexpr int E = D == 4 ? 1 : (G == 1 ? 3 : 2);   // (rings four deep -- 4 unit tiles, or G = 4 -- spare one stage)
     auto arrive = [&]() __attribute__((always_inline)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1755,7 +1755,8 @@ extern "C" int dsp_k_init(void) {
                          (const void*)dsp_lstmc_kernel<4, 4, true, 3>, (const void*)dsp_lstmc_kernel<4, 4, true, 0, 8>,
                          (const void*)dsp_lstmc_kernel<1, 4, false, 0, 4, true>, (const void*)dsp_lstmc_kernel<1, 4, false, 2, 4, true>,
                          (const void*)dsp_lstmc_kernel<1, 4, false, 3, 4, true>, (const void*)dsp_lstmc_kernel<2, 4, false, 0, 4, true>,
-                         (const void*)dsp_lstmc_kernel<2, 4, false, 2, 4, true>, (const void*)dsp_lstmc_kernel<2, 4, false, 3, 4, true>};
+                         (const void*)dsp_lstmc_kernel<2, 4, false, 2, 4, true>, (const void*)dsp_lstmc_kernel<2, 4, false, 3, 4, true>,
+                         (const void*)dsp_lstmc_kernel<1, 4>, (const void*)dsp_lstmc_kernel<2, 4>};
     for (const void* f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
@@ -1784,9 +1785,12 @@ extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
         // a front end (4 unit tiles, an x part of exactly four k-groups) spread over 4 / G workgroups: rings four deep
         const bool xshort = !local && (a->UT == 4 || a->UT == 8) && nqx == 4 && (G == 1 || G == 2);   // (8 unit tiles: the seq front end of
         // a seq-only model at hidden 193..256 -- BASELINE configs[2]'s shape)
-        const int D = xshort ? 4 : (G == 4 ? 4 : (G == 2 ? 8 : 16));
+        // dense layers of 4 unit tiles (hidden 97..128: the combined stack of a hid_rnn-128 model) clustered like those of 8:
+        // P = 4 / G workgroups, rings four deep
+        const bool dense4 = !local && !xshort && a->UT == 4 && (G == 1 || G == 2);
+        const int D = (xshort || dense4) ? 4 : (G == 4 ? 4 : (G == 2 ? 8 : 16));
         if ((G != 1 && G != 2 && G != 4) || a->UT % G || a->NP > 1 || (!local && !a->cflags) || a->NQ != ((a->Ipad + a->Hp) >> 3) ||
-            nqx % D || nqx < ((local || xshort) ? D : 2 * D) || a->NQ % D || a->NQ < 2 * D || (!local && !xshort && a->UT != 8))
+            nqx % D || nqx < ((local || xshort) ? D : 2 * D) || a->NQ % D || a->NQ < 2 * D || (!local && !xshort && !dense4 && a->UT != 8))
             return (int)hipErrorInvalidValue;
         // (zero-padded x-part k-groups -- nqx_lo, nqx_used -- are computed like live ones here: their weights are zero)
         const int P = local ? 1 : a->UT / G;
@@ -1806,6 +1810,8 @@ extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
         else if (xshort && dead == 3) hipLaunchKernelGGL((dsp_lstmc_kernel<2, 4, false, 3, 4, true>), dim3(grid), dim3(256), lds, s, *a);
         else if (xshort && dead == 2) hipLaunchKernelGGL((dsp_lstmc_kernel<2, 4, false, 2, 4, true>), dim3(grid), dim3(256), lds, s, *a);
         else if (xshort) hipLaunchKernelGGL((dsp_lstmc_kernel<2, 4, false, 0, 4, true>), dim3(grid), dim3(256), lds, s, *a);
+        else if (dense4 && G == 1) hipLaunchKernelGGL((dsp_lstmc_kernel<1, 4>), dim3(grid), dim3(256), lds, s, *a);
+        else if (dense4) hipLaunchKernelGGL((dsp_lstmc_kernel<2, 4>), dim3(grid), dim3(256), lds, s, *a);
         else if (G == 4) hipLaunchKernelGGL((dsp_lstmc_kernel<4, 4>), dim3(grid), dim3(256), lds, s, *a);
         else if (G == 2) hipLaunchKernelGGL((dsp_lstmc_kernel<2, 8>), dim3(grid), dim3(256), lds, s, *a);
         else hipLaunchKernelGGL((dsp_lstmc_kernel<1, 16>), dim3(grid), dim3(256), lds, s, *a);
