@@ -267,3 +267,50 @@ def test_forward_captures_into_a_hip_graph_and_replays_the_same_bits(n):
         g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, eager[1])
+
+
+def test_small_batches_really_take_the_clustered_forms(tmp_path):
+    """The small-batch forms are chosen silently (a handle whose XCC probe fails, a shape a form does not take: the launch
+    falls back to a slower kernel with the same bits) -- round 5's first probe switched clustering off for every handle but a
+    process's first and every bit-identity test still passed.  So: what DSP_DEBUG_LSTM prints for three model shapes at 512
+    sites, in a fresh process -- gates per wave of every LSTM launch (CG: 1 = a cluster of UT workgroups; 4 = one workgroup)."""
+    import os
+    import subprocess
+    import sys
+    from tests.helpers import ROOT
+    script = tmp_path / "shapes.py"
+    script.write_text('''
+import sys
+sys.path.insert(0, %r)
+import torch
+from deepsignal_plant_amd import synth
+from deepsignal_plant_amd.models import ModelBiLSTM
+for kw in (dict(), dict(module="seq_bilstm", num_layers1=2), dict(hidden_size=128), dict(module="signal_bilstm", num_layers1=1)):
+    for rep in range(2):   # a process's SECOND handle of a shape too
+        m = ModelBiLSTM(init_state="randn", seed=3, **kw)
+        m.load_state_dict(synth.random_state_dict(m, seed=5)); m.cuda(0)
+        assert m.query("clustering") == 1 and m.query("xcc_probe_failed") == 0
+        sys.stderr.write("== %%s %%d\\n" %% (sorted(kw.items()), rep)); sys.stderr.flush()
+        m(*synth.feature_batch(512, device="cuda:0", seed=9)); torch.cuda.synchronize()
+''' % ROOT)
+    env = dict(os.environ, DSP_DEBUG_LSTM="1")
+    for k in ("DSP_LSTM_CLUSTER", "DSP_LSTM_FRONT_CLUSTER", "DSP_TWO_STREAMS", "DSP_LSTM_TILING"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    runs, cur = {}, None
+    for line in r.stderr.splitlines():
+        if line.startswith("== "):
+            cur = line[3:]
+            runs[cur] = []
+        elif line.startswith("[lstm] ") and " CG=" in line and cur is not None:
+            w = line.split()
+            runs[cur].append((w[1], int([x for x in w if x.startswith("CG=")][0][3:]), int([x for x in w if x.startswith("UT=")][0][3:])))
+    assert len(runs) == 8, list(runs)
+    for name, launches in runs.items():
+        assert launches, name
+        for lstm, cg, ut in launches:
+            if ut in (4, 8):   # every layer of 4 or 8 unit tiles of these shapes has a clustered form at 512 sites
+                assert cg == 1, (name, launches)
+    default = [v for k, v in runs.items() if k.startswith("[] ")][0]
+    assert [x[0] for x in default] == ["lstm_seq", "lstm_signal", "lstm_comb", "lstm_comb", "lstm_comb"] and all(x[1] == 1 for x in default)

@@ -1,10 +1,10 @@
-import os, sys
+import sys, os
 sys.path.insert(0, "/root/repo")
-os.environ["DSP_DEBUG_LSTM"] = "1"
+os.environ["DSP_DEBUG_LSTM"]="1"
 import torch
 from deepsignal_plant_amd import synth
 from deepsignal_plant_amd.models import ModelBiLSTM
 m = ModelBiLSTM(init_state="randn", seed=3)
 m.load_state_dict(synth.random_state_dict(m, seed=5)); m.cuda(0)
-ins = synth.feature_batch(512, device="cuda:0", seed=9)
-m(*ins); torch.cuda.synchronize()
+sys.stderr.write("== default\n"); sys.stderr.flush()
+m(*synth.feature_batch(512, device="cuda:0", seed=9)); torch.cuda.synchronize()
