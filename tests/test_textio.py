@@ -101,6 +101,32 @@ def test_underscores_in_numbers_follow_pythons_float_and_int():
         else:
             got = textio.parse_rows(text, 13, 16).means[0][4]
             assert got == want, (tok, got, want)
+    # ... and 600 random spellings with underscores dropped in anywhere: accepted <=> float() accepts, same float32
+    rng = np.random.default_rng(12)
+    bases = ["%.*g" % (int(rng.integers(1, 12)), x) for x in rng.standard_normal(600) * 10.0 ** rng.integers(-6, 6, 600)]
+    agree_ok = agree_bad = 0
+    for tok in bases:
+        chars = list(tok)
+        for _ in range(int(rng.integers(1, 3))):
+            chars.insert(int(rng.integers(0, len(chars) + 1)), "_")
+        tok = "".join(chars)
+        try:
+            want = np.float32(float(tok))
+        except ValueError:
+            want = None
+        r = list(row)
+        means = r[7].split(",")
+        means[7] = tok
+        r[7] = ",".join(means)
+        text = ("\t".join(r) + "\n").encode()
+        if want is None:
+            with pytest.raises(ValueError):
+                textio.parse_rows(text, 13, 16)
+            agree_bad += 1
+        else:
+            assert textio.parse_rows(text, 13, 16).means[0][7] == want, tok
+            agree_ok += 1
+    assert agree_ok > 100 and agree_bad > 100, (agree_ok, agree_bad)
     for tok in ["1_0", "2_5", "0_7", "1_0_0", "_5", "5_", "1__0", "-_3", "+1_2", "1_2.0", "1e2"]:
         try:
             want = int(tok)
