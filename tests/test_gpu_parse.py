@@ -199,6 +199,11 @@ def test_cli_gives_the_same_bytes_whichever_side_parses(tmp_path):
     w[7] = b"+" + w[7]                                   # '+0.123...' : legal for float(), not plain
     w[8] = w[8].replace(b",", b",0000000000000000000", 1)  # a 20+ digit mantissa
     lines[700] = b" " + b"\t".join(w)                     # leading blank (line.strip())
+    w = lines[333].split(b"\t")
+    m = w[7].split(b",")
+    m[2] = b"-1_0.2_5"                                    # Python's float(): one underscore between two digits (round 5)
+    w[7] = b",".join(m)
+    lines[333] = b"\t".join(w)
     data = b"\n".join(lines)
     plain = str(tmp_path / "rows.tsv")
     open(plain, "wb").write(data)
