@@ -946,32 +946,75 @@ static int32_t forward_chunk(dsp_model* m, void* stream, int64_t n, const void* 
                              const dsp_init_state* init, float* logits, float* probs, uint8_t* labels);
 
 // Sites are independent and the in-kernel initial states are keyed by the site's global index, so a call may be cut anywhere
-// without changing a bit.  Round 5: the 64-site workgroups of batches above 4,096 sites fill the chip in rounds of 8,192 sites
-// (one workgroup per CU; two per CU share its matrix pipe and gain nothing), so 10,000 sites cost two rounds = 13.3 ms -- while
-// the small-batch forms run a remainder of <= 4,096 sites in 0.6-3.4 ms.  A call whose size is not a whole number of rounds
-// runs its whole rounds first and its remainder on the small-batch forms (10,000 sites: 8.4 ms; 5,000: 4.4 instead of 6.6).
+// without changing a bit.  Round 5: what a forward costs is a STEP function of its size -- the 64-site workgroups of batches
+// above 4,096 sites fill the chip in rounds of 8,192 sites (one workgroup per CU; two per CU share its matrix pipe and gain
+// nothing: 10,000 sites cost two rounds = 13.3 ms), and below that the small-batch forms come in classes of 512 / 1,024 /
+// 2,048 / 4,096 sites (clusters of 8 / 4 / 2 CUs, one workgroup per CU) costing 0.57 / 0.98 / 1.77 / 3.38 ms whatever the
+// size inside the class.  A call runs its whole rounds first and its remainder as the cheapest sequence of small-batch pieces
+// (a 16-entry table below: e.g. 1,100 sites = 1,024 + 76 -> 1.55 instead of 1.77 ms, 3,000 = 2,048 + 952 -> 2.75 instead of
+// 3.38, 5,000 = 4,096 + 904 -> 4.4 instead of 6.65, 10,000 = 8,192 + 1,808 -> 8.4 instead of 13.3).
 // Not with explicit initial states (their layout has the site index in the middle dimension) and not in the split-precision
 // modes (their kernels have no small-batch forms).  DSP_FORWARD_SPLIT=0 turns it off (A/B switch).
+namespace {
+// pieces (in units of 512 sites: 1, 2, 4, 8 = the small-batch classes; 16 = one round of the 64-site workgroups) that cover u
+// units at the least cost; costs in microseconds of one forward of the default model on MI355X (profiles/r5/batch_sweep.txt,
+// small_batch_ab_final.txt) -- only their ratios matter, and those are set by the cluster sizes
+struct PiecePlan { int n; int units[6]; };
+PiecePlan plan_pieces(int u) {
+    static const int cap[5] = {1, 2, 4, 8, 16};
+    static const int cost[5] = {610, 1020, 1810, 3420, 6650};   // (+40 us per small piece: a cut must pay for itself clearly)
+    int best[17], pick[17];
+    best[0] = 0; pick[0] = -1;
+    for (int k = 1; k <= 16; ++k) {
+        best[k] = 1 << 30;
+        for (int p = 0; p < 5; ++p) {
+            const int rest = k > cap[p] ? k - cap[p] : 0;
+            const int c = cost[p] + best[rest];
+            if (c < best[k]) { best[k] = c; pick[k] = p; }
+        }
+    }
+    PiecePlan pl{0, {0, 0, 0, 0, 0, 0}};
+    for (int k = u; k > 0 && pl.n < 6;) {
+        pl.units[pl.n++] = cap[pick[k]];
+        k = k > cap[pick[k]] ? k - cap[pick[k]] : 0;
+    }
+    std::sort(pl.units, pl.units + pl.n, [](int x, int y) { return x > y; });   // largest first: the partial piece is the smallest
+    return pl;
+}
+}  // namespace
+
 int32_t dsp_forward(dsp_model* m, void* stream, int64_t n, const void* kmer, int32_t kmer_dtype, const float* means,
                     const float* stds, const void* lens, int32_t lens_dtype, const float* signals,
                     const dsp_init_state* init, float* logits, float* probs, uint8_t* labels) {
     if (!m) return fail(DSP_EINVAL, "model is NULL");
     if (n < 0) return fail(DSP_EINVAL, "n_sites < 0");
     const int mode = init ? init->mode : DSP_INIT_ZEROS;
-    const int64_t kRound = 8192, kSmall = 4096;
-    const int64_t r = n % kRound;
-    // the remainder pays when it fits the small-batch forms: <= 4,096 sites in one piece, <= 6,144 as 4,096 + the rest
-    // (two pieces of up to 4,096 cost what the round costs)
-    const bool cut = m->forward_split && n > kSmall && r != 0 && r <= kSmall + kSmall / 2 && mode != DSP_INIT_EXPLICIT &&
+    const int64_t kRound = 8192, kUnit = 512;
+    const int64_t whole = n / kRound * kRound, r = n - whole;
+    PiecePlan pl{0, {0, 0, 0, 0, 0, 0}};
+    if (r > 0) pl = plan_pieces((int)((r + kUnit - 1) / kUnit));
+    const bool tail_is_a_round = pl.n == 1 && pl.units[0] == 16;
+    const bool cut = m->forward_split && (whole > 0 ? (r > 0 && !tail_is_a_round) : pl.n > 1) && mode != DSP_INIT_EXPLICIT &&
                      m->precision == DSP_PREC_FP32 && m->cluster != 0 && kmer_dtype >= 0 && kmer_dtype <= 3 && lens_dtype >= 0 &&
                      lens_dtype <= 3;
     m->last_split = cut;
     if (!cut) return forward_chunk(m, stream, n, kmer, kmer_dtype, means, stds, lens, lens_dtype, signals, init, logits, probs, labels);
     static const size_t dt_size[4] = {4, 1, 2, 4};   // DSP_DT_F32, U8, U16, I32
     const Dims& d = m->d;
-    int64_t pieces[3] = {n - r, r <= kSmall ? r : kSmall, r <= kSmall ? 0 : r - kSmall};
+    int64_t pieces[8];
+    int np = 0;
+    if (whole > 0) pieces[np++] = whole;
+    {
+        int64_t left = r;
+        for (int i = 0; i < pl.n && left > 0; ++i) {
+            const int64_t len = (i + 1 == pl.n) ? left : std::min<int64_t>(left, (int64_t)pl.units[i] * kUnit);
+            pieces[np++] = len;
+            left -= len;
+        }
+    }
     int64_t at = 0;
-    for (int64_t len : pieces) {
+    for (int i = 0; i < np; ++i) {
+        const int64_t len = pieces[i];
         if (len <= 0) continue;
         dsp_init_state st{};
         if (init) {

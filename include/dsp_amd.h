@@ -124,8 +124,8 @@ size_t dsp_workspace_bytes(const dsp_model* m, int64_t max_sites);
  * never stored in the handle: batches of up to 4,096 sites (on 256 CUs) run the combined stack with 32-site workgroups,
  * one per CU -- 3.7 ms per forward instead of the 6.6 ms of one round of 64-site workgroups, the same bytes out
  * (DSP_LSTM_TILING=0 / =21 force either tiling); the rate is flat from 16,384 sites on (INTEGRATION.md "Batch size").
- * A call above 4,096 sites that is not a whole number of 8,192-site rounds is run as its whole rounds + a remainder on the
- * small-batch forms (round 5: 9,000 sites 13.8 -> 7.7 ms, the same bytes out; not with DSP_INIT_EXPLICIT states, whose layout
+ * A call is run as its whole 8,192-site rounds + its remainder as the cheapest sequence of small-batch pieces (classes of 512 /
+ * 1,024 / 2,048 / 4,096 sites; round 5: 3,000 sites 3.3 -> 2.75 ms, 9,000 sites 13.8 -> 7.7 ms, the same bytes out; not with DSP_INIT_EXPLICIT states, whose layout
  * has the site index in the middle dimension, nor in the split-precision modes; DSP_FORWARD_SPLIT=0 turns it off);
  * dsp_debug_read_activation refuses after such a call (the scratch holds its last piece only).
  * hidden_size <= 2048 is the one model-shape limit of this build (one workgroup of 8 waves

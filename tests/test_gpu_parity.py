@@ -526,7 +526,7 @@ def test_small_batch_kernels_do_not_change_a_bit(kw, label, monkeypatch):
     from oracle import forward_np as onp
     cfg = onp.OracleConfig(**kw)
     w = onp.make_weights(cfg, 92, 2.0)
-    sizes = (1, 31, 512, 513, 1024, 1025, 2048, 2049, 3000, 4096, 4097, 9001, 14000)   # (14,000 = 8,192 + 4,096 + 1,712)
+    sizes = (1, 31, 512, 513, 1024, 1025, 1400, 2048, 2049, 3000, 4096, 4097, 5700, 9001, 14000)   # (pieces: 1,025 = 1,024 + 1; 3,000 = 2,048 + 952; 5,700 = 4,096 + 1,024 + 580; 14,000 = 8,192 + 4,096 + 1,712)
     ins = {n: synth.feature_batch(n, device="cuda:0", seed=500 + n) for n in sizes}
     n_x = 700
     states = {k: torch.from_numpy(v).cuda(0) for k, v in onp.make_init_states(cfg, n_x, 9).items()}
@@ -539,8 +539,8 @@ def test_small_batch_kernels_do_not_change_a_bit(kw, label, monkeypatch):
              # (auto) -- against round 4's drain + workgroup barrier + one arrival per workgroup, at every cluster size
              "round4_handoff": {"DSP_LSTM_HANDOFF": "0"},
              "round4_handoff_G2_front_G2": {"DSP_LSTM_HANDOFF": "0", "DSP_LSTM_CLUSTER": "2", "DSP_LSTM_FRONT_CLUSTER": "2"},
-             # round 5: a call above 4,096 sites that is not a whole number of 8,192-site rounds runs its rounds, then its remainder
-             # on the small-batch forms (4,097 = 4,096 + 1; 9,001 = 8,192 + 809) -- off
+             # round 5: a call runs its whole 8,192-site rounds, then its remainder as the cheapest sequence of small-batch pieces
+             # (4,097 = 4,096 + 1; 9,001 = 8,192 + 809; 3,000 = 2,048 + 952) -- off
              "one_piece": {"DSP_FORWARD_SPLIT": "0"},
              "round4_fc_kernel": {"DSP_FC_SMALL": "0"},   # (auto, round 5: one accumulator tile per wave in the fc projections)
              "fc_small_one_stream": {"DSP_TWO_STREAMS": "0"},   # ... and in the shared fc_seq+fc_signal launch
