@@ -5,7 +5,7 @@
 out=${1:-gpurun_out/batch_sweep.jsonl}
 mkdir -p "$(dirname "$out")"
 : > "$out"
-for b in 64 512 1024 2048 4096 5000 8192 10000 16384 32768 65536 66000 131072 262144; do
+for b in 64 512 1024 1100 2048 3000 4096 5000 8192 10000 16384 32768 65536 66000 131072 262144; do
     steps=$(( 6000000 / b )); [ $steps -gt 2000 ] && steps=2000; [ $steps -lt 20 ] && steps=20
     python bench.py --batch $b --steps $steps --warmup 5 --no_cpu_baseline --no_alt | tail -1 >> "$out"
 done
