@@ -314,6 +314,8 @@ struct dsp_model {
                              // batches whose 32-site tiles x 2 directions fit the CUs at once (small-batch latency); DSP_LSTM_TILING=21
                              // always, =0 never (A/B switch)
     bool wave_handoff = true;   // per-wave, deferred arrivals in the clustered launches (round 5); DSP_LSTM_HANDOFF=0: round 4's (A/B switch)
+    bool small_classes = false; // the combined stack has the clustered small-batch forms (8 or 4 unit tiles, dense): batches <= 4,096 sites
+                                // then cost by class (512 / 1,024 / 2,048 / 4,096) and dsp_forward plans a remainder's pieces by them
     bool forward_split = true;  // dsp_forward cuts a call into whole rounds of 8,192 sites + a small-batch remainder (round 5); DSP_FORWARD_SPLIT=0 (A/B switch)
     bool fc_small = true;    // dsp_linear1_kernel for batches <= 4,096 sites (A/B switch DSP_FC_SMALL=0)
     bool fc_fused = true;    // fc_seq + fc_signal in one launch when they have one shape (A/B switch DSP_FC_FUSED=0)
@@ -861,6 +863,7 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
     m->xoff_seq = d.hseq ? front_end_offset(d.Iseq, m->Fseq, pad_hidden(d.hseq)) : 0;
     m->xoff_sig = d.hsig ? front_end_offset(d.S, m->Fsig, pad_hidden(d.hsig)) : 0;
     m->Fcomb = m->hseq_p + m->hsig_p;
+    m->small_classes = (m->Hp == 256 && m->Fcomb % 128 == 0 && m->Fcomb >= 256) || (m->Hp == 128 && m->Fcomb % 32 == 0 && m->Fcomb >= 64);
     m->Fwide = 2 * m->Hp;
     if (2 * m->hseq_p > m->Fwide) m->Fwide = 2 * m->hseq_p;
     if (2 * m->hsig_p > m->Fwide) m->Fwide = 2 * m->hsig_p;
@@ -992,7 +995,12 @@ int32_t dsp_forward(dsp_model* m, void* stream, int64_t n, const void* kmer, int
     const int64_t kRound = 8192, kUnit = 512;
     const int64_t whole = n / kRound * kRound, r = n - whole;
     PiecePlan pl{0, {0, 0, 0, 0, 0, 0}};
-    if (r > 0) pl = plan_pieces((int)((r + kUnit - 1) / kUnit));
+    if (r > 0) {
+        const int u = (int)((r + kUnit - 1) / kUnit);
+        if (m->small_classes) pl = plan_pieces(u);
+        else { pl.n = 1; pl.units[0] = u <= 8 ? 8 : 16; }   // a combined stack without clustered forms: <= 4,096 sites cost 3.7 ms flat
+        // (one 32-site workgroup per CU), so the remainder runs in one piece when it fits that and as a round otherwise
+    }
     const bool tail_is_a_round = pl.n == 1 && pl.units[0] == 16;
     const bool cut = m->forward_split && (whole > 0 ? (r > 0 && !tail_is_a_round) : pl.n > 1) && mode != DSP_INIT_EXPLICIT &&
                      m->precision == DSP_PREC_FP32 && m->cluster != 0 && kmer_dtype >= 0 && kmer_dtype <= 3 && lens_dtype >= 0 &&

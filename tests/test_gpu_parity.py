@@ -655,3 +655,31 @@ def test_a_workspace_that_cannot_be_had_is_refused_and_leaves_the_handle_usable(
     with pytest.raises(RuntimeError, match="workspace hipMalloc"):
         m.reserve(too_many)
     assert torch.equal(m.forward(*ins)[1], ref)
+
+
+@pytest.mark.parametrize("kw,label", [(dict(hidden_size=160, num_layers1=2), "hidden160_no_clustered_forms"),
+                                      (dict(module="seq_bilstm", num_layers1=2), "configs2_seq_only"),
+                                      (dict(hidden_size=128), "hidden128")])
+def test_a_call_cut_into_rounds_and_pieces_gives_the_bits_of_one_piece(kw, label, monkeypatch):
+    """dsp_forward runs a call as its whole 8,192-site rounds + its remainder as small-batch pieces (round 5).  For a model
+    whose combined stack has no clustered forms (hidden 160: five unit tiles) the remainder is one piece or a round; either
+    way the bits are those of the call run in one piece -- Philox states keyed by the global site index, per-site keys too."""
+    torch = _torch()
+    from deepsignal_plant_amd import synth
+    from oracle import forward_np as onp
+    cfg = onp.OracleConfig(**kw)
+    w = onp.make_weights(cfg, 95, 2.0)
+    sizes = (1100, 3000, 5000, 7000, 9001, 12300, 17000)
+    ins = {n: synth.feature_batch(n, device="cuda:0", seed=700 + n) for n in sizes}
+    keys = torch.arange(3_000_000_000, 3_000_000_000 + 17000, device="cuda:0")
+    res = {}
+    for split in ("0", "1"):
+        monkeypatch.setenv("DSP_FORWARD_SPLIT", split)
+        m = build_model(cfg, w, init_state="randn", seed=19)
+        for n in sizes:
+            m.site_offset = 13 * n
+            res[split, n] = m.forward(*ins[n])[1].clone()
+        res[split, "keys"] = m.forward(*ins[17000], site_keys=keys)[1].clone()
+    torch.cuda.synchronize()
+    for n in list(sizes) + ["keys"]:
+        assert torch.equal(res["0", n], res["1", n]), (label, n)
