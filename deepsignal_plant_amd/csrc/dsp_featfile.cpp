@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "dsp_amd.h"
+#include "dsp_threads.h"
 
 extern "C" void dsp_set_error_(const char* msg);
 
@@ -337,14 +338,7 @@ int64_t dsp_feat_read_block(const dsp_feat_file* f, int64_t block, int64_t max_r
         for (size_t j = t; j < jobs.size(); j += nt)
             if (!pread_all(f->fd, jobs[j].dst, jobs[j].bytes, jobs[j].off)) bad[t] = 1;
     };
-    if (nt == 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; t++) th.emplace_back(work, t);
-        work(0);
-        for (auto& x : th) x.join();
-    }
+    if (!dsp::run_indexed(nt, work)) return fail(DSP_ENOMEM, "dsp_feat_read_block: a worker failed in block %s%lld", "", (long long)block);
     for (int t = 0; t < nt; t++)
         if (bad[t]) return fail(DSP_EPARSE, "dsp_feat_read_block: short read in block %s%lld", "", (long long)block);
     if (info_len) {

@@ -12,6 +12,7 @@
 // arithmetic, exactly the decimal values the per-read file would have carried, so skipping the text
 // round-trip cannot change a single digit.
 #include "dsp_amd.h"
+#include "dsp_threads.h"
 
 #include <algorithm>
 #include <cmath>
@@ -374,14 +375,7 @@ int64_t dsp_freq_add_calls_text(dsp_freq* f, const char* text, size_t len, const
             p = nl ? nl + 1 : ce;
         }
     };
-    if (nt == 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
-        work(0);
-        for (auto& x : th) x.join();
-    }
+    if (!dsp::run_indexed(nt, work)) return freq_fail(DSP_ENOMEM, "out of memory in a worker thread");
     // sequential: how many records count (everything before the first malformed line), chromosome interning
     int64_t nline = 0;
     int bad_t = -1;
@@ -407,14 +401,7 @@ int64_t dsp_freq_add_calls_text(dsp_freq* f, const char* text, size_t len, const
                 f->parts[part].apply(r.cid, r.pos, r.strand, r.strand_len, r.pis, r.p0, r.p1, r.label, r.kmer, r.kmer_len, my_seq);
             }
     };
-    if (workers <= 1) {
-        apply(0);
-    } else {
-        std::vector<std::thread> th;
-        for (int wk = 1; wk < workers; ++wk) th.emplace_back(apply, wk);
-        apply(0);
-        for (auto& x : th) x.join();
-    }
+    if (!dsp::run_indexed(workers, apply)) return freq_fail(DSP_ENOMEM, "out of memory in a worker thread");
     f->seq += (uint64_t)nline;
     if (contig) {  // `count` counts the records of the requested contig only (call_mods_freq.py:53-56)
         for (int t = 0; t < t_end; ++t)
@@ -521,14 +508,7 @@ int64_t dsp_freq_block_keys(dsp_freq* f, const char* text, const uint64_t* row_o
             meta[r] = m;
         }
     };
-    if (nt <= 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
-        work(0);
-        for (auto& x : th) x.join();
-    }
+    if (!dsp::run_indexed(nt, work)) return freq_fail(DSP_ENOMEM, "out of memory in a worker thread");
     for (int t = 0; t < nt; ++t)
         if (bad[t] >= 0)
             return why[t] == 1 ? freq_fail(DSP_EPARSE, "row %lld: bad pos / pos_in_strand column", (long long)bad[t])
@@ -582,11 +562,8 @@ int64_t dsp_freq_add_sites(dsp_freq* f, int64_t n, const int64_t* key, const int
     };
     if (workers == 1 || n < 65536) {
         for (int wk = 0; wk < workers; ++wk) hash_range(wk);
-    } else {
-        std::vector<std::thread> th;
-        for (int wk = 1; wk < workers; ++wk) th.emplace_back(hash_range, wk);
-        hash_range(0);
-        for (auto& x : th) x.join();
+    } else if (!dsp::run_indexed(workers, hash_range)) {
+        return freq_fail(DSP_ENOMEM, "out of memory in a worker thread");
     }
     for (int wk = 0; wk < workers; ++wk)
         if (bad[wk] >= 0) return freq_fail(DSP_EINVAL, "site %lld: unknown chromosome id", bad[wk]);
@@ -627,11 +604,8 @@ int64_t dsp_freq_add_sites(dsp_freq* f, int64_t n, const int64_t* key, const int
     };
     if (workers == 1 || n < 65536) {
         for (int wk = 0; wk < workers; ++wk) work(wk);
-    } else {
-        std::vector<std::thread> th;
-        for (int wk = 1; wk < workers; ++wk) th.emplace_back(work, wk);
-        work(0);
-        for (auto& x : th) x.join();
+    } else if (!dsp::run_indexed(workers, work)) {
+        return freq_fail(DSP_ENOMEM, "out of memory in a worker thread");
     }
     for (int wk = 0; wk < workers; ++wk)
         if (bad[wk] >= 0)
@@ -722,15 +696,8 @@ int64_t dsp_freq_format(const dsp_freq* f, int32_t is_sort, int32_t is_bed, char
     int nt = f->nthreads < 1 ? 1 : f->nthreads;
     if ((size_t)nt > order.size() / 4096 + 1) nt = (int)(order.size() / 4096 + 1);
     std::vector<std::string> chunks((size_t)nt);
-    if (nt == 1) {
-        format_range(0, order.size(), chunks[0]);
-    } else {
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; ++t)
-            th.emplace_back([&, t] { format_range(order.size() * t / nt, order.size() * (t + 1) / nt, chunks[t]); });
-        format_range(0, order.size() / nt, chunks[0]);
-        for (auto& x : th) x.join();
-    }
+    if (!dsp::run_indexed(nt, [&](int t) { format_range(order.size() * t / nt, order.size() * (t + 1) / nt, chunks[t]); }))
+        return freq_fail(DSP_ENOMEM, "out of memory in a worker thread");
     size_t total = 0;
     for (const std::string& c : chunks) total += c.size();
     std::string& s = f->format_cache;

@@ -25,6 +25,8 @@
 #include <thread>
 #include <vector>
 
+#include "dsp_threads.h"
+
 extern "C" void dsp_set_error_(const char* msg);
 
 namespace {
@@ -193,10 +195,7 @@ int64_t dsp_gz_inflate_members(const uint8_t* src, const uint64_t* member_off, c
         }
         if (dec) ld.free_d(dec);
     };
-    std::vector<std::thread> th;
-    for (int t = 1; t < nt; ++t) th.emplace_back(work);
-    work();
-    for (auto& x : th) x.join();
+    if (!dsp::run_indexed(nt, [&](int) { work(); })) return gz_fail(DSP_ENOMEM, "dsp_gz_inflate_members: out of memory in a worker");
     if (bad.load() >= 0) return gz_fail(DSP_EPARSE, "corrupt gzip member %lld (inflate / CRC / size check failed)", (long long)bad.load());
     return (int64_t)off[(size_t)m];
 }
@@ -272,10 +271,7 @@ int64_t dsp_bgzf_compress(const uint8_t* in, size_t len, uint8_t* out, size_t ou
         if (comp) ld.free_c(comp);
         if (comp0) ld.free_c(comp0);
     };
-    std::vector<std::thread> th;
-    for (int t = 1; t < nt; ++t) th.emplace_back(work);
-    work();
-    for (auto& x : th) x.join();
+    if (!dsp::run_indexed(nt, [&](int) { work(); })) return gz_fail(DSP_ENOMEM, "dsp_bgzf_compress: out of memory in a worker");
     if (err.load()) return gz_fail(DSP_EHIP, "dsp_bgzf_compress: deflate failed");
     size_t total = 0;
     for (size_t b = 0; b < nb; ++b) total += sz[b];

@@ -21,6 +21,7 @@
 // The reader thread pulls text with dsp_pgz_read like from dsp_gz_read; rounds of chunks are decoded ahead of it.
 // DSP_GZ_SEQUENTIAL=1 keeps callers on the zlib reader (A/B switch).
 #include "dsp_amd.h"
+#include "dsp_threads.h"
 
 #include <dlfcn.h>
 #include <fcntl.h>
@@ -40,6 +41,7 @@
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -529,17 +531,10 @@ void pgz_fail(dsp_pgz* z, int code, const std::string& msg) {
 void run_parallel(int nthreads, int n, const std::function<void(int)>& fn) {
     if (n <= 0) return;
     std::atomic<int> next{0};
-    std::atomic<bool> threw{false};
-    auto work = [&] {   // (an exception must not leave a std::thread: remember it, rethrow after the join)
-        try { for (int i; (i = next.fetch_add(1)) < n;) fn(i); }
-        catch (...) { threw.store(true); }
-    };
-    std::vector<std::thread> th;
-    const int nt = std::min(nthreads, n);
-    for (int t = 1; t < nt; ++t) th.emplace_back(work);
-    work();
-    for (auto& x : th) x.join();
-    if (threw.load()) throw std::runtime_error("out of memory");
+    // (an exception must not leave a std::thread, and a thread the system refuses is work done here: dsp_threads.h;
+    // rethrown after the join)
+    if (!dsp::run_indexed(std::min(nthreads, n), [&](int) { for (int i; (i = next.fetch_add(1)) < n;) fn(i); }))
+        throw std::runtime_error("out of memory");
 }
 
 // The second half of a round, run by a finisher thread while the decoder threads are already inflating the next round:
@@ -715,11 +710,13 @@ void decoder_main(dsp_pgz* z) {
                 break;
             }
             const bool last = r->last;
-            finisher = std::thread([z, r] {
+            auto finish = [z, r] {
                 try { finish_round(z, r); }
                 catch (const std::exception& e) { pgz_fail(z, DSP_ENOMEM, std::string("parallel inflate: ") + e.what()); }
                 delete r;
-            });
+            };
+            try { finisher = std::thread(finish); }
+            catch (const std::system_error&) { finish(); }   // (no thread to be had: the round is finished here)
             if (last) break;
         }
     } catch (const std::exception& e) {
@@ -749,9 +746,15 @@ dsp_pgz* dsp_pgz_open(const char* path, int32_t nthreads, uint64_t chunk_bytes) 
     z->nthreads = nthreads < 1 ? 1 : nthreads;
     if (chunk_bytes >= (1u << 16)) z->chunk_bytes = (size_t)chunk_bytes;
     z->next_bit = (uint64_t)q * 8;
-    z->window.assign(kWin, kPoison);
     if (chunk_bytes < (1u << 16) && z->nthreads >= 8) z->chunk_bytes = 4u << 20;   // two rounds are in flight: keep their memory bounded
-    z->decoder = std::thread(decoder_main, z);
+    try {
+        z->window.assign(kWin, kPoison);
+        z->decoder = std::thread(decoder_main, z);
+    } catch (const std::exception&) {   // (no memory / no thread to be had: an error, not std::terminate across the C ABI)
+        dsp_pgz_close(z);
+        dsp_set_error_("dsp_pgz_open: cannot start the decoder thread");
+        return nullptr;
+    }
     return z;
 }
 

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "dsp_amd.h"
+#include "dsp_threads.h"
 
 extern "C" void dsp_set_error_(const char* msg);
 
@@ -148,10 +149,7 @@ void parallel_reads(int64_t n_reads, int nthreads, F f) {
             for (int64_t r = r0; r < r0 + 8 && r < n_reads; r++) f(r);
         }
     };
-    std::vector<std::thread> th;
-    for (int t = 1; t < nthreads; t++) th.emplace_back(work);
-    work();
-    for (auto& x : th) x.join();
+    (void)dsp::run_indexed(nthreads, [&](int) { work(); });   // (the callers' f allocates nothing: no worker can throw)
 }
 
 }  // namespace

@@ -10,6 +10,7 @@
 // and only then narrowed.  The formatter performs the reference's float32 operations literally (this file is
 // compiled with -ffp-contract=off).
 #include "dsp_amd.h"
+#include "dsp_threads.h"
 
 #include <errno.h>
 #include <unistd.h>
@@ -445,18 +446,18 @@ inline float np_round6_f32(float x) {
     return z;
 }
 
-void run_threads(int nthreads, int64_t n, const std::function<void(int, int64_t, int64_t)>& fn) {
+// fn(piece, a, b) over [0, n) cut into <= nthreads pieces; false when a piece threw (dsp_threads.h)
+bool run_threads(int nthreads, int64_t n, const std::function<void(int, int64_t, int64_t)>& fn) {
     if (nthreads < 1) nthreads = 1;
     if ((int64_t)nthreads > n) nthreads = (int)(n > 0 ? n : 1);
-    if (nthreads == 1) { fn(0, 0, n); return; }
-    std::vector<std::thread> th;
     const int64_t per = (n + nthreads - 1) / nthreads;
-    for (int t = 0; t < nthreads; ++t) {
+    int pieces = 0;
+    while (pieces < nthreads && (int64_t)pieces * per < n) ++pieces;
+    if (pieces == 0) pieces = 1;   // (n == 0: one call with an empty range, as before)
+    return dsp::run_indexed(pieces, [&](int t) {
         const int64_t a = t * per, b = std::min<int64_t>(n, a + per);
-        if (a >= b) break;
-        th.emplace_back(fn, t, a, b);
-    }
-    for (auto& x : th) x.join();
+        fn(t, a, b);
+    });
 }
 }  // namespace
 
@@ -596,7 +597,7 @@ int64_t dsp_parse_feature_rows(const char* text, size_t len, int32_t seq_len, in
         cut[t] = p < cut[t - 1] ? cut[t - 1] : p;
     }
     std::vector<int64_t> first((size_t)nt + 1, 0);
-    run_threads(nt, nt, [&](int, int64_t a, int64_t b) {
+    if (!run_threads(nt, nt, [&](int, int64_t a, int64_t b) {
         for (int64_t t = a; t < b; ++t) {
             int64_t n = 0;
             const char* p = cut[t];
@@ -608,14 +609,14 @@ int64_t dsp_parse_feature_rows(const char* text, size_t len, int32_t seq_len, in
             }
             first[t + 1] = n;
         }
-    });
+    })) return text_fail(DSP_ENOMEM, "out of memory in a worker thread");
     for (int t = 0; t < nt; ++t) first[t + 1] += first[t];
     const int64_t n = first[nt];
     if (n > max_rows) return text_fail(DSP_ENOMEM, "buffer holds %lld rows but capacity is %lld", (long long)n, (long long)max_rows);
     RowOut o{kmer, means, stds, lens, signals, labels, row_off, info_len, read_off, read_len};
     std::vector<int64_t> bad_row((size_t)nt, -1);
     std::vector<int> bad_code((size_t)nt, 0);
-    run_threads(nt, nt, [&](int, int64_t a, int64_t b) {
+    if (!run_threads(nt, nt, [&](int, int64_t a, int64_t b) {
         for (int64_t t = a; t < b; ++t) {
             int64_t r = first[t];
             const char* p = cut[t];
@@ -631,7 +632,7 @@ int64_t dsp_parse_feature_rows(const char* text, size_t len, int32_t seq_len, in
                 p = nl + 1;
             }
         }
-    });
+    })) return text_fail(DSP_ENOMEM, "out of memory in a worker thread");
     for (size_t t = 0; t < bad_row.size(); ++t)
         if (bad_row[t] >= 0) {
             if ((bad_code[t] & 0xff) == 8) {
@@ -658,7 +659,7 @@ int64_t dsp_format_calls(const char* text, const uint64_t* row_off, const uint32
     const int k1 = center + 3 <= seq_len ? center + 3 : seq_len;
     if (nthreads < 1) nthreads = 1;
     std::vector<std::string> parts((size_t)nthreads);
-    run_threads(nthreads, n, [&](int t, int64_t a, int64_t b) {
+    if (!run_threads(nthreads, n, [&](int t, int64_t a, int64_t b) {
         std::string& s = parts[t];
         s.reserve((size_t)(b - a) * 96);
         char num[64];
@@ -680,7 +681,7 @@ int64_t dsp_format_calls(const char* text, const uint64_t* row_off, const uint32
             for (int i = k0; i < k1; ++i) s.push_back(code2base[kmer[r * seq_len + i] & 15]);
             s.push_back('\n');
         }
-    });
+    })) return text_fail(DSP_ENOMEM, "out of memory in a worker thread");
     size_t total = 0;
     for (auto& s : parts) total += s.size();
     if (total > out_cap) return text_fail(DSP_ENOMEM, "output needs %zu bytes, capacity %zu", total, out_cap);
@@ -759,13 +760,13 @@ int64_t dsp_format_feature_rows_parts(const char* text, const uint64_t* row_off,
         parts = t + 1;
     }
     if (off > out_cap) return text_fail(DSP_ENOMEM, "output needs %zu bytes of capacity, got %zu", off, out_cap);
-    run_threads(nthreads, n, [&](int t, int64_t a, int64_t b) {
+    if (!run_threads(nthreads, n, [&](int t, int64_t a, int64_t b) {
         char* o = out + part_off[t];
         for (int64_t r = a; r < b; ++r)
             o = put_feature_row(o, text + row_off[r], info_len[r], kmer + r * L, means + r * L, stds + r * L, lens + r * L,
                                 signals + (size_t)r * L * S, labels[r], L, S);
         part_len[t] = (uint64_t)(o - (out + part_off[t]));
-    });
+    })) return text_fail(DSP_ENOMEM, "out of memory in a worker thread");
     return parts;
 }
 
@@ -782,7 +783,7 @@ int64_t dsp_format_feature_rows(const char* text, const uint64_t* row_off, const
     const int L = seq_len, S = signal_len;
     if (nthreads < 1) nthreads = 1;
     std::vector<std::string> parts((size_t)nthreads);
-    run_threads(nthreads, n, [&](int t, int64_t a, int64_t b) {
+    if (!run_threads(nthreads, n, [&](int t, int64_t a, int64_t b) {
         std::string& s = parts[t];
         s.reserve((size_t)(b - a) * (size_t)(160 + L * (S + 3) * 10));
         char num[64];
@@ -818,7 +819,7 @@ int64_t dsp_format_feature_rows(const char* text, const uint64_t* row_off, const
             s.append(num, (size_t)snprintf(num, sizeof(num), "%d", (int)labels[r]));
             s.push_back('\n');
         }
-    });
+    })) return text_fail(DSP_ENOMEM, "out of memory in a worker thread");
     size_t total = 0;
     for (auto& s : parts) total += s.size();
     if (total > out_cap) return text_fail(DSP_ENOMEM, "output needs %zu bytes, capacity %zu", total, out_cap);

@@ -12,6 +12,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_runtest_logstart(nodeid, location):
+    """A breadcrumb per GPU test under gpurun_out/ (scratch, merged back from the GPU box): a run that dies of a fatal
+    signal inside a native call -- one of seven full runs at round 5's last sources did, its output cut to the last lines --
+    leaves the name of the test it died in."""
+    if "test_gpu_" not in nodeid:
+        return
+    import time
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "gpu_suite_trail.txt"), "a") as f:
+            f.write("%.1f pid %d %s\n" % (time.time(), os.getpid(), nodeid))
+    except OSError:
+        pass
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
