@@ -12,6 +12,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """The eight-rank launches (tests/test_gpu_ranks8.py: 8 processes sharing the box's one GPU) run FIRST, while the pytest
+    process itself has not touched the GPU yet.  A precaution, not a diagnosis: the one unexplained death of a GPU-suite run
+    (DESIGN.md 5 "Open") fell into the minutes where this process -- idle, but holding a HIP context and its queues from the
+    in-process tests before -- waited for those eight: nine processes with compute queues on one device, more than the
+    driver has address spaces (VMIDs) for at once.  In front, the eight have the GPU to themselves.  (No test module
+    initialises the GPU at import time; the tests do not depend on their order.)"""
+    first = [it for it in items if "test_gpu_ranks8" in it.nodeid]
+    if first and len(first) < len(items):
+        items[:] = first + [it for it in items if "test_gpu_ranks8" not in it.nodeid]
+
+
 def pytest_runtest_logstart(nodeid, location):
     """A breadcrumb per GPU test under gpurun_out/ (scratch, merged back from the GPU box): a run that dies of a fatal
     signal inside a native call -- one of seven full runs at round 5's last sources did, its output cut to the last lines --
