@@ -7,34 +7,40 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+from tests import gpu_isolation  # noqa: E402
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # every GPU test module in one fresh child process, the pytest process itself without a HIP context (tests/gpu_isolation.py)
+    gpu_isolation.configure(config)
 
 
 def pytest_collection_modifyitems(config, items):
-    """The eight-rank launches (tests/test_gpu_ranks8.py: 8 processes sharing the box's one GPU) run FIRST, while the pytest
-    process itself has not touched the GPU yet.  A precaution, not a diagnosis: the one unexplained death of a GPU-suite run
-    (DESIGN.md 5 "Open") fell into the minutes where this process -- idle, but holding a HIP context and its queues from the
-    in-process tests before -- waited for those eight: nine processes with compute queues on one device, more than the
-    driver has address spaces (VMIDs) for at once.  In front, the eight have the GPU to themselves.  (No test module
-    initialises the GPU at import time; the tests do not depend on their order.)"""
+    """DSP_GPU_RANKS8_FIRST=1: the eight-rank launches (tests/test_gpu_ranks8.py: 8 processes sharing the box's one GPU) run
+    first.  Round 5 made that the default as a precaution against its one unexplained death of a GPU-suite run -- a guess (nine
+    processes with compute queues on one device), and a reordering around a guess hides the fault if the guess is wrong
+    (ADVICE r5).  Since round 6 the pytest process holds no HIP context at all (every GPU module runs in its own child), the
+    suite runs in file order again, and a death names its test; the switch stays for reproducing the round-5 order."""
+    if os.environ.get("DSP_GPU_RANKS8_FIRST", "0") != "1":
+        return
     first = [it for it in items if "test_gpu_ranks8" in it.nodeid]
     if first and len(first) < len(items):
         items[:] = first + [it for it in items if "test_gpu_ranks8" not in it.nodeid]
 
 
-def pytest_runtest_logstart(nodeid, location):
-    """A breadcrumb per GPU test under gpurun_out/ (scratch, merged back from the GPU box): a run that dies of a fatal
-    signal inside a native call -- one of seven full runs at round 5's last sources did, its output cut to the last lines --
-    leaves the name of the test it died in."""
-    if "test_gpu_" not in nodeid:
+@pytest.hookimpl(tryfirst=True)
+def pytest_runtest_setup(item):
+    """A breadcrumb per GPU test under gpurun_out/ (scratch, merged back from the GPU box), written by the process that runs
+    the test, before it starts: a run that dies of a fatal signal inside a native call leaves the name of the test it died in.
+    Keyed on the `gpu` marker (round 5 matched the substring `test_gpu_` and caught a CPU test of that name)."""
+    if item.get_closest_marker("gpu") is None:
         return
     import time
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "gpu_suite_trail.txt"), "a") as f:
-            f.write("%.1f pid %d %s\n" % (time.time(), os.getpid(), nodeid))
+            f.write("%.1f pid %d %s\n" % (time.time(), os.getpid(), item.nodeid))
     except OSError:
         pass
 
