@@ -6,8 +6,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DSP_AMD_LIB") or os.path.join(_HERE, "libdsp_amd.so")
+ABI_VERSION = 3   # include/dsp_amd.h DSP_AMD_ABI_VERSION
 
-DSP_OK, DSP_EINVAL, DSP_ESHAPE, DSP_EHIP, DSP_ENOMEM, DSP_EPARSE, DSP_EKEY = 0, -1, -2, -3, -4, -5, -6
+DSP_OK, DSP_EINVAL, DSP_ESHAPE, DSP_EHIP, DSP_ENOMEM, DSP_EPARSE, DSP_EKEY, DSP_EBOUNDS = 0, -1, -2, -3, -4, -5, -6, -7
 MODULE_CODE = {"both_bilstm": 0, "seq_bilstm": 1, "signal_bilstm": 2}
 DT_F32, DT_U8, DT_U16, DT_I32 = 0, 1, 2, 3
 INIT_ZEROS, INIT_EXPLICIT, INIT_PHILOX = 0, 1, 2
@@ -62,6 +63,12 @@ def lib():
     L = ctypes.CDLL(LIB_PATH)
     L.dsp_last_error.restype = ctypes.c_char_p
     L.dsp_abi_version.restype = ctypes.c_int32
+    # an older or variant library (DSP_AMD_LIB is how the A/B scripts and the bounds / trace builds are loaded) must say so
+    # itself, not fail later with a bare AttributeError on the first symbol it lacks
+    if L.dsp_abi_version() != ABI_VERSION:
+        raise RuntimeError("%s implements C-ABI version %d, this package binds version %d (include/dsp_amd.h "
+                           "DSP_AMD_ABI_VERSION): rebuild it with `make -C deepsignal_plant_amd/csrc`"
+                           % (LIB_PATH, L.dsp_abi_version(), ABI_VERSION))
     L.dsp_weight_count.restype = ctypes.c_int32
     L.dsp_weight_count.argtypes = [ctypes.POINTER(ModelCfg)]
     L.dsp_weight_spec.restype = ctypes.c_int32
@@ -255,8 +262,18 @@ def lib():
     for fn in (L.dsp_device_pci_bdf, L.dsp_device_uuid):
         fn.restype = ctypes.c_int64
         fn.argtypes = [ctypes.c_int32, ctypes.c_char_p, ctypes.c_size_t]
+    L.dsp_debug_range_probe.restype = ctypes.c_int32
+    L.dsp_debug_range_probe.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]
     _lib = L
     return L
+
+
+def range_probe(device: int = 0):
+    """(lanes in range that read their data, lanes past the extent by VGPR offset that read zeros, ... by SGPR offset,
+    floats untouched by 64 out-of-range stores): expect (16, 48, 64, 1024) -- include/dsp_amd.h dsp_debug_range_probe"""
+    out = (ctypes.c_int32 * 4)()
+    check(int(lib().dsp_debug_range_probe(int(device), out)))
+    return tuple(int(v) for v in out)
 
 
 def device_pci_bdf(device: int) -> str:

@@ -343,6 +343,15 @@ struct dsp_model {
     bool split_ready = false;  // the split-precision weight pieces are on the device (ensure_split)
     bool fp16_safe = true;         // every operand of the combined stack provably inside the fp16 range (fp16x3 only then)
     int precision = DSP_PREC_FP32; // products of the combined stack: fp32 MFMA, or split-bf16 emulation (dsp_lstm6_kernel)
+    // Buffer-descriptor extents (round 6): every pointer a kernel addresses through a descriptor travels with the end of its
+    // allocation.  1 (default) = the end of the workspace region / weight upload the pointer lies in; 2 = the tight logical
+    // extent of THIS call (its tiles, this layer's weights: what the bounds-recording build checks against); 0 = the 2 GiB
+    // windows of rounds 1-5 (DSP_RSRC_EXTENTS=wide: A/B switch and escape hatch -- the hardware range check off again)
+    int extents = 1;
+    size_t test_shrink = 0;   // bounds build only (DSP_BOUNDS_TEST_SHRINK): bytes taken off every LSTM launch's input extent -- the
+                              // negative control of the bounds tests (an access the record must name)
+    std::vector<std::pair<const char*, size_t>> uploads;   // every weight upload: base, bytes
+    size_t ws_off[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};        // the workspace's regions (ws_layout) + its size
     // scratch
     void* ws = nullptr;
     int64_t ws_sites = 0;
@@ -368,9 +377,35 @@ int upload(dsp_model* m, const std::vector<float>& h, float** out) {
         return fail(DSP_ENOMEM, "hipMalloc(%zu) failed: %s", h.size() * sizeof(float), hipGetErrorString(e));
     }
     m->dev_allocs.push_back(p);
+    m->uploads.emplace_back((const char*)p, h.size() * sizeof(float));
     HIP_TRY(hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
     *out = (float*)p;
     return 0;
+}
+
+// The end of the allocation `p` lies in: a weight upload, or a region of the workspace (ws_layout).  NULL for a pointer this
+// handle does not own -- the launch wrappers refuse a descriptor without an end, so a pointer that got lost fails its launch
+// instead of reading through a window onto somebody else's memory.
+const void* alloc_end(const dsp_model* m, const void* p) {
+    const char* c = (const char*)p;
+    if (!c) return nullptr;
+    if (m->ws) {
+        const char* b = (const char*)m->ws;
+        if (c >= b && c < b + m->ws_off[8])
+            for (int i = 0; i < 8; ++i)
+                if (c >= b + m->ws_off[i] && c < b + m->ws_off[i + 1]) return b + m->ws_off[i + 1];
+    }
+    for (const auto& u : m->uploads)
+        if (c >= u.first && c < u.first + u.second) return u.first + u.second;
+    return nullptr;
+}
+// ... as a descriptor's end: `logical` = the bytes this launch may touch behind p
+const void* rsrc_end(const dsp_model* m, const void* p, size_t logical) {
+    if (!p) return nullptr;
+    if (m->extents == 0) return (const char*)p + (1ull << 40);   // clamps to the old 0x7ffffff0 window in the kernel
+    const char* e = (const char*)alloc_end(m, p);
+    if (e && m->extents == 2 && (const char*)p + logical < e) e = (const char*)p + logical;
+    return e;
 }
 
 int build_stack(dsp_model* m, const float* const* w, int in, int hid, int layers, std::vector<int> in_map0,
@@ -476,6 +511,7 @@ int ensure_ws(dsp_model* m, int64_t sites, hipStream_t stream) {
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipFree(m->ws));
         m->ws = nullptr; m->ws_sites = 0;
+        for (size_t& o : m->ws_off) o = 0;
     }
     size_t off[8];
     long long NTp;
@@ -487,6 +523,8 @@ int ensure_ws(dsp_model* m, int64_t sites, hipStream_t stream) {
         return fail(DSP_ENOMEM, "workspace hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     }
     char* b = (char*)m->ws;
+    for (int i = 0; i < 8; ++i) m->ws_off[i] = off[i];
+    m->ws_off[8] = bytes;
     m->xseq = (float*)(b + off[0]); m->xsig = (float*)(b + off[1]);
     m->bufA = (float*)(b + off[2]); m->bufB = (float*)(b + off[3]); m->comb_in = (float*)(b + off[4]);
     m->h0buf = (float*)(b + off[5]);
@@ -699,6 +737,24 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
             if (!L.side_by_side || (a.UT == 4 && a.CG < 4)) a.flags |= 4;
             if (m->wave_handoff) a.flags |= 64;
         }
+        {   // the extents behind this launch's descriptors (after the split switch: a.wpk0 / a.NQ are the launch's own)
+            const size_t tile_x = (size_t)a.T * (size_t)(a.Ipad >> 2) * 512, tile_o = (size_t)a.T * (size_t)(a.Fout >> 2) * 512;
+            const size_t wbytes = split ? (size_t)a.UT * a.NQ * 4096 * (prec == DSP_PREC_FP16X3 ? 2 : 3) : (size_t)a.UT * a.NQ * 4096;
+            a.x_end = rsrc_end(m, a.x, (size_t)a.NTp * tile_x);
+            if (m->test_shrink && a.x_end) a.x_end = (const char*)a.x_end - m->test_shrink;
+            a.out_end = rsrc_end(m, a.out, (size_t)a.NTp * tile_o);
+            a.h0buf_end = rsrc_end(m, a.h0buf, (size_t)a.NTp * (size_t)(a.Fout >> 2) * 512);
+            a.wpk0_end = rsrc_end(m, a.wpk0, wbytes);
+            a.wpk1_end = rsrc_end(m, a.wpk1, wbytes);
+            // the cell-state scratch of the many-pass kernel: one 64 KiB slice per pass and workgroup (NTp workgroups); an
+            // empty region when no layer needs it (its end is then its start)
+            const char* cb = (const char*)a.cbuf;
+            const char* cregion = m->ws ? (const char*)m->ws + m->ws_off[7] : nullptr;
+            a.cbuf_end = !cb ? nullptr : (m->extents == 0 ? cb + (1ull << 40) :
+                         (m->extents == 2 && a.NP >= 2 ? std::min(cregion, cb + (size_t)a.NTp * a.NP * 65536) : cregion));
+            a.cflags_end = a.cflags ? (const char*)m->cflags + (size_t)m->n_cflag_words * sizeof(unsigned int) : nullptr;
+            if (a.cflags && m->extents == 2) a.cflags_end = (const char*)a.cflags + (size_t)kClusterWordsPerLaunch * sizeof(unsigned int);
+        }
         if (m->debug_lstm)   // DSP_DEBUG_LSTM (read once, in dsp_model_create)
             fprintf(stderr, "[lstm] %s k=%zu split=%d CG=%d Ipad=%d H=%d Hp=%d UT=%d SG=%d NQ=%d NTp=%lld n=%lld T=%d Fout=%d x=%p out=%p\n", name, k,
                     (int)split, a.CG, a.Ipad, a.H, a.Hp, a.UT, a.SG, a.NQ, a.NTp, a.n, a.T, a.Fout, (const void*)a.x, (void*)a.out);
@@ -802,6 +858,11 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
     if (const char* v = getenv("DSP_LSTM_FRONT_CLUSTER")) m->front_cluster = atoi(v);      // A/B switch
     if (const char* v = getenv("DSP_CLUSTER_TIMEOUT")) m->cluster_timeout = strtoull(v, nullptr, 10);
     if (const char* v = getenv("DSP_TWO_STREAMS")) m->two_streams = atoi(v) != 0 ? 1 : 0;   // A/B switch
+    m->extents = dsp_k_bounds_build() ? 2 : 1;   // (the bounds-recording build checks the tight extents of every call)
+    if (dsp_k_bounds_build())
+        if (const char* v = getenv("DSP_BOUNDS_TEST_SHRINK")) m->test_shrink = (size_t)strtoull(v, nullptr, 10);
+    if (const char* v = getenv("DSP_RSRC_EXTENTS"))
+        m->extents = !strcmp(v, "wide") ? 0 : (!strcmp(v, "tight") ? 2 : (!strcmp(v, "region") ? 1 : m->extents));
     if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess) {
         (void)hipGetLastError();
@@ -986,10 +1047,43 @@ PiecePlan plan_pieces(int u) {
 }
 }  // namespace
 
+static int32_t forward_pieces(dsp_model* m, void* stream, int64_t n, const void* kmer, int32_t kmer_dtype, const float* means,
+                              const float* stds, const void* lens, int32_t lens_dtype, const float* signals,
+                              const dsp_init_state* init, float* logits, float* probs, uint8_t* labels);
+
+// The bounds-recording build (make bounds -> libdsp_amd_bounds.so; never the product library): every access through a buffer
+// descriptor -- and the flat stores of the pack / fc launches, the counters of the clustered launches -- was compared with the
+// tight extent of its operand; the first one out of range comes back here as DSP_EBOUNDS with the kernel source line, the
+// operand, the workgroup, the thread, the offset and the extent.  The forward is synchronous in that build.
+static int32_t bounds_verdict(dsp_model* m, void* stream) {
+    if (!dsp_k_bounds_build()) return 0;
+    int prev = 0;
+    HIP_TRY(hipGetDevice(&prev));
+    if (prev != m->device) HIP_TRY(hipSetDevice(m->device));
+    const hipError_t se = hipStreamSynchronize((hipStream_t)stream);
+    unsigned rec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int re = se == hipSuccess ? dsp_k_bounds_read(rec) : (int)se;
+    if (prev != m->device) hipSetDevice(prev);
+    if (re) return fail(DSP_EHIP, "bounds build: reading the record failed: %s", hipGetErrorString((hipError_t)re));
+    if (!rec[0]) return 0;
+    static const char* kinds[] = {"?", "weights", "K4 input", "K4 output", "h0 scratch", "cell-state scratch", "cluster counters", "flat K4 store"};
+    return fail(DSP_EBOUNDS, "%u access(es) out of range; the first: dsp_kernels.hip:%u, operand %s, workgroup %u, thread %u, byte offset %llu "
+                "(+16) against an extent of %u bytes", rec[0], rec[1], kinds[rec[2] < 8 ? rec[2] : 0], rec[3], rec[4],
+                (unsigned long long)rec[5] | ((unsigned long long)rec[6] << 32), rec[7]);
+}
+
 int32_t dsp_forward(dsp_model* m, void* stream, int64_t n, const void* kmer, int32_t kmer_dtype, const float* means,
                     const float* stds, const void* lens, int32_t lens_dtype, const float* signals,
                     const dsp_init_state* init, float* logits, float* probs, uint8_t* labels) {
     if (!m) return fail(DSP_EINVAL, "model is NULL");
+    const int32_t rc = forward_pieces(m, stream, n, kmer, kmer_dtype, means, stds, lens, lens_dtype, signals, init, logits, probs, labels);
+    if (rc) return rc;
+    return bounds_verdict(m, stream);
+}
+
+static int32_t forward_pieces(dsp_model* m, void* stream, int64_t n, const void* kmer, int32_t kmer_dtype, const float* means,
+                              const float* stds, const void* lens, int32_t lens_dtype, const float* signals,
+                              const dsp_init_state* init, float* logits, float* probs, uint8_t* labels) {
     if (n < 0) return fail(DSP_EINVAL, "n_sites < 0");
     const int mode = init ? init->mode : DSP_INIT_ZEROS;
     const int64_t kRound = 8192, kUnit = 512;
@@ -1085,6 +1179,10 @@ static int32_t forward_chunk(dsp_model* m, void* stream, int64_t n, const void* 
         p.zero_words = m->cflags;
         p.n_zero_words = launches * kClusterWordsPerLaunch;
     }
+    p.xseq_end = rsrc_end(m, p.xseq, (size_t)NTp * d.T * (size_t)(m->Fseq >> 2) * 512);
+    p.xsig_end = rsrc_end(m, p.xsig, (size_t)NTp * d.T * (size_t)(m->Fsig >> 2) * 512);
+    p.zero_words_end = p.zero_words ? (const char*)p.zero_words + (size_t)(m->extents == 2 ? p.n_zero_words : m->n_cflag_words) * sizeof(unsigned int)
+                                    : nullptr;
     L.run("pack", [&] { return dsp_k_pack(&p, s); });
 
     // (fc2 != NULL: both branches' projections in ONE launch -- same shape, disjoint output columns)
@@ -1097,6 +1195,10 @@ static int32_t forward_chunk(dsp_model* m, void* stream, int64_t n, const void* 
         // batches of <= 4,096 sites: one accumulator tile per wave (round 5: 512 sites 35 -> ~12 us per projection; the
         // 8-tile wave of dsp_linear_kernel runs 28 us whatever the batch).  DSP_FC_SMALL=0 turns it off (A/B switch)
         a.small = (m->fc_small && NTp * 2 <= (long long)m->n_cus) ? 1 : 0;
+        const size_t xbytes = (size_t)a.ncols * (size_t)(a.Fin >> 2) * 512, wbytes = (size_t)a.ORT * (size_t)(a.Fin >> 3) * 1024;
+        a.x_end = rsrc_end(m, a.x, xbytes); a.wpk_end = rsrc_end(m, a.wpk, wbytes);
+        a.x2_end = rsrc_end(m, a.x2, xbytes); a.wpk2_end = rsrc_end(m, a.wpk2, wbytes);
+        a.out_end = rsrc_end(m, a.out, (size_t)a.ncols * (size_t)(a.Fout >> 2) * 512);
         L.run(name, [&] { return dsp_k_linear(&a, L.s); });
     };
     // The seq and the signal branch are independent until the combined stack (models.py:181-217).  On batches that leave
@@ -1139,6 +1241,8 @@ static int32_t forward_chunk(dsp_model* m, void* stream, int64_t n, const void* 
     h.x = o; h.w1pk = m->fc1.wpk; h.b1 = m->fc1.bias; h.w2 = m->w2; h.b2 = m->b2;
     h.logits = logits; h.probs = probs; h.labels = labels; h.n = n; h.Hp = m->Hp; h.T = d.T; h.C = d.C;
     h.flags = m->head_st4 ? 1 : 0;
+    h.x_end = rsrc_end(m, h.x, (size_t)NTp * d.T * (size_t)((2 * m->Hp) >> 2) * 512);
+    h.w1pk_end = rsrc_end(m, h.w1pk, (size_t)(m->Hp >> 5) * (size_t)((2 * m->Hp) >> 3) * 1024);
     L.run("head", [&] { return dsp_k_head(&h, s); });
     L.close_bracket();
 
@@ -1172,6 +1276,33 @@ int32_t dsp_debug_read_activation(dsp_model* m, void* stream, int32_t which, int
                 const size_t k4 = ((((size_t)(site / 32) * d.T + t) * (F / 4) + f / 4) * 32 + site % 32) * 4 + f % 4;
                 host_out[((size_t)site * d.T + t) * Fref + map[f]] = tmp[k4];
             }
+    return 0;
+}
+
+int32_t dsp_debug_range_probe(int32_t device, int32_t out[4]) {
+    if (!out) return fail(DSP_EINVAL, "out is NULL");
+    int prev = 0;
+    HIP_TRY(hipGetDevice(&prev));
+    HIP_TRY(hipSetDevice(device));
+    float* buf = nullptr;
+    unsigned* cnt = nullptr;
+    std::vector<float> ones(1024, 1.0f), back(1024, 0.f);
+    unsigned host[3] = {0, 0, 0};
+    hipError_t e = hipMalloc((void**)&buf, 4096);
+    if (e == hipSuccess) e = hipMalloc((void**)&cnt, sizeof host);
+    if (e == hipSuccess) e = hipMemcpy(buf, ones.data(), 4096, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(cnt, 0, sizeof host);
+    if (e == hipSuccess) e = (hipError_t)dsp_k_range_probe(buf, cnt, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(host, cnt, sizeof host, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(back.data(), buf, 4096, hipMemcpyDeviceToHost);
+    if (buf) hipFree(buf);
+    if (cnt) hipFree(cnt);
+    hipSetDevice(prev);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(DSP_EHIP, "dsp_debug_range_probe: %s", hipGetErrorString(e)); }
+    int untouched = 0;
+    for (float v : back) untouched += v == 1.0f ? 1 : 0;
+    out[0] = (int32_t)host[0]; out[1] = (int32_t)host[1]; out[2] = (int32_t)host[2]; out[3] = untouched;
     return 0;
 }
 

@@ -22,6 +22,9 @@ struct PackArgs {
     int is_base, is_siglen;
     int Fseq, Fsig;
     int xoff_seq, xoff_sig;  // first padded feature that carries data (the features sit at the end of a padded block)
+    const void* xseq_end;      // ends of the allocations behind xseq / xsig / zero_words (flat stores: read by the bounds build)
+    const void* xsig_end;
+    const void* zero_words_end;
     unsigned int* zero_words;  // arrival counters of this forward's clustered LSTM launches (dsp_lstmc_kernel): zeroed here, by
     int n_zero_words;          // the first launch of the forward (a kernel boundary orders it before every later launch)
 };
@@ -51,6 +54,17 @@ struct LstmArgs {
     unsigned int* cflags;  // clustered launches (CG > 0): arrival counters of this launch, one per (site tile, direction), 32 words apart
     unsigned long long cluster_timeout;  // s_memtime ticks a member of a cluster waits for the others to become resident before it
                            // abandons the cluster to the clean-up launch
+    // Round 6: the END of the allocation behind every pointer the kernels address through a buffer descriptor (the region of
+    // the handle's workspace, the weight upload): a descriptor's num_records = end - base, so the hardware range check is live on
+    // every operand -- a load past the end returns 0, a store past it is dropped, a wild offset is a parity failure with a test
+    // name instead of a memory fault that ends the process.  The launch wrappers refuse a NULL or inverted end.
+    const void* x_end;
+    const void* out_end;
+    const void* wpk0_end;
+    const void* wpk1_end;
+    const void* h0buf_end;
+    const void* cbuf_end;   // (NULL with cbuf)
+    const void* cflags_end; // (NULL with cflags; the counters are addressed flat: the end is what the bounds build checks)
     int CG;                // 0, or gates per wave of dsp_lstmc_kernel: 4 / 2 / 1 = a (site tile, direction) spread over UT/CG workgroups
     int flags;             // bit 0: issue priority by phase (k-loop 2, cell 0); bit 1: <2 unit tiles, 1 site tile> per wave; bit 2: ... and one such workgroup per CU; bit 3: the workgroup-local form of dsp_lstmc_kernel with eight waves; bit 4: ... as the clean-up launch behind a clustered one (abandoned clusters only); bit 6: the per-wave hand-off of the clustered launches (round 5: arrivals per wave, deferred into the next step's x part; poll one block early); bit 8: stamp this launch, bits 9..11: its stamping wave (DSP_TRACE builds only)
 };
@@ -67,6 +81,12 @@ struct LinArgs {
     const float* wpk2;
     const float* bias2;
     int out_off2;
+    // ends of the allocations behind x / x2 / wpk / wpk2 / out (see LstmArgs)
+    const void* x_end;
+    const void* x2_end;
+    const void* wpk_end;
+    const void* wpk2_end;
+    const void* out_end;
     unsigned nbx;          // workgroups (of 8 column blocks) per problem (set by dsp_k_linear)
     int small;             // 1: dsp_linear1_kernel (one accumulator tile per wave: batches that leave CUs idle)
 };
@@ -80,10 +100,15 @@ struct HeadArgs {
     float* logits;         // [n, C] or NULL
     float* probs;          // [n, C] or NULL
     uint8_t* labels;       // [n] or NULL
+    const void* x_end;     // ends of the allocations behind x / w1pk (see LstmArgs)
+    const void* w1pk_end;
     long long n;
     int Hp, T, C;
     int flags;             // bit 0: keep four site tiles per workgroup whatever the batch (A/B switch DSP_HEAD_ST4=1)
 };
+
+/* operand kinds in a bounds record */
+enum { DSP_BND_W = 1, DSP_BND_X = 2, DSP_BND_OUT = 3, DSP_BND_H0 = 4, DSP_BND_C = 5, DSP_BND_FLAGS = 6, DSP_BND_FLAT_OUT = 7 };
 
 #ifdef __cplusplus
 extern "C" {
@@ -95,6 +120,14 @@ int dsp_k_lstm6(const LstmArgs* a, int nprod, hipStream_t s);
 int dsp_k_linear(const LinArgs* a, hipStream_t s);
 int dsp_k_head(const HeadArgs* a, hipStream_t s);
 int dsp_k_probe_xcc(unsigned* dev_out, int blocks, hipStream_t s);   /* out[b] = XCC_ID block b ran on */
+int dsp_k_range_probe(float* dev_buf4k, unsigned* dev_out, hipStream_t s);   /* see dsp_debug_range_probe */
+/* 1 in the bounds-recording build (make bounds -> libdsp_amd_bounds.so), else 0 */
+int dsp_k_bounds_build(void);
+/* bounds build: the first out-of-range access recorded since the last read (and clears it); rec[0] = accesses out of range
+   (0: none), rec[1] = source line of the access, rec[2] = which operand (DSP_BND_*), rec[3] = workgroup, rec[4] = thread,
+   rec[5] / rec[6] = byte offset from the descriptor's base (low / high word), rec[7] = the descriptor's extent in bytes.
+   Returns a hipError_t; all zeros in the product build. */
+int dsp_k_bounds_read(unsigned rec[8]);
 #ifdef __cplusplus
 }
 #endif

@@ -18,7 +18,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <initializer_list>
 #include <type_traits>
+#include <utility>
 
 #include "dsp_kernels.h"
 
@@ -44,6 +46,73 @@ __device__ __forceinline__ void gst16(f32x4* p, f32x4 v) {  // a plain 16-byte g
     *p = v;
     store_data_guard(v);
 }
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// Buffer descriptors with REAL extents (round 6).  Until round 5 every descriptor was a 2 GiB window from
+// wherever the workgroup's base landed (num_records 0x7ffffff0): the hardware range check was switched off, and an offset
+// gone wrong would have faulted the process (HSA's memory-access-fault abort: no test name, no message from this library).
+// Now num_records = the bytes left in the allocation behind the base (`end` travels in the argument blocks: the region of
+// the handle's workspace the pointer lies in, or the weight upload): a load past it returns 0 and a store past it is
+// dropped.  Costs one s_sub / s_min per descriptor in the prologue, nothing in the MFMA stream (the descriptor words are
+// SGPRs either way).  A base at or past its end gives num_records 0: every access through it is out of range.
+//   DSP_BOUNDS builds (make bounds -> libdsp_amd_bounds.so, never the product): every access through a descriptor is also
+// compared with the extent in software, exactly as the address unit forms it -- voffset + soffset without wrapping at 32 bits
+// -- and the first offender is recorded (source line, operand, workgroup, thread, offset, extent) for dsp_forward to return as
+// DSP_EBOUNDS; the host passes the TIGHT logical extents of the call there (this call's tiles, this layer's weights).
+constexpr long long kRsrcMax = 0x7ffffff0ll;   // (a workgroup never reaches 2 GiB past its base)
+__device__ __forceinline__ uint32_t rsrc_records(const void* base, const void* end) {
+    // (32-bit scalar compares on the two halves of end - base: a 64-bit signed compare is a VALU instruction on this target,
+    // its result a lane mask in an SGPR pair -- enough extra scalar pressure to spill SGPRs in the widest kernels)
+    const unsigned long long left = (unsigned long long)end - (unsigned long long)base;   // wraps above 2^63 when base > end
+    uint32_t lo = (uint32_t)left, hi = (uint32_t)(left >> 32);
+    asm("" : "+s"(lo), "+s"(hi));   // (the halves stay apart, in SGPRs: hipcc otherwise folds the tests back into 64-bit VALU compares)
+    const uint32_t in32 = lo < (uint32_t)kRsrcMax ? lo : (uint32_t)kRsrcMax;
+    return hi == 0u ? in32 : ((int32_t)hi < 0 ? 0u : (uint32_t)kRsrcMax);
+}
+#ifdef DSP_BOUNDS
+struct rsrc_t { __amdgpu_buffer_rsrc_t r; uint32_t nrec; int kind; };
+__device__ unsigned int g_bounds[8];
+__device__ __forceinline__ void bounds_note(int line, int kind, unsigned long long off, uint32_t nrec) {
+    if (atomicAdd(&g_bounds[0], 1u) == 0u) {
+        g_bounds[1] = (unsigned)line; g_bounds[2] = (unsigned)kind; g_bounds[3] = blockIdx.x; g_bounds[4] = threadIdx.x;
+        g_bounds[5] = (unsigned)off; g_bounds[6] = (unsigned)(off >> 32); g_bounds[7] = nrec;
+    }
+}
+__device__ __forceinline__ void bounds_check(const rsrc_t& r, uint32_t voff, uint32_t soff, int line) {
+    const unsigned long long off = (unsigned long long)voff + (unsigned long long)soff;   // as the address unit adds them
+    if (off + 16ull > (unsigned long long)r.nrec) bounds_note(line, r.kind, off, r.nrec);
+}
+// a flat (pointer) access of `bytes` at p against the end of its allocation
+__device__ __forceinline__ void bounds_flat(const void* p, size_t bytes, const void* base, const void* end, int kind, int line) {
+    if ((const char*)p < (const char*)base || (const char*)p + bytes > (const char*)end)
+        bounds_note(line, kind, (unsigned long long)((const char*)p - (const char*)base), rsrc_records(base, end));
+}
+#define BOUNDS_FLAT(p, bytes, base, end, kind) bounds_flat((p), (bytes), (base), (end), (kind), __LINE__)
+#define RS(x) ((x).r)
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, const void* end, int kind) {
+    const uint32_t n = rsrc_records(base, end);
+    return rsrc_t{__builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)n, 0x00020000), n, kind};
+}
+#else
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+#define BOUNDS_FLAT(p, bytes, base, end, kind) do { } while (0)
+#define RS(x) (x)
+__device__ __forceinline__ void bounds_check(const rsrc_t&, uint32_t, uint32_t, int) {}
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, const void* end, int /*kind*/) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)rsrc_records(base, end), 0x00020000);
+}
+#endif
+__device__ __forceinline__ f32x4 bld16_(const rsrc_t& r, uint32_t voff, uint32_t soff, int line) {
+    bounds_check(r, voff, soff, line);
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(RS(r), (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void bst16_(const rsrc_t& r, uint32_t voff, uint32_t soff, f32x4 v, int line) {
+    bounds_check(r, voff, soff, line);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), RS(r), (int)voff, (int)soff, 0);
+    store_data_guard(v);
+}
+#define bld16(r, voff, soff) bld16_((r), (voff), (soff), __LINE__)
+#define bst16(r, voff, soff, v) bst16_((r), (voff), (soff), (v), __LINE__)
 
 // ------------------------------------------------------------------------------------------------
 // math helpers: v_exp_f32 / v_rcp_f32 based (about 1 ulp each); abs error of sigmoid/tanh ~1e-7
@@ -129,7 +198,10 @@ __global__ __launch_bounds__(256) void dsp_pack_kernel(PackArgs a) {
     // the arrival counters of this forward's clustered LSTM launches start from zero (first launch of the forward: the
     // kernel boundary orders these stores before every later launch)
     if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < a.n_zero_words; i += 256) a.zero_words[i] = 0u;
+        for (int i = threadIdx.x; i < a.n_zero_words; i += 256) {
+            BOUNDS_FLAT(&a.zero_words[i], 4, a.zero_words, a.zero_words_end, DSP_BND_FLAGS);
+            a.zero_words[i] = 0u;
+        }
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const int sl = (int)(idx & 31);
     const long long rem = idx >> 5;
@@ -166,6 +238,7 @@ __global__ __launch_bounds__(256) void dsp_pack_kernel(PackArgs a) {
                 }
                 v[i] = x;
             }
+            BOUNDS_FLAT(&dst[(size_t)g * 32], 16, a.xseq, a.xseq_end, DSP_BND_FLAT_OUT);
             gst16(&dst[(size_t)g * 32], v);
         }
     }
@@ -179,6 +252,7 @@ __global__ __launch_bounds__(256) void dsp_pack_kernel(PackArgs a) {
                 const int f = 4 * g + i - a.xoff_sig;
                 v[i] = (live && f >= 0 && f < a.S) ? src[f] : 0.f;
             }
+            BOUNDS_FLAT(&dst[(size_t)g * 32], 16, a.xsig, a.xsig_end, DSP_BND_FLAT_OUT);
             gst16(&dst[(size_t)g * 32], v);
         }
     }
@@ -273,17 +347,6 @@ __device__ __forceinline__ f32x4 init_state4(const float* src, int mode, long lo
 // not the issue.  A 16-feature padding with a re-request of the h-part slots after the barrier was measured in round 2:
 // +0.6 % on the front-end launches, noise level; not kept.)
 // ------------------------------------------------------------------------------------------------
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7ffffff0, 0x00020000);
-}
-__device__ __forceinline__ f32x4 bld16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
-}
-__device__ __forceinline__ void bst16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, f32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, (int)soff, 0);
-    store_data_guard(v);
-}
 
 template <int N> using ic = std::integral_constant<int, N>;
 
@@ -357,13 +420,13 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
 
     // first site tile of this wave; its two tiles are adjacent, so one descriptor per buffer serves both
     const long long gt0 = ((long long)grp * a.SG + sg) * 2;
-    const __amdgpu_buffer_rsrc_t rw = make_rsrc((const char*)(dir ? a.wpk1 : a.wpk0) + (size_t)ug * NQ * 4096);
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)a.x + (size_t)gt0 * T * xrow);
-    const __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)a.out + (size_t)gt0 * T * orow + (size_t)dir * HQ * 512);
-    const __amdgpu_buffer_rsrc_t rh0 = make_rsrc((const char*)a.h0buf + (size_t)gt0 * orow + (size_t)dir * HQ * 512);
+    const rsrc_t rw = make_rsrc((const char*)(dir ? a.wpk1 : a.wpk0) + (size_t)ug * NQ * 4096, dir ? a.wpk1_end : a.wpk0_end, DSP_BND_W);
+    const rsrc_t rx = make_rsrc((const char*)a.x + (size_t)gt0 * T * xrow, a.x_end, DSP_BND_X);
+    const rsrc_t ro = make_rsrc((const char*)a.out + (size_t)gt0 * T * orow + (size_t)dir * HQ * 512, a.out_end, DSP_BND_OUT);
+    const rsrc_t rh0 = make_rsrc((const char*)a.h0buf + (size_t)gt0 * orow + (size_t)dir * HQ * 512, a.h0buf_end, DSP_BND_H0);
     const f32x4* bias4 = (const f32x4*)(dir ? a.sbias1 : a.sbias0);
     // CG: this workgroup's slice of the cell-state scratch, [pass][2 site tiles][4 groups][nthr] float4
-    const __amdgpu_buffer_rsrc_t rc = make_rsrc((const char*)a.cbuf + (CG ? (size_t)blockIdx.x * (size_t)np * 8 * nthr * 16 : 0));
+    const rsrc_t rc = make_rsrc((const char*)a.cbuf + (CG ? (size_t)blockIdx.x * (size_t)np * 8 * nthr * 16 : 0), a.cbuf_end, DSP_BND_C);
     auto c_off = [&](int p, int m, int aa) __attribute__((always_inline)) {
         return (uint32_t)((((p * 2 + m) * 4 + aa) * nthr + w * 64) * 16);
     };
@@ -399,7 +462,7 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
 
     // B-operand source of a step (all uniform): x_t from rx, h_{t-1} from the K4 output of the previous step
     // (ro) or, at step 0, from the h0 scratch (rh0).  Offsets are biased so that both parts are "base + q*1024".
-    __amdgpu_buffer_rsrc_t rhp = rh0;
+    rsrc_t rhp = rh0;
     uint32_t xo[2], ho[2];
     auto set_bases = [&](int step) __attribute__((always_inline)) {
         const int t = dir ? (T - 1 - step) : step;
@@ -417,7 +480,7 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
     auto loadB = [&](f32x4 (&Bs)[2], int q) __attribute__((always_inline)) {
         const int qc = q < nq ? q : nq - 1;  // padded k-groups have zero weights: any finite B will do
         const bool isx = qc < nqx;
-        const __amdgpu_buffer_rsrc_t r = isx ? rx : rhp;
+        const rsrc_t r = isx ? rx : rhp;
 #pragma unroll
         for (int m = 0; m < 2; ++m) Bs[m] = bld16(r, voff, (isx ? xo[m] : ho[m]) + (uint32_t)qc * 1024u);
     };
@@ -610,10 +673,10 @@ __global__ __launch_bounds__(256, 2) void dsp_lstm21_kernel(LstmArgs a) {
     const int u0 = 2 * ug;
 
     const long long gt0 = (long long)grp * a.SG + sg;   // this wave's site tile
-    const __amdgpu_buffer_rsrc_t rw = make_rsrc((const char*)(dir ? a.wpk1 : a.wpk0) + (size_t)u0 * NQ * 4096);
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)a.x + (size_t)gt0 * T * xrow);
-    const __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)a.out + (size_t)gt0 * T * orow + (size_t)dir * HQ * 512);
-    const __amdgpu_buffer_rsrc_t rh0 = make_rsrc((const char*)a.h0buf + (size_t)gt0 * orow + (size_t)dir * HQ * 512);
+    const rsrc_t rw = make_rsrc((const char*)(dir ? a.wpk1 : a.wpk0) + (size_t)u0 * NQ * 4096, dir ? a.wpk1_end : a.wpk0_end, DSP_BND_W);
+    const rsrc_t rx = make_rsrc((const char*)a.x + (size_t)gt0 * T * xrow, a.x_end, DSP_BND_X);
+    const rsrc_t ro = make_rsrc((const char*)a.out + (size_t)gt0 * T * orow + (size_t)dir * HQ * 512, a.out_end, DSP_BND_OUT);
+    const rsrc_t rh0 = make_rsrc((const char*)a.h0buf + (size_t)gt0 * orow + (size_t)dir * HQ * 512, a.h0buf_end, DSP_BND_H0);
     const f32x4* bias4 = (const f32x4*)(dir ? a.sbias1 : a.sbias0);
 
     for (int i = tid; i < a.Hp; i += nthr) {
@@ -641,7 +704,7 @@ __global__ __launch_bounds__(256, 2) void dsp_lstm21_kernel(LstmArgs a) {
     }
     barrier_after_global_stores();
 
-    __amdgpu_buffer_rsrc_t rhp = rh0;
+    rsrc_t rhp = rh0;
     uint32_t xo = 0, ho = 0;
     auto set_bases = [&](int step) __attribute__((always_inline)) {
         const int t = dir ? (T - 1 - step) : step;
@@ -765,13 +828,17 @@ __global__ __launch_bounds__(256, 2) void dsp_lstm21_kernel(LstmArgs a) {
 // Requirements (host-checked): 8 unit tiles (hidden 193..256), no padded k-groups, nqx a multiple of D and >= 2 D.
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(1))) unsigned int gu32;
-__device__ __forceinline__ f32x4 bld16_sc1(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 16));   // aux 16 = sc1
+__device__ __forceinline__ f32x4 bld16_sc1_(const rsrc_t& r, uint32_t voff, uint32_t soff, int line) {
+    bounds_check(r, voff, soff, line);
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(RS(r), (int)voff, (int)soff, 16));   // aux 16 = sc1
 }
-__device__ __forceinline__ void bst16_sc1(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, f32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, (int)soff, 16);
+__device__ __forceinline__ void bst16_sc1_(const rsrc_t& r, uint32_t voff, uint32_t soff, f32x4 v, int line) {
+    bounds_check(r, voff, soff, line);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), RS(r), (int)voff, (int)soff, 16);
     store_data_guard(v);
 }
+#define bld16_sc1(r, voff, soff) bld16_sc1_((r), (voff), (soff), __LINE__)
+#define bst16_sc1(r, voff, soff, v) bst16_sc1_((r), (voff), (soff), (v), __LINE__)
 constexpr unsigned kClusterAbandon = 0x80000000u;
 // wait until `target` arrivals have been counted (every wave polls for itself: no workgroup barrier inside the k-loop).
 // Returns false when the cluster was given up: a member that sees no progress for seconds (a member that never became
@@ -852,17 +919,17 @@ __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, co
     const uint32_t orow = (uint32_t)F4 * 512u;
     const bool prio = (a.flags & 1) != 0;
 
-    const __amdgpu_buffer_rsrc_t rw = make_rsrc((const char*)(dir ? a.wpk1 : a.wpk0) + (size_t)u * NQ * 4096);
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)a.x + (size_t)gt0 * T * xrow);
-    const __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)a.out + (size_t)gt0 * T * orow + (size_t)dir * HQ * 512);
-    const __amdgpu_buffer_rsrc_t rh0 = make_rsrc((const char*)a.h0buf + (size_t)gt0 * orow + (size_t)dir * HQ * 512);
+    const rsrc_t rw = make_rsrc((const char*)(dir ? a.wpk1 : a.wpk0) + (size_t)u * NQ * 4096, dir ? a.wpk1_end : a.wpk0_end, DSP_BND_W);
+    const rsrc_t rx = make_rsrc((const char*)a.x + (size_t)gt0 * T * xrow, a.x_end, DSP_BND_X);
+    const rsrc_t ro = make_rsrc((const char*)a.out + (size_t)gt0 * T * orow + (size_t)dir * HQ * 512, a.out_end, DSP_BND_OUT);
+    const rsrc_t rh0 = make_rsrc((const char*)a.h0buf + (size_t)gt0 * orow + (size_t)dir * HQ * 512, a.h0buf_end, DSP_BND_H0);
     const f32x4* bias4 = (const f32x4*)(dir ? a.sbias1 : a.sbias0);
     const uint32_t voffA = voff + (uint32_t)(gs * G) * 1024u;   // this wave's gates within a k-group's 4 KiB of weights
     const uint32_t voffO = voff + (uint32_t)(gs * G) * 1024u;   // this wave's row groups within a unit tile's 4 KiB of h
 
     // (the rings are filled FIRST: weights and x rows depend on nothing computed here, and their round trip runs under the
     // Philox / Box-Muller work of the initial states below instead of behind it)
-    __amdgpu_buffer_rsrc_t rhp = rh0;
+    rsrc_t rhp = rh0;
     uint32_t xo = 0, ho = 0;
     auto set_bases = [&](int step) __attribute__((always_inline)) {
         const int t = dir ? (T - 1 - step) : step;
@@ -1163,6 +1230,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dsp_lstmc_kernel(LstmArgs a) {
     const int dir = (int)(c & 1);
     const long long gt0 = c >> 1;
     gu32* flag = (gu32*)a.cflags + c * 32;   // word 0: arrivals of the steps; word 1: admission (count | abandoned)
+    if (!LOCAL || (a.flags & 16)) BOUNDS_FLAT((const unsigned*)a.cflags + c * 32, 8, a.cflags, a.cflags_end, DSP_BND_FLAGS);
     if constexpr (LOCAL) {
         // the clean-up launch behind a clustered one (flags bit 4): only the clusters that were abandoned are computed here
         if ((a.flags & 16) && !(__hip_atomic_load(flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kClusterAbandon)) return;
@@ -1250,10 +1318,10 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm6_kernel(LstmArgs a) {
     const uint32_t xvoff = (uint32_t)half * 1024u + (uint32_t)ls * 16u;
 
     const long long gt0 = (long long)grp * (a.SG * 2) + sg * 2;
-    const __amdgpu_buffer_rsrc_t rw = make_rsrc((const char*)(dir ? a.wpk1 : a.wpk0) + (size_t)u * NQ * (4096 * NP));
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)a.x + (size_t)gt0 * T * xrow);
-    const __amdgpu_buffer_rsrc_t ro = make_rsrc((const char*)a.out + (size_t)gt0 * T * orow + (size_t)dir * HQ * 512);
-    const __amdgpu_buffer_rsrc_t rh0 = make_rsrc((const char*)a.h0buf + (size_t)gt0 * orow + (size_t)dir * HQ * 512);
+    const rsrc_t rw = make_rsrc((const char*)(dir ? a.wpk1 : a.wpk0) + (size_t)u * NQ * (4096 * NP), dir ? a.wpk1_end : a.wpk0_end, DSP_BND_W);
+    const rsrc_t rx = make_rsrc((const char*)a.x + (size_t)gt0 * T * xrow, a.x_end, DSP_BND_X);
+    const rsrc_t ro = make_rsrc((const char*)a.out + (size_t)gt0 * T * orow + (size_t)dir * HQ * 512, a.out_end, DSP_BND_OUT);
+    const rsrc_t rh0 = make_rsrc((const char*)a.h0buf + (size_t)gt0 * orow + (size_t)dir * HQ * 512, a.h0buf_end, DSP_BND_H0);
     const f32x4* bias4 = (const f32x4*)(dir ? a.sbias1 : a.sbias0);
 
     for (int i = tid; i < a.Hp; i += blockDim.x) {
@@ -1281,7 +1349,7 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm6_kernel(LstmArgs a) {
     }
     barrier_after_global_stores();  // h0 stored before any wave reads it back
 
-    __amdgpu_buffer_rsrc_t rhp = rh0;
+    rsrc_t rhp = rh0;
     uint32_t xo[2], ho[2];
     auto set_bases = [&](int step) __attribute__((always_inline)) {
         const int t = dir ? (T - 1 - step) : step;
@@ -1299,7 +1367,7 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm6_kernel(LstmArgs a) {
     f32x16 acc[4][2];
     auto loadX = [&](int q) __attribute__((always_inline)) {
         const bool isx = q < nqx;
-        const __amdgpu_buffer_rsrc_t r = isx ? rx : rhp;
+        const rsrc_t r = isx ? rx : rhp;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             // never form a negative intermediate: the buffer unit adds voffset + soffset + imm without wrapping at 32 bits
@@ -1415,8 +1483,8 @@ __global__ __launch_bounds__(256, 2) void dsp_linear_kernel(LinArgs a) {
     const int nq = a.Fin >> 3;   // a multiple of 8 (Fin = 2*Hp, Hp a multiple of 32)
     const int nrt = a.ORT - rt0 < 4 ? a.ORT - rt0 : 4;
     const uint32_t xrow = (uint32_t)(a.Fin >> 2) * 512u;  // bytes of one column block of the input
-    const __amdgpu_buffer_rsrc_t rw = make_rsrc((const char*)(second ? a.wpk2 : a.wpk) + (size_t)rt0 * nq * 1024);
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)(second ? a.x2 : a.x) + (size_t)col0 * xrow);
+    const rsrc_t rw = make_rsrc((const char*)(second ? a.wpk2 : a.wpk) + (size_t)rt0 * nq * 1024, second ? a.wpk2_end : a.wpk_end, DSP_BND_W);
+    const rsrc_t rx = make_rsrc((const char*)(second ? a.x2 : a.x) + (size_t)col0 * xrow, second ? a.x2_end : a.x_end, DSP_BND_X);
     const uint32_t wrow = (uint32_t)nq * 1024u;           // bytes between row tiles
     const uint32_t x1 = two ? xrow : 0u;                  // a lone last column block is computed twice, stored once
     const f32x4* bias4 = (const f32x4*)(second ? a.bias2 : a.bias);
@@ -1492,6 +1560,7 @@ __global__ __launch_bounds__(256, 2) void dsp_linear_kernel(LinArgs a) {
                     const float y = acc[r][c][4 * aa + i];
                     v[i] = a.relu ? fmaxf(y, 0.f) : y;
                 }
+                BOUNDS_FLAT(&out4[(size_t)((rt0 + r) * 8 + aa * 2) * 32], 16, a.out, a.out_end, DSP_BND_FLAT_OUT);
                 gst16(&out4[(size_t)((rt0 + r) * 8 + aa * 2) * 32], v);
             }
         }
@@ -1514,8 +1583,8 @@ __global__ __launch_bounds__(256, 2) void dsp_linear1_kernel(LinArgs a) {
     if (col >= a.ncols || rt >= a.ORT) return;
     const int nq = a.Fin >> 3;   // a multiple of 8
     const uint32_t xrow = (uint32_t)(a.Fin >> 2) * 512u;
-    const __amdgpu_buffer_rsrc_t rw = make_rsrc((const char*)(second ? a.wpk2 : a.wpk) + (size_t)rt * nq * 1024);
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)(second ? a.x2 : a.x) + (size_t)col * xrow);
+    const rsrc_t rw = make_rsrc((const char*)(second ? a.wpk2 : a.wpk) + (size_t)rt * nq * 1024, second ? a.wpk2_end : a.wpk_end, DSP_BND_W);
+    const rsrc_t rx = make_rsrc((const char*)(second ? a.x2 : a.x) + (size_t)col * xrow, second ? a.x2_end : a.x_end, DSP_BND_X);
     const f32x4* bias4 = (const f32x4*)(second ? a.bias2 : a.bias);
     const int out_off = second ? a.out_off2 : a.out_off;
     f32x16 acc;
@@ -1553,6 +1622,7 @@ __global__ __launch_bounds__(256, 2) void dsp_linear1_kernel(LinArgs a) {
             const float y = acc[4 * aa + i];
             v[i] = a.relu ? fmaxf(y, 0.f) : y;
         }
+        BOUNDS_FLAT(&out4[(size_t)(rt * 8 + aa * 2) * 32], 16, a.out, a.out_end, DSP_BND_FLAT_OUT);
         gst16(&out4[(size_t)(rt * 8 + aa * 2) * 32], v);
     }
 }
@@ -1590,8 +1660,8 @@ __global__ __launch_bounds__(256, 2) void dsp_head_kernel(HeadArgs a) {
     // every operand through a buffer descriptor + SGPR offset + lane*16, like the LSTM kernel: no 64-bit pointer VGPRs
     const uint32_t voff = (uint32_t)lane * 16u;
     const uint32_t xrow = (uint32_t)F4 * 512u;                           // bytes of one (tile, t) block
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc((const char*)a.x + tile0 * a.T * (size_t)xrow);
-    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.w1pk);
+    const rsrc_t rx = make_rsrc((const char*)a.x + tile0 * a.T * (size_t)xrow, a.x_end, DSP_BND_X);
+    const rsrc_t rw = make_rsrc(a.w1pk, a.w1pk_end, DSP_BND_W);
     uint32_t xfo[kHeadST], xro[kHeadST];                                 // h_fwd at t = T-1, h_bwd at t = 0
 #pragma unroll
     for (int st = 0; st < kHeadST; ++st) {
@@ -1745,6 +1815,32 @@ extern "C" int dsp_k_probe_xcc(unsigned* dev_out, int blocks, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+// What does the hardware do with an access past a descriptor's num_records?  (dsp_debug_range_probe: the test that the range
+// check the extents rely on is really there, and that the SGPR offset -- where these kernels carry almost all of an address --
+// takes part in it.)  buf: 4 KiB of 1.0f, all mapped; the descriptor covers its first 256 bytes.
+__global__ void dsp_range_probe_kernel(float* buf, unsigned* out) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)buf, 0, (int)rsrc_records(buf, (const char*)buf + 256), 0x00020000);
+    const uint32_t lane16 = threadIdx.x * 16u;   // one wave: lanes 0..63 -> voffset 0..1008
+    const uint32_t s256 = __builtin_amdgcn_readfirstlane(256u), s512 = __builtin_amdgcn_readfirstlane(512u);
+    const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane16, 0, 0));        // lanes 0..15 in range
+    const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane16, (int)s256, 0)); // all past the end by soffset
+    // stores: every lane writes 2.0f at voffset + 512 (soffset): all out of range -> dropped
+    const f32x4 two = {2.f, 2.f, 2.f, 2.f};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, two), r, (int)lane16, (int)s512, 0);
+    store_data_guard(two);
+    unsigned in_ok = 0, v_oob_zero = 0, s_oob_zero = 0;
+    if (threadIdx.x < 16) in_ok = (a[0] == 1.f && a[1] == 1.f && a[2] == 1.f && a[3] == 1.f) ? 1u : 0u;
+    else v_oob_zero = (a[0] == 0.f && a[1] == 0.f && a[2] == 0.f && a[3] == 0.f) ? 1u : 0u;
+    s_oob_zero = (b[0] == 0.f && b[1] == 0.f && b[2] == 0.f && b[3] == 0.f) ? 1u : 0u;
+    atomicAdd(&out[0], in_ok);        // 16: every in-range lane read its data
+    atomicAdd(&out[1], v_oob_zero);   // 48: every lane past the end by VOFFSET read zeros
+    atomicAdd(&out[2], s_oob_zero);   // 64: every lane past the end by SOFFSET read zeros
+}
+extern "C" int dsp_k_range_probe(float* dev_buf4k, unsigned* dev_out, hipStream_t s) {
+    hipLaunchKernelGGL(dsp_range_probe_kernel, dim3(1), dim3(64), 0, s, dev_buf4k, dev_out);
+    return (int)hipGetLastError();
+}
+
 extern "C" int dsp_k_init(void) {
     const void* fns[] = {(const void*)dsp_lstm_kernel<0, 1>, (const void*)dsp_lstm_kernel<1, 1>,
                          (const void*)dsp_lstm_kernel<2, 1, 1>, (const void*)dsp_lstm_kernel<2, 1, 2>, (const void*)dsp_lstm_kernel<2, 1, 3>,
@@ -1766,6 +1862,42 @@ extern "C" int dsp_k_init(void) {
     return (int)hipFuncSetAttribute((const void*)dsp_head_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
 }
 
+// every pointer that is addressed through a buffer descriptor comes with the end of its allocation: a NULL or inverted end
+// would make a descriptor of zero records (loads of zeros, dropped stores -- silently wrong results), so it is refused here
+static bool ends_ok(std::initializer_list<std::pair<const void*, const void*>> v) {
+    for (const auto& pe : v)
+        if (pe.first && (!pe.second || (const char*)pe.second <= (const char*)pe.first)) return false;
+    return true;
+}
+static bool lstm_ends_ok(const LstmArgs* a) {
+    return a->x && a->out && a->wpk0 && a->wpk1 && a->h0buf &&
+           ends_ok({{a->x, a->x_end}, {a->out, a->out_end}, {a->wpk0, a->wpk0_end}, {a->wpk1, a->wpk1_end}, {a->h0buf, a->h0buf_end},
+                    {a->cflags, a->cflags_end}}) &&
+           (!a->cbuf || (a->cbuf_end && (const char*)a->cbuf_end >= (const char*)a->cbuf));   // (an empty cell-state scratch is legal)
+}
+
+extern "C" int dsp_k_bounds_build(void) {
+#ifdef DSP_BOUNDS
+    return 1;
+#else
+    return 0;
+#endif
+}
+extern "C" int dsp_k_bounds_read(unsigned rec[8]) {
+#ifdef DSP_BOUNDS
+    hipError_t e = hipMemcpyFromSymbol(rec, HIP_SYMBOL(g_bounds), sizeof(unsigned) * 8);
+    if (e != hipSuccess) return (int)e;
+    if (rec[0]) {
+        const unsigned zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_bounds), zero, sizeof zero);
+    }
+    return (int)e;
+#else
+    for (int i = 0; i < 8; ++i) rec[i] = 0;
+    return 0;
+#endif
+}
+
 extern "C" int dsp_k_pack(const PackArgs* a, hipStream_t s) {
     const long long threads = (long long)a->NTp * a->T * 32;
     const unsigned blocks = (unsigned)((threads + 255) / 256);
@@ -1775,6 +1907,7 @@ extern "C" int dsp_k_pack(const PackArgs* a, hipStream_t s) {
 
 // a wave owns one unit tile (per pass) x two site tiles; a->SG site groups (of two tiles) per workgroup; a->NP passes
 extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
+    if (!lstm_ends_ok(a)) return (int)hipErrorInvalidValue;
     if (a->CG > 0) {
         // a (site tile, direction) spread over a cluster of UT / CG workgroups (dsp_lstmc_kernel); the caller has checked the
         // residency.  CG = 4 with 4 unit tiles: the workgroup holds the whole layer (the front ends at hidden 128), no counters
@@ -1878,6 +2011,7 @@ extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
 
 // split variants: a->wpk0/1 = split weights, a->NQ = k-stages of 16, nprod = 6 / 9 (bf16 pieces) or 3 (fp16 pieces)
 extern "C" int dsp_k_lstm6(const LstmArgs* a, int nprod, hipStream_t s) {
+    if (!lstm_ends_ok(a)) return (int)hipErrorInvalidValue;
     const int waves = a->UT * a->SG;
     const unsigned groups = (unsigned)(a->NTp / (a->SG * 2));
     const size_t lds = (size_t)8 * 512 * 16 + (size_t)a->Hp * 16;
@@ -1888,6 +2022,9 @@ extern "C" int dsp_k_lstm6(const LstmArgs* a, int nprod, hipStream_t s) {
 }
 
 extern "C" int dsp_k_linear(const LinArgs* a, hipStream_t s) {
+    if (!a->x || !a->wpk || !a->out || (a->x2 && !a->wpk2) ||
+        !ends_ok({{a->x, a->x_end}, {a->wpk, a->wpk_end}, {a->x2, a->x2_end}, {a->wpk2, a->wpk2_end}, {a->out, a->out_end}}))
+        return (int)hipErrorInvalidValue;
     if (a->small) {   // batches that leave CUs idle: one accumulator tile per wave (dsp_linear1_kernel)
         LinArgs b = *a;
         b.nbx = (unsigned)a->ncols;
@@ -1902,6 +2039,7 @@ extern "C" int dsp_k_linear(const LinArgs* a, hipStream_t s) {
 }
 
 extern "C" int dsp_k_head(const HeadArgs* a, hipStream_t s) {
+    if (!a->x || !a->w1pk || !ends_ok({{a->x, a->x_end}, {a->w1pk, a->w1pk_end}})) return (int)hipErrorInvalidValue;
     // batches of a few thousand sites: one site tile per workgroup (four times the workgroups, deeper operand rings)
     const bool small = a->n <= 4096 && !(a->flags & 1);
     const int st = small ? 1 : 4;

@@ -22,7 +22,8 @@
 extern "C" {
 #endif
 
-#define DSP_AMD_ABI_VERSION 2   /* 2: dsp_init_state.site_keys */
+#define DSP_AMD_ABI_VERSION 3   /* 2: dsp_init_state.site_keys; 3: dsp_model_query, dsp_device_pci_bdf / _uuid, dsp_profile_enable
+                                   mode 2 (round 5's additions, numbered in round 6), DSP_EBOUNDS */
 
 typedef enum dsp_status {
     DSP_OK = 0,
@@ -31,8 +32,12 @@ typedef enum dsp_status {
     DSP_EHIP = -3,        /* HIP runtime error (message carries hipGetErrorString) */
     DSP_ENOMEM = -4,      /* host or device allocation failure */
     DSP_EPARSE = -5,      /* malformed feature row (reference: ValueError in the row parser) */
-    DSP_EKEY = -6         /* a base letter outside base2code_dna (reference: KeyError, call_modifications.py:84); the message
+    DSP_EKEY = -6,        /* a base letter outside base2code_dna (reference: KeyError, call_modifications.py:84); the message
                              starts with the quoted letter */
+    DSP_EBOUNDS = -7      /* only from the bounds-recording debug build (libdsp_amd_bounds.so, `make bounds`): a kernel of the
+                             forward addressed memory outside the extent of its operand; the message names the source line, the
+                             operand, the workgroup, the thread, the offset and the extent.  The product library cannot return it:
+                             there the hardware range check of the buffer descriptors drops such an access (loads return 0). */
 } dsp_status;
 
 /* module codes: ModelBiLSTM(module=...) at deepsignal_plant/models.py:120-128 */
@@ -512,6 +517,13 @@ int32_t dsp_model_query(const dsp_model* m, int32_t what);
  * the runtime does not know the device; dsp_device_uuid writes the 16 bytes of hipDeviceProp_t::uuid as 32 hex digits. */
 int64_t dsp_device_pci_bdf(int32_t device, char* out, size_t cap);
 int64_t dsp_device_uuid(int32_t device, char* out, size_t cap);
+
+/* Test hook (round 6): what this device does with an access past a buffer descriptor's num_records -- the hardware range
+ * check the forward's descriptors rely on since they carry real extents.  One wave reads 1,024 bytes of ones through a
+ * descriptor of 256 bytes: out[0] = lanes inside the extent that read their data (expect 16), out[1] = lanes past it by VGPR
+ * offset that read zeros (48), out[2] = lanes past it by SGPR offset that read zeros (64: the kernels carry almost all of an
+ * address there), out[3] = floats of the 4 KiB buffer still 1.0 after 64 out-of-range stores (1,024: dropped). */
+int32_t dsp_debug_range_probe(int32_t device, int32_t out[4]);
 
 const char* dsp_last_error(void);
 int32_t dsp_abi_version(void);

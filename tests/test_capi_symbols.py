@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 10
     for s in syms:
         assert hasattr(lib, s), "libdsp_amd.so does not export %s" % s
-    assert lib.dsp_abi_version() == 2
+    assert lib.dsp_abi_version() == 3
 
 
 def test_weight_spec_and_flops_match_oracle_spec():

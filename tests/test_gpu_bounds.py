@@ -1,0 +1,64 @@
+"""GPU: buffer descriptors with real extents (round 6).
+
+  * the hardware does range-check: a load past num_records returns zeros, a store past it is dropped -- by VGPR offset AND by
+    SGPR offset (where the kernels carry almost all of an address);
+  * the product library gives the same bytes with the extents of the allocation (default), the tight extents of the call, and
+    the 2 GiB windows of rounds 1-5, over every kernel form (tools/extents_sweep.py: 11 model shapes, 45 batch sizes, four
+    precisions, Philox / explicit / zero states);
+  * the bounds-recording build (libdsp_amd_bounds.so: every descriptor access compared in software with the TIGHT extent of
+    its operand) runs the same sweep without a record and with the same bytes;
+  * negative control: with 4 KiB taken off every LSTM launch's input extent the bounds build returns DSP_EBOUNDS naming the
+    operand, the source line, the workgroup and the offset."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests.helpers import ROOT
+
+pytestmark = pytest.mark.gpu
+BOUNDS_LIB = os.path.join(ROOT, "deepsignal_plant_amd", "libdsp_amd_bounds.so")
+
+
+def _sweep(env_extra, *cases, expect_rc=0):
+    env = {k: v for k, v in os.environ.items() if k not in ("DSP_AMD_LIB", "DSP_RSRC_EXTENTS", "DSP_BOUNDS_TEST_SHRINK")}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "extents_sweep.py")] + list(cases), cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == expect_rc, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    return r
+
+
+def test_the_hardware_range_check_is_there_for_both_offsets():
+    from deepsignal_plant_amd import _native
+    got = _native.range_probe(0)
+    print("range probe (in range, past by voffset -> 0, past by soffset -> 0, floats untouched by OOB stores):", got)
+    assert got == (16, 48, 64, 1024), got
+
+
+@pytest.fixture(scope="module")
+def product_digest():
+    return json.loads(_sweep({}).stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("mode", ["wide", "tight"])
+def test_extents_do_not_change_a_bit(product_digest, mode):
+    got = json.loads(_sweep({"DSP_RSRC_EXTENTS": mode}).stdout.strip().splitlines()[-1])
+    assert len(got) == len(product_digest) > 100
+    diff = [k for k in product_digest if got.get(k) != product_digest[k]]
+    assert not diff, diff[:10]
+
+
+def test_the_bounds_build_runs_every_kernel_form_without_a_record_and_with_the_same_bytes(product_digest):
+    assert os.path.exists(BOUNDS_LIB), "make -C deepsignal_plant_amd/csrc bounds (build() does)"
+    got = json.loads(_sweep({"DSP_AMD_LIB": BOUNDS_LIB}).stdout.strip().splitlines()[-1])
+    diff = [k for k in product_digest if got.get(k) != product_digest[k]]
+    assert len(got) == len(product_digest) and not diff, diff[:10]
+
+
+def test_the_bounds_build_names_an_access_past_a_shortened_extent():
+    r = _sweep({"DSP_AMD_LIB": BOUNDS_LIB, "DSP_BOUNDS_TEST_SHRINK": "4096"}, "default", expect_rc=3)
+    assert "out of range" in r.stderr and "operand K4 input" in r.stderr and "dsp_kernels.hip:" in r.stderr, r.stderr[-2000:]
+    print(r.stderr.strip().splitlines()[-1])

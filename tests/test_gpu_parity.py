@@ -532,7 +532,7 @@ def test_small_batch_kernels_do_not_change_a_bit(kw, label, monkeypatch):
     states = {k: torch.from_numpy(v).cuda(0) for k, v in onp.make_init_states(cfg, n_x, 9).items()}
     ins_x = synth.feature_batch(n_x, device="cuda:0", seed=77)
     switches = ("DSP_LSTM_CLUSTER", "DSP_LSTM_LOCAL8", "DSP_TWO_STREAMS", "DSP_HEAD_ST4", "DSP_LSTM_TILING", "DSP_CLUSTER_TIMEOUT",
-                "DSP_FC_FUSED", "DSP_LSTM_FRONT_CLUSTER", "DSP_FC_SMALL", "DSP_LSTM_HANDOFF", "DSP_FORWARD_SPLIT")
+                "DSP_FC_FUSED", "DSP_LSTM_FRONT_CLUSTER", "DSP_FC_SMALL", "DSP_LSTM_HANDOFF", "DSP_FORWARD_SPLIT", "DSP_RSRC_EXTENTS")
     modes = {"round3": {"DSP_LSTM_CLUSTER": "0", "DSP_LSTM_LOCAL8": "0", "DSP_TWO_STREAMS": "0", "DSP_HEAD_ST4": "1",
                         "DSP_FC_FUSED": "0", "DSP_FC_SMALL": "0"},
              # round 5: arrivals counted per wave and deferred into the next step's x part, the counter requested a block early
@@ -552,6 +552,12 @@ def test_small_batch_kernels_do_not_change_a_bit(kw, label, monkeypatch):
              "front_G2_one_stream_abandoned": {"DSP_LSTM_FRONT_CLUSTER": "2", "DSP_TWO_STREAMS": "0", "DSP_CLUSTER_TIMEOUT": "0"},
              "fc_launches_apart": {"DSP_FC_FUSED": "0"},   # (auto: fc_seq and fc_signal share a launch when the branches share a stream)
              "auto": {},
+             # round 6: every buffer descriptor carries the end of the allocation behind it (auto: the workspace region / the
+             # weight upload) -- against the 2 GiB windows of rounds 1-5 (range check off) and against the tight extent of the
+             # call; a legitimate access past any of them would read zeros / be dropped and change the bytes
+             "descriptors_2GiB_windows": {"DSP_RSRC_EXTENTS": "wide"},
+             "descriptors_tight": {"DSP_RSRC_EXTENTS": "tight"},
+             "descriptors_tight_every_cluster_abandoned": {"DSP_RSRC_EXTENTS": "tight", "DSP_CLUSTER_TIMEOUT": "0"},
              "one_stream": {"DSP_TWO_STREAMS": "0"},
              "two_streams_always": {"DSP_TWO_STREAMS": "1"},
              "G4": {"DSP_LSTM_CLUSTER": "4"}, "G2": {"DSP_LSTM_CLUSTER": "2"}, "G1": {"DSP_LSTM_CLUSTER": "1"},
