@@ -540,6 +540,7 @@ struct Launcher {
     long long NTp;  // padded tile count of THIS call (launch geometry is per call, never stored in the handle)
     int rc = 0;
     bool side_by_side = false;   // the seq and signal branches of this call run on two streams
+    bool counters_zeroed = false;   // this forward's pack launch zeroes the arrival / admission counters of its clustered launches
     hipEvent_t last_ev = nullptr;   // profiling: the event behind the previous launch ...
     hipStream_t last_s = nullptr;   // ... and its stream
     hipEvent_t pending_a = nullptr, pending_b = nullptr;   // dominant-only profiling: the open bracket
@@ -737,6 +738,12 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
             if (!L.side_by_side || (a.UT == 4 && a.CG < 4)) a.flags |= 4;
             if (m->wave_handoff) a.flags |= 64;
         }
+        // A clustered launch on counters that were not zeroed would admit at once and find every arrival "already in" (the
+        // previous forward's counts): h rows read before they exist, silently.  The pack launch zeroes them under the same
+        // size condition the cluster sizes are picked by (NTp x 4 <= CUs); should the two ever drift apart, fail here.
+        if (a.CG > 0 && !((a.CG == 4 && a.UT == 4) || (a.flags & 8)) && !L.counters_zeroed && !L.rc)
+            L.rc = fail(DSP_EINVAL, "internal: a clustered launch (%s, layer %zu, %lld tiles) on counters this forward did not zero", name, k,
+                        (long long)L.NTp);
         {   // the extents behind this launch's descriptors (after the split switch: a.wpk0 / a.NQ are the launch's own)
             const size_t tile_x = (size_t)a.T * (size_t)(a.Ipad >> 2) * 512, tile_o = (size_t)a.T * (size_t)(a.Fout >> 2) * 512;
             const size_t wbytes = split ? (size_t)a.UT * a.NQ * 4096 * (prec == DSP_PREC_FP16X3 ? 2 : 3) : (size_t)a.UT * a.NQ * 4096;
@@ -1178,6 +1185,7 @@ static int32_t forward_chunk(dsp_model* m, void* stream, int64_t n, const void* 
         const int launches = std::min(kClusterLaunches, (d.hseq ? d.l2 : 0) + (d.hsig ? d.l2 : 0) + d.l1);
         p.zero_words = m->cflags;
         p.n_zero_words = launches * kClusterWordsPerLaunch;
+        L.counters_zeroed = true;
     }
     p.xseq_end = rsrc_end(m, p.xseq, (size_t)NTp * d.T * (size_t)(m->Fseq >> 2) * 512);
     p.xsig_end = rsrc_end(m, p.xsig, (size_t)NTp * d.T * (size_t)(m->Fsig >> 2) * 512);

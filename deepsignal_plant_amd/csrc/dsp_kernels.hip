@@ -22,6 +22,7 @@
 #include <type_traits>
 #include <utility>
 
+#include "dsp_cluster_protocol.h"
 #include "dsp_kernels.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -839,54 +840,31 @@ __device__ __forceinline__ void bst16_sc1_(const rsrc_t& r, uint32_t voff, uint3
 }
 #define bld16_sc1(r, voff, soff) bld16_sc1_((r), (voff), (soff), __LINE__)
 #define bst16_sc1(r, voff, soff, v) bst16_sc1_((r), (voff), (soff), (v), __LINE__)
-constexpr unsigned kClusterAbandon = 0x80000000u;
-// wait until `target` arrivals have been counted (every wave polls for itself: no workgroup barrier inside the k-loop).
-// Returns false when the cluster was given up: a member that sees no progress for seconds (a member that never became
-// resident or died -- admission makes that all but impossible) marks the cluster abandoned in its admission word, every
-// member notices within 4,096 polls and leaves, and the clean-up launch behind this one computes the cluster from scratch
-// (it recomputes every step, so what the members had written is overwritten).  Until round 5 this was a trap: one stuck
-// poll ended the process -- with 8 ranks, the job.
-__device__ __forceinline__ bool wait_arrivals(gu32* flag, unsigned target) {
-    for (unsigned spins = 0;; ++spins) {
-        const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        if (v >= target) return true;
-        __builtin_amdgcn_s_sleep(1);
-        if ((spins & 0xfffu) == 0xfffu) {
-            const unsigned st = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            if (st & kClusterAbandon) return false;
-            if (spins > (1u << 24)) {
-                __hip_atomic_fetch_or(flag + 1, kClusterAbandon, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
-        }
+// The two lock-free functions of the protocol -- admission of the members, the wait for the arrivals of a step -- live in
+// dsp_cluster_protocol.h, written against an Ops policy: the same source runs here (relaxed agent-scope atomics, s_sleep,
+// s_memtime) and, with std::atomic under ThreadSanitizer, in tests/native/cluster_model.cpp.
+struct ClusterOpsDev {
+    gu32* flag;   // word 0: arrivals of the steps; word 1: admission (count | abandoned)
+    static constexpr unsigned kCheckMask = 0xfffu;       // the abandoned bit is looked at every 4,096 polls
+    static constexpr unsigned kSpinLimit = 1u << 24;     // polls without progress (seconds) before a member gives the cluster up
+    __device__ __forceinline__ unsigned load_arrivals() const {
+        return __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
-}
-
-// Admission of a cluster (lane 0 of every member workgroup, before anything else): the members wait for each other at every
-// step, so ALL of them must be resident -- which the dispatcher does not promise once other launches compete for the CUs
-// (five concurrent clustered dispatches sharing an XCD's 32 slots evenly hold 6 members of 8 each: nobody ever completes).
-// Each member counts itself in and waits until all P are there; a member that has waited `limit` cycles ABANDONS the cluster
-// for all (one CAS on the word that also holds the count, so that "all arrived" and "abandoned" exclude each other): every
-// member, present or still to come, exits at once, and the clean-up launch behind this one (the workgroup-local form, no
-// waiting between workgroups) computes the abandoned clusters.  Returns true when the cluster runs.
-__device__ __forceinline__ bool cluster_admit(gu32* state, unsigned P, unsigned long long limit) {
-    unsigned s = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (;;) {
-        if (s & kClusterAbandon) return false;
-        if (__hip_atomic_compare_exchange_strong(state, &s, s + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    __device__ __forceinline__ unsigned load_state() const {
+        return __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    for (;;) {
-        s = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (s & kClusterAbandon) return false;
-        if ((s & 0xffffu) >= P) return true;
-        if (__builtin_amdgcn_s_memtime() - t0 > limit) {
-            if (__hip_atomic_compare_exchange_strong(state, &s, s | kClusterAbandon, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                return false;
-            continue;   // (the word moved: somebody arrived or abandoned meanwhile -- look again)
-        }
-        __builtin_amdgcn_s_sleep(1);
+    __device__ __forceinline__ void or_state(unsigned bits) const {
+        __hip_atomic_fetch_or(flag + 1, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    __device__ __forceinline__ bool cas_state(unsigned& expected, unsigned desired) const {
+        return __hip_atomic_compare_exchange_strong(flag + 1, &expected, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ __forceinline__ void pause() const { __builtin_amdgcn_s_sleep(1); }
+    __device__ __forceinline__ unsigned long long now() const { return __builtin_amdgcn_s_memtime(); }
+};
+__device__ __forceinline__ bool wait_arrivals(gu32* flag, unsigned target) { return dsp_wait_arrivals(ClusterOpsDev{flag}, target); }
+__device__ __forceinline__ bool cluster_admit(gu32* flag, unsigned P, unsigned long long limit) {
+    return dsp_cluster_admit(ClusterOpsDev{flag}, P, limit);
 }
 
 template <int LO, int HI, class F>
@@ -1238,7 +1216,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dsp_lstmc_kernel(LstmArgs a) {
         // (the verdict travels through the first word of the dynamic LDS -- no static LDS next to a 160 KiB dynamic limit --,
         // which the bias table overwrites only after everybody has read it)
         int* verdict = (int*)smem;
-        if (tid == 0) *verdict = cluster_admit(flag + 1, (unsigned)P, a.cluster_timeout) ? 1 : 0;
+        if (tid == 0) *verdict = cluster_admit(flag, (unsigned)P, a.cluster_timeout) ? 1 : 0;
         __syncthreads();
         const int admitted = *(volatile int*)verdict;
         __syncthreads();
