@@ -36,11 +36,11 @@
 #include <string.h>
 
 #include "dsp_amd.h"
+#include "dsp_parse_arith.h"   // fast_float / fast_int / base_code / is_space / eq_mask4 / delim_mask4: shared with the host sanitizer test
 
 namespace {
 
-__constant__ double kPow10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
-                                  1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+using namespace dsp_parse_arith;
 
 // a byte cursor over global memory: 16-byte words, the next one requested while the current one is consumed.  The pointers
 // carry the GLOBAL address space: through a generic `const char*` hipcc emits flat_load, which counts on vmcnt AND lgkmcnt
@@ -81,67 +81,6 @@ struct Reader {
     __device__ __forceinline__ void adv() { shift(); ++pos; }
 };
 
-// [-]digits[.digits][e[+-]digits], at most 18 digits; false = not a plain number (the row goes to the host parser)
-template <class RD>
-__device__ __forceinline__ bool fast_float(RD& r, float* dst) {
-    const bool neg = r.cur() == '-';
-    if (neg) r.adv();
-    uint64_t m = 0;
-    unsigned d;
-    int nd = 0, e10 = 0;
-    while ((d = r.cur() - '0') < 10u) { m = m * 10 + d; r.adv(); ++nd; }
-    if (nd == 0) return false;
-    if (r.cur() == '.') {
-        r.adv();
-        int nf = 0;
-        while ((d = r.cur() - '0') < 10u) { m = m * 10 + d; r.adv(); ++nf; if (nd + nf > 19) return false; }
-        e10 = -nf;
-        nd += nf;
-    }
-    if (nd > 18) return false;
-    if ((r.cur() | 0x20u) == 'e') {
-        r.adv();
-        const unsigned c = r.cur();
-        const bool eneg = c == '-';
-        if (c == '-' || c == '+') r.adv();
-        int ex = 0, ne = 0;
-        while ((d = r.cur() - '0') < 10u && ne < 4) { ex = ex * 10 + (int)d; r.adv(); ++ne; }
-        if (ne == 0 || (r.cur() - '0') < 10u) return false;
-        e10 += eneg ? -ex : ex;
-    }
-    if (m >= (1ull << 53) || e10 < -22 || e10 > 22) {
-        if (m != 0) return false;
-        e10 = 0;
-    }
-    double v = (double)m;                                   // exact: m < 2^53
-    v = e10 < 0 ? v / kPow10[-e10] : v * kPow10[e10];       // ONE correctly rounded operation (Clinger's fast path)
-    *dst = (float)(neg ? -v : v);
-    return true;
-}
-
-template <class RD>
-__device__ __forceinline__ bool fast_int(RD& r, int* out) {
-    const bool neg = r.cur() == '-';
-    if (neg) r.adv();
-    long long v = 0;
-    unsigned d;
-    int nd = 0;
-    while ((d = r.cur() - '0') < 10u && nd < 9) { v = v * 10 + (long long)d; r.adv(); ++nd; }   // 9 digits fit an int32
-    if (nd == 0 || (r.cur() - '0') < 10u) return false;
-    *out = (int)(neg ? -v : v);
-    return true;
-}
-
-// base2code_dna (utils/process_utils.py:25-29): "ACGTNWSMKRYBVDHZ" -> 0..15, anything else -1
-__device__ __forceinline__ int base_code(unsigned c) {
-    switch (c) {
-        case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; case 'N': return 4; case 'W': return 5;
-        case 'S': return 6; case 'M': return 7; case 'K': return 8; case 'R': return 9; case 'Y': return 10; case 'B': return 11;
-        case 'V': return 12; case 'D': return 13; case 'H': return 14; case 'Z': return 15; default: return -1;
-    }
-}
-__device__ __forceinline__ bool is_space(unsigned c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\f' || c == '\v'; }
-
 struct ParseArgs {
     const char* text; const uint64_t* row_off; long long n; int L, S;
     uint8_t* kmer; float* means; float* stds; int* lens; float* signals; int* labels;
@@ -160,11 +99,6 @@ __device__ __forceinline__ void flag_row(const ParseArgs& a, long long r) {
 // same iteration, four iterations ahead: no lane-divergent refills) that only looks for delimiters: the first 11 tabs and
 // the ';' of the signals field.  Then the short pieces -- k-mer, the L lengths, the label, the sampleinfo addressing -- and
 // the segment table of the float lists for kernel 2.
-__device__ __forceinline__ uint32_t eq_mask4(uint32_t w, uint32_t pat) {   // bit 7 of every byte of w that equals pat's byte
-    const uint32_t x = w ^ pat;
-    return ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);   // exact zero-byte detector
-}
-
 __global__ __launch_bounds__(64) void dsp_parse_scan_kernel(ParseArgs a) {
     const long long r = (long long)blockIdx.x * 64 + threadIdx.x;
     if (r >= a.n) return;
@@ -340,10 +274,6 @@ struct LdsReader {
     }
 };
 
-__device__ __forceinline__ uint32_t delim_mask4(uint32_t w) {
-    return eq_mask4(w, 0x2c2c2c2cu) | eq_mask4(w, 0x3b3b3b3bu) | eq_mask4(w, 0x09090909u) | eq_mask4(w, 0x0a0a0a0au);
-}
-
 template <int RB>
 __global__ __launch_bounds__(256, 6) void dsp_parse_tokens_kernel(ParseArgs a) {
     constexpr int kTokCapBytes = RB * kTokRowBytes;
@@ -454,54 +384,7 @@ __global__ __launch_bounds__(256, 6) void dsp_parse_tokens_kernel(ParseArgs a) {
             if (k >= NTOK) continue;
             const uint32_t ts = k == 0 ? st : (uint32_t)dpos[db + k - 1] + 1u;
             const uint32_t te = dpos[db + k];
-            const unsigned term = bb[te];
-            bool ok = true;
-            if (k < 6) {                                            // sampleinfo: kept verbatim, only addressed
-                ok = term == '\t';
-                if (k == 4) { a.read_off[row] = ts - st; a.read_len[row] = te - ts; }
-                if (k == 5) a.info_len[row] = te - st;
-            } else if (k == 6) {                                    // the k-mer: exactly L letters of base2code_dna
-                ok = term == '\t' && te - ts == (uint32_t)L;
-                if (ok) {
-                    uint8_t* km = a.kmer + row * L;
-                    for (int i = 0; i < L; ++i) {
-                        const int c = base_code(bb[ts + i]);
-                        if (c < 0) { ok = false; break; }
-                        km[i] = (uint8_t)c;
-                    }
-                }
-            } else if (k == NTOK - 1) {                             // the label: an integer, LF or CRLF behind it
-                LdsReader rd;
-                rd.init(buf, ts);
-                int lab;
-                ok = term == '\n' && fast_int(rd, &lab) && (rd.pos == te - ts || (rd.cur() == '\r' && rd.pos + 1 == te - ts));
-                if (ok) a.labels[row] = lab;
-            } else {
-                const int q = k - 7;
-                const bool is_int = q >= 2 * L && q < 3 * L;
-                int idx, cnt1;
-                unsigned last;
-                if (q < 3 * L) { idx = q % L; cnt1 = L; last = '\t'; }
-                else { idx = (q - 3 * L) % S; cnt1 = S; last = (q - 3 * L) / S == L - 1 ? '\t' : ';'; }
-                ok = term == (idx == cnt1 - 1 ? last : (unsigned)',');
-                if (ok) {
-                    LdsReader rd;
-                    rd.init(buf, ts);
-                    if (is_int) {
-                        int val;
-                        ok = fast_int(rd, &val) && rd.pos == te - ts;
-                        if (ok) a.lens[row * L + (q - 2 * L)] = val;
-                    } else {
-                        float val;
-                        ok = fast_float(rd, &val) && rd.pos == te - ts;
-                        if (ok) {
-                            if (q < L) a.means[row * L + q] = val;
-                            else if (q < 2 * L) a.stds[row * L + (q - L)] = val;
-                            else a.signals[(size_t)row * L * S + (q - 3 * L)] = val;
-                        }
-                    }
-                }
-            }
+            const bool ok = parse_token<LdsReader>(a, row, k, NTOK, L, S, st, ts, te, bb, buf);
             if (!ok) rflag[r] = 1;                                  // (benign race: every writer writes 1)
         }
     }

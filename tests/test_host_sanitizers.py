@@ -55,3 +55,36 @@ def test_thread_pools_survive_a_system_that_refuses_threads(tmp_path, sanitizers
     assert r.returncode == 0 and "threads_refused: ok" in r.stdout, (r.stdout[-2000:], r.stderr[-6000:])
     assert "WARNING: ThreadSanitizer" not in r.stderr, r.stderr[-6000:]
     assert int(r.stdout.split("(")[1].split()[0]) > 10      # the refusals really happened
+
+
+def test_device_parser_arithmetic_is_clean_under_asan_and_ubsan_and_equals_the_host_parser(tmp_path):
+    """csrc/dsp_parse_arith.h is what dsp_parse_dev.hip compiles for gfx950 -- fast_float / fast_int / base_code / the SWAR
+    delimiter masks and the per-token grammar (parse_token) -- and GPU sanitizers are not to be had on this pool.
+    tests/native/parse_dev_host.cpp runs the token-parallel kernel's algorithm with that very source on the host under ASan +
+    UBSan: 200,000 rows of random float spellings, 4,000 rows of the writer's grammar, 30,000 byte-mutated blocks.  Every row it
+    accepts equals the host parser's bit for bit, every row the host parser rejects is flagged, plain rows are never flagged,
+    and the sanitizers report nothing.  Test infrastructure: the product parses on the GPU only."""
+    exe = os.path.join(str(tmp_path), "parse_dev_host")
+    csrc = os.path.join(ROOT, "deepsignal_plant_amd", "csrc")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-ffp-contract=off", "-pthread", "-I", os.path.join(ROOT, "include"), "-I", csrc, os.path.join(ROOT, "tests", "native", "parse_dev_host.cpp"),
+           os.path.join(csrc, "dsp_text.cpp"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-4000:]
+    r = subprocess.run([exe, "200000", "30000"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert r.returncode == 0 and "parse_dev_host: ok" in r.stdout, (r.stdout[-2000:], r.stderr[-6000:])
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-6000:]
+    print(r.stdout)
+    same = int(r.stdout.split("200000 rows, ")[1].split()[0])
+    assert same > 100000      # (the rest: exponents beyond +-22, long mantissas, '+', blanks -- the host parser's)
+    assert "never accepted what the host rejects" in r.stdout
+
+
+def test_the_device_parser_compiles_the_shared_arithmetic_header():
+    """... and the kernels really use it: no private copy of the number parsing left in the .hip"""
+    src = open(os.path.join(ROOT, "deepsignal_plant_amd", "csrc", "dsp_parse_dev.hip")).read()
+    assert '#include "dsp_parse_arith.h"' in src
+    for name in ("bool fast_float(", "bool fast_int(", "int base_code(", "uint32_t eq_mask4(", "uint32_t delim_mask4(", "kPow10[23]"):
+        assert name not in src, name
+    assert "parse_token<LdsReader>(" in src
