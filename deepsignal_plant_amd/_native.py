@@ -262,6 +262,11 @@ def lib():
     for fn in (L.dsp_device_pci_bdf, L.dsp_device_uuid):
         fn.restype = ctypes.c_int64
         fn.argtypes = [ctypes.c_int32, ctypes.c_char_p, ctypes.c_size_t]
+    L.dsp_debug_plan.restype = ctypes.c_int32
+    L.dsp_debug_plan.argtypes = [ctypes.POINTER(ModelCfg), ctypes.c_int32, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64),
+                                 ctypes.POINTER(ctypes.c_double)]
+    L.dsp_debug_piece_cost.restype = ctypes.c_double
+    L.dsp_debug_piece_cost.argtypes = [ctypes.POINTER(ModelCfg), ctypes.c_int32, ctypes.c_int64]
     L.dsp_debug_range_probe.restype = ctypes.c_int32
     L.dsp_debug_range_probe.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]
     _lib = L

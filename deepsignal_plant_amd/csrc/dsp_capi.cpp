@@ -147,6 +147,10 @@ struct DevLstmLayer {
     std::vector<float> host_wih[2], host_whh[2];
 };
 struct DevLinear { int Fin, ORT; float* wpk; float* bias; };
+// what the launch geometry of an LSTM layer depends on (no weights): derive_geometry fills these for every layer of the
+// three stacks, so that the forward's plan -- which kernel form a batch size takes, what a piece costs -- can be made, and
+// tested, without a device (dsp_debug_plan)
+struct LayerShape { int Ipad, Ilo, Iused, H, Hp; };
 
 // A fragments for gates^T = W * act^T :  [UT][NQ][4 gates][64 lanes][4]
 //   value = Wcat[g*H + u*32 + (lane&31)][8q + 4*(lane>>5) + i],  Wcat = [W_ih(in_map) | W_hh]
@@ -299,6 +303,7 @@ struct dsp_model {
     std::vector<void*> dev_allocs;
     float* embed = nullptr;
     std::vector<DevLstmLayer> seq, sig, comb;
+    std::vector<LayerShape> seq_shape, sig_shape, comb_shape;
     DevLinear fc_seq{}, fc_sig{}, fc1{};
     float* w2 = nullptr; float* b2 = nullptr;
     int hseq_p = 0, hsig_p = 0, Hp = 0, Fseq = 0, Fsig = 0, Fcomb = 0, Fwide = 0;
@@ -406,6 +411,46 @@ const void* rsrc_end(const dsp_model* m, const void* p, size_t logical) {
     const char* e = (const char*)alloc_end(m, p);
     if (e && m->extents == 2 && (const char*)p + logical < e) e = (const char*)p + logical;
     return e;
+}
+
+// the shapes of a stack's layers from its input map (the same arithmetic build_stack applies to the weights' packing)
+void stack_shapes(int hid, int layers, const std::vector<int>& in_map0, std::vector<LayerShape>& out) {
+    const int Hp = pad_hidden(hid);
+    out.clear();
+    for (int k = 0; k < layers; ++k) {
+        const std::vector<int> in_map = k == 0 ? in_map0 : map_bidir(hid, Hp);
+        LayerShape L{(int)in_map.size(), (int)in_map.size(), 0, hid, Hp};
+        for (int i = 0; i < L.Ipad; ++i)
+            if (in_map[i] >= 0) { L.Iused = i + 1; L.Ilo = std::min(L.Ilo, i); }
+        out.push_back(L);
+    }
+}
+
+// Everything about a handle that follows from its configuration alone (padded sizes, input maps, layer shapes): no device
+// call in here -- dsp_model_create runs it before it uploads anything, dsp_debug_plan runs it on a handle that never sees a GPU.
+void derive_geometry(dsp_model* m) {
+    const Dims& d = m->d;
+    m->hseq_p = d.hseq ? pad_hidden(d.hseq) : 0;
+    m->hsig_p = d.hsig ? pad_hidden(d.hsig) : 0;
+    m->Hp = pad_hidden(d.H);
+    // front-end inputs are padded to >= 32 features so that the first four k-groups of every step are
+    // x-part groups: the LSTM kernel requests them before h_t exists (dsp_kernels.hip, SPARSE note)
+    m->Fseq = d.hseq ? std::max(32, rup(d.Iseq, 8)) : 0;
+    m->Fsig = d.hsig ? std::max(32, rup(d.S, 8)) : 0;
+    m->xoff_seq = d.hseq ? front_end_offset(d.Iseq, m->Fseq, pad_hidden(d.hseq)) : 0;
+    m->xoff_sig = d.hsig ? front_end_offset(d.S, m->Fsig, pad_hidden(d.hsig)) : 0;
+    m->Fcomb = m->hseq_p + m->hsig_p;
+    m->small_classes = (m->Hp == 256 && m->Fcomb % 128 == 0 && m->Fcomb >= 256) || (m->Hp == 128 && m->Fcomb % 32 == 0 && m->Fcomb >= 64);
+    m->Fwide = 2 * m->Hp;
+    if (2 * m->hseq_p > m->Fwide) m->Fwide = 2 * m->hseq_p;
+    if (2 * m->hsig_p > m->Fwide) m->Fwide = 2 * m->hsig_p;
+    m->comb_in_map.assign(m->Fcomb, -1);
+    for (int i = 0; i < d.hseq; ++i) m->comb_in_map[i] = i;
+    for (int i = 0; i < d.hsig; ++i) m->comb_in_map[m->hseq_p + i] = d.hseq + i;
+    m->seq_shape.clear(); m->sig_shape.clear();
+    if (d.hseq) stack_shapes(d.hseq, d.l2, map_pad(d.Iseq, m->Fseq, m->xoff_seq), m->seq_shape);
+    if (d.hsig) stack_shapes(d.hsig, d.l2, map_pad(d.S, m->Fsig, m->xoff_sig), m->sig_shape);
+    stack_shapes(d.H, d.l1, m->comb_in_map, m->comb_shape);
 }
 
 int build_stack(dsp_model* m, const float* const* w, int in, int hid, int layers, std::vector<int> in_map0,
@@ -674,6 +719,38 @@ int pick_cluster(const dsp_model* m, const LstmArgs& a, long long NTp, bool spli
     return G;
 }
 
+// The launch geometry of one LSTM layer at a batch of NTp tiles -- everything that does not need a pointer: dimensions, unit
+// tiles / passes / site groups, the small-batch tiling flags.  One source for the forward (run_stack) and for the plan of a
+// call's pieces (piece_cost_us below).
+void shape_lstm(const dsp_model* m, const LayerShape& ly, int lstm_id, long long NTp, LstmArgs& a) {
+    a.NTp = NTp;
+    a.Ipad = ly.Ipad; a.H = ly.H; a.Hp = ly.Hp; a.T = m->d.T; a.Fout = 2 * ly.Hp;
+    a.NQ = rup((ly.Ipad + ly.Hp) / 8, 4);
+    a.nqx_used = (ly.Iused + 7) / 8; a.nqx_lo = ly.Ilo / 8;
+    a.UT = ly.Hp / 32;
+    a.NP = a.UT > 8 ? a.UT / 8 : (a.UT == 8 && lstm_id == 2 ? m->np8 : 1);
+    a.SG = a.NP >= 2 ? 1 : pick_site_groups(m, a.UT);
+    // small batches: 32-site workgroups of UT/2 waves put twice as many CUs to work and halve the launch's latency (a
+    // batch of 512 sites: 32 workgroups of one wave per SIMD instead of 16 of two); from the size where every CU has
+    // its 64-site workgroup the shipped tiling is the faster one (0.25 %: dsp_kernels.hip)
+    const bool use21 = m->tiling21 > 0 || (m->tiling21 < 0 && NTp * 2 <= (long long)m->n_cus);
+    // (automatic choice: one such workgroup per CU -- bit 2 -- so that forwards issued concurrently on other streams
+    // spread over the idle CUs instead of doubling up on busy ones)
+    a.flags = (m->phase_prio ? 1 : 0) | (use21 ? 2 : 0) | (use21 && m->tiling21 < 0 ? 4 : 0);
+}
+// ... and which form of the kernel it takes: a.CG (0, or gates per wave of dsp_lstmc_kernel) and the flags that go with it
+void pick_form(const dsp_model* m, LstmArgs& a, long long NTp, bool split, bool side_by_side, bool counters) {
+    // batches that leave most CUs idle: the layer's unit tiles spread over a cluster of workgroups (dsp_lstmc_kernel)
+    a.CG = counters ? pick_cluster(m, a, NTp, split, side_by_side ? 2 : 1) : 0;
+    if (a.CG < 0) { a.CG = -a.CG; a.flags |= 8; }
+    if (a.CG) {
+        // one workgroup per CU: not for the workgroup-local forms of two branches that run side by side on two streams (they
+        // may share CUs); the CLUSTERED front ends of two branches were sized so that both grids fit the CUs together
+        if (!side_by_side || (a.UT == 4 && a.CG < 4)) a.flags |= 4;
+        if (m->wave_handoff) a.flags |= 64;
+    }
+}
+
 // run one BiLSTM stack; returns the buffer holding the last layer's output
 float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>& layers, int lstm_id, const float* x,
                  int64_t n, const dsp_init_state* init, const float* h0, const float* c0, bool side = false) {
@@ -689,26 +766,14 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
         LstmArgs a{};
         a.x = cur; a.out = dst;
         a.wpk0 = ly.wpk[0]; a.wpk1 = ly.wpk[1]; a.sbias0 = ly.sbias[0]; a.sbias1 = ly.sbias[1];
-        a.n = n; a.NTp = L.NTp;
-        a.Ipad = ly.Ipad; a.H = ly.H; a.Hp = ly.Hp; a.T = m->d.T; a.Fout = 2 * ly.Hp;
-        a.NQ = rup((ly.Ipad + ly.Hp) / 8, 4);
-        a.nqx_used = (ly.Iused + 7) / 8; a.nqx_lo = ly.Ilo / 8;
+        a.n = n;
+        shape_lstm(m, LayerShape{ly.Ipad, ly.Ilo, ly.Iused, ly.H, ly.Hp}, lstm_id, L.NTp, a);
         a.h0buf = side ? m->h0buf2 : m->h0buf;
         a.cbuf = m->cbuf;
-        a.UT = ly.Hp / 32;
-        a.NP = a.UT > 8 ? a.UT / 8 : (a.UT == 8 && lstm_id == 2 ? m->np8 : 1);
-        a.SG = a.NP >= 2 ? 1 : pick_site_groups(m, a.UT);
         a.init_mode = init ? init->mode : DSP_INIT_ZEROS;
         a.seed = init ? init->seed : 0; a.site_offset = init ? init->site_offset : 0;
         a.site_keys = (init && init->mode == DSP_INIT_PHILOX) ? (const unsigned long long*)init->site_keys : nullptr;
         a.stream_base = lstm_id * 64 + (int)k * 4;
-        // small batches: 32-site workgroups of UT/2 waves put twice as many CUs to work and halve the launch's latency (a
-        // batch of 512 sites: 32 workgroups of one wave per SIMD instead of 16 of two); from the size where every CU has
-        // its 64-site workgroup the shipped tiling is the faster one (0.25 %: dsp_kernels.hip)
-        const bool use21 = m->tiling21 > 0 || (m->tiling21 < 0 && L.NTp * 2 <= (long long)m->n_cus);
-        // (automatic choice: one such workgroup per CU -- bit 2 -- so that forwards issued concurrently on other streams
-        // spread over the idle CUs instead of doubling up on busy ones)
-        a.flags = (m->phase_prio ? 1 : 0) | (use21 ? 2 : 0) | (use21 && m->tiling21 < 0 ? 4 : 0);
         if (m->trace_launch >= 0 && m->trace_launch == m->lstm_launch_no) a.flags |= 256 | (m->trace_wave << 9);  // DSP_TRACE builds
         const int launch_no = m->lstm_launch_no;
         ++m->lstm_launch_no;
@@ -727,16 +792,10 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
             a.NQ = (ly.Ipad + ly.Hp) / 16;
             a.SG = 8 / a.UT;
         }
-        // batches that leave most CUs idle: the layer's unit tiles spread over a cluster of workgroups (dsp_lstmc_kernel)
-        a.CG = (launch_no < kClusterLaunches && m->cflags) ? pick_cluster(m, a, L.NTp, split, L.side_by_side ? 2 : 1) : 0;
-        if (a.CG < 0) { a.CG = -a.CG; a.flags |= 8; }
+        pick_form(m, a, L.NTp, split, L.side_by_side, launch_no < kClusterLaunches && m->cflags);
         if (a.CG) {
             a.cluster_timeout = m->cluster_timeout;
             a.cflags = m->cflags + (size_t)launch_no * kClusterWordsPerLaunch;
-            // one workgroup per CU: not for the workgroup-local forms of two branches that run side by side on two streams (they
-            // may share CUs); the CLUSTERED front ends of two branches were sized so that both grids fit the CUs together
-            if (!L.side_by_side || (a.UT == 4 && a.CG < 4)) a.flags |= 4;
-            if (m->wave_handoff) a.flags |= 64;
         }
         // A clustered launch on counters that were not zeroed would admit at once and find every arrival "already in" (the
         // previous forward's counts): h rows read before they exist, silently.  The pack launch zeroes them under the same
@@ -921,23 +980,7 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
     if (const char* v = getenv("DSP_PRECISION"))
         m->precision = !strcmp(v, "bf16x6") ? DSP_PREC_BF16X6 : (!strcmp(v, "bf16x9") ? DSP_PREC_BF16X9 :
                        (!strcmp(v, "fp16x3") ? DSP_PREC_FP16X3 : DSP_PREC_FP32));
-    m->hseq_p = d.hseq ? pad_hidden(d.hseq) : 0;
-    m->hsig_p = d.hsig ? pad_hidden(d.hsig) : 0;
-    m->Hp = pad_hidden(d.H);
-    // front-end inputs are padded to >= 32 features so that the first four k-groups of every step are
-    // x-part groups: the LSTM kernel requests them before h_t exists (dsp_kernels.hip, SPARSE note)
-    m->Fseq = d.hseq ? std::max(32, rup(d.Iseq, 8)) : 0;
-    m->Fsig = d.hsig ? std::max(32, rup(d.S, 8)) : 0;
-    m->xoff_seq = d.hseq ? front_end_offset(d.Iseq, m->Fseq, pad_hidden(d.hseq)) : 0;
-    m->xoff_sig = d.hsig ? front_end_offset(d.S, m->Fsig, pad_hidden(d.hsig)) : 0;
-    m->Fcomb = m->hseq_p + m->hsig_p;
-    m->small_classes = (m->Hp == 256 && m->Fcomb % 128 == 0 && m->Fcomb >= 256) || (m->Hp == 128 && m->Fcomb % 32 == 0 && m->Fcomb >= 64);
-    m->Fwide = 2 * m->Hp;
-    if (2 * m->hseq_p > m->Fwide) m->Fwide = 2 * m->hseq_p;
-    if (2 * m->hsig_p > m->Fwide) m->Fwide = 2 * m->hsig_p;
-    m->comb_in_map.assign(m->Fcomb, -1);
-    for (int i = 0; i < d.hseq; ++i) m->comb_in_map[i] = i;
-    for (int i = 0; i < d.hsig; ++i) m->comb_in_map[m->hseq_p + i] = d.hseq + i;
+    derive_geometry(m);
 
     const float* const* w = host_weights;
     int wi = 0;
@@ -1027,29 +1070,137 @@ static int32_t forward_chunk(dsp_model* m, void* stream, int64_t n, const void* 
 // Not with explicit initial states (their layout has the site index in the middle dimension) and not in the split-precision
 // modes (their kernels have no small-batch forms).  DSP_FORWARD_SPLIT=0 turns it off (A/B switch).
 namespace {
-// pieces (in units of 512 sites: 1, 2, 4, 8 = the small-batch classes; 16 = one round of the 64-site workgroups) that cover u
-// units at the least cost; costs in microseconds of one forward of the default model on MI355X (profiles/r5/batch_sweep.txt,
-// small_batch_ab_final.txt) -- only their ratios matter, and those are set by the cluster sizes
-struct PiecePlan { int n; int units[6]; };
-PiecePlan plan_pieces(int u) {
-    static const int cap[5] = {1, 2, 4, 8, 16};
-    static const int cost[5] = {610, 1020, 1810, 3420, 6650};   // (+40 us per small piece: a cut must pay for itself clearly)
-    int best[17], pick[17];
-    best[0] = 0; pick[0] = -1;
-    for (int k = 1; k <= 16; ++k) {
-        best[k] = 1 << 30;
-        for (int p = 0; p < 5; ++p) {
-            const int rest = k > cap[p] ? k - cap[p] : 0;
-            const int c = cost[p] + best[rest];
-            if (c < best[k]) { best[k] = c; pick[k] = p; }
+// ---- what a piece costs, and how a call is cut (round 6: from the model and the device, not from a constant table) ---------
+// Round 5 planned the pieces of a call with five measured costs of the DEFAULT model on a 256-CU device ({610, 1020, 1810, 3420,
+// 6650} us for 512 / 1,024 / 2,048 / 4,096 sites / one round) and fixed sizes (round 8,192 = 256 CUs x 32 sites, unit 512): wrong
+// ratios for every other model with small-batch forms (hidden 128: the 512 and 1,024 classes cost the same) and wrong sizes on
+// another CU count.  Now: the sizes where a forward's cost steps are where the launch geometry
+// changes -- asked of the same functions that pick it (shape_lstm / pick_form) -- and a piece's cost is summed over its
+// launches from their geometry: an LSTM launch = rounds x T steps x (waves per SIMD x k-groups x accumulator tiles per wave x
+// 256 cycles of fp32 MFMA + the step's fixed part) + the launch's fixed part.  The constants are the measured ones of
+// DESIGN.md 3 / 3b (one accumulator tile x one k-group = 4 MFMAs = 256 cycles; cell phase 5.1 k cycles per 8 tiles; hand-off
+// 3.1 k cycles per clustered step, + 2.4 k where no x part hides the hop; ~14 us per clustered launch with its clean-up launch);
+// against profiles/r5 the sums land within 4 % (tests/test_forward_plan.py holds the table).  Only RATIOS matter: a cut never
+// changes a bit of the result.
+constexpr double kPlanClockGHz = 2.35;
+constexpr double kPlanCutPenaltyUs = 40.0;   // a cut must pay for itself clearly
+
+double lstm_launch_us(const dsp_model* m, const LstmArgs& a, long long NTp) {
+    const int nq_live = a.NQ - a.nqx_lo;           // leading k-groups of pure padding issue no MFMAs (the front ends)
+    const double tile_kgroup = 256.0;
+    const long long cus = m->n_cus;
+    double step = 0, fixed_us = 6.0;
+    long long rounds = 1;
+    if (a.CG > 0) {
+        const bool local8 = a.CG == 4 && a.UT == 8 && (a.flags & 8);
+        const bool local = (a.CG == 4 && a.UT == 4) || local8;
+        if (local) {
+            step = (local8 ? 2.0 : 1.0) * nq_live * 4 * tile_kgroup + (local8 ? 10000.0 : 4000.0);
+            rounds = (NTp * 2 + cus - 1) / cus;
+        } else {
+            const bool xshort = (a.Ipad >> 3) == 4;
+            step = (double)nq_live * a.CG * tile_kgroup + 3100.0 + (xshort ? 2400.0 : 0.0);
+            fixed_us = 14.0;                        // (with the clean-up launch behind it)
+        }
+    } else if ((a.flags & 2) && a.NP <= 1 && a.UT >= 2 && a.UT % 2 == 0 && a.nqx_lo == 0 && a.nqx_used == (a.Ipad >> 3) &&
+               a.NQ == ((a.Ipad + a.Hp) >> 3) && (a.Ipad >> 3) >= 4) {   // dsp_lstm21_kernel (dsp_k_lstm's condition)
+        const int sg = a.UT >= 8 ? 1 : 8 / a.UT;
+        const long long wgs = NTp / sg * 2;
+        step = (double)a.NQ * 8 * tile_kgroup + 6000.0;
+        rounds = (wgs + cus - 1) / cus;
+    } else {                                        // dsp_lstm_kernel: a wave = 1 unit tile x 4 gates x 2 site tiles per pass
+        const int np = a.NP < 1 ? 1 : a.NP;
+        const int waves = (a.UT / np) * a.SG;
+        const int per_simd = (waves + 3) / 4;
+        const long long wgs = NTp / (a.SG * 2) * 2;
+        step = (double)np * per_simd * ((double)nq_live * 8 * tile_kgroup + 5100.0);
+        // (two 4-wave workgroups share a CU and its matrix pipes: their k-loops add up)
+        rounds = (wgs + cus - 1) / cus;
+    }
+    return (double)rounds * a.T * step / (kPlanClockGHz * 1e3) + fixed_us;
+}
+
+// microseconds of one forward of `sites` sites as ONE piece on this handle (fp32 path)
+double piece_cost_us(const dsp_model* m, long long sites) {
+    const Dims& d = m->d;
+    const long long NTp = (((sites + 31) / 32) + 15) / 16 * 16;
+    const bool two = d.hseq && d.hsig && d.l2 == 1 && m->hseq_p <= 256 && m->hsig_p <= 256 &&
+                     (m->two_streams > 0 || (m->two_streams < 0 && NTp * 4 <= (long long)m->n_cus));
+    auto stack = [&](const std::vector<LayerShape>& shapes, int lstm_id, bool side_by_side) {
+        double us = 0;
+        for (const LayerShape& ly : shapes) {
+            LstmArgs a{};
+            shape_lstm(m, ly, lstm_id, NTp, a);
+            pick_form(m, a, NTp, false, side_by_side, m->cluster != 0);
+            us += lstm_launch_us(m, a, NTp) + 2.0;
+        }
+        return us;
+    };
+    const double k_sites = (double)NTp * 32 / 1000.0;
+    const double seq = d.hseq ? stack(m->seq_shape, 0, two) : 0, sig = d.hsig ? stack(m->sig_shape, 1, two) : 0;
+    double us = 10.0 + 1.0 * k_sites;                                   // pack
+    us += two ? std::max(seq, sig) : seq + sig;                         // the front ends (side by side on small batches)
+    const bool small_fc = NTp * 2 <= (long long)m->n_cus;
+    const double fc_flops = (double)d.T * 2.0 * ((double)m->hseq_p * 2 * m->hseq_p + (double)m->hsig_p * 2 * m->hsig_p) * (double)NTp * 32;
+    us += (d.hseq ? (small_fc ? 8.0 : 4.0) : 0) + (d.hsig ? (small_fc ? 8.0 : 4.0) : 0) + fc_flops / (130e6);   // fc_seq / fc_signal at ~130 TFLOP/s
+    us += stack(m->comb_shape, 2, false);
+    us += 25.0 + 1.6 * k_sites;                                         // head
+    return us;
+}
+
+// The sizes (in sites) at which the launch geometry of a forward changes on this device: where the combined stack's cluster
+// size steps down (P = 8 / 4 / 2: NTp x 16 / 8 / 4 <= CUs), where the workgroup-local forms end (NTp x 2 <= CUs), and one
+// round of the 64-site workgroups (one per CU); tile counts are padded to 16, so every class is a multiple of 512 sites.
+int class_caps(const dsp_model* m, long long caps[5]) {
+    const long long cus = m->n_cus;
+    const long long cand[5] = {cus / 16, cus / 8, cus / 4, cus / 2, cus};
+    int n = 0;
+    for (long long c : cand) {
+        const long long tiles = c / 16 * 16;
+        if (tiles >= 16 && (n == 0 || tiles * 32 > caps[n - 1])) caps[n++] = tiles * 32;
+    }
+    return n;
+}
+long long round_sites(const dsp_model* m) { const long long t = (long long)m->n_cus / 16 * 16; return (t >= 16 ? t : 16) * 32; }
+
+// the remainder r (< one round) of a call as the cheapest sequence of pieces, largest first (the partial piece is the smallest)
+struct PiecePlan { int n; long long sites[8]; bool tail_round; };   // tail_round: the one piece is of the round class
+PiecePlan plan_remainder(const dsp_model* m, long long r) {
+    PiecePlan pl{0, {0, 0, 0, 0, 0, 0, 0, 0}, false};
+    if (r <= 0) return pl;
+    long long caps[5];
+    const int nc = class_caps(m, caps);
+    double cost[5];
+    for (int c = 0; c < nc; ++c) cost[c] = piece_cost_us(m, caps[c]) + kPlanCutPenaltyUs;
+    const int kUnit = 512;
+    const int u = (int)((r + kUnit - 1) / kUnit);
+    std::vector<double> best((size_t)u + 1, 0.0);
+    std::vector<int> pick((size_t)u + 1, -1);
+    for (int k = 1; k <= u; ++k) {
+        best[(size_t)k] = 1e300;
+        for (int c = 0; c < nc; ++c) {
+            const int cap = (int)(caps[c] / kUnit);
+            const int rest = k > cap ? k - cap : 0;
+            const double t = cost[c] + best[(size_t)rest];
+            if (t < best[(size_t)k] - 1e-9) { best[(size_t)k] = t; pick[(size_t)k] = c; }
         }
     }
-    PiecePlan pl{0, {0, 0, 0, 0, 0, 0}};
-    for (int k = u; k > 0 && pl.n < 6;) {
-        pl.units[pl.n++] = cap[pick[k]];
-        k = k > cap[pick[k]] ? k - cap[pick[k]] : 0;
+    long long got[8]; int n = 0;
+    for (int k = u; k > 0 && n < 7;) {
+        const int cap = (int)(caps[pick[(size_t)k]] / kUnit);
+        got[n++] = caps[pick[(size_t)k]];
+        k = k > cap ? k - cap : 0;
+        if (n == 7 && k > 0) { n = 0; break; }   // (more pieces than the plan holds: one piece)
     }
-    std::sort(pl.units, pl.units + pl.n, [](int x, int y) { return x > y; });   // largest first: the partial piece is the smallest
+    if (n == 0) { pl.n = 1; pl.sites[0] = r; pl.tail_round = nc < 2 || r > caps[nc - 2]; return pl; }
+    pl.tail_round = n == 1 && got[0] == caps[nc - 1] && nc >= 2;
+    std::sort(got, got + n, [](long long x, long long y) { return x > y; });
+    long long left = r;
+    for (int i = 0; i < n && left > 0; ++i) {
+        const long long len = (i + 1 == n) ? left : std::min(left, got[i]);
+        pl.sites[pl.n++] = len;
+        left -= len;
+    }
     return pl;
 }
 }  // namespace
@@ -1093,34 +1244,23 @@ static int32_t forward_pieces(dsp_model* m, void* stream, int64_t n, const void*
                               const dsp_init_state* init, float* logits, float* probs, uint8_t* labels) {
     if (n < 0) return fail(DSP_EINVAL, "n_sites < 0");
     const int mode = init ? init->mode : DSP_INIT_ZEROS;
-    const int64_t kRound = 8192, kUnit = 512;
+    const int64_t kRound = round_sites(m);
     const int64_t whole = n / kRound * kRound, r = n - whole;
-    PiecePlan pl{0, {0, 0, 0, 0, 0, 0}};
-    if (r > 0) {
-        const int u = (int)((r + kUnit - 1) / kUnit);
-        if (m->small_classes) pl = plan_pieces(u);
-        else { pl.n = 1; pl.units[0] = u <= 8 ? 8 : 16; }   // a combined stack without clustered forms: <= 4,096 sites cost 3.7 ms flat
-        // (one 32-site workgroup per CU), so the remainder runs in one piece when it fits that and as a round otherwise
-    }
-    const bool tail_is_a_round = pl.n == 1 && pl.units[0] == 16;
-    const bool cut = m->forward_split && (whole > 0 ? (r > 0 && !tail_is_a_round) : pl.n > 1) && mode != DSP_INIT_EXPLICIT &&
-                     m->precision == DSP_PREC_FP32 && m->cluster != 0 && kmer_dtype >= 0 && kmer_dtype <= 3 && lens_dtype >= 0 &&
-                     lens_dtype <= 3;
+    const bool may_cut = m->forward_split && mode != DSP_INIT_EXPLICIT && m->precision == DSP_PREC_FP32 && m->cluster != 0 && kmer_dtype >= 0 &&
+                         kmer_dtype <= 3 && lens_dtype >= 0 && lens_dtype <= 3;
+    PiecePlan pl{0, {0, 0, 0, 0, 0, 0, 0, 0}, false};
+    if (may_cut && r > 0) pl = plan_remainder(m, r);
+    // (nothing to cut: the call is whole rounds, or at most one round whose cheapest cover is one piece; a remainder whose one
+    // piece is itself of the round class runs with the whole rounds in front of it)
+    const bool cut = may_cut && (whole > 0 ? (r > 0 && !pl.tail_round) : pl.n > 1);
     m->last_split = cut;
     if (!cut) return forward_chunk(m, stream, n, kmer, kmer_dtype, means, stds, lens, lens_dtype, signals, init, logits, probs, labels);
     static const size_t dt_size[4] = {4, 1, 2, 4};   // DSP_DT_F32, U8, U16, I32
     const Dims& d = m->d;
-    int64_t pieces[8];
+    int64_t pieces[9];
     int np = 0;
     if (whole > 0) pieces[np++] = whole;
-    {
-        int64_t left = r;
-        for (int i = 0; i < pl.n && left > 0; ++i) {
-            const int64_t len = (i + 1 == pl.n) ? left : std::min<int64_t>(left, (int64_t)pl.units[i] * kUnit);
-            pieces[np++] = len;
-            left -= len;
-        }
-    }
+    for (int i = 0; i < pl.n; ++i) pieces[np++] = pl.sites[i];
     int64_t at = 0;
     for (int i = 0; i < np; ++i) {
         const int64_t len = pieces[i];
@@ -1285,6 +1425,37 @@ int32_t dsp_debug_read_activation(dsp_model* m, void* stream, int32_t which, int
                 host_out[((size_t)site * d.T + t) * Fref + map[f]] = tmp[k4];
             }
     return 0;
+}
+
+int32_t dsp_debug_plan(const dsp_model_cfg* cfg, int32_t n_cus, int64_t n_sites, int64_t pieces[9], double cost_us[9]) {
+    Dims d;
+    const int rc = derive(cfg, &d);
+    if (rc) return rc;
+    if (n_cus < 16 || n_sites < 0 || !pieces) return fail(DSP_EINVAL, "dsp_debug_plan: bad arguments");
+    dsp_model host;                       // never sees a device: geometry and plan only
+    host.cfg = *cfg; host.d = d; host.n_cus = n_cus;
+    derive_geometry(&host);
+    const int64_t round = round_sites(&host), whole = n_sites / round * round, r = n_sites - whole;
+    PiecePlan pl{0, {0, 0, 0, 0, 0, 0, 0, 0}, false};
+    if (r > 0) pl = plan_remainder(&host, r);
+    int np = 0;
+    const bool cut = whole > 0 ? (r > 0 && !pl.tail_round) : pl.n > 1;
+    if (!cut) { if (n_sites > 0) pieces[np++] = n_sites; }
+    else {
+        if (whole > 0) pieces[np++] = whole;
+        for (int i = 0; i < pl.n; ++i) pieces[np++] = pl.sites[i];
+    }
+    if (cost_us) for (int i = 0; i < np; ++i) cost_us[i] = piece_cost_us(&host, pieces[i]);
+    return np;
+}
+
+double dsp_debug_piece_cost(const dsp_model_cfg* cfg, int32_t n_cus, int64_t n_sites) {
+    Dims d;
+    if (derive(cfg, &d) || n_cus < 16 || n_sites < 1) return -1.0;
+    dsp_model host;
+    host.cfg = *cfg; host.d = d; host.n_cus = n_cus;
+    derive_geometry(&host);
+    return piece_cost_us(&host, n_sites);
 }
 
 int32_t dsp_debug_range_probe(int32_t device, int32_t out[4]) {

@@ -518,6 +518,14 @@ int32_t dsp_model_query(const dsp_model* m, int32_t what);
 int64_t dsp_device_pci_bdf(int32_t device, char* out, size_t cap);
 int64_t dsp_device_uuid(int32_t device, char* out, size_t cap);
 
+/* Test hook (round 6; no device involved): how dsp_forward cuts a call of n_sites sites of model `cfg` on a device of n_cus
+ * compute units -- whole rounds of n_cus x 32 sites first, the remainder as the cheapest sequence of small-batch pieces by the
+ * launch geometry's cost model (csrc/dsp_capi.cpp piece_cost_us) -- and what it estimates for each piece (microseconds; may be
+ * NULL).  pieces / cost_us: room for 9 entries.  Returns the number of pieces (1: the call runs as one). */
+int32_t dsp_debug_plan(const dsp_model_cfg* cfg, int32_t n_cus, int64_t n_sites, int64_t pieces[9], double cost_us[9]);
+/* ... and the model's estimate for n_sites sites run as ONE piece (microseconds; < 0: bad arguments) */
+double dsp_debug_piece_cost(const dsp_model_cfg* cfg, int32_t n_cus, int64_t n_sites);
+
 /* Test hook (round 6): what this device does with an access past a buffer descriptor's num_records -- the hardware range
  * check the forward's descriptors rely on since they carry real extents.  One wave reads 1,024 bytes of ones through a
  * descriptor of 256 bytes: out[0] = lanes inside the extent that read their data (expect 16), out[1] = lanes past it by VGPR
