@@ -328,8 +328,8 @@ def main(argv=None):
                  "cpus": dsp_dist.cpus_text(my_cpus if my_cpus is not None else sorted(os.sched_getaffinity(0))),
                  "pinned": my_cpus is not None, "ms_per_step": round(dt_mine / max(K, 1) * 1e3, 3),
                  "visible_devices": ndev}
-        devices = [None] * world
-        dist.all_gather_object(devices, ident)
+        # (one fixed-width byte tensor per rank through dist.comm_device: no pickled-object collective on the RCCL group)
+        devices = dsp_dist.all_gather_json(ident, world, dev)
         # a device the runtime could not name counts by its index on its host (the check must not refuse a good run)
         key = lambda d: (d["host"], d["pci_bdf"], d["uuid"]) if d["pci_bdf"] else (d["host"], "hip device %d" % d["hip_device"])
         distinct = len({key(d) for d in devices}) == world

@@ -265,6 +265,8 @@ def lib():
     L.dsp_debug_plan.restype = ctypes.c_int32
     L.dsp_debug_plan.argtypes = [ctypes.POINTER(ModelCfg), ctypes.c_int32, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64),
                                  ctypes.POINTER(ctypes.c_double)]
+    L.dsp_debug_split_bf16.restype = None
+    L.dsp_debug_split_bf16.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     L.dsp_debug_piece_cost.restype = ctypes.c_double
     L.dsp_debug_piece_cost.argtypes = [ctypes.POINTER(ModelCfg), ctypes.c_int32, ctypes.c_int64]
     L.dsp_debug_range_probe.restype = ctypes.c_int32

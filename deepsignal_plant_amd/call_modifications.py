@@ -257,10 +257,8 @@ def _call_mods_file(args, rank, local_rank, world):
             # dealt round-robin (block i -> rank i % world), so a rank's part file is not a contiguous piece of the
             # output: the writer remembers where each block's calls end and rank 0 interleaves the pieces again
             interleaved = True
-            def gather(obj):
-                out = [None] * world
-                dist.all_gather_object(out, obj)
-                return out
+            def gather(obj):   # (names / flags of the shared-memory ring: json through dist.comm_device, no pickled-object collective)
+                return dsp_dist.all_gather_json(obj, world, coll_dev)
             gz_ring = feed.open_gz_ring(input_path, rank, world, int(os.environ.get("LOCAL_RANK", rank)),
                                         int(os.environ.get("LOCAL_WORLD_SIZE", world)), gather)
     if not input_path.endswith(".gz") and multi and not featfile.is_feature_file(input_path):

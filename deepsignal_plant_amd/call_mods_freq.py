@@ -268,9 +268,7 @@ class DeviceSiteFrequency(object):
         from . import dist as dsp_dist
         multi = dsp_dist.collective(world)   # several ranks, or a forced one-rank RCCL group (DSP_FORCE_DIST=1)
         if multi:
-            import torch.distributed as dist
-            lists = [None] * world
-            dist.all_gather_object(lists, names)
+            lists = dsp_dist.all_gather_json(list(names), world, dev)   # (chromosome names: json through dist.comm_device)
             glob, ids = [], {}
             for lst in lists:
                 for nm in lst:

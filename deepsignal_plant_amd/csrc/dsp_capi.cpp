@@ -16,6 +16,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -938,37 +940,6 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) m->n_cus = prop.multiProcessorCount;
     }
-    if (m->cluster != 0) {
-        // The clustered launches assume block b of a launch runs on XCD b % 8 (members of a cluster = consecutive entries of
-        // one XCD's dispatch list).  Observed, not promised: ask this device once -- 64 blocks report their XCC_ID -- and keep
-        // to the workgroup-local forms when it answers anything else (CPX / partition modes, CU masks, another XCD count).
-        // DSP_LSTM_CLUSTER_PROBE=0 skips the question.
-        const char* pv = getenv("DSP_LSTM_CLUSTER_PROBE");
-        if (!(pv && atoi(pv) == 0)) {
-            unsigned* dp = nullptr;
-            unsigned host[64];
-            (void)hipGetLastError();   // (whatever an earlier, unrelated call of this thread left behind -- torch's event queries leave
-            // hipErrorNotReady -- is not the probe's error: the launch wrapper reports the thread's last error)
-            bool ok = hipMalloc((void**)&dp, sizeof host) == hipSuccess && dsp_k_probe_xcc(dp, 64, nullptr) == 0 &&
-                      hipMemcpy(host, dp, sizeof host, hipMemcpyDeviceToHost) == hipSuccess;
-            if (dp) hipFree(dp);
-            const bool read_ok = ok;
-            // (the dispatcher's round robin carries on where the previous launch stopped: block 0 lands on ANY XCD, block b on the
-            // b-th after it -- what the clustered launches need is that blocks 8 apart share an XCD)
-            for (int b = 0; ok && b < 64; ++b) ok = host[b] < 8 && host[b] == (host[0] + (unsigned)b) % 8;
-            if (m->debug_lstm && read_ok) {
-                fprintf(stderr, "[lstm] XCC probe:");
-                for (int b = 0; b < 64; ++b) fprintf(stderr, " %u", host[b]);
-                fprintf(stderr, "\n");
-            }
-            if (!ok) {
-                (void)hipGetLastError();
-                m->cluster = 0;
-                m->xcc_probe_failed = true;
-                if (m->debug_lstm) fprintf(stderr, "[lstm] XCC probe: block b does not run on XCD b %% 8 here: clustered launches off\n");
-            }
-        }
-    }
     {   // arrival counters of the clustered launches (zeroed by every forward's first launch; 1.5 MB)
         void* p = nullptr;
         const size_t bytes = (size_t)kClusterLaunches * kClusterWordsPerLaunch * sizeof(unsigned int);
@@ -976,6 +947,49 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
         m->dev_allocs.push_back(p);
         m->cflags = (unsigned int*)p;
         m->n_cflag_words = kClusterLaunches * kClusterWordsPerLaunch;
+    }
+    if (m->cluster != 0) {
+        // The clustered launches assume block b of a launch runs on XCD b % 8 (members of a cluster = consecutive entries of
+        // one XCD's dispatch list).  Observed, not promised: ask the device -- 64 blocks report their XCC_ID -- and keep to the
+        // workgroup-local forms when it answers anything else (CPX / partition modes, CU masks, another XCD count).
+        // DSP_LSTM_CLUSTER_PROBE=0 skips the question.  Round 6: asked ONCE per device and process,
+        // not per handle; on the handle's non-blocking side stream with the answer landing in the counters' own allocation
+        // (no hipMalloc / hipFree pair, no launch on the legacy stream -- illegal while another stream captures --, no
+        // device-wide sync); and a device that fails the probe says so on stderr instead of only through dsp_model_query.
+        static std::mutex probe_mu;
+        static std::map<int, int> probe_result;   // device -> 1: blocks 8 apart share an XCD, 0: they do not
+        const char* pv = getenv("DSP_LSTM_CLUSTER_PROBE");
+        if (!(pv && atoi(pv) == 0)) {
+            std::lock_guard<std::mutex> lock(probe_mu);
+            auto it = probe_result.find(device);
+            if (it == probe_result.end()) {
+                unsigned host[64];
+                (void)hipGetLastError();   // (whatever an earlier, unrelated call of this thread left behind -- torch's event queries leave
+                // hipErrorNotReady -- is not the probe's error: the launch wrapper reports the thread's last error)
+                hipStream_t ps = m->side;   // (NULL only when no side stream could be made: the legacy stream then, as until round 5)
+                bool ok = dsp_k_probe_xcc(m->cflags, 64, ps) == 0 &&
+                          hipMemcpyAsync(host, m->cflags, sizeof host, hipMemcpyDeviceToHost, ps) == hipSuccess &&
+                          hipStreamSynchronize(ps) == hipSuccess;
+                const bool read_ok = ok;
+                // (the dispatcher's round robin carries on where the previous launch stopped: block 0 lands on ANY XCD, block b on the
+                // b-th after it -- what the clustered launches need is that blocks 8 apart share an XCD)
+                for (int b = 0; ok && b < 64; ++b) ok = host[b] < 8 && host[b] == (host[0] + (unsigned)b) % 8;
+                if (m->debug_lstm && read_ok) {
+                    fprintf(stderr, "[lstm] XCC probe:");
+                    for (int b = 0; b < 64; ++b) fprintf(stderr, " %u", host[b]);
+                    fprintf(stderr, "\n");
+                }
+                if (!ok) {
+                    (void)hipGetLastError();
+                    fprintf(stderr, "libdsp_amd: device %d: %s -- the clustered small-batch launches stay off on this device "
+                                    "(batches <= 2,048 sites run the workgroup-local forms; DSP_LSTM_CLUSTER_PROBE=0 skips the question)\n", device,
+                            read_ok ? "consecutive blocks of a launch do not run on consecutive XCDs here (XCC_ID probe: a partition mode, a CU mask, another XCD count?)"
+                                    : "the XCC_ID probe could not run");
+                }
+                it = probe_result.emplace(device, ok ? 1 : 0).first;
+            }
+            if (!it->second) { m->cluster = 0; m->xcc_probe_failed = true; }
+        }
     }
     if (const char* v = getenv("DSP_PRECISION"))
         m->precision = !strcmp(v, "bf16x6") ? DSP_PREC_BF16X6 : (!strcmp(v, "bf16x9") ? DSP_PREC_BF16X9 :
@@ -1447,6 +1461,15 @@ int32_t dsp_debug_plan(const dsp_model_cfg* cfg, int32_t n_cus, int64_t n_sites,
     }
     if (cost_us) for (int i = 0; i < np; ++i) cost_us[i] = piece_cost_us(&host, pieces[i]);
     return np;
+}
+
+void dsp_debug_split_bf16(const float* x, int64_t n, uint16_t* hi, uint16_t* mid, uint16_t* lo) {
+    for (int64_t i = 0; i < n; ++i) {   // (exactly the statements of pack_lstm_dir_split's bf16 branch)
+        hi[i] = bf16_rne(x[i]);
+        const float r1 = x[i] - bf16_to_f32(hi[i]);
+        mid[i] = bf16_rne(r1);
+        lo[i] = bf16_rne(r1 - bf16_to_f32(mid[i]));
+    }
 }
 
 double dsp_debug_piece_cost(const dsp_model_cfg* cfg, int32_t n_cus, int64_t n_sites) {

@@ -202,8 +202,8 @@ def pin_rank(local_rank, local_world, pci_bus_id=None, peer_bus_ids=None):
     sysfs name, dist.pci_bdf / _native.device_pci_bdf); when the caller names the GPUs of ALL local ranks (peer_bus_ids[r] =
     name of local rank r's GPU) the node's CPUs are split in equal slices among the ranks whose GPUs share that node;
     without that list every rank of the node takes the whole node (and threads_per_rank divides by the ranks per node as
-    if unpinned).  A GPU whose node the kernel does not report (one memory domain) falls back to slice -- said on stderr
-    when numa was asked for explicitly.
+    if unpinned).  A GPU whose node the kernel does not report (one memory domain): with DSP_RANK_AFFINITY=numa asked for
+    explicitly the rank falls back to slice (said on stderr); by default it stays unpinned.
     Returns the CPU list set, or None.  A rank whose affinity became its own share records it for threads_per_rank."""
     global _PINNED_SHARE
     mode = affinity_mode(local_world)
@@ -227,6 +227,10 @@ def pin_rank(local_rank, local_world, pci_bus_id=None, peer_bus_ids=None):
             sys.stderr.write("[dist] DSP_RANK_AFFINITY=numa: no NUMA node for GPU %r of local rank %d under %s "
                              "(numa_node < 0 or unreadable): taking an equal slice of the allowed CPUs instead\n"
                              % (pci_bus_id, local_rank, _SYSFS))
+        else:
+            # numa by DEFAULT and the kernel reports one memory domain (or an outer launcher hid the device): nothing to be
+            # next to -- narrowing every rank to a hard 1 / local_world slice would only cap its threads: unpinned
+            return None
     if cpus is None:
         k = max(1, len(allowed) // max(1, local_world))
         cpus = allowed[local_rank * k:(local_rank + 1) * k]
@@ -261,7 +265,9 @@ def place_rank(rank, local_rank, local_world, ndev):
         peers = None
     if mode:
         cpus = pin_rank(local_rank, local_world, bdf, peers)
-    if os.environ.get("DSP_TIMING") or (cpus is not None and rank == 0 and os.environ.get("DSP_RANK_AFFINITY")):
+    # one line from rank 0 whenever the pinning CHANGED this process's affinity (it is on by default for several ranks: a
+    # behaviour the user has not asked for must not be silent); every rank under DSP_TIMING
+    if os.environ.get("DSP_TIMING") or (cpus is not None and rank == 0):
         import sys
         node = _numa_node_cpus(bdf)[0]
         sys.stderr.write("[dist] rank %d (local %d of %d): GPU %s, NUMA node %s, affinity %s -> CPUs %s\n" % (
@@ -342,6 +348,44 @@ def all_gather_ints(value, world, device=None):
     return [int(x.item()) for x in out]
 
 
+def all_gather_text(text, world, device=None):
+    """One string per rank -> list of all ranks' strings: the lengths by one all_gather of an int, then ONE all_gather of
+    uint8 tensors padded to the longest, on the collective's device (RCCL on GPU tensors, gloo on host tensors --
+    comm_device).  No pickled-object collective runs on the RCCL group (until round 5 bench.py's proof-of-N-GPUs line, the
+    chromosome names of the sharded call_freq and the shared-memory ring's names went through dist.all_gather_object --
+    first-contact code on real hardware: pickles moved through byte tensors on whatever device the backend picks)."""
+    if not collective(world):
+        return [str(text)]
+    import torch
+    import torch.distributed as dist
+    raw = str(text).encode("utf-8")
+    cdev = comm_device(device)
+    sizes = all_gather_ints(len(raw), world, cdev)
+    width = max(max(sizes), 1)
+    buf = bytearray(width)
+    buf[:len(raw)] = raw
+    t = torch.frombuffer(buf, dtype=torch.uint8).clone().to(cdev)
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [bytes(o.cpu().numpy().tobytes())[:n].decode("utf-8") for o, n in zip(out, sizes)]
+
+
+def all_gather_json(obj, world, device=None):
+    """... of anything json can carry (names, small records): every rank's object, in rank order"""
+    import json
+    return [json.loads(t) for t in all_gather_text(json.dumps(obj), world, device)]
+
+
+def _post_and_wait(ops):
+    """point-to-point operations posted as ONE group (batch_isend_irecv: a single ncclGroupStart / End on RCCL, so that the
+    root's receives from all ranks progress together instead of in the order they were posted), then waited for"""
+    import torch.distributed as dist
+    if not ops:
+        return
+    for q in dist.batch_isend_irecv(ops):
+        q.wait()
+
+
 def all_reduce_int(value, world, op="sum", device=None):
     """One integer per rank -> its sum / min / max over the ranks"""
     if not collective(world):
@@ -404,13 +448,11 @@ def gather_probs(probs, world, dst=0):
     probs = probs.contiguous().to(cdev)
     if me != dst:
         if sizes[me]:
-            dist.send(probs, dst)
+            _post_and_wait([dist.P2POp(dist.isend, probs, dst)])
         return None
     out = [probs if r == me else torch.empty((sizes[r],) + tuple(probs.shape[1:]), dtype=probs.dtype, device=cdev)
            for r in range(world)]
-    reqs = [dist.irecv(out[r], r) for r in range(world) if r != me and sizes[r]]
-    for q in reqs:
-        q.wait()
+    _post_and_wait([dist.P2POp(dist.irecv, out[r], r) for r in range(world) if r != me and sizes[r]])
     return out
 
 
@@ -428,10 +470,9 @@ def gather_columns(cols, world, device=None):
     me = dist.get_rank()
     if me != 0:
         if n:
-            dist.send(rec, 0)
+            _post_and_wait([dist.P2POp(dist.isend, rec, 0)])
         return None
     got = [rec if r == 0 else torch.empty((sizes[r], len(cols)), dtype=rec.dtype, device=cdev) for r in range(world)]
-    for q in [dist.irecv(got[r], r) for r in range(1, world) if sizes[r]]:
-        q.wait()
+    _post_and_wait([dist.P2POp(dist.irecv, got[r], r) for r in range(1, world) if sizes[r]])
     out = torch.cat(got)
     return [out[:, j].contiguous() for j in range(len(cols))]

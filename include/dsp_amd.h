@@ -518,6 +518,13 @@ int32_t dsp_model_query(const dsp_model* m, int32_t what);
 int64_t dsp_device_pci_bdf(int32_t device, char* out, size_t cap);
 int64_t dsp_device_uuid(int32_t device, char* out, size_t cap);
 
+/* Test hook (round 6; no device involved): the three bf16 pieces the split-precision modes cut an fp32 weight into
+ * (csrc/dsp_capi.cpp pack_lstm_dir_split: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid), round to nearest even);
+ * tests/test_split_exact.py holds hi + mid + lo == x bit for bit over 1e7 random values and every exponent edge, and states
+ * what happens where it cannot hold (|x| < 2^-109: the low piece underflows bf16's subnormals -- an absolute error below
+ * 2^-133; |x| > the largest bf16: hi is infinite -- visible, never silent). */
+void dsp_debug_split_bf16(const float* x, int64_t n, uint16_t* hi, uint16_t* mid, uint16_t* lo);
+
 /* Test hook (round 6; no device involved): how dsp_forward cuts a call of n_sites sites of model `cfg` on a device of n_cus
  * compute units -- whole rounds of n_cus x 32 sites first, the remainder as the cheapest sequence of small-batch pieces by the
  * launch geometry's cost model (csrc/dsp_capi.cpp piece_cost_us) -- and what it estimates for each piece (microseconds; may be

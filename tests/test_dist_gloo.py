@@ -433,10 +433,11 @@ def test_ranks_are_placed_next_to_their_gpus_by_default(monkeypatch, tmp_path, c
         capsys.readouterr()
         assert dd.pin_rank(1, 4, zero, [zero] * 4) == list(range(32, 64))
         assert "no NUMA node for GPU" in capsys.readouterr().err
-        # by default (not asked for explicitly) the same fallback is silent
+        # by default (not asked for explicitly) one memory domain means there is nothing to be next to: the rank stays
+        # unpinned (round 6, ADVICE r5: a hard 1 / local_world slice nobody asked for only capped the rank's threads)
         monkeypatch.delenv("DSP_RANK_AFFINITY")
         state["aff"] = set(range(128))
-        assert dd.pin_rank(1, 4, zero, [zero] * 4) == list(range(32, 64)) and capsys.readouterr().err == ""
+        assert dd.pin_rank(1, 4, zero, [zero] * 4) is None and state["aff"] == set(range(128)) and capsys.readouterr().err == ""
         # opt-out, and a lone rank
         monkeypatch.setenv("DSP_RANK_AFFINITY", "off")
         state["aff"] = set(range(128))
@@ -457,6 +458,16 @@ def test_ranks_are_placed_next_to_their_gpus_by_default(monkeypatch, tmp_path, c
         dd._PLACED = None
         bdf, cpus = dd.place_rank(6, 6, 8, 1)             # eight ranks sharing ONE GPU (the dev box): eight slices of its node
         assert bdf == bdfs[0] and cpus == list(range(48, 56))
+        # the pinning is on by default: rank 0 says where it landed WITHOUT being asked (no DSP_TIMING, no DSP_RANK_AFFINITY);
+        # the other ranks stay quiet
+        monkeypatch.delenv("DSP_TIMING")
+        for r, expect in ((0, True), (3, False)):
+            dd._PLACED = None
+            state["aff"] = set(range(128))
+            capsys.readouterr()
+            _, cpus = dd.place_rank(r, r, 8, 8)
+            assert cpus == list(range(16 * r, 16 * r + 16))
+            assert ("rank %d (local %d of 8)" % (r, r) in capsys.readouterr().err) == expect
     finally:
         dd._PINNED_SHARE = None
         dd._PLACED = None
@@ -483,3 +494,69 @@ def test_a_plain_text_output_named_gz_merges_as_plain_text(tmp_path):
             f.write(b"x%d\n" % r + cm._BGZF_EOF)
     cm._merge_parts(out, world, False, is_gzip=False)
     assert open(out, "rb").read() == b"x0\n" + cm._BGZF_EOF + b"x1\n" + cm._BGZF_EOF
+
+
+# ---- round 6: first-contact hardening for the 8-GPU run ---------------------------------------------
+
+def _first_contact_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import json
+
+    import torch
+    import torch.distributed as dist
+
+    from deepsignal_plant_amd import dist as dd
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # (1) bench.py's proof-of-N-GPUs record: one fixed-width byte tensor per rank, no pickled-object collective
+    ident = {"rank": rank, "host": "node-%d" % (rank // 4), "pci_bdf": "0000:%02x:00.0" % (5 + 0x20 * rank), "uuid": "%032x" % (rank * 7919),
+             "name": "AMD Instinct MI355X µ", "cpus": "%d-%d" % (16 * rank, 16 * rank + 15), "ms_per_step": 52.5 + rank / 8}
+    got = dd.all_gather_json(ident, world)
+    assert [g["rank"] for g in got] == list(range(world)) and got[rank] == ident
+    assert len({(g["host"], g["pci_bdf"], g["uuid"]) for g in got}) == world
+    # ragged lengths, an empty string, None (the shared-memory ring's "no name"), a list of chromosome names
+    assert dd.all_gather_text("x" * (3000 * rank), world) == ["x" * (3000 * r) for r in range(world)]
+    assert dd.all_gather_json(None if rank % 2 else "/dsp_ring_%d" % rank, world) == [None if r % 2 else "/dsp_ring_%d" % r for r in range(world)]
+    assert dd.all_gather_json(["chr%d" % k for k in range(rank)], world) == [["chr%d" % k for k in range(r)] for r in range(world)]
+    # (2) gather_probs: ragged, two ranks empty, the receives of the root posted as ONE group; to a root that is not rank 0 too
+    n = [700, 0, 3, 1200, 1, 0, 64, 5][rank % 8]
+    first = sum([700, 0, 3, 1200, 1, 0, 64, 5][r % 8] for r in range(rank))
+    idx = torch.arange(first, first + n, dtype=torch.float32)
+    probs = torch.stack((idx, 1 - idx), 1) if n else torch.zeros((0, 2))
+    for dst in (0, world - 1):
+        out = dd.gather_probs(probs, world, dst=dst)
+        if rank == dst:
+            allp = torch.cat(out)
+            assert [int(o.shape[0]) for o in out] == [[700, 0, 3, 1200, 1, 0, 64, 5][r % 8] for r in range(world)]
+            assert torch.equal(allp[:, 0], torch.arange(allp.shape[0], dtype=torch.float32))
+        else:
+            assert out is None
+    # (3) gather_columns, same shape of problem
+    cols = [torch.arange(n, dtype=torch.int64) + first, torch.full((n,), rank, dtype=torch.int64)]
+    gc = dd.gather_columns(cols, world)
+    if rank == 0:
+        assert gc[0].tolist() == list(range(int(gc[0].numel()))) and gc[1].tolist() == sorted(gc[1].tolist())
+        with open(os.path.join(outdir, "ok"), "w") as f:
+            f.write(str(int(gc[0].numel())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_the_bench_identity_gather_and_the_grouped_point_to_point_gathers(tmp_path, world):
+    """What the driver's 8-GPU run touches for the first time on real hardware: bench.py's per-rank identity records, the sharded
+    call_freq's chromosome names and the shared-memory ring's names (now dist.all_gather_json: lengths, then one all_gather of
+    padded uint8 tensors through comm_device -- no all_gather_object on the RCCL group) and the final gathers, whose sends / receives are posted as one batch_isend_irecv group."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.start_processes(_first_contact_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    want = sum([700, 0, 3, 1200, 1, 0, 64, 5][r % 8] for r in range(world))
+    assert int(open(os.path.join(str(tmp_path), "ok")).read()) == want
+
+
+def test_no_pickled_object_collective_is_left():
+    for rel in ["bench.py"] + [os.path.join("deepsignal_plant_amd", f) for f in os.listdir(os.path.join(ROOT, "deepsignal_plant_amd"))
+                               if f.endswith(".py")]:
+        src = open(os.path.join(ROOT, rel)).read()
+        for name in ("all_gather_object", "gather_object", "broadcast_object_list", "scatter_object_list"):
+            assert "dist." + name + "(" not in src, (rel, name)
