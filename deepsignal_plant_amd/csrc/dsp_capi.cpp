@@ -411,7 +411,11 @@ const void* rsrc_end(const dsp_model* m, const void* p, size_t logical) {
     if (!p) return nullptr;
     if (m->extents == 0) return (const char*)p + (1ull << 40);   // clamps to the old 0x7ffffff0 window in the kernel
     const char* e = (const char*)alloc_end(m, p);
-    if (e && m->extents == 2 && (const char*)p + logical < e) e = (const char*)p + logical;
+    // (what the launch is entitled to touch must lie inside the allocation: a region sized for fewer tiles than this call uses
+    // would otherwise have its legitimate tail clipped by the range check -- zeros read, stores dropped, silently.  NULL makes
+    // the launch wrapper refuse the launch.)
+    if (e && (const char*)p + logical > e) return nullptr;
+    if (e && m->extents == 2) e = (const char*)p + logical;
     return e;
 }
 
@@ -630,7 +634,12 @@ struct Launcher {
             if (!take_events(&ea, &eb)) return;
         }
         const int e = f();
-        if (e != 0) { rc = fail(DSP_EHIP, "launch %s failed: %s", name, hipGetErrorString((hipError_t)e)); return; }
+        if (e != 0) {
+            rc = fail(DSP_EHIP, "launch %s failed: %s%s", name, hipGetErrorString((hipError_t)e),
+                      e == (int)hipErrorInvalidValue ? " (a pointer of the launch without the end of its allocation, or a launch that would reach past it: "
+                                                       "the launch wrappers refuse a buffer descriptor without a real extent)" : "");
+            return;
+        }
         if (bracket) ++pending_n;
         else if (timed) { hipEventRecord(eb, s); m->prof_entries.push_back({name, ea, eb, 1}); last_ev = eb; last_s = s; }
         else last_ev = nullptr;

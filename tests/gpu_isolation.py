@@ -275,6 +275,15 @@ class GpuIsolation:
         for it in items:
             if is_gpu_item(it):
                 self.by_module.setdefault(str(it.path), []).append(it.nodeid)
+        if self.by_module:
+            # The collecting process maps the product library too (dlopen + the pure dsp_abi_version() of _native.lib(): no HIP
+            # call, no device touched -- the tests still run in the children): whoever audits "which in-tree .so did the pytest
+            # process load" by looking at THIS process finds the library the children compute with, not an empty list.
+            try:
+                from deepsignal_plant_amd import _native
+                _native.lib()
+            except Exception:   # (no library built: the children's tests say so themselves, loudly)
+                pass
 
     @pytest.hookimpl(tryfirst=True)
     def pytest_runtest_protocol(self, item, nextitem):
