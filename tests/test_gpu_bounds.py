@@ -2,8 +2,8 @@
 
   * the hardware does range-check: a load past num_records returns zeros, a store past it is dropped -- by VGPR offset AND by
     SGPR offset (where the kernels carry almost all of an address);
-  * the product library gives the same bytes with the extents of the allocation (default), the tight extents of the call, and
-    the 2 GiB windows of rounds 1-5, over every kernel form (tools/extents_sweep.py: 11 model shapes, 45 batch sizes, four
+  * the product library gives the same bytes with the extents of the allocation (default) and the tight extents of the call
+    (and the 2 GiB windows of rounds 1-5: tests/test_gpu_parity.py), over every kernel form (tools/extents_sweep.py: 11 model shapes, 45 batch sizes, four
     precisions, Philox / explicit / zero states);
   * the bounds-recording build (libdsp_amd_bounds.so: every descriptor access compared in software with the TIGHT extent of
     its operand) runs the same sweep without a record and with the same bytes;
@@ -43,7 +43,7 @@ def product_digest():
     return json.loads(_sweep({}).stdout.strip().splitlines()[-1])
 
 
-@pytest.mark.parametrize("mode", ["wide", "tight"])
+@pytest.mark.parametrize("mode", ["tight"])   # ("wide" against the default: test_small_batch_kernels_do_not_change_a_bit, five shapes x fifteen sizes)
 def test_extents_do_not_change_a_bit(product_digest, mode):
     got = json.loads(_sweep({"DSP_RSRC_EXTENTS": mode}).stdout.strip().splitlines()[-1])
     assert len(got) == len(product_digest) > 100

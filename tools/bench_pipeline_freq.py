@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""BASELINE.json configs[4] scaled to one GPU: feature TSV -> call_mods -> per-read calls, with the per-site frequency
+"""BASELINE.json configs[4] scaled to one GPU and to `rows` rows (default 4 M; the config says ~1 B on 8 GPUs -- every line this prints
+carries its row count): feature TSV -> call_mods -> per-read calls, with the per-site frequency
 (`--freq_file`, what the reference gets by piping the calls into call_mods_freq) from the device-side reduction and from
 the host table, next to the plain call_mods run and to `call_freq` on the written file.  One JSON line per run.
 usage: bench_pipeline_freq.py [rows] [coverage]   (coverage: calls per genome site; default 1 = every call its own site, the

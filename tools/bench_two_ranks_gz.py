@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""BASELINE.json configs[4] in miniature on the 1-GPU box: a reference-style single-member .gz of N feature rows -> call_mods
+"""BASELINE.json configs[4] in miniature on the 1-GPU box (N rows, default 2 M, printed on the line; the config says ~1 B on 8 GPUs): a reference-style single-member .gz of N feature rows -> call_mods
 on TWO ranks sharing the GPU (one inflater for the node through the shared-memory ring, parallel inflate, blocks dealt
 round-robin, device-side call_freq with the all_to_all over gloo, parts merged back into input order) against the same
 command on one rank: byte-identical per-read calls and frequency file, wall times.  One JSON line.
