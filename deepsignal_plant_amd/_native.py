@@ -265,6 +265,9 @@ def lib():
     L.dsp_debug_plan.restype = ctypes.c_int32
     L.dsp_debug_plan.argtypes = [ctypes.POINTER(ModelCfg), ctypes.c_int32, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64),
                                  ctypes.POINTER(ctypes.c_double)]
+    L.dsp_debug_dry_run.restype = ctypes.c_int32
+    L.dsp_debug_dry_run.argtypes = [ctypes.POINTER(ModelCfg), ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_char_p,
+                                    ctypes.c_char_p, ctypes.c_size_t]
     L.dsp_debug_split_bf16.restype = None
     L.dsp_debug_split_bf16.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     L.dsp_debug_piece_cost.restype = ctypes.c_double

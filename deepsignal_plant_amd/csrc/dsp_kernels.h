@@ -121,6 +121,9 @@ int dsp_k_linear(const LinArgs* a, hipStream_t s);
 int dsp_k_head(const HeadArgs* a, hipStream_t s);
 int dsp_k_probe_xcc(unsigned* dev_out, int blocks, hipStream_t s);   /* out[b] = XCC_ID block b ran on */
 int dsp_k_range_probe(float* dev_buf4k, unsigned* dev_out, hipStream_t s);   /* see dsp_debug_range_probe */
+/* dry runs (dsp_debug_dry_run): on != 0 -> the wrappers above check and NOTE their launches (one text line each appended to the
+   std::string behind log_string, may be NULL) instead of making them; per thread */
+void dsp_k_set_dry(int on, void* log_string);
 /* 1 in the bounds-recording build (make bounds -> libdsp_amd_bounds.so), else 0 */
 int dsp_k_bounds_build(void);
 /* bounds build: the first out-of-range access recorded since the last read (and clears it); rec[0] = accesses out of range

@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #include <initializer_list>
+#include <string>
 #include <type_traits>
 #include <utility>
 
@@ -1840,6 +1841,29 @@ extern "C" int dsp_k_init(void) {
     return (int)hipFuncSetAttribute((const void*)dsp_head_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
 }
 
+// Dry runs (round 6; dsp_debug_dry_run, no device): the wrappers below run every check they make and work out every launch's
+// geometry, then NOTE the launch -- kernel, grid, block, dynamic LDS -- instead of making it.  The host half of a forward (which
+// kernel form a batch size takes, the extents behind every descriptor, the cut into pieces) is thereby testable on a machine
+// without a GPU: tests/test_dry_run.py.  Off unless dsp_k_set_dry(1) was called on this thread.
+static thread_local int g_dry = 0;
+static thread_local std::string* g_dry_log = nullptr;
+extern "C" void dsp_k_set_dry(int on, void* log_string) { g_dry = on; g_dry_log = (std::string*)log_string; }
+static bool dry_note(const char* kern, dim3 grid, dim3 block, size_t lds) {
+    if (!g_dry) return false;
+    if (g_dry_log) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "%s grid %u,%u block %u lds %zu\n", kern, grid.x, grid.y, block.x, lds);
+        *g_dry_log += buf;
+    }
+    return true;
+}
+#define DSP_LAUNCH(kern, grid, block, lds, stream, ...)                               \
+    do {                                                                              \
+        if (dry_note(#kern, grid, block, lds)) break;                                 \
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);              \
+    } while (0)
+#define DSP_LAUNCH_RESULT() (g_dry ? 0 : (int)hipGetLastError())
+
 // every pointer that is addressed through a buffer descriptor comes with the end of its allocation: a NULL or inverted end
 // would make a descriptor of zero records (loads of zeros, dropped stores -- silently wrong results), so it is refused here
 static bool ends_ok(std::initializer_list<std::pair<const void*, const void*>> v) {
@@ -1879,8 +1903,8 @@ extern "C" int dsp_k_bounds_read(unsigned rec[8]) {
 extern "C" int dsp_k_pack(const PackArgs* a, hipStream_t s) {
     const long long threads = (long long)a->NTp * a->T * 32;
     const unsigned blocks = (unsigned)((threads + 255) / 256);
-    hipLaunchKernelGGL(dsp_pack_kernel, dim3(blocks), dim3(256), 0, s, *a);
-    return (int)hipGetLastError();
+    DSP_LAUNCH(dsp_pack_kernel, dim3(blocks), dim3(256), 0, s, *a);
+    return DSP_LAUNCH_RESULT();
 }
 
 // a wave owns one unit tile (per pass) x two site tiles; a->SG site groups (of two tiles) per workgroup; a->NP passes
@@ -1911,21 +1935,21 @@ extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
         if (a->flags & 4) lds = lds < 84 * 1024 ? 84 * 1024 : lds;   // more than half a CU's LDS: one workgroup per CU
         // the front ends' zero-padded leading k-groups (features at the end of the 32-wide block) issue no MFMAs
         const int dead = ((local || xshort) && nqx == 4 && a->nqx_used == 4 && (a->nqx_lo == 2 || a->nqx_lo == 3)) ? a->nqx_lo : 0;
-        if (local8) hipLaunchKernelGGL((dsp_lstmc_kernel<4, 4, true, 0, 8>), dim3(grid), dim3(512), lds, s, *a);
-        else if (local && dead == 3) hipLaunchKernelGGL((dsp_lstmc_kernel<4, 4, true, 3>), dim3(grid), dim3(256), lds, s, *a);
-        else if (local && dead == 2) hipLaunchKernelGGL((dsp_lstmc_kernel<4, 4, true, 2>), dim3(grid), dim3(256), lds, s, *a);
-        else if (local) hipLaunchKernelGGL((dsp_lstmc_kernel<4, 4, true>), dim3(grid), dim3(256), lds, s, *a);
-        else if (xshort && G == 1 && dead == 3) hipLaunchKernelGGL((dsp_lstmc_kernel<1, 4, false, 3, 4, true>), dim3(grid), dim3(256), lds, s, *a);
-        else if (xshort && G == 1 && dead == 2) hipLaunchKernelGGL((dsp_lstmc_kernel<1, 4, false, 2, 4, true>), dim3(grid), dim3(256), lds, s, *a);
-        else if (xshort && G == 1) hipLaunchKernelGGL((dsp_lstmc_kernel<1, 4, false, 0, 4, true>), dim3(grid), dim3(256), lds, s, *a);
-        else if (xshort && dead == 3) hipLaunchKernelGGL((dsp_lstmc_kernel<2, 4, false, 3, 4, true>), dim3(grid), dim3(256), lds, s, *a);
-        else if (xshort && dead == 2) hipLaunchKernelGGL((dsp_lstmc_kernel<2, 4, false, 2, 4, true>), dim3(grid), dim3(256), lds, s, *a);
-        else if (xshort) hipLaunchKernelGGL((dsp_lstmc_kernel<2, 4, false, 0, 4, true>), dim3(grid), dim3(256), lds, s, *a);
-        else if (dense4 && G == 1) hipLaunchKernelGGL((dsp_lstmc_kernel<1, 4>), dim3(grid), dim3(256), lds, s, *a);
-        else if (dense4) hipLaunchKernelGGL((dsp_lstmc_kernel<2, 4>), dim3(grid), dim3(256), lds, s, *a);
-        else if (G == 4) hipLaunchKernelGGL((dsp_lstmc_kernel<4, 4>), dim3(grid), dim3(256), lds, s, *a);
-        else if (G == 2) hipLaunchKernelGGL((dsp_lstmc_kernel<2, 8>), dim3(grid), dim3(256), lds, s, *a);
-        else hipLaunchKernelGGL((dsp_lstmc_kernel<1, 16>), dim3(grid), dim3(256), lds, s, *a);
+        if (local8) DSP_LAUNCH((dsp_lstmc_kernel<4, 4, true, 0, 8>), dim3(grid), dim3(512), lds, s, *a);
+        else if (local && dead == 3) DSP_LAUNCH((dsp_lstmc_kernel<4, 4, true, 3>), dim3(grid), dim3(256), lds, s, *a);
+        else if (local && dead == 2) DSP_LAUNCH((dsp_lstmc_kernel<4, 4, true, 2>), dim3(grid), dim3(256), lds, s, *a);
+        else if (local) DSP_LAUNCH((dsp_lstmc_kernel<4, 4, true>), dim3(grid), dim3(256), lds, s, *a);
+        else if (xshort && G == 1 && dead == 3) DSP_LAUNCH((dsp_lstmc_kernel<1, 4, false, 3, 4, true>), dim3(grid), dim3(256), lds, s, *a);
+        else if (xshort && G == 1 && dead == 2) DSP_LAUNCH((dsp_lstmc_kernel<1, 4, false, 2, 4, true>), dim3(grid), dim3(256), lds, s, *a);
+        else if (xshort && G == 1) DSP_LAUNCH((dsp_lstmc_kernel<1, 4, false, 0, 4, true>), dim3(grid), dim3(256), lds, s, *a);
+        else if (xshort && dead == 3) DSP_LAUNCH((dsp_lstmc_kernel<2, 4, false, 3, 4, true>), dim3(grid), dim3(256), lds, s, *a);
+        else if (xshort && dead == 2) DSP_LAUNCH((dsp_lstmc_kernel<2, 4, false, 2, 4, true>), dim3(grid), dim3(256), lds, s, *a);
+        else if (xshort) DSP_LAUNCH((dsp_lstmc_kernel<2, 4, false, 0, 4, true>), dim3(grid), dim3(256), lds, s, *a);
+        else if (dense4 && G == 1) DSP_LAUNCH((dsp_lstmc_kernel<1, 4>), dim3(grid), dim3(256), lds, s, *a);
+        else if (dense4) DSP_LAUNCH((dsp_lstmc_kernel<2, 4>), dim3(grid), dim3(256), lds, s, *a);
+        else if (G == 4) DSP_LAUNCH((dsp_lstmc_kernel<4, 4>), dim3(grid), dim3(256), lds, s, *a);
+        else if (G == 2) DSP_LAUNCH((dsp_lstmc_kernel<2, 8>), dim3(grid), dim3(256), lds, s, *a);
+        else DSP_LAUNCH((dsp_lstmc_kernel<1, 16>), dim3(grid), dim3(256), lds, s, *a);
         if (!local) {
             // the clean-up launch: clusters whose members did not all become resident in time were abandoned by them and are
             // computed here, one workgroup each (eight waves for 8 unit tiles, four for 4), nothing waiting on another
@@ -1935,15 +1959,15 @@ extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
             const unsigned g1 = (clusters + 7) / 8 * 8;
             if (a->UT == 8) {
                 b.flags = (a->flags | 8 | 16) & ~4;
-                hipLaunchKernelGGL((dsp_lstmc_kernel<4, 4, true, 0, 8>), dim3(g1), dim3(512), (size_t)a->Hp * 16, s, b);
+                DSP_LAUNCH((dsp_lstmc_kernel<4, 4, true, 0, 8>), dim3(g1), dim3(512), (size_t)a->Hp * 16, s, b);
             } else {
                 b.flags = (a->flags | 16) & ~(4 | 8);
-                if (dead == 3) hipLaunchKernelGGL((dsp_lstmc_kernel<4, 4, true, 3>), dim3(g1), dim3(256), (size_t)a->Hp * 16, s, b);
-                else if (dead == 2) hipLaunchKernelGGL((dsp_lstmc_kernel<4, 4, true, 2>), dim3(g1), dim3(256), (size_t)a->Hp * 16, s, b);
-                else hipLaunchKernelGGL((dsp_lstmc_kernel<4, 4, true>), dim3(g1), dim3(256), (size_t)a->Hp * 16, s, b);
+                if (dead == 3) DSP_LAUNCH((dsp_lstmc_kernel<4, 4, true, 3>), dim3(g1), dim3(256), (size_t)a->Hp * 16, s, b);
+                else if (dead == 2) DSP_LAUNCH((dsp_lstmc_kernel<4, 4, true, 2>), dim3(g1), dim3(256), (size_t)a->Hp * 16, s, b);
+                else DSP_LAUNCH((dsp_lstmc_kernel<4, 4, true>), dim3(g1), dim3(256), (size_t)a->Hp * 16, s, b);
             }
         }
-        return (int)hipGetLastError();
+        return DSP_LAUNCH_RESULT();
     }
     if ((a->flags & 2) && a->NP <= 1 && a->UT >= 2 && a->UT % 2 == 0 && a->nqx_lo == 0 && a->nqx_used == (a->Ipad >> 3) &&
         a->NQ == ((a->Ipad + a->Hp) >> 3) && (a->Ipad >> 3) >= 4) {
@@ -1954,8 +1978,8 @@ extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
         const int threads = (a->UT / 2) * sg * 64;
         size_t lds = (size_t)8 * threads * 16 + (size_t)a->Hp * 16;
         if (a->flags & 4) lds = lds < 84 * 1024 ? 84 * 1024 : lds;   // more than half a CU's LDS: one workgroup per CU
-        hipLaunchKernelGGL(dsp_lstm21_kernel, dim3((unsigned)(a->NTp / sg) * 2), dim3(threads), lds, s, b);
-        return (int)hipGetLastError();
+        DSP_LAUNCH(dsp_lstm21_kernel, dim3((unsigned)(a->NTp / sg) * 2), dim3(threads), lds, s, b);
+        return DSP_LAUNCH_RESULT();
     }
     const int np = a->NP < 1 ? 1 : a->NP;   // 1, 2: the cell state in LDS; more: in a->cbuf (dsp_lstm_kernel<., 0>)
     const int threads = (a->UT / np) * a->SG * 64;
@@ -1974,17 +1998,17 @@ extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
     if (sparse == 1 && a->nqx_lo != 0) return (int)hipErrorInvalidValue;  // the tested k-loop starts on a live k-group
     const dim3 g(groups * 2), b(threads);
     if (sparse == 2) {
-        if (a->nqx_lo == 3) hipLaunchKernelGGL((dsp_lstm_kernel<2, 1, 1>), g, b, lds, s, *a);
-        else if (a->nqx_lo == 2) hipLaunchKernelGGL((dsp_lstm_kernel<2, 1, 2>), g, b, lds, s, *a);
-        else hipLaunchKernelGGL((dsp_lstm_kernel<2, 1, 3>), g, b, lds, s, *a);
+        if (a->nqx_lo == 3) DSP_LAUNCH((dsp_lstm_kernel<2, 1, 1>), g, b, lds, s, *a);
+        else if (a->nqx_lo == 2) DSP_LAUNCH((dsp_lstm_kernel<2, 1, 2>), g, b, lds, s, *a);
+        else DSP_LAUNCH((dsp_lstm_kernel<2, 1, 3>), g, b, lds, s, *a);
     } else if (many) {
-        if (sparse) hipLaunchKernelGGL((dsp_lstm_kernel<1, 0>), g, b, lds, s, *a);
-        else hipLaunchKernelGGL((dsp_lstm_kernel<0, 0>), g, b, lds, s, *a);
+        if (sparse) DSP_LAUNCH((dsp_lstm_kernel<1, 0>), g, b, lds, s, *a);
+        else DSP_LAUNCH((dsp_lstm_kernel<0, 0>), g, b, lds, s, *a);
     } else {
-        if (sparse) hipLaunchKernelGGL((dsp_lstm_kernel<1, 1>), g, b, lds, s, *a);
-        else hipLaunchKernelGGL((dsp_lstm_kernel<0, 1>), g, b, lds, s, *a);
+        if (sparse) DSP_LAUNCH((dsp_lstm_kernel<1, 1>), g, b, lds, s, *a);
+        else DSP_LAUNCH((dsp_lstm_kernel<0, 1>), g, b, lds, s, *a);
     }
-    return (int)hipGetLastError();
+    return DSP_LAUNCH_RESULT();
 }
 
 // split variants: a->wpk0/1 = split weights, a->NQ = k-stages of 16, nprod = 6 / 9 (bf16 pieces) or 3 (fp16 pieces)
@@ -1993,10 +2017,10 @@ extern "C" int dsp_k_lstm6(const LstmArgs* a, int nprod, hipStream_t s) {
     const int waves = a->UT * a->SG;
     const unsigned groups = (unsigned)(a->NTp / (a->SG * 2));
     const size_t lds = (size_t)8 * 512 * 16 + (size_t)a->Hp * 16;
-    if (nprod == 9) hipLaunchKernelGGL(dsp_lstm6_kernel<9>, dim3(groups * 2), dim3(waves * 64), lds, s, *a);
-    else if (nprod == 3) hipLaunchKernelGGL(dsp_lstm6_kernel<3>, dim3(groups * 2), dim3(waves * 64), lds, s, *a);
-    else hipLaunchKernelGGL(dsp_lstm6_kernel<6>, dim3(groups * 2), dim3(waves * 64), lds, s, *a);
-    return (int)hipGetLastError();
+    if (nprod == 9) DSP_LAUNCH(dsp_lstm6_kernel<9>, dim3(groups * 2), dim3(waves * 64), lds, s, *a);
+    else if (nprod == 3) DSP_LAUNCH(dsp_lstm6_kernel<3>, dim3(groups * 2), dim3(waves * 64), lds, s, *a);
+    else DSP_LAUNCH(dsp_lstm6_kernel<6>, dim3(groups * 2), dim3(waves * 64), lds, s, *a);
+    return DSP_LAUNCH_RESULT();
 }
 
 extern "C" int dsp_k_linear(const LinArgs* a, hipStream_t s) {
@@ -2006,14 +2030,14 @@ extern "C" int dsp_k_linear(const LinArgs* a, hipStream_t s) {
     if (a->small) {   // batches that leave CUs idle: one accumulator tile per wave (dsp_linear1_kernel)
         LinArgs b = *a;
         b.nbx = (unsigned)a->ncols;
-        hipLaunchKernelGGL(dsp_linear1_kernel, dim3(a->x2 ? 2 * b.nbx : b.nbx, (unsigned)((a->ORT + 3) / 4)), dim3(256), 0, s, b);
-        return (int)hipGetLastError();
+        DSP_LAUNCH(dsp_linear1_kernel, dim3(a->x2 ? 2 * b.nbx : b.nbx, (unsigned)((a->ORT + 3) / 4)), dim3(256), 0, s, b);
+        return DSP_LAUNCH_RESULT();
     }
     const unsigned bx = (unsigned)((a->ncols + 7) / 8);  // 4 waves x 2 column blocks per workgroup
     LinArgs b = *a;
     b.nbx = bx;
-    hipLaunchKernelGGL(dsp_linear_kernel, dim3(a->x2 ? 2 * bx : bx, (unsigned)((a->ORT + 3) / 4)), dim3(256), 0, s, b);
-    return (int)hipGetLastError();
+    DSP_LAUNCH(dsp_linear_kernel, dim3(a->x2 ? 2 * bx : bx, (unsigned)((a->ORT + 3) / 4)), dim3(256), 0, s, b);
+    return DSP_LAUNCH_RESULT();
 }
 
 extern "C" int dsp_k_head(const HeadArgs* a, hipStream_t s) {
@@ -2023,7 +2047,7 @@ extern "C" int dsp_k_head(const HeadArgs* a, hipStream_t s) {
     const int st = small ? 1 : 4;
     const size_t lds = (size_t)(5 * a->C * st * 32) * sizeof(float);
     const unsigned groups = (unsigned)((a->n + 32 * st - 1) / (32 * st));  // the K4 buffers are padded to 16 tiles
-    if (small) hipLaunchKernelGGL(dsp_head_kernel<1>, dim3(groups), dim3(256), lds, s, *a);
-    else hipLaunchKernelGGL(dsp_head_kernel<4>, dim3(groups), dim3(256), lds, s, *a);
-    return (int)hipGetLastError();
+    if (small) DSP_LAUNCH(dsp_head_kernel<1>, dim3(groups), dim3(256), lds, s, *a);
+    else DSP_LAUNCH(dsp_head_kernel<4>, dim3(groups), dim3(256), lds, s, *a);
+    return DSP_LAUNCH_RESULT();
 }

@@ -518,6 +518,16 @@ int32_t dsp_model_query(const dsp_model* m, int32_t what);
 int64_t dsp_device_pci_bdf(int32_t device, char* out, size_t cap);
 int64_t dsp_device_uuid(int32_t device, char* out, size_t cap);
 
+/* Test hook (round 6; no device involved): a DRY RUN of dsp_forward for model `cfg` on a device of n_cus compute units -- a
+ * handle whose allocations are made-up addresses runs the whole host half of a forward of n_sites sites (the cut into pieces, the
+ * kernel form of every launch, the extents behind every buffer descriptor, the checks of the launch wrappers), and every launch
+ * is NOTED -- "(kernel<...>) grid x,y block b lds n", one line each in `log` -- instead of made.  init_mode: DSP_INIT_*;
+ * precision: DSP_PREC_*; extents: "region" (default) / "tight" / "wide" (DSP_RSRC_EXTENTS).  Returns the number of launches, or
+ * the dsp_status a real forward of that shape would have failed with before reaching the device (a refused launch: a pointer
+ * without the end of its allocation, an extent past it, a clustered launch on counters that were not zeroed, ...). */
+int32_t dsp_debug_dry_run(const dsp_model_cfg* cfg, int32_t n_cus, int64_t n_sites, int32_t init_mode, int32_t precision,
+                          const char* extents, char* log, size_t log_cap);
+
 /* Test hook (round 6; no device involved): the three bf16 pieces the split-precision modes cut an fp32 weight into
  * (csrc/dsp_capi.cpp pack_lstm_dir_split: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid), round to nearest even);
  * tests/test_split_exact.py holds hi + mid + lo == x bit for bit over 1e7 random values and every exponent edge, and states
