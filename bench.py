@@ -36,7 +36,7 @@ REFERENCE_CPU = {"hardware": "8 vCPU Xeon 2.10 GHz (survey container, BASELINE.m
                  "forward_only_b512_8threads_sites_per_s": 2401.0,
                  "config": "both_bilstm bn13_sn16, 100k-row feature TSV, batch 512 (BASELINE.json configs[0])"}
 KERNEL_SOURCES = ("deepsignal_plant_amd/csrc/dsp_kernels.hip", "deepsignal_plant_amd/csrc/dsp_kernels.h",
-                  "deepsignal_plant_amd/csrc/dsp_capi.cpp")
+                  "deepsignal_plant_amd/csrc/dsp_cluster_protocol.h", "deepsignal_plant_amd/csrc/dsp_capi.cpp")
 
 
 def kernel_source_hash():
