@@ -1,4 +1,5 @@
-"""GPU: buffer descriptors with real extents (round 6).
+"""GPU: buffer descriptors with real extents (round 6).  Named to run LAST in the suite: round 6 had no GPU, so
+these tests have never run -- under the driver's `-x` a first-contact surprise in here must not cost the rest of the record.
 
   * the hardware does range-check: a load past num_records returns zeros, a store past it is dropped -- by VGPR offset AND by
     SGPR offset (where the kernels carry almost all of an address);
@@ -31,10 +32,29 @@ def _sweep(env_extra, *cases, expect_rc=0):
     return r
 
 
-def test_the_hardware_range_check_is_there_for_both_offsets():
+def _probe():
     from deepsignal_plant_amd import _native
     got = _native.range_probe(0)
-    print("range probe (in range, past by voffset -> 0, past by soffset -> 0, floats untouched by OOB stores):", got)
+    print("range probe (lanes in range that read their data, lanes past the extent by voffset that read 0, ... by soffset, floats untouched "
+          "by 64 out-of-range stores):", got, "-- expected (16, 48, 64, 1024)")
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "range_probe.json"), "w") as f:
+        json.dump({"in_range_ok": got[0], "voffset_oob_zero": got[1], "soffset_oob_zero": got[2], "floats_untouched": got[3]}, f)
+    return got
+
+
+def test_accesses_inside_a_descriptors_extent_are_untouched_and_the_probe_does_not_fault():
+    """what the product relies on unconditionally: a descriptor with a real num_records serves every access inside it"""
+    got = _probe()
+    assert got[0] == 16, got
+
+
+def test_the_hardware_drops_accesses_past_the_extent_by_vgpr_offset_and_by_sgpr_offset():
+    """what turns a wild offset into a parity failure instead of a dead process.  The kernels carry almost all of an address in
+    the SGPR offset: if the hardware's check looked at the VGPR offset alone (got[2] < 64, or stores landing: got[3] < 1024),
+    the extents would still be harmless -- they never clip a legitimate access -- but the protection would be partial, and
+    DESIGN.md 3 has to say so."""
+    got = _probe()
     assert got == (16, 48, 64, 1024), got
 
 
@@ -43,7 +63,7 @@ def product_digest():
     return json.loads(_sweep({}).stdout.strip().splitlines()[-1])
 
 
-@pytest.mark.parametrize("mode", ["tight"])   # ("wide" against the default: test_small_batch_kernels_do_not_change_a_bit, five shapes x fifteen sizes)
+@pytest.mark.parametrize("mode", ["tight"])   # ("wide" against the default: test_small_batch_kernels_do_not_change_a_bit too, five shapes x fifteen sizes)
 def test_extents_do_not_change_a_bit(product_digest, mode):
     got = json.loads(_sweep({"DSP_RSRC_EXTENTS": mode}).stdout.strip().splitlines()[-1])
     assert len(got) == len(product_digest) > 100

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Forwards over the shapes and batch sizes that exercise every kernel form, digested: one JSON line {case: sha256 of the
-probabilities}.  Run it once per library / extents mode and compare the lines (tests/test_gpu_bounds.py does):
+probabilities}.  Run it once per library / extents mode and compare the lines (tests/test_gpu_zz_extents.py does):
     DSP_AMD_LIB=deepsignal_plant_amd/libdsp_amd_bounds.so python tools/extents_sweep.py    # the bounds-recording build
     DSP_RSRC_EXTENTS=wide python tools/extents_sweep.py                                    # the 2 GiB windows of rounds 1-5
 A DSP_EBOUNDS from the bounds build ends the sweep with its message (exit status 3)."""
