@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cctype>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -869,7 +870,11 @@ extern "C" {
 
 const char* dsp_last_error(void) { return g_err.c_str(); }
 void dsp_set_error_(const char* msg) { g_err = msg ? msg : ""; }  // used by dsp_text.cpp
+#ifdef DSP_EMU   // the test-suite's SIMT interpreter build (tests/native/emu): never loadable as the product
+int32_t dsp_abi_version(void) { return DSP_AMD_ABI_VERSION + 1000; }
+#else
 int32_t dsp_abi_version(void) { return DSP_AMD_ABI_VERSION; }
+#endif
 
 int32_t dsp_weight_count(const dsp_model_cfg* cfg) {
     Dims d;

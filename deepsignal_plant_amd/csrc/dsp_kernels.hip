@@ -26,6 +26,18 @@
 #include "dsp_cluster_protocol.h"
 #include "dsp_kernels.h"
 
+// The five places where this file speaks gfx950 assembly or HIP's LDS declaration syntax, as macros -- so that the test-suite's
+// SIMT interpreter (tests/native/emu: the kernels of this file compiled for the HOST and run lane by lane, workgroups
+// concurrently, buffer descriptors with the hardware's range-check semantics; tests/test_kernel_emu.py; never the product) can
+// give them its own meaning.  The product build sees exactly the statements these macros name.
+#ifndef DSP_EMU
+#define DSP_STORE_GUARD(v) asm volatile("s_nop 1" : : "v"(v))
+#define DSP_KEEP_SGPR2(a, b) asm("" : "+s"(a), "+s"(b))
+#define DSP_DRAIN_STORES() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define DSP_READ_XCC_ID(x) asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x))
+#define DSP_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) float name[]
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // explicit address spaces keep hipcc from merging a global and an LDS load of the same variable into one
@@ -42,7 +54,7 @@ typedef __attribute__((address_space(3))) const f32x4 lf32x4;  // LDS
 // registers as an input, i.e. keeps them live until after the nop: nothing that writes them can be scheduled in between.  tools/check_store_hazard.py
 // scans the assembly of every build for the pattern (the csrc Makefile fails without it).
 __device__ __forceinline__ void store_data_guard(const f32x4& v) {
-    asm volatile("s_nop 1" : : "v"(v));
+    DSP_STORE_GUARD(v);
 }
 __device__ __forceinline__ void gst16(f32x4* p, f32x4 v) {  // a plain 16-byte global store, same guard
     *p = v;
@@ -67,7 +79,7 @@ __device__ __forceinline__ uint32_t rsrc_records(const void* base, const void* e
     // its result a lane mask in an SGPR pair -- enough extra scalar pressure to spill SGPRs in the widest kernels)
     const unsigned long long left = (unsigned long long)end - (unsigned long long)base;   // wraps above 2^63 when base > end
     uint32_t lo = (uint32_t)left, hi = (uint32_t)(left >> 32);
-    asm("" : "+s"(lo), "+s"(hi));   // (the halves stay apart, in SGPRs: hipcc otherwise folds the tests back into 64-bit VALU compares)
+    DSP_KEEP_SGPR2(lo, hi);   // (the halves stay apart, in SGPRs: hipcc otherwise folds the tests back into 64-bit VALU compares)
     const uint32_t in32 = lo < (uint32_t)kRsrcMax ? lo : (uint32_t)kRsrcMax;
     return hi == 0u ? in32 : ((int32_t)hi < 0 ? 0u : (uint32_t)kRsrcMax);
 }
@@ -395,7 +407,7 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
     const int np = CG ? a.NP : NP;
     constexpr int NF = 4;                  // A fragments (gates) per k-group
     constexpr int DA = 4, DB = 4;          // ring depths in k-groups
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    DSP_DYN_LDS(smem);
 #ifdef DSP_TRACE
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
 #endif
@@ -651,7 +663,7 @@ __global__ __launch_bounds__(512, 2) void dsp_lstm_kernel(LstmArgs a) {
 __global__ __launch_bounds__(256, 2) void dsp_lstm21_kernel(LstmArgs a) {
     constexpr int NF = 8;                  // A fragments per k-group: 2 unit tiles x 4 gates
     constexpr int DA = 2, DB = 4;          // ring depths in k-groups
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    DSP_DYN_LDS(smem);
     const int nthr = blockDim.x;
     f32x4* c_lds = (f32x4*)smem;           // [2 unit tiles][4 groups][nthr] float4
     f32x4* b_lds = c_lds + 8 * nthr;       // [unit tile][aa][gate][half] float4
@@ -879,7 +891,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <int G, int D, bool LOCAL, int DEAD, int NW, bool XSHORT>
 __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, const long long gt0, const int pi, gu32* flag) {
     constexpr int WPU = 4 / G;             // waves per unit tile = gate slices; unit tiles per workgroup = G
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    DSP_DYN_LDS(smem);
     f32x4* b_lds = (f32x4*)smem;           // [unit tile][aa][gate][half] float4 (Hp float4)
     f32x4* xch = b_lds + a.Hp;             // G < 4: [local unit tile][gate][aa][64 lanes] float4
     const int tid = threadIdx.x;
@@ -1050,7 +1062,7 @@ __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, co
     // behind the drain is issued with no MFMA in flight); round 4's hand-off 0.5716 / 0.9943 / 1.7962
     constexpr int E = D == 4 ? 1 : (G == 1 ? 3 : 2);   // (rings four deep -- 4 unit tiles, or G = 4 -- spare one stage)
     auto arrive = [&]() __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        DSP_DRAIN_STORES();
         if (lane == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     // publish: every wave drains its write-through stores, the workgroup meets, one lane counts the arrival
@@ -1058,7 +1070,7 @@ __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, co
         if constexpr (LOCAL) {
             barrier_after_global_stores();   // same CU: the stores of this workgroup's waves are ahead of the loads issued after it
         } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            DSP_DRAIN_STORES();
             __syncthreads();
             if (tid == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -1198,7 +1210,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dsp_lstmc_kernel(LstmArgs a) {
     // LOCAL (G = 4, layers of 4 unit tiles: the front ends at hidden 128): the workgroup holds the whole hidden state, P = 1 --
     // the h exchange is the step barrier of dsp_lstm21_kernel (plain stores, one s_barrier, plain loads), no counter; the x
     // part may be as short as the ring (nqx == D: the h part's first requests then leave right behind the barrier)
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    DSP_DYN_LDS(smem);
     const int tid = threadIdx.x;
     const int P = LOCAL ? 1 : a.UT / G;
     // cluster c = (site tile, direction); its P members are consecutive entries of one XCD's dispatch list
@@ -1276,7 +1288,7 @@ template <int NPROD>
 __global__ __launch_bounds__(512, 2) void dsp_lstm6_kernel(LstmArgs a) {
     constexpr bool F16 = NPROD == 3;     // two fp16 pieces instead of three bf16 pieces
     constexpr int NP = F16 ? 2 : 3;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    DSP_DYN_LDS(smem);
     f32x4* c_lds = (f32x4*)smem;           // [2 site tiles][4 groups][512 threads] float4
     f32x4* b_lds = c_lds + 8 * 512;        // [unit tile][aa][gate][half] float4
     const int tid = threadIdx.x;
@@ -1623,7 +1635,7 @@ __global__ __launch_bounds__(256, 2) void dsp_linear1_kernel(LinArgs a) {
 // forward of 512 sites; same sums in the same order: bit-identical).
 template <int kHeadST>
 __global__ __launch_bounds__(256, 2) void dsp_head_kernel(HeadArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    DSP_DYN_LDS(smem);
     float* part = smem;                         // [4 waves][C][kHeadST * 32]
     float* lg = smem + 4 * a.C * kHeadST * 32;  // [C][kHeadST * 32]
     const int tid = threadIdx.x;
@@ -1786,7 +1798,7 @@ __global__ __launch_bounds__(256, 2) void dsp_head_kernel(HeadArgs a) {
 // ONE XCD's dispatch list (block b on XCD b % 8: observed on MI355X in SPX mode, promised by nobody).  dsp_model_create asks once.
 __global__ void dsp_xcc_probe_kernel(unsigned* out) {
     unsigned x;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    DSP_READ_XCC_ID(x);
     if (threadIdx.x == 0) out[blockIdx.x] = x & 0xf;
 }
 extern "C" int dsp_k_probe_xcc(unsigned* dev_out, int blocks, hipStream_t s) {

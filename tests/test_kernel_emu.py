@@ -1,0 +1,322 @@
+"""CPU: the KERNELS' OWN SOURCE run on the host (round 6; GPU access was closed for the whole round).
+
+tests/native/emu is a SIMT interpreter for the test-suite: csrc/dsp_kernels.hip + csrc/dsp_capi.cpp compiled for the host
+(-DDSP_EMU, a hip/ header pair in front of the real one), every GPU thread a fiber, 64 of them a wave, MFMAs / readfirstlane /
+shuffles / the workgroup barrier carried out when the wave (the workgroup) has arrived, the workgroups of a launch scheduled
+concurrently -- the clustered launches' members really wait for each other --, buffer descriptors with the hardware's
+range-check semantics (a load past num_records returns zeros, a store past it is dropped).  It checks the kernels' LOGIC --
+indexing, extents, the hand-off protocol's control flow, the clean-up path, the piece cut -- never their speed or the memory
+model (sequentially consistent here: tests/native/cluster_model.cpp is where store buffers live).
+
+What is held, all through the C ABI of that library (dsp_model_create / dsp_forward, bound here by hand: the package's loader
+REFUSES the library -- it answers dsp_abi_version() with 1003 -- so it can never stand in for the product):
+  * parity of the kernels' source with the REFERENCE's outputs on F1 fixtures (1e-6; the GPU suite's bound is 2e-5);
+  * every kernel form gives the same bytes: the A/B switch matrix of test_small_batch_kernels_do_not_change_a_bit on a small model
+    (full-batch kernels, <2 unit tiles, 1 site tile>, clusters of every size, round-4 hand-off, every cluster abandoned to the
+    clean-up launch, one stream, one-tile fc / head off) and an adversarial wave schedule (DSP_EMU_SEED);
+  * the round-6 extents: region / tight / wide bit-identical; the BOUNDS-RECORDING build (-DDSP_BOUNDS) runs every form without
+    a record -- the tight extents fit every access the kernels make -- and names the operand when an extent is shortened;
+  * Philox states against the C oracle's same generator; ragged sizes; a call cut into pieces; the many-pass kernel (hidden
+    320); the split-precision kernels against the fp32 path.
+The interpreter runs about 10^7 lane-instructions a second: by default this module takes under two minutes and runs a
+representative cut of everything above; DSP_EMU_LONG=1 runs all of it -- the whole switch matrix on two models with three
+state modes, the default architecture (hidden 256 x 3 layers, clusters of 8: a minute per forward), every bounds-build case --
+in a quarter of an hour (profiles/r6/kernel_emu_long.txt is that run's log)."""
+import contextlib
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from deepsignal_plant_amd import _native as nat   # (the ctypes structures only: the emulated library is bound by hand below)
+from oracle import c_oracle as oc
+from oracle import forward_np as onp
+from tests.helpers import ROOT, load_f1
+
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+CSRC = os.path.join(ROOT, "deepsignal_plant_amd", "csrc")
+EMU = os.path.join(ROOT, "tests", "native", "emu")
+SWITCHES = ("DSP_LSTM_CLUSTER", "DSP_LSTM_LOCAL8", "DSP_TWO_STREAMS", "DSP_HEAD_ST4", "DSP_LSTM_TILING", "DSP_CLUSTER_TIMEOUT", "DSP_FC_FUSED",
+            "DSP_LSTM_FRONT_CLUSTER", "DSP_FC_SMALL", "DSP_LSTM_HANDOFF", "DSP_FORWARD_SPLIT", "DSP_RSRC_EXTENTS", "DSP_EMU_SEED", "DSP_BOUNDS_TEST_SHRINK",
+            "DSP_PRECISION", "EMU_CUS")
+
+pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="the image's clang++ builds the interpreter")
+LONG = bool(os.environ.get("DSP_EMU_LONG"))
+
+
+def _build(out, *flags):
+    cmd = [CLANG, "-std=c++17", "-O2", "-march=native", "-fPIC", "-shared", "-DDSP_EMU", "-Wno-unused-value", "-I", EMU, "-I", os.path.join(ROOT, "include"),
+           "-I", CSRC, "-x", "c++", os.path.join(CSRC, "dsp_kernels.hip"), os.path.join(CSRC, "dsp_capi.cpp"), os.path.join(EMU, "hip_emu.cpp"), "-o", out,
+           "-pthread"] + list(flags)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    L = ctypes.CDLL(out)
+    L.dsp_last_error.restype = ctypes.c_char_p
+    L.dsp_forward.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                              ctypes.c_int32, ctypes.c_void_p, ctypes.POINTER(nat.InitState), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.dsp_model_destroy.argtypes = [ctypes.c_void_p]
+    L.dsp_model_set_precision.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    assert L.dsp_abi_version() == nat.ABI_VERSION + 1000
+    return L
+
+
+@pytest.fixture(scope="module")
+def libs(tmp_path_factory):
+    """the interpreter build of the library and its bounds-recording twin, compiled side by side"""
+    import concurrent.futures
+    d = tmp_path_factory.mktemp("emu")
+    with concurrent.futures.ThreadPoolExecutor(2) as ex:
+        a = ex.submit(_build, str(d / "libdsp_amd_emu.so"))
+        b = ex.submit(_build, str(d / "libdsp_amd_emu_bounds.so"), "-DDSP_BOUNDS")
+        return a.result(), b.result()
+
+
+@pytest.fixture(scope="module")
+def emu(libs):
+    return libs[0]
+
+
+@pytest.fixture(scope="module")
+def emu_bounds(libs):
+    return libs[1]
+
+
+@contextlib.contextmanager
+def env(**kw):
+    saved = {k: os.environ.get(k) for k in SWITCHES}
+    for k in SWITCHES:
+        os.environ.pop(k, None)
+    os.environ.update({k: str(v) for k, v in kw.items()})
+    try:
+        yield
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+
+
+class Model(object):
+    """dsp_model_create / dsp_forward of the emulated library on host arrays (by hand)"""
+
+    def __init__(self, L, cfg, w, precision=None):
+        self.L, self.cfg = L, cfg
+        mod = {"both_bilstm": 0, "seq_bilstm": 1, "signal_bilstm": 2}[cfg.module]
+        c = nat.ModelCfg(cfg.seq_len, cfg.signal_len, cfg.num_layers1, cfg.num_layers2, cfg.num_classes, cfg.hidden_size, cfg.vocab_size,
+                         cfg.embedding_size, int(cfg.is_base), int(cfg.is_signallen), mod)
+        ws = [np.ascontiguousarray(w[k], dtype=np.float32) for k, _ in onp.state_dict_spec(cfg)]
+        self.h = ctypes.c_void_p()
+        rc = L.dsp_model_create(ctypes.byref(c), (ctypes.c_void_p * len(ws))(*[x.ctypes.data for x in ws]), (ctypes.c_int64 * len(ws))(*[x.size for x in ws]),
+                                len(ws), 0, ctypes.byref(self.h))
+        assert rc == 0, L.dsp_last_error()
+        if precision:
+            assert L.dsp_model_set_precision(self.h, nat.PRECISION[precision]) == 0, L.dsp_last_error()
+
+    def forward(self, inputs, states=None, philox=None, expect_rc=0):
+        """states: the reference layout (explicit); philox: (seed, site_offset); neither: zero states -> (probs, logits, labels)"""
+        n = int(inputs[0].shape[0])
+        a = [np.ascontiguousarray(x, dtype=np.float32) for x in inputs]
+        keep = []
+        if states is not None:
+            st = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in states.items()}
+            keep.append(st)
+            init = nat.InitState(1, 0, 0, *[st[k].ctypes.data if k in st else None for k in ("h_seq", "c_seq", "h_sig", "c_sig", "h_comb", "c_comb")], None)
+        elif philox is not None:
+            init = nat.InitState(2, philox[0], philox[1], None, None, None, None, None, None, None)
+        else:
+            init = nat.InitState(0, 0, 0, None, None, None, None, None, None, None)
+        C = self.cfg.num_classes
+        logits, probs, labels = np.zeros((n, C), np.float32), np.zeros((n, C), np.float32), np.zeros(n, np.uint8)
+        rc = self.L.dsp_forward(self.h, None, n, a[0].ctypes.data, 0, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data, 0, a[4].ctypes.data,
+                                ctypes.byref(init), logits.ctypes.data, probs.ctypes.data, labels.ctypes.data)
+        if expect_rc:
+            assert rc == expect_rc, (rc, self.L.dsp_last_error())
+            return self.L.dsp_last_error().decode()
+        assert rc == 0, self.L.dsp_last_error()
+        return probs, logits, labels
+
+    def close(self):
+        self.L.dsp_model_destroy(self.h)
+
+
+# ---- parity of the kernels' source with the reference's outputs ------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", ["tiny_h64_l2", "nobase_h128"] + (["nosiglen_h128", "both_default", "signal_only", "seq_cfg3"] if LONG else []))
+def test_the_kernels_source_reproduces_the_reference_fixture(emu, name):
+    f = load_f1(name)
+    with env():
+        m = Model(emu, f["cfg"], f["w"])
+        probs, logits, labels = m.forward(f["inputs"], states=f["states"])
+        m.close()
+    dp = float(np.abs(probs - f["probs"]).max())
+    print(name, "interpreted kernels vs the reference: max|dprob| %.2e (n = %d)" % (dp, f["n"]))
+    assert dp <= 1e-6 and np.abs(logits - f["logits"]).max() <= 2e-5
+    sure = np.abs(f["probs"][:, 1] - 0.5) >= 1e-4 if f["probs"].shape[1] == 2 else np.ones(f["n"], bool)
+    assert np.array_equal(labels[sure], f["probs"].argmax(1)[sure])
+
+
+# ---- a small model with every kernel form: front ends of 4 unit tiles (hidden 128 each), a combined stack of 8 ---------------------
+
+T_SMALL = 5 if LONG else 2
+SMALL = dict(seq_len=T_SMALL, signal_len=8, hidden_size=256, num_layers1=1, num_layers2=1)     # both_bilstm: hseq = hsig = 128 (UT 4), combined 256 (UT 8)
+SMALL4 = dict(seq_len=T_SMALL, signal_len=8, hidden_size=128, num_layers1=2, num_layers2=1)    # combined stack of 4 unit tiles (the clustered dense4 forms), front ends of 2
+SHORT = ("auto", "full_batch_kernels", "every_cluster_abandoned", "adversarial_schedule_2_G2", "descriptors_tight", "descriptors_2GiB_windows")
+
+
+def _case(kw, n, seed=3):
+    cfg = onp.OracleConfig(**kw)
+    return cfg, onp.make_weights(cfg, 50 + seed, 2.0), onp.make_inputs(cfg, n, 60 + seed), onp.make_init_states(cfg, n, 70 + seed)
+
+
+MODES = {
+    "auto": {},
+    "full_batch_kernels": {"DSP_LSTM_CLUSTER": "0", "DSP_LSTM_TILING": "0", "DSP_LSTM_LOCAL8": "0", "DSP_TWO_STREAMS": "0", "DSP_HEAD_ST4": "1", "DSP_FC_FUSED": "0",
+                           "DSP_FC_SMALL": "0"},
+    "lstm21": {"DSP_LSTM_CLUSTER": "0", "DSP_LSTM_TILING": "21"},
+    "G4": {"DSP_LSTM_CLUSTER": "4"}, "G2": {"DSP_LSTM_CLUSTER": "2"}, "G1": {"DSP_LSTM_CLUSTER": "1"},
+    "front_G1_one_stream": {"DSP_LSTM_FRONT_CLUSTER": "1", "DSP_TWO_STREAMS": "0"}, "front_G2": {"DSP_LSTM_FRONT_CLUSTER": "2"},
+    "front_local": {"DSP_LSTM_FRONT_CLUSTER": "0"},
+    "round4_handoff": {"DSP_LSTM_HANDOFF": "0"},
+    "every_cluster_abandoned": {"DSP_CLUSTER_TIMEOUT": "0"},
+    "every_cluster_abandoned_round4_handoff_G2": {"DSP_CLUSTER_TIMEOUT": "0", "DSP_LSTM_HANDOFF": "0", "DSP_LSTM_CLUSTER": "2", "DSP_LSTM_FRONT_CLUSTER": "2"},
+    "adversarial_schedule_1": {"DSP_EMU_SEED": "1"}, "adversarial_schedule_2_G2": {"DSP_EMU_SEED": "2", "DSP_LSTM_CLUSTER": "2"},
+    "descriptors_tight": {"DSP_RSRC_EXTENTS": "tight"}, "descriptors_2GiB_windows": {"DSP_RSRC_EXTENTS": "wide"},
+    "descriptors_tight_abandoned": {"DSP_RSRC_EXTENTS": "tight", "DSP_CLUSTER_TIMEOUT": "0"},
+    "64_compute_units": {"EMU_CUS": "64"},
+}
+
+
+@pytest.mark.parametrize("kw,label", [(SMALL, "UT8_stack_UT4_front_ends")] + ([(SMALL4, "UT4_stack_UT2_front_ends")] if LONG else []))
+def test_every_kernel_form_gives_the_same_bytes(emu, kw, label):
+    cfg, w, ins, st = _case(kw, 45)
+    want = oc.forward(cfg, w, *ins, states=st)[1]
+    first = None
+    for mode, sw in MODES.items():
+        if not LONG and mode not in SHORT:
+            continue
+        with env(**sw):
+            m = Model(emu, cfg, w)
+            probs = m.forward(ins, states=st)[0]
+            pz = m.forward(ins)[0] if LONG or first is None else first[1]
+            pp = m.forward(ins, philox=(11, 1000))[0] if LONG or first is None or mode == "every_cluster_abandoned" else first[2]
+            m.close()
+        if first is None:
+            first = (probs, pz, pp)
+            assert np.abs(probs - want).max() <= 1e-6, (label, mode)
+            assert np.abs(pz - oc.forward(cfg, w, *ins, init_mode="zeros")[1]).max() <= 1e-6
+            assert np.abs(pp - oc.forward(cfg, w, *ins, init_mode="philox", seed=11, site_offset=1000)[1]).max() <= 2e-6
+        else:
+            for got, ref, what in zip((probs, pz, pp), first, ("explicit", "zeros", "philox")):
+                assert np.array_equal(got, ref), (label, mode, what, float(np.abs(got - ref).max()))
+
+
+def test_ragged_sizes_and_a_cut_call(emu):
+    """1, 33, 513 sites (tile tails, two classes of cluster sizes) and 1,100 sites = 1,024 + 76: the cut changes no bit"""
+    kw = dict(seq_len=3 if LONG else 2, signal_len=8, hidden_size=128, num_layers1=1, num_layers2=1)
+    cfg = onp.OracleConfig(**kw)
+    w = onp.make_weights(cfg, 5, 2.0)
+    for n in ((1, 33, 513) if LONG else (33,)):
+        ins = onp.make_inputs(cfg, n, 100 + n)
+        with env():
+            m = Model(emu, cfg, w)
+            pp = m.forward(ins, philox=(7, 5 * n))[0]
+            m.close()
+        assert np.abs(pp - oc.forward(cfg, w, *ins, init_mode="philox", seed=7, site_offset=5 * n)[1]).max() <= 2e-6, n
+    ins = onp.make_inputs(cfg, 1100, 9)
+    out = {}
+    for split in ("1", "0"):
+        with env(DSP_FORWARD_SPLIT=split):
+            m = Model(emu, cfg, w)
+            out[split] = m.forward(ins, philox=(7, 0))[0]
+            m.close()
+    assert np.array_equal(out["1"], out["0"])
+    assert np.abs(out["1"] - oc.forward(cfg, w, *ins, init_mode="philox", seed=7, site_offset=0)[1]).max() <= 2e-6
+
+
+def test_the_many_pass_kernel_and_padded_shapes(emu):
+    """hidden 320 (two passes per step, the cell state in the scratch behind a descriptor), hidden 100 (padded unit tiles), a
+    signal window wider than 32 features, no k-mer / no lengths"""
+    cases = (dict(seq_len=3, signal_len=8, hidden_size=320, num_layers1=1), dict(seq_len=3, signal_len=8, hidden_size=100, num_layers1=2),
+             dict(seq_len=3, signal_len=40, hidden_size=64, num_layers1=1), dict(seq_len=3, signal_len=8, hidden_size=64, is_base=False, is_signallen=False))
+    for kw in (cases if LONG else (dict(seq_len=2, signal_len=8, hidden_size=320, num_layers1=1), cases[2])):
+        cfg, w, ins, st = _case(kw, 37)
+        with env():
+            m = Model(emu, cfg, w)
+            probs = m.forward(ins, states=st)[0]
+            m.close()
+        assert np.abs(probs - oc.forward(cfg, w, *ins, states=st)[1]).max() <= 1e-6, kw
+
+
+def test_split_precision_kernels_against_the_fp32_path(emu):
+    cfg, w, ins, st = _case(dict(seq_len=3 if LONG else 2, signal_len=16, hidden_size=256, num_layers1=1), 40)
+    with env():
+        m = Model(emu, cfg, w)
+        ref = m.forward(ins, states=st)[0]
+        m.close()
+        for precision, tol in ((("bf16x9", 2e-7), ("bf16x6", 2e-6), ("fp16x3", 2e-6)) if LONG else (("bf16x9", 2e-7),)):
+            m = Model(emu, cfg, w, precision=precision)
+            got = m.forward(ins, states=st)[0]
+            m.close()
+            assert np.abs(got - ref).max() <= tol, (precision, float(np.abs(got - ref).max()))
+
+
+# ---- the bounds-recording build: the TIGHT extents fit every access the kernels make -----------------------------------------------
+
+def test_the_bounds_build_records_nothing_over_the_kernel_forms(emu, emu_bounds):
+    cfg, w, ins, st = _case(SMALL, 45)
+    with env():
+        m = Model(emu, cfg, w)
+        want = m.forward(ins, states=st)[0]
+        m.close()
+    for mode in (("auto", "full_batch_kernels", "lstm21", "G4", "G2", "front_G1_one_stream", "front_local", "round4_handoff", "every_cluster_abandoned") if LONG
+                 else ("auto", "every_cluster_abandoned")):
+        with env(**MODES[mode]):
+            m = Model(emu_bounds, cfg, w)
+            got = m.forward(ins, states=st)[0]        # (a record would come back as DSP_EBOUNDS: the assert inside forward())
+            gz = m.forward(ins, philox=(3, 9))[0]
+            m.close()
+        assert np.array_equal(got, want), mode
+        assert np.isfinite(gz).all()
+    for kw in ((SMALL4, dict(seq_len=3, signal_len=8, hidden_size=320, num_layers1=1), dict(seq_len=3, signal_len=40, hidden_size=64, num_layers1=1)) if LONG
+               else (dict(seq_len=2, signal_len=8, hidden_size=128, num_layers1=1), dict(seq_len=2, signal_len=8, hidden_size=320, num_layers1=1))):
+        cfg, w, ins, st = _case(kw, 70)
+        for precision in ((None, "bf16x9", "fp16x3") if LONG else (None, "bf16x9")):
+            with env():
+                m = Model(emu_bounds, cfg, w, precision=precision)
+                m.forward(ins, states=st)
+                m.close()
+    # a cut call: whole round + pieces, every piece under its own tight extents
+    cfg = onp.OracleConfig(seq_len=3 if LONG else 2, signal_len=8, hidden_size=64, num_layers1=1)
+    w = onp.make_weights(cfg, 5, 2.0)
+    with env(EMU_CUS="32"):
+        m = Model(emu_bounds, cfg, w)
+        m.forward(onp.make_inputs(cfg, 1100, 9), philox=(7, 0))
+        m.close()
+
+
+def test_the_bounds_build_names_an_access_past_a_shortened_extent(emu_bounds):
+    cfg, w, ins, st = _case(SMALL, 45)
+    with env(DSP_BOUNDS_TEST_SHRINK="4096"):
+        m = Model(emu_bounds, cfg, w)
+        msg = m.forward(ins, states=st, expect_rc=-7)     # DSP_EBOUNDS
+        m.close()
+    print(msg)
+    assert "out of range" in msg and "operand K4 input" in msg and "dsp_kernels.hip:" in msg
+
+
+def test_the_range_check_drops_what_lies_past_an_extent(emu):
+    """the interpreter's descriptors behave as dsp_debug_range_probe expects of the hardware (tests/test_gpu_zz_extents.py)"""
+    emu.dsp_debug_range_probe.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]
+    out = (ctypes.c_int32 * 4)()
+    assert emu.dsp_debug_range_probe(0, out) == 0
+    assert tuple(out) == (16, 48, 64, 1024)
+
+
+def test_the_package_refuses_the_interpreter_as_its_library(emu, tmp_path):
+    """no way to run the product on the CPU through it: the loader checks the ABI version the library answers with"""
+    import sys
+    r = subprocess.run([sys.executable, "-c", "from deepsignal_plant_amd import _native; _native.lib()"], cwd=ROOT, capture_output=True, text=True,
+                       env=dict(os.environ, DSP_AMD_LIB=emu._name), timeout=300)
+    assert r.returncode != 0 and "implements C-ABI version 1003" in r.stderr, r.stderr[-2000:]
