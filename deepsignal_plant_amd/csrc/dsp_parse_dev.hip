@@ -38,6 +38,12 @@
 #include "dsp_amd.h"
 #include "dsp_parse_arith.h"   // fast_float / fast_int / base_code / is_space / eq_mask4 / delim_mask4: shared with the host sanitizer test
 
+// (the one spot of HIP's LDS declaration syntax, as a macro: the test-suite's SIMT interpreter -- tests/native/emu -- gives it its own
+// meaning when it runs these kernels on the host under AddressSanitizer; the product build sees exactly the declaration it names)
+#ifndef DSP_EMU
+#define DSP_DYN_LDS_T(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
+#endif
+
 namespace {
 
 using namespace dsp_parse_arith;
@@ -277,7 +283,7 @@ struct LdsReader {
 template <int RB>
 __global__ __launch_bounds__(256, 6) void dsp_parse_tokens_kernel(ParseArgs a) {
     constexpr int kTokCapBytes = RB * kTokRowBytes;
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    DSP_DYN_LDS_T(uint32_t, lds);
     const int L = a.L, S = a.S, NTOK = 7 + 3 * L + L * S + 1;
     const int kTokCapDelims = (RB * NTOK + 64 + 7) & ~7;          // (the host sized the dynamic LDS with the same formula)
     uint32_t* buf = lds;                                          // kTokCapBytes + 48 bytes of text

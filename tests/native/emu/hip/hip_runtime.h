@@ -89,6 +89,7 @@ static inline hipError_t hipMemcpyToSymbol(void* sym, const void* src, size_t n)
 #define DSP_DRAIN_STORES() ((void)0)
 #define DSP_READ_XCC_ID(x) ((x) = blockIdx.x % 8u)
 #define DSP_DYN_LDS(name) float* name = emu::cur()->lds
+#define DSP_DYN_LDS_T(type, name) type* name = (type*)emu::cur()->lds          /* csrc/dsp_parse_dev.hip */
 
 // builtins of the amdgcn target
 #define __builtin_amdgcn_readfirstlane(x) emu::readfirstlane(x)

@@ -13,6 +13,9 @@
 //   (1) N rows of random float spellings (fixed / scientific, 1..17 significant digits, signs, leading zeros, exponents to +-25;
 //       one row in ten holds one token outside the plain grammar: '+', blanks, inf / nan, 25 digits, 1e400)
 //   (2) M blocks of 1..3 rows with 1..3 bytes overwritten from "\t,;.-+eE0123456789 \nACGTNX\r:_"
+// -DPARSE_THROUGH_KERNELS (tests/test_kernel_emu.py): instead of the transcription below, the KERNELS of csrc/dsp_parse_dev.hip run
+// -- compiled for the host by the SIMT interpreter tests/native/emu, all three of them (DSP_PARSE_KERNEL=rows: the thread-per-row
+// pair that takes rows longer than the LDS piece), with ASan's red zones around every array they touch.
 // Checks: a row the device algorithm accepts is accepted by the host parser with bit-identical arrays; a row the host parser
 // rejects is flagged; plain rows are not flagged.  usage: parse_dev_host [N=200000] [M=30000]
 #include <cinttypes>
@@ -192,7 +195,19 @@ void check_block(const std::string& block, Tally& t, bool expect_plain_unflagged
     if (n == 0) return;
     const uint64_t text_bytes = row_off[(size_t)n];
     Arrays dev((size_t)n), host(1);
+#ifdef PARSE_THROUGH_KERNELS
+    // the KERNELS themselves (csrc/dsp_parse_dev.hip compiled for the host by the test-suite's SIMT interpreter, tests/native/emu):
+    // the token-parallel kernel, or -- DSP_PARSE_KERNEL=rows -- the thread-per-row pair; every array exactly sized for ASan
+    {
+        std::vector<uint32_t> seg((size_t)n * (L + 4)), n_flagged(1);
+        const int32_t rc = dsp_parse_rows_device(nullptr, staged.data(), row_off.data(), n, L, S, dev.kmer.data(), dev.means.data(), dev.stds.data(), dev.lens.data(),
+                                                 dev.signals.data(), dev.labels.data(), dev.info_len.data(), dev.read_off.data(), dev.read_len.data(),
+                                                 dev.status.data(), n_flagged.data(), seg.data(), text_bytes);
+        if (rc) { fprintf(stderr, "dsp_parse_rows_device: %s\n", dsp_last_error()); exit(1); }
+    }
+#else
     for (long long r0 = 0; r0 < n; r0 += RB) device_algorithm(staged, row_off, text_bytes, n, r0, dev);
+#endif
     for (long long i = 0; i < n; ++i) {
         const char* row = staged.data() + row_off[(size_t)i];
         const size_t len = (size_t)(row_off[(size_t)i + 1] - row_off[(size_t)i]);
@@ -271,6 +286,10 @@ int main(int argc, char** argv) {
     }
     printf("mutated blocks: %ld blocks, %ld rows: accepted and bit-identical %ld, flagged though the host parser takes them %ld, rejected by the host "
            "parser and flagged %ld; never accepted what the host rejects\n", M, b.rows, b.same, b.flagged_plain, b.host_rejected);
+#ifdef PARSE_THROUGH_KERNELS
+    printf("parse_dev_host: ok (through the interpreted kernels%s)\n", getenv("DSP_PARSE_KERNEL") ? ", thread-per-row pair" : ", token-parallel kernel");
+#else
     printf("parse_dev_host: ok\n");
+#endif
     return 0;
 }

@@ -320,3 +320,54 @@ def test_the_package_refuses_the_interpreter_as_its_library(emu, tmp_path):
     r = subprocess.run([sys.executable, "-c", "from deepsignal_plant_amd import _native; _native.lib()"], cwd=ROOT, capture_output=True, text=True,
                        env=dict(os.environ, DSP_AMD_LIB=emu._name), timeout=300)
     assert r.returncode != 0 and "implements C-ABI version 1003" in r.stderr, r.stderr[-2000:]
+
+
+@pytest.mark.skipif(not LONG, reason="DSP_EMU_LONG=1: two minutes of compilation, a quarter of an hour of interpreted forwards under sanitizers")
+def test_the_kernels_under_address_and_ub_sanitizers(tmp_path):
+    """GPU sanitizers are not available on this pool -- but the interpreter is a host build of the kernels whose every "device"
+    allocation is a malloc block: tests/native/emu_asan_driver.cpp runs every kernel form with DSP_RSRC_EXTENTS=wide (nothing
+    between a kernel's offsets and AddressSanitizer) and again with the default extents, bit-identical, without a report."""
+    exe = str(tmp_path / "emu_asan")
+    cmd = [CLANG, "-std=c++17", "-O1", "-g", "-march=native", "-Wno-psabi", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-DDSP_EMU", "-Wno-unused-value", "-I", EMU, "-I", os.path.join(ROOT, "include"), "-I", CSRC, os.path.join(ROOT, "tests", "native", "emu_asan_driver.cpp"),
+           "-x", "c++", os.path.join(CSRC, "dsp_kernels.hip"), os.path.join(CSRC, "dsp_capi.cpp"), os.path.join(EMU, "hip_emu.cpp"), "-o", exe, "-pthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stderr[-4000:]
+    with env():
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=5400,
+                           env=dict(os.environ, ASAN_OPTIONS="detect_stack_use_after_return=0:detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1"))
+    print(r.stdout)
+    assert r.returncode == 0 and "emu_asan_driver: ok" in r.stdout, (r.stdout[-2000:], r.stderr[-6000:])
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-6000:]
+
+
+@pytest.mark.parametrize("kernel", ["tokens", "rows"])
+def test_the_row_parsers_kernels_under_sanitizers_against_the_host_parser(tmp_path_factory, kernel):
+    """csrc/dsp_parse_dev.hip -- the token-parallel kernel and the thread-per-row pair -- compiled for the host by the interpreter
+    and run under ASan + UBSan over random float spellings, the writer's grammar and byte-mutated blocks
+    (tests/native/parse_dev_host.cpp -DPARSE_THROUGH_KERNELS): every array the kernels touch -- the staged text and its 64 bytes
+    of slack, the row offsets, the segment table, the outputs -- is exactly sized, so a cursor that runs past a row, a table
+    entry followed out of the block, a token stored one too far is a report.  Every accepted row equals the host parser's bit for
+    bit, every row it rejects is flagged.  (Round 5's one unexplained death of a GPU-suite run fell between test_gpu_parse.py and
+    the eight-rank bench: this is those kernels with a sanitizer on.)"""
+    d = tmp_path_factory.getbasetemp() / "parse_kernels"
+    exe = str(d / "parse_kernels_asan")
+    if not os.path.exists(exe):
+        d.mkdir(exist_ok=True)
+        cmd = [CLANG, "-std=c++17", "-O1", "-g", "-march=native", "-Wno-psabi", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+               "-ffp-contract=off", "-DDSP_EMU", "-DPARSE_THROUGH_KERNELS", "-Wno-unused-value", "-Wno-unused-function", "-I", EMU, "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+               os.path.join(ROOT, "tests", "native", "parse_dev_host.cpp"), os.path.join(CSRC, "dsp_text.cpp"), "-x", "c++", os.path.join(CSRC, "dsp_parse_dev.hip"),
+               os.path.join(EMU, "hip_emu.cpp"), "-o", exe, "-pthread"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-4000:]
+    n, m = ("200000", "30000") if LONG else ("20000", "3000")
+    e = {k: v for k, v in os.environ.items() if k not in ("DSP_PARSE_KERNEL", "DSP_PARSE_RB")}
+    e.update(ASAN_OPTIONS="detect_stack_use_after_return=0", UBSAN_OPTIONS="print_stacktrace=1")
+    if kernel == "rows":
+        e["DSP_PARSE_KERNEL"] = "rows"
+    r = subprocess.run([exe, n, m], capture_output=True, text=True, timeout=3000, env=e)
+    print(r.stdout)
+    assert r.returncode == 0 and "parse_dev_host: ok (through the interpreted kernels" in r.stdout, (r.stdout[-2000:], r.stderr[-6000:])
+    assert ("thread-per-row" in r.stdout) == (kernel == "rows")
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-6000:]
+    assert "never accepted what the host rejects" in r.stdout
