@@ -46,12 +46,24 @@ pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="the image's c
 LONG = bool(os.environ.get("DSP_EMU_LONG"))
 
 
+def _cache_dir(*flags):
+    """a build directory keyed by the sources it is built from (tests/native/_build/, git-ignored): a second run of the suite on
+    unchanged sources does not compile the interpreter again"""
+    import hashlib
+    h = hashlib.sha256(" ".join(flags).encode())
+    for f in sorted(os.listdir(CSRC)) + sorted(os.path.join("..", "..", "tests", "native", "emu", x) for x in ("hip_emu.cpp", "hip/hip_runtime.h", "hip/hip_runtime_api.h")) + \
+            [os.path.join("..", "..", "tests", "native", x) for x in ("parse_dev_host.cpp",)] + [os.path.join("..", "..", "include", "dsp_amd.h")]:
+        path = os.path.join(CSRC, f)
+        if os.path.isfile(path) and path.endswith((".hip", ".h", ".cpp")):
+            h.update(open(path, "rb").read())
+    d = os.path.join(ROOT, "tests", "native", "_build", h.hexdigest()[:16])
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
 def _build(out, *flags):
-    cmd = [CLANG, "-std=c++17", "-O2", "-march=native", "-fPIC", "-shared", "-DDSP_EMU", "-Wno-unused-value", "-I", EMU, "-I", os.path.join(ROOT, "include"),
-           "-I", CSRC, "-x", "c++", os.path.join(CSRC, "dsp_kernels.hip"), os.path.join(CSRC, "dsp_capi.cpp"), os.path.join(EMU, "hip_emu.cpp"), "-o", out,
-           "-pthread"] + list(flags)
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-4000:]
+    if not os.path.exists(out):
+        _compile(out, *flags)
     L = ctypes.CDLL(out)
     L.dsp_last_error.restype = ctypes.c_char_p
     L.dsp_forward.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -62,14 +74,24 @@ def _build(out, *flags):
     return L
 
 
+def _compile(out, *flags):
+    tmp = out + ".tmp%d" % os.getpid()
+    cmd = [CLANG, "-std=c++17", "-O2", "-march=native", "-fPIC", "-shared", "-DDSP_EMU", "-Wno-unused-value", "-I", EMU, "-I", os.path.join(ROOT, "include"),
+           "-I", CSRC, "-x", "c++", os.path.join(CSRC, "dsp_kernels.hip"), os.path.join(CSRC, "dsp_capi.cpp"), os.path.join(EMU, "hip_emu.cpp"), "-o", tmp,
+           "-pthread"] + list(flags)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    os.replace(tmp, out)
+
+
 @pytest.fixture(scope="module")
 def libs(tmp_path_factory):
     """the interpreter build of the library and its bounds-recording twin, compiled side by side"""
     import concurrent.futures
-    d = tmp_path_factory.mktemp("emu")
+    d = _cache_dir("emu")
     with concurrent.futures.ThreadPoolExecutor(2) as ex:
-        a = ex.submit(_build, str(d / "libdsp_amd_emu.so"))
-        b = ex.submit(_build, str(d / "libdsp_amd_emu_bounds.so"), "-DDSP_BOUNDS")
+        a = ex.submit(_build, os.path.join(d, "libdsp_amd_emu.so"))
+        b = ex.submit(_build, os.path.join(d, "libdsp_amd_emu_bounds.so"), "-DDSP_BOUNDS")
         return a.result(), b.result()
 
 
@@ -350,16 +372,16 @@ def test_the_row_parsers_kernels_under_sanitizers_against_the_host_parser(tmp_pa
     entry followed out of the block, a token stored one too far is a report.  Every accepted row equals the host parser's bit for
     bit, every row it rejects is flagged.  (Round 5's one unexplained death of a GPU-suite run fell between test_gpu_parse.py and
     the eight-rank bench: this is those kernels with a sanitizer on.)"""
-    d = tmp_path_factory.getbasetemp() / "parse_kernels"
-    exe = str(d / "parse_kernels_asan")
+    exe = os.path.join(_cache_dir("parse"), "parse_kernels_asan")
     if not os.path.exists(exe):
-        d.mkdir(exist_ok=True)
+        tmp = exe + ".tmp%d" % os.getpid()
         cmd = [CLANG, "-std=c++17", "-O1", "-g", "-march=native", "-Wno-psabi", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
                "-ffp-contract=off", "-DDSP_EMU", "-DPARSE_THROUGH_KERNELS", "-Wno-unused-value", "-Wno-unused-function", "-I", EMU, "-I", os.path.join(ROOT, "include"), "-I", CSRC,
                os.path.join(ROOT, "tests", "native", "parse_dev_host.cpp"), os.path.join(CSRC, "dsp_text.cpp"), "-x", "c++", os.path.join(CSRC, "dsp_parse_dev.hip"),
-               os.path.join(EMU, "hip_emu.cpp"), "-o", exe, "-pthread"]
+               os.path.join(EMU, "hip_emu.cpp"), "-o", tmp, "-pthread"]
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-4000:]
+        os.replace(tmp, exe)
     n, m = ("200000", "30000") if LONG else ("20000", "3000")
     e = {k: v for k, v in os.environ.items() if k not in ("DSP_PARSE_KERNEL", "DSP_PARSE_RB")}
     e.update(ASAN_OPTIONS="detect_stack_use_after_return=0", UBSAN_OPTIONS="print_stacktrace=1")
