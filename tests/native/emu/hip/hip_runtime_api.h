@@ -40,7 +40,14 @@ static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e =
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
-static inline hipError_t hipMalloc(void** p, size_t n) { *p = n ? aligned_alloc(256, (n + 255) / 256 * 256) : aligned_alloc(256, 256); return *p ? hipSuccess : hipErrorOutOfMemory; }
+// (device memory is not zeroed by hipMalloc: every fresh block is filled with 0xff -- quiet NaNs as floats, a set "abandoned" bit and an
+// absurd count as a cluster's counters -- so that a kernel reading scratch it has not written shows in the results)
+static inline hipError_t hipMalloc(void** p, size_t n) {
+    const size_t m = n ? (n + 255) / 256 * 256 : 256;
+    *p = aligned_alloc(256, m);
+    if (*p) memset(*p, 0xff, m);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, enum hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, enum hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }

@@ -193,7 +193,11 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
     std::vector<Wave> waves;
     const int wpw = (int)((nthr + 63) / 64);
     for (size_t g = 0; g < nwg; ++g) {
-        wgs[g].lds.assign(lds_bytes / 4 + 64, 0.f);   // (+ slack: a kernel that asks for no dynamic LDS still gets a valid pointer)
+        // LDS is not zeroed either: quiet NaNs.  Exactly the bytes the launch asked for (AddressSanitizer then sees an overrun;
+        // a kernel that asks for none gets a pointer it must not follow)
+        const uint32_t poison = 0x7fc0dead;
+        float pf; memcpy(&pf, &poison, 4);
+        wgs[g].lds.assign((lds_bytes + 3) / 4, pf);
         wgs[g].first_wave = (int)waves.size();
         wgs[g].n_waves = wpw;
         for (int w = 0; w < wpw; ++w) {
