@@ -393,3 +393,33 @@ def test_the_row_parsers_kernels_under_sanitizers_against_the_host_parser(tmp_pa
     assert ("thread-per-row" in r.stdout) == (kernel == "rows")
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-6000:]
     assert "never accepted what the host rejects" in r.stdout
+
+
+def test_random_model_shapes_through_the_interpreter(emu):
+    """tools/parity_sweep.py's idea at the interpreter's scale: random model shapes -- every flag of the reference's constructor,
+    hidden sizes 20 ... 200 (padded unit tiles, 1 ... 8 of them), 1 ... 2 layers, odd k-mer lengths, any signal window, 2 ... 5
+    classes -- x random batch sizes with tile tails, explicit N(0,1) states against the C oracle"""
+    rng = np.random.default_rng(2026)
+    worst = 0.0
+    for case in range(40 if LONG else 10):
+        module = ["both_bilstm", "seq_bilstm", "signal_bilstm"][int(rng.integers(0, 3))]
+        hidden = int(rng.choice([20, 32, 50, 64, 96, 100, 128, 160, 200]))
+        if module == "both_bilstm" and hidden % 2:
+            hidden += 1
+        cfg = onp.OracleConfig(seq_len=int(rng.choice([1, 2, 3, 5])), signal_len=int(rng.choice([4, 8, 12, 16, 24, 40])), num_layers1=int(rng.integers(1, 3)),
+                               num_layers2=int(rng.integers(1, 3)), num_classes=int(rng.choice([2, 2, 3, 5])), hidden_size=hidden, vocab_size=int(rng.choice([5, 16])),
+                               embedding_size=int(rng.choice([2, 4, 6])), is_base=bool(rng.integers(0, 2)), is_signallen=bool(rng.integers(0, 2)), module=module)
+        n = int(rng.choice([1, 5, 31, 32, 33, 64, 65, 100]))
+        w = onp.make_weights(cfg, 10_000 + case, float(rng.choice([1.0, 2.0, 3.0])))
+        ins = onp.make_inputs(cfg, n, 20_000 + case, wide_alphabet=cfg.vocab_size == 16)
+        if cfg.vocab_size < 16:
+            ins = (np.minimum(ins[0], cfg.vocab_size - 1),) + tuple(ins[1:])
+        st = onp.make_init_states(cfg, n, 30_000 + case)
+        with env():
+            m = Model(emu, cfg, w)
+            probs = m.forward(ins, states=st)[0]
+            m.close()
+        d = float(np.abs(probs - oc.forward(cfg, w, *ins, states=st)[1]).max())
+        worst = max(worst, d)
+        assert d <= 2e-6, (case, cfg, n, d)
+    print("worst max|dprob| of the interpreted kernels against the C oracle over the random shapes: %.2e" % worst)
