@@ -44,6 +44,13 @@ emu_swap:
 .size emu_swap, .-emu_swap
 )");
 
+// what the interpreter has carried out since the last call (tests: the MFMAs a forward ISSUES against the flops it is credited with)
+static unsigned long long g_total[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+extern "C" void emu_stats(unsigned long long out[4]) {
+    out[0] = g_total[1]; out[1] = g_total[2]; out[2] = g_total[0]; out[3] = g_total[3];   // fp32 MFMAs (32x32x2), k16 MFMAs (32x32x16), launches, readfirstlanes
+    for (auto& t : g_total) t = 0;
+}
+
 extern "C" int emu_compute_units(void) {
     const char* v = getenv("EMU_CUS");
     const int n = v ? atoi(v) : 256;
@@ -269,6 +276,7 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
                     if (n_first == W.n) { for (int i = 0; i < W.n; ++i) grp.push_back(W.first + i); }
                     else for (int i = 0; i < W.n; ++i) { const Lane& l = g_lanes[(size_t)(W.first + i)]; if (!l.done && l.op == first_wave_op) grp.push_back(W.first + i); }
                     ++g_ops[first_wave_op];
+                    ++g_total[first_wave_op];
                     execute(grp, first_wave_op, W.n, waves);
                     for (int i : grp) g_lanes[(size_t)i].op = NONE;
                     continue;
@@ -284,6 +292,7 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
         if (!progress) die("no lane could run and no barrier could be released: deadlock", waves);
     }
     g_body = nullptr;
+    ++g_total[0];
     if (getenv("DSP_EMU_STATS")) {   // what the launch cost the interpreter
         static struct timespec last; struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
         fprintf(stderr, "hip_emu: launch of %zu x %zu lanes: lane runs %llu, mfma %llu + %llu, readfirstlane %llu, shuffle %llu; %.3f s since the previous launch ended\n", nwg, nthr,

@@ -423,3 +423,32 @@ def test_random_model_shapes_through_the_interpreter(emu):
         worst = max(worst, d)
         assert d <= 2e-6, (case, cfg, n, d)
     print("worst max|dprob| of the interpreted kernels against the C oracle over the random shapes: %.2e" % worst)
+
+
+def test_issued_matrix_work_against_the_flops_a_forward_is_credited_with(emu):
+    """bench.py's roofline credits a forward with dsp_flops_per_site x sites (the reference's multiply-adds); the kernels ISSUE
+    whole 32x32x2 MFMAs over padded tiles.  Counted by the interpreter for 512 sites (whole tiles, so that only the padding of the
+    SHAPES shows): issued / credited is 1 plus the front ends' zero-padded input features -- the combined stack issues exactly
+    its credited work."""
+    emu.emu_stats.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
+    emu.dsp_flops_per_site.restype = ctypes.c_int64
+    out = (ctypes.c_ulonglong * 4)()
+    cases = ((dict(seq_len=1, signal_len=16, hidden_size=256, num_layers1=1), 1.0, 1.02),
+             (dict(seq_len=2, signal_len=16, hidden_size=256, num_layers1=1, module="seq_bilstm"), 1.0, 1.02))
+    for kw, lo, hi in (cases if LONG else cases[:1]):
+        cfg = onp.OracleConfig(**kw)
+        w = onp.make_weights(cfg, 3, 1.0)
+        ins = onp.make_inputs(cfg, 512, 4)
+        with env():
+            m = Model(emu, cfg, w)
+            emu.emu_stats(out)
+            m.forward(ins)
+            emu.emu_stats(out)
+            m.close()
+        issued = out[0] * 32 * 32 * 2 * 2
+        mod = {"both_bilstm": 0, "seq_bilstm": 1, "signal_bilstm": 2}[cfg.module]
+        c = nat.ModelCfg(cfg.seq_len, cfg.signal_len, cfg.num_layers1, cfg.num_layers2, cfg.num_classes, cfg.hidden_size, cfg.vocab_size, cfg.embedding_size,
+                         int(cfg.is_base), int(cfg.is_signallen), mod)
+        credited = int(emu.dsp_flops_per_site(ctypes.byref(c))) * 512
+        print(kw, "issued %.3f GFLOP in %d fp32 MFMAs over %d launches; credited %.3f GFLOP; ratio %.3f" % (issued / 1e9, out[0], out[2], credited / 1e9, issued / credited))
+        assert lo <= issued / credited <= hi, (issued, credited)
