@@ -21,6 +21,18 @@
 #include "dsp_amd.h"
 #include "dsp_kernels.h"
 
+// (HIP's dynamic-LDS declaration as a macro: the test-suite's SIMT interpreter, tests/native/emu, gives it its own meaning when it
+// runs these kernels on the host under AddressSanitizer; the product build sees exactly the declaration it names)
+#ifndef DSP_EMU
+#define DSP_DYN_LDS_T(type, name) extern __shared__ type name[]
+// (a wave runs in lockstep: what one lane stored to LDS an instruction ago is there for the next lane's load.  The interpreter runs
+// a wave's lanes one after another between cross-lane instructions and needs to be TOLD where the kernel relies on that.)
+#define DSP_WAVE_LOCKSTEP() ((void)0)
+// (... and a piece of LDS that the lanes of a group all write with the SAME values in lockstep -- read-then-write in one
+// instruction each -- is given to every lane as its own copy there)
+#define DSP_LOCKSTEP_SHARED(type, ptr) ((void)0)
+#endif
+
 namespace {
 
 constexpr double kMadC = 0.6744897501960817;  // norm.ppf(3/4): statsmodels robust.mad's c
@@ -83,6 +95,7 @@ template <class F>
 __device__ double pw_chunk8(const F& f, int64_t lo, int n, int l8, PwStack* st) {  // n <= 8192
     if (n <= 128) return pw_block8(f, lo, n, l8);
     // post-order walk of numpy's recursion; all 8 lanes execute it identically (same-value LDS writes are benign)
+    DSP_LOCKSTEP_SHARED(PwStack, st);
     int sp = 0;
     st->lo[0] = 0; st->n[0] = n; st->phase[0] = 0;
     double ret = 0.0;
@@ -460,7 +473,7 @@ __device__ bool mad_by_histogram(const int16_t* raw, int64_t n, double scaling, 
 }
 
 __global__ __launch_bounds__(1024) void dsp_ext_mad_kernel(dsp_read_batch b, double* shift_out, double* scale_out) {
-    extern __shared__ uint32_t fine_lds[];  // kWin bins
+    DSP_DYN_LDS_T(uint32_t, fine_lds);  // kWin bins
     __shared__ SelectLds sel;
     __shared__ MadLds mad;
     const int64_t r = blockIdx.x;
@@ -744,7 +757,7 @@ typedef GatherArgsT<float> GatherArgs;
 // a base longer than S, draws the sorted subset into LDS for the pair's other threads.
 template <typename T>
 __global__ __launch_bounds__(256) void dsp_ext_gather_kernel(GatherArgsT<T> a) {
-    extern __shared__ int sel_lds[];  // [pairs touched by this workgroup][S]
+    DSP_DYN_LDS_T(int, sel_lds);  // [pairs touched by this workgroup][S]
     const int S = a.S;
     const int64_t total = a.n_sites * a.L * (int64_t)S;
     const int64_t t0 = (int64_t)blockIdx.x * blockDim.x;
@@ -813,7 +826,7 @@ constexpr int kSampleMaxS = 64;  // widest signal_len the sampling pass serves (
 // Fast path for signal_len = 4, 8, ..., 256 (a power of two): S/4 adjacent lanes per (site, base) pair, each lane
 // producing four consecutive samples and storing them as one 16-byte vector.
 __global__ __launch_bounds__(256) void dsp_ext_gather4_kernel(GatherArgs a, int log2_lpp) {
-    extern __shared__ int sel_lds[];  // [pairs per workgroup][S]
+    DSP_DYN_LDS_T(int, sel_lds);  // [pairs per workgroup][S]
     const int S = a.S;
     const int lpp = 1 << log2_lpp;                 // lanes per pair = S / 4
     const int ppb = 256 >> log2_lpp;               // pairs per workgroup
@@ -927,7 +940,7 @@ __device__ void sample_one(const GatherArgs& a, int64_t pair, uint32_t* bits /* 
 __global__ __launch_bounds__(256) void dsp_ext_sample_kernel(GatherArgs a) {
     __shared__ uint32_t bits_lds[4][kSelWords * 64];
     __shared__ int64_t queue_lds[4][128];
-    extern __shared__ int idx_lds[];  // [4 waves][S][64]
+    DSP_DYN_LDS_T(int, idx_lds);  // [4 waves][S][64]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t* bits = bits_lds[w] + lane;
     int* idx = idx_lds + (size_t)w * a.S * 64 + lane;
@@ -948,13 +961,16 @@ __global__ __launch_bounds__(256) void dsp_ext_sample_kernel(GatherArgs a) {
         const uint64_t m = __ballot(is_long);
         if (is_long) queue[qn + __popcll(m & ((1ull << lane) - 1))] = pair;
         qn += __popcll(m);
+        DSP_WAVE_LOCKSTEP();   // every lane's queue entry is in LDS before any lane takes one
         if (qn >= 64) {
             sample_one(a, queue[lane], bits, idx);
             qn -= 64;
+            DSP_WAVE_LOCKSTEP();
             if (lane < qn) {
                 const int64_t keep = queue[64 + lane];
                 queue[lane] = keep;
             }
+            DSP_WAVE_LOCKSTEP();
         }
     }
     if (lane < qn) sample_one(a, queue[lane], bits, idx);

@@ -29,10 +29,13 @@ namespace emu {
 struct LaneCtx { dim3 tid, bid, bdim, gdim; float* lds; int lane; };
 extern LaneCtx* g_cur;                                   // the lane that is running
 inline LaneCtx* cur() { return g_cur; }
-void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body);
+// sequential: one workgroup at a time (kernels whose workgroups never wait for each other; what makes `static` a faithful
+// stand-in for a kernel's static __shared__ variables -- DSP_EMU_STATIC_LDS)
+void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body, bool sequential = false);
 // instructions that involve other lanes (hip_emu.cpp)
 uint32_t readfirstlane_u32(uint32_t v);
-uint32_t shfl_u32(uint32_t v, int kind, int arg);        // kind 0: xor mask, 1: up delta
+uint64_t shfl_u64(uint64_t v, int kind, int arg, int width);   // kind 0: xor mask, 1: up delta, 2: source lane (within groups of `width`)
+uint64_t ballot(bool pred);                              // bit l set: lane l is active and its predicate holds
 void mfma_f32(float a, float b, emu_f32x16* acc);        // 32x32x2: acc += A * B
 void mfma_k16(const float a[8], const float b[8], emu_f32x16* acc);   // 32x32x16 (bf16 / f16 operands already widened)
 void barrier();
@@ -43,9 +46,9 @@ template <class T> inline T readfirstlane(T v) {
     static_assert(sizeof(T) == 4, "readfirstlane of a 32-bit value");
     uint32_t u; memcpy(&u, &v, 4); u = readfirstlane_u32(u); memcpy(&v, &u, 4); return v;
 }
-template <class T> inline T shfl(T v, int kind, int arg) {
-    static_assert(sizeof(T) == 4, "shuffle of a 32-bit value");
-    uint32_t u; memcpy(&u, &v, 4); u = shfl_u32(u, kind, arg); memcpy(&v, &u, 4); return v;
+template <class T> inline T shfl(T v, int kind, int arg, int width = 64) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "shuffle of a 32- or 64-bit value");
+    uint64_t u = 0; memcpy(&u, &v, sizeof(T)); u = shfl_u64(u, kind, arg, width); memcpy(&v, &u, sizeof(T)); return v;
 }
 inline emu_f32x16 mfma_f32_32x32x2(float a, float b, emu_f32x16 c) { mfma_f32(a, b, &c); return c; }
 template <class V> inline emu_f32x16 mfma_32x32x16(V a, V b, emu_f32x16 c) {
@@ -81,7 +84,12 @@ inline void buffer_store_b128(emu_u32x4 v, __amdgpu_buffer_rsrc_t r, int voff, i
 #define HIP_SYMBOL(x) (&(x))
 static inline hipError_t hipMemcpyFromSymbol(void* dst, const void* sym, size_t n) { memcpy(dst, sym, n); return hipSuccess; }
 static inline hipError_t hipMemcpyToSymbol(void* sym, const void* src, size_t n) { memcpy(sym, src, n); return hipSuccess; }
+#ifdef DSP_EMU_STATIC_LDS   // a translation unit with static __shared__ variables (csrc/dsp_extract.hip): its workgroups run one after another
+#define __shared__ static
+#define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...) emu::launch(grid, block, lds, [=]() { kern(__VA_ARGS__); }, true)
+#else
 #define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...) emu::launch(grid, block, lds, [=]() { kern(__VA_ARGS__); })
+#endif
 
 // the five arch macros of csrc/dsp_kernels.hip
 #define DSP_STORE_GUARD(v) ((void)(v))
@@ -89,7 +97,9 @@ static inline hipError_t hipMemcpyToSymbol(void* sym, const void* src, size_t n)
 #define DSP_DRAIN_STORES() ((void)0)
 #define DSP_READ_XCC_ID(x) ((x) = blockIdx.x % 8u)
 #define DSP_DYN_LDS(name) float* name = emu::cur()->lds
-#define DSP_DYN_LDS_T(type, name) type* name = (type*)emu::cur()->lds          /* csrc/dsp_parse_dev.hip */
+#define DSP_DYN_LDS_T(type, name) type* name = (type*)emu::cur()->lds          /* csrc/dsp_parse_dev.hip, dsp_extract.hip */
+#define DSP_LOCKSTEP_SHARED(type, ptr) type ptr##_of_this_lane; ptr = &ptr##_of_this_lane
+#define DSP_WAVE_LOCKSTEP() ((void)emu::ballot(true))   /* every lane of the wave that is here has executed what precedes */
 
 // builtins of the amdgcn target
 #define __builtin_amdgcn_readfirstlane(x) emu::readfirstlane(x)
@@ -111,6 +121,24 @@ static inline hipError_t hipMemcpyToSymbol(void* sym, const void* src, size_t n)
 #define __syncthreads() emu::barrier()
 #define __shfl_xor(v, m) emu::shfl((v), 0, (m))
 #define __shfl_up(v, d) emu::shfl((v), 1, (d))
+#define EMU_SHFL_PICK(_1, _2, _3, NAME, ...) NAME
+#define EMU_SHFL2(v, src) emu::shfl((v), 2, (src))
+#define EMU_SHFL3(v, src, width) emu::shfl((v), 2, (src), (width))
+#define __shfl(...) EMU_SHFL_PICK(__VA_ARGS__, EMU_SHFL3, EMU_SHFL2)(__VA_ARGS__)
+#define __ballot(p) emu::ballot((p))
+#define __popcll(x) __builtin_popcountll((unsigned long long)(x))
+#define __ffsll(x) __builtin_ffsll((long long)(x))
+#define __ffs(x) __builtin_ffs((int)(x))
+static inline long long __double_as_longlong(double v) { long long u; memcpy(&u, &v, 8); return u; }
+static inline double __longlong_as_double(long long u) { double v; memcpy(&v, &u, 8); return v; }
+static inline int atomicAdd(int* p, int v) { const int o = *p; *p = o + v; return o; }
+// HIP's short vector types as far as the kernels use them
+struct alignas(16) int4 { int x, y, z, w; };
+static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+struct alignas(16) float4 { float x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+struct alignas(16) double2 { double x, y; };
+static inline double2 make_double2(double x, double y) { return double2{x, y}; }
 static inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((unsigned long long)a * b) >> 32); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
 static inline unsigned atomicCAS(unsigned* p, unsigned cmp, unsigned v) { const unsigned o = *p; if (o == cmp) *p = v; return o; }

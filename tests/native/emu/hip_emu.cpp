@@ -63,7 +63,7 @@ LaneCtx* g_cur = nullptr;
 
 namespace {
 
-enum Op { NONE = 0, MFMA_F32, MFMA_K16, RFL, SHFL, BARRIER, YIELD };
+enum Op { NONE = 0, MFMA_F32, MFMA_K16, RFL, SHFL, BARRIER, YIELD, BALLOT };
 
 struct Lane {
     LaneCtx ctx;           // (first member: g_cur points here)
@@ -74,7 +74,7 @@ struct Lane {
     float a = 0, b = 0;
     const float* a8 = nullptr; const float* b8 = nullptr;
     emu_f32x16* acc = nullptr;
-    uint32_t u = 0; int kind = 0, arg = 0;
+    uint64_t u = 0; int kind = 0, arg = 0, width = 64;
 };
 
 struct Wave { int first = 0, n = 0, wg = 0; bool finished = false, at_barrier = false; };
@@ -112,8 +112,8 @@ void run_lane(Lane& l) {
         if (waves[w].finished) continue;
         int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dn = 0;
         for (int i = 0; i < waves[w].n; ++i) { const Lane& l = g_lanes[(size_t)(waves[w].first + i)]; if (l.done) ++dn; else ++cnt[l.op]; }
-        fprintf(stderr, "  wave %zu (workgroup %d): done %d, running %d, mfma %d/%d, readfirstlane %d, shuffle %d, barrier %d, yield %d\n", w, waves[w].wg, dn,
-                cnt[NONE], cnt[MFMA_F32], cnt[MFMA_K16], cnt[RFL], cnt[SHFL], cnt[BARRIER], cnt[YIELD]);
+        fprintf(stderr, "  wave %zu (workgroup %d): done %d, running %d, mfma %d/%d, readfirstlane %d, shuffle %d, ballot %d, barrier %d, yield %d\n", w, waves[w].wg, dn,
+                cnt[NONE], cnt[MFMA_F32], cnt[MFMA_K16], cnt[RFL], cnt[SHFL], cnt[BALLOT], cnt[BARRIER], cnt[YIELD]);
         ++shown;
     }
     abort();
@@ -122,22 +122,37 @@ void run_lane(Lane& l) {
 // carry out the wave-level instruction of the lanes in `grp` (indices into g_lanes), all parked at the same kind
 void execute(const std::vector<int>& grp, int op, int wave_n, const std::vector<Wave>& waves) {
     if (op == RFL) {
-        const uint32_t v = g_lanes[(size_t)grp[0]].u;     // the first ACTIVE lane
+        const uint64_t v = g_lanes[(size_t)grp[0]].u;     // the first ACTIVE lane
         for (int i : grp) g_lanes[(size_t)i].u = v;
         return;
     }
-    if ((int)grp.size() != wave_n || wave_n != 64) die("an MFMA / shuffle reached by a part of the wave only (or a wave that is not 64 lanes)", waves);
-    const int base = grp[0];
+    if (op == BALLOT) {                                   // over the lanes that are here: the exec mask
+        const int wave0 = grp[0] - g_lanes[(size_t)grp[0]].ctx.lane;
+        uint64_t m = 0;
+        for (int i : grp) if (g_lanes[(size_t)i].u) m |= 1ull << (i - wave0);
+        for (int i : grp) g_lanes[(size_t)i].u = m;
+        return;
+    }
     if (op == SHFL) {
-        uint32_t in[64];
-        for (int l = 0; l < 64; ++l) in[l] = g_lanes[(size_t)(base + l)].u;
-        for (int l = 0; l < 64; ++l) {
-            Lane& L = g_lanes[(size_t)(base + l)];
-            if (L.kind == 0) L.u = in[(l ^ L.arg) & 63];
-            else L.u = l >= L.arg ? in[l - L.arg] : in[l];
+        // (sub-wave groups in divergent control flow -- the 8-lane groups of csrc/dsp_extract.hip -- shuffle among the lanes that are
+        // here; a source lane that is not gives the lane its own value back, where the hardware's answer is undefined)
+        const int wave0 = grp[0] - g_lanes[(size_t)grp[0]].ctx.lane;
+        uint64_t in[64]; bool here[64];
+        for (int l = 0; l < 64; ++l) here[l] = false;
+        for (int i : grp) { in[i - wave0] = g_lanes[(size_t)i].u; here[i - wave0] = true; }
+        for (int i : grp) {
+            Lane& L = g_lanes[(size_t)i];
+            const int l = i - wave0, w = L.width > 0 && L.width <= 64 ? L.width : 64, g0 = l & ~(w - 1);
+            int src = l;
+            if (L.kind == 0) src = l ^ L.arg;
+            else if (L.kind == 1) src = (l - g0) >= L.arg ? l - L.arg : l;
+            else src = g0 + (L.arg & (w - 1));
+            if (src >= 0 && src < 64 && (src & ~(w - 1)) == g0 && here[src]) L.u = in[src];
         }
         return;
     }
+    if ((int)grp.size() != wave_n || wave_n != 64) die("an MFMA reached by a part of the wave only (or a wave that is not 64 lanes)", waves);
+    const int base = grp[0];
     if (op == MFMA_F32) {
         // D[row][j] = C[row][j] + A[row][0] B[0][j] + A[row][1] B[1][j]; lane l holds column j = l % 32 of the 16 rows
         // 8 (r / 4) + 4 (l / 32) + r % 4: the rows' A values as two 16-vectors per half-wave, two vector FMAs per lane
@@ -176,17 +191,26 @@ void execute(const std::vector<int>& grp, int op, int wave_n, const std::vector<
 
 }  // namespace
 
-uint32_t readfirstlane_u32(uint32_t v) { Lane* l = (Lane*)g_cur; l->u = v; l->op = RFL; park(); return l->u; }
-uint32_t shfl_u32(uint32_t v, int kind, int arg) { Lane* l = (Lane*)g_cur; l->u = v; l->kind = kind; l->arg = arg; l->op = SHFL; park(); return l->u; }
+uint32_t readfirstlane_u32(uint32_t v) { Lane* l = (Lane*)g_cur; l->u = v; l->op = RFL; park(); return (uint32_t)l->u; }
+uint64_t shfl_u64(uint64_t v, int kind, int arg, int width) { Lane* l = (Lane*)g_cur; l->u = v; l->kind = kind; l->arg = arg; l->width = width; l->op = SHFL; park(); return l->u; }
+uint64_t ballot(bool pred) { Lane* l = (Lane*)g_cur; l->u = pred ? 1 : 0; l->op = BALLOT; park(); return l->u; }
 void mfma_f32(float a, float b, emu_f32x16* acc) { Lane* l = (Lane*)g_cur; l->a = a; l->b = b; l->acc = acc; l->op = MFMA_F32; park(); }
 void mfma_k16(const float a[8], const float b[8], emu_f32x16* acc) { Lane* l = (Lane*)g_cur; l->a8 = a; l->b8 = b; l->acc = acc; l->op = MFMA_K16; park(); }
 void barrier() { Lane* l = (Lane*)g_cur; l->op = BARRIER; park(); }
 void yield() { Lane* l = (Lane*)g_cur; l->op = YIELD; park(); }
 unsigned long long now() { return g_tick; }
 
-void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body) {
+static void run_workgroups(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body, size_t wg_begin, size_t nwg);
+
+void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body, bool sequential) {
     if (g_cur) { fprintf(stderr, "hip_emu: a launch from inside a kernel\n"); abort(); }
-    const size_t nwg = (size_t)grid.x * grid.y * grid.z, nthr = (size_t)block.x * block.y * block.z, total = nwg * nthr;
+    const size_t all = (size_t)grid.x * grid.y * grid.z;
+    if (!sequential) { run_workgroups(grid, block, lds_bytes, body, 0, all); return; }
+    for (size_t g = 0; g < all; ++g) run_workgroups(grid, block, lds_bytes, body, g, 1);   // one workgroup at a time
+}
+
+static void run_workgroups(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>& body, size_t wg_begin, size_t nwg) {
+    const size_t nthr = (size_t)block.x * block.y * block.z, total = nwg * nthr;
     if (total == 0) return;
     if (g_stacks_bytes < total * kStack) {
         if (g_stacks) munmap(g_stacks, g_stacks_bytes);
@@ -217,7 +241,8 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
         for (size_t t = 0; t < nthr; ++t) {
             Lane& l = g_lanes[g * nthr + t];
             l.ctx.tid = dim3((unsigned)(t % block.x), (unsigned)(t / block.x % block.y), (unsigned)(t / ((size_t)block.x * block.y)));
-            l.ctx.bid = dim3((unsigned)(g % grid.x), (unsigned)(g / grid.x % grid.y), (unsigned)(g / ((size_t)grid.x * grid.y)));
+            const size_t gg = wg_begin + g;   // (g: the workgroup's place among the ones running now; gg: its index in the grid)
+            l.ctx.bid = dim3((unsigned)(gg % grid.x), (unsigned)(gg / grid.x % grid.y), (unsigned)(gg / ((size_t)grid.x * grid.y)));
             l.ctx.bdim = block; l.ctx.gdim = grid;
             l.ctx.lds = wgs[g].lds.data();
             l.ctx.lane = (int)(t & 63);

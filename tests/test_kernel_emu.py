@@ -452,3 +452,86 @@ def test_issued_matrix_work_against_the_flops_a_forward_is_credited_with(emu):
         credited = int(emu.dsp_flops_per_site(ctypes.byref(c))) * 512
         print(kw, "issued %.3f GFLOP in %d fp32 MFMAs over %d launches; credited %.3f GFLOP; ratio %.3f" % (issued / 1e9, out[0], out[2], credited / 1e9, issued / credited))
         assert lo <= issued / credited <= hi, (issued, credited)
+
+
+# ---- the extraction kernels (csrc/dsp_extract.hip: SURVEY.md 8(f)-3) through the interpreter -------------------------------------
+
+@pytest.fixture(scope="module")
+def emu_extract():
+    """dsp_extract.hip (its static __shared__ variables as `static`, its workgroups one after another: -DDSP_EMU_STATIC_LDS) +
+    the host-side site enumerator, for the host; float64 arithmetic in numpy's evaluation order: -ffp-contract=off as in the product"""
+    d = _cache_dir("extract")
+    out = os.path.join(d, "libdsp_extract_emu.so")
+    if not os.path.exists(out):
+        stub = os.path.join(d, "err_stub.cpp")
+        with open(stub, "w") as f:
+            f.write('#include <string>\nstatic std::string g;\nextern "C" void dsp_set_error_(const char* m) { g = m ? m : ""; }\n'
+                    'extern "C" const char* dsp_last_error(void) { return g.c_str(); }\n')
+        tmp = out + ".tmp%d" % os.getpid()
+        cmd = [CLANG, "-std=c++17", "-O2", "-march=native", "-Wno-psabi", "-fPIC", "-shared", "-DDSP_EMU", "-DDSP_EMU_STATIC_LDS", "-ffp-contract=off", "-Wno-unused-value",
+               "-I", EMU, "-I", os.path.join(ROOT, "include"), "-I", CSRC, stub, os.path.join(EMU, "hip_emu.cpp"), "-x", "c++", os.path.join(CSRC, "dsp_extract.hip"),
+               "-o", tmp, "-pthread"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-4000:]
+        os.replace(tmp, out)
+    L = ctypes.CDLL(out)
+    L.dsp_last_error.restype = ctypes.c_char_p
+    return L
+
+
+def _extract_through_the_interpreter(L, fx, reads, first_read_uid=0):
+    """FeatureExtractor.stage + .launch (deepsignal_plant_amd/extract_features.py) on host arrays: the host half is the product's own
+    code (_select_reads, _sites = csrc/dsp_sites.cpp), the three kernel entry points are the interpreted ones"""
+    from deepsignal_plant_amd.extract_features import ReadBatchC
+    uid_of = {id(r): first_read_uid + i for i, r in enumerate(reads)}
+    sel, lo, hi = fx._select_reads(reads)
+    R = len(sel)
+    i64 = lambda xs: np.concatenate([[0], np.cumsum(xs)]).astype(np.int64)
+    raw_off, ev_off = i64([r.raw.shape[0] for r in sel]), i64([r.ev_base.shape[0] for r in sel])
+    cat = lambda xs, dt: np.ascontiguousarray(np.concatenate(xs) if xs else np.zeros(0), dtype=dt)
+    ev_base = cat([r.ev_base for r in sel], np.uint8)
+    site_read, site_loc, info, row_off, info_len, _, _ = fx._sites(sel, ev_base, ev_off, lo, hi) if R else (np.zeros(0, np.int32),) * 2 + (None,) * 5
+    n, E = int(site_read.shape[0]), int(ev_off[-1])
+    raw = cat([r.raw for r in sel], np.int16)
+    scaling, offset = np.array([r.scaling for r in sel], np.float64), np.array([r.offset for r in sel], np.float64)
+    ev_start, ev_len = cat([r.ev_start for r in sel], np.int64), cat([r.ev_len for r in sel], np.int64)
+    uid = np.array([uid_of[id(r)] for r in sel], np.uint64)
+    site_read, site_loc = np.ascontiguousarray(site_read, np.int32), np.ascontiguousarray(site_loc, np.int32)
+    p = lambda a: ctypes.c_void_p(a.ctypes.data)
+    batch = ReadBatchC(R, int(raw_off[-1]), E, raw.ctypes.data, raw_off.ctypes.data, scaling.ctypes.data, offset.ctypes.data, ev_start.ctypes.data, ev_len.ctypes.data,
+                       ev_base.ctypes.data, ev_off.ctypes.data)
+    shift, scale = np.empty(R), np.empty(R)
+    base_mean, base_std = np.empty(E), np.empty(E)
+    base_len, base_lo, blk_off = np.empty(E, np.int32), np.empty(E, np.int64), np.empty(R + 1, np.int64)
+    out = dict(kmer=np.empty((n, fx.L), np.uint8), means=np.empty((n, fx.L), np.float32), stds=np.empty((n, fx.L), np.float32), lens=np.empty((n, fx.L), np.int32),
+               signals=np.empty((n, fx.L, fx.S), np.float32))
+    ok = lambda rc: (_ for _ in ()).throw(AssertionError(L.dsp_last_error())) if rc else None
+    ok(L.dsp_extract_normalize(None, ctypes.byref(batch), fx.method, p(shift), p(scale)))
+    ok(L.dsp_extract_base_stats(None, ctypes.byref(batch), p(shift), p(scale), p(blk_off), p(base_mean), p(base_std), p(base_len), p(base_lo)))
+    if n:
+        ok(L.dsp_extract_gather(None, ctypes.byref(batch), p(shift), p(scale), p(base_mean), p(base_std), p(base_len), p(base_lo), ctypes.c_int64(n), p(site_read),
+                                p(site_loc), fx.L, fx.S, int(fx.round_stats), ctypes.c_uint64(fx.seed & ((1 << 64) - 1)), p(uid), p(out["kmer"]), p(out["means"]),
+                                p(out["stds"]), p(out["lens"]), p(out["signals"])))
+    out["sampleinfo"] = [bytes(info[int(row_off[i]):int(row_off[i]) + int(info_len[i])]).decode() for i in range(n)]
+    return out
+
+
+def test_the_extraction_kernels_match_the_oracle_bit_for_bit(emu_extract):
+    """tests/test_gpu_extract.py's first test on the host: read statistics (MAD by code histograms / radix select, z-score by
+    numpy's pairwise sums), per-base means and stds, the window gather and the seeded subset draw of long bases -- float64 in
+    numpy's evaluation order, compared to the last bit with oracle/extract_np.py (itself pinned by F6, the reference's own output)"""
+    from deepsignal_plant_amd import extract_features as ef
+    from oracle import extract_np as ox
+    from tests.test_extract_oracle import CASES, case_inputs
+    for c in (CASES if LONG else CASES[:1] + CASES[4:]):
+        rs, motif_seqs, chrom2len, region, positions, g = case_inputs(c)
+        for round_stats in ((False, True) if LONG else (False,)):
+            fx = ef.FeatureExtractor(motifs=c["motifs"], mod_loc=c["mod_loc"], seq_len=c["k"], signal_len=c["s"], normalize_method=c["method"], chrom2len=chrom2len,
+                                     positions=positions, region=region, seed=77, round_stats=round_stats)
+            got = _extract_through_the_interpreter(emu_extract, fx, rs, first_read_uid=5)
+            feats = ox.extract_features(rs, c["method"], motif_seqs, c["mod_loc"], chrom2len, c["k"], c["s"], 1, positions, region, sampler="hash", seed=77, first_read_uid=5)
+            want = ox.features_to_arrays(feats, c["k"], c["s"], round_stats=round_stats)
+            assert got["sampleinfo"] == want["sampleinfo"] and len(want["sampleinfo"]) == int(g("n_sites")), c["name"]
+            for k in ("kmer", "means", "stds", "lens", "signals"):
+                a, b = np.asarray(got[k]), np.asarray(want[k])
+                assert a.shape == b.shape and a.tobytes() == b.astype(a.dtype).tobytes(), (c["name"], k)
