@@ -302,9 +302,9 @@ def test_the_bounds_build_records_nothing_over_the_kernel_forms(emu, emu_bounds)
         assert np.array_equal(got, want), mode
         assert np.isfinite(gz).all()
     for kw in ((SMALL4, dict(seq_len=3, signal_len=8, hidden_size=320, num_layers1=1), dict(seq_len=3, signal_len=40, hidden_size=64, num_layers1=1)) if LONG
-               else (dict(seq_len=2, signal_len=8, hidden_size=128, num_layers1=1), dict(seq_len=2, signal_len=8, hidden_size=320, num_layers1=1))):
+               else (dict(seq_len=2, signal_len=8, hidden_size=128, num_layers1=1), dict(seq_len=1, signal_len=8, hidden_size=320, num_layers1=1))):
         cfg, w, ins, st = _case(kw, 70)
-        for precision in ((None, "bf16x9", "fp16x3") if LONG else (None, "bf16x9")):
+        for precision in ((None, "bf16x9", "fp16x3") if LONG else ((None, "bf16x9") if kw["hidden_size"] == 128 else (None,))):
             with env():
                 m = Model(emu_bounds, cfg, w, precision=precision)
                 m.forward(ins, states=st)
@@ -382,7 +382,7 @@ def test_the_row_parsers_kernels_under_sanitizers_against_the_host_parser(tmp_pa
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-4000:]
         os.replace(tmp, exe)
-    n, m = ("200000", "30000") if LONG else ("20000", "3000")
+    n, m = ("200000", "30000") if LONG else ("10000", "1500")
     e = {k: v for k, v in os.environ.items() if k not in ("DSP_PARSE_KERNEL", "DSP_PARSE_RB")}
     e.update(ASAN_OPTIONS="detect_stack_use_after_return=0", UBSAN_OPTIONS="print_stacktrace=1")
     if kernel == "rows":
