@@ -132,6 +132,7 @@ static inline hipError_t hipMemcpyToSymbol(void* sym, const void* src, size_t n)
 static inline long long __double_as_longlong(double v) { long long u; memcpy(&u, &v, 8); return u; }
 static inline double __longlong_as_double(long long u) { double v; memcpy(&v, &u, 8); return v; }
 static inline int atomicAdd(int* p, int v) { const int o = *p; *p = o + v; return o; }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p = o + v; return o; }
 // HIP's short vector types as far as the kernels use them
 struct alignas(16) int4 { int x, y, z, w; };
 static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }

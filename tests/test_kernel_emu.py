@@ -535,3 +535,79 @@ def test_the_extraction_kernels_match_the_oracle_bit_for_bit(emu_extract):
             for k in ("kmer", "means", "stds", "lens", "signals"):
                 a, b = np.asarray(got[k]), np.asarray(want[k])
                 assert a.shape == b.shape and a.tobytes() == b.astype(a.dtype).tobytes(), (c["name"], k)
+
+
+# ---- the call_freq kernels (csrc/dsp_freq_dev.hip: SURVEY.md 8(f)-1) through the interpreter -------------------------------------
+
+def test_the_call_freq_kernels_reproduce_the_references_tables():
+    """call_mods_freq.DeviceSiteFrequency's device half on the host: the encode / iota / gather / count / reduce kernels of
+    csrc/dsp_freq_dev.hip interpreted (rocPRIM's radix sort of (key, index) as the stable sort it is), the host half -- block
+    keys, the site table, the formatter -- the product's own (csrc/dsp_freq.cpp): byte-identical to the reference's call_freq
+    outputs (F5: tsv, sorted bedMethyl, prob_cf 0 / 0.2 / 0.5), in one block and in seven"""
+    from deepsignal_plant_amd import call_mods_freq as cf
+    from tests.helpers import GOLDEN
+    from tests.test_call_freq import CALLS, _rows_from_calls
+    d = _cache_dir("freq")
+    out = os.path.join(d, "libdsp_freq_emu.so")
+    if not os.path.exists(out):
+        stub = os.path.join(d, "err_stub.cpp")
+        with open(stub, "w") as f:
+            f.write('#include <string>\nstatic std::string g;\nextern "C" void dsp_set_error_(const char* m) { g = m ? m : ""; }\n'
+                    'extern "C" const char* dsp_last_error(void) { return g.c_str(); }\n')
+        tmp = out + ".tmp%d" % os.getpid()
+        cmd = [CLANG, "-std=c++17", "-O2", "-march=native", "-Wno-psabi", "-fPIC", "-shared", "-DDSP_EMU", "-ffp-contract=off", "-Wno-unused-value", "-I", EMU,
+               "-I", os.path.join(ROOT, "include"), "-I", CSRC, stub, os.path.join(EMU, "hip_emu.cpp"), "-x", "c++", os.path.join(CSRC, "dsp_freq_dev.hip"), "-o", tmp, "-pthread"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-4000:]
+        os.replace(tmp, out)
+    K = ctypes.CDLL(out)
+    K.dsp_last_error.restype = ctypes.c_char_p
+    H = nat.lib()                      # the host half: the product library's own host functions
+    p = lambda a: ctypes.c_void_p(a.ctypes.data)
+    ok = lambda rc: (_ for _ in ()).throw(AssertionError(K.dsp_last_error())) if rc else None
+    lines = open(CALLS).read().splitlines()
+    r, probs, labels = _rows_from_calls(lines)
+    for tag, kw in (("tsv", {}), ("bed_sorted", dict(bed=True, sort=True)), ("tsv_cf0", dict(prob_cf=0.0)), ("bed_cf02", dict(bed=True, prob_cf=0.2))):
+        for blocks in (1, 7):
+            cfv = kw.get("prob_cf", 0.5)
+            agg = cf.SiteFrequency(cfv, nthreads=2)
+            keys, packs, piss, rows = [], [], [], []
+            cuts = np.linspace(0, r.n, blocks + 1).astype(int)
+            for a, b in zip(cuts[:-1], cuts[1:]):      # DeviceSiteFrequency.add_block
+                n = int(b - a)
+                key, pis, meta = np.empty(n, np.int64), np.empty(n, np.int64), np.empty(n, np.uint32)
+                assert H.dsp_freq_block_keys(agg._h, p(r.text), p(r.row_off[a:b]), p(r.info_len[a:b]), p(np.ascontiguousarray(r.kmer[a:b])), 5, n, p(key), p(pis), p(meta)) == n
+                key_o, packed = np.empty(n, np.int64), np.empty(n, np.int64)
+                pr, lb = np.ascontiguousarray(probs[a:b]), np.ascontiguousarray(labels[a:b])
+                ok(K.dsp_freq_dev_encode(None, ctypes.c_int64(n), p(pr), 2, p(lb), p(key), p(meta), ctypes.c_double(cfv), p(key_o), p(packed)))
+                keys.append(key_o); packs.append(packed); piss.append(pis); rows.append(np.arange(a, b, dtype=np.int64))
+            key, packed, pis, row = (np.concatenate(x) for x in (keys, packs, piss, rows))      # DeviceSiteFrequency.finish, one rank
+            live = key != 0x7fffffffffffffff
+            key, packed, pis, row = (np.ascontiguousarray(x[live]) for x in (key, packed, pis, row))
+            n = int(key.size)
+            outs = [np.empty(n, np.int64) for _ in range(4)]
+            need = ctypes.c_size_t(0)
+            args = [None, ctypes.c_int64(n)] + [p(t) for t in (key, packed, pis, row)] + [p(t) for t in outs]
+            ok(K.dsp_freq_dev_sort_records(*args, None, ctypes.byref(need)))
+            tmpbuf = np.empty(max(need.value, 1), np.uint8)
+            ok(K.dsp_freq_dev_sort_records(*args, p(tmpbuf), ctypes.byref(need)))
+            key, packed, pis, row = outs
+            cnt = np.zeros(1, np.int64)
+            ok(K.dsp_freq_dev_count_sites(None, ctypes.c_int64(n), p(key), p(cnt)))
+            ns = int(cnt[0])
+            oi = [np.empty(ns, np.int64) for _ in range(6)]
+            od = [np.empty(ns, np.float64) for _ in range(2)]
+            cnt[0] = 0
+            ok(K.dsp_freq_dev_reduce(None, ctypes.c_int64(n), p(key), p(packed), p(pis), p(row), p(cnt), ctypes.c_int64(ns), p(oi[0]), p(oi[1]), p(oi[2]), p(oi[3]),
+                                     p(od[0]), p(od[1]), p(oi[4]), p(oi[5])))
+            order = np.argsort(oi[1], kind="stable")
+            cols = [np.ascontiguousarray(c[order]) for c in (oi[0], oi[1], oi[2], oi[3], od[0], od[1], oi[4], oi[5])]
+            table = cf.SiteFrequency(cfv)
+            for i in range(H.dsp_freq_chrom_count(agg._h)):
+                k = int(H.dsp_freq_chrom_name(agg._h, i, None, 0))
+                buf = ctypes.create_string_buffer(max(k, 1))
+                H.dsp_freq_chrom_name(agg._h, i, buf, k)
+                assert H.dsp_freq_intern_chrom(table._h, buf.raw[:k], k) == i
+            assert H.dsp_freq_add_sites(table._h, ns, *[p(c) for c in cols]) == ns
+            H.dsp_freq_add_counts(table._h, r.n)
+            assert table.format(kw.get("sort", False), kw.get("bed", False)) == open(os.path.join(GOLDEN, "f5_freq_%s.txt" % tag), "rb").read(), (tag, blocks)
