@@ -154,6 +154,7 @@ struct DevLinear { int Fin, ORT; float* wpk; float* bias; };
 // three stacks, so that the forward's plan -- which kernel form a batch size takes, what a piece costs -- can be made, and
 // tested, without a device (dsp_debug_plan)
 struct LayerShape { int Ipad, Ilo, Iused, H, Hp; };
+constexpr int kWsRegions = 9;   // regions of a handle's workspace (ws_layout)
 
 // A fragments for gates^T = W * act^T :  [UT][NQ][4 gates][64 lanes][4]
 //   value = Wcat[g*H + u*32 + (lane&31)][8q + 4*(lane>>5) + i],  Wcat = [W_ih(in_map) | W_hh]
@@ -321,6 +322,12 @@ struct dsp_model {
     int tiling21 = -1;       // <2 unit tiles, 1 site tile> per wave on the dense one-pass layers (dsp_lstm21_kernel): -1 = for
                              // batches whose 32-site tiles x 2 directions fit the CUs at once (small-batch latency); DSP_LSTM_TILING=21
                              // always, =0 never (A/B switch)
+    // "x ahead" (round 6, opt-in -- never timed on a GPU: DSP_LSTM_XAHEAD=1): on calls of <= xahead_tiles live site tiles the x
+    // part of the clustered dense layers is summed for all T steps at once by dsp_xahead_kernel, the recurrent launch keeps one
+    // ring of it (LstmArgs::xs; bit-identical results).  DSP_LSTM_XAHEAD_TILES: 1..16, default 8 (256 sites)
+    int xahead = 0;
+    int xahead_tiles = 8;
+    float* xacc = nullptr;      // workspace region 8: [live cluster][T][8 unit tiles][4 gates][4][64] float4
     bool wave_handoff = true;   // per-wave, deferred arrivals in the clustered launches (round 5); DSP_LSTM_HANDOFF=0: round 4's (A/B switch)
     bool small_classes = false; // the combined stack has the clustered small-batch forms (8 or 4 unit tiles, dense): batches <= 4,096 sites
                                 // then cost by class (512 / 1,024 / 2,048 / 4,096) and dsp_forward plans a remainder's pieces by them
@@ -361,7 +368,7 @@ struct dsp_model {
     size_t test_shrink = 0;   // bounds build only (DSP_BOUNDS_TEST_SHRINK): bytes taken off every LSTM launch's input extent -- the
                               // negative control of the bounds tests (an access the record must name)
     std::vector<std::pair<const char*, size_t>> uploads;   // every weight upload: base, bytes
-    size_t ws_off[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};        // the workspace's regions (ws_layout) + its size
+    size_t ws_off[kWsRegions + 1] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // the workspace's regions (ws_layout) + its size
     // scratch
     void* ws = nullptr;
     int64_t ws_sites = 0;
@@ -378,6 +385,12 @@ struct dsp_model {
 };
 
 namespace {
+
+// DSP_LSTM_XAHEAD / DSP_LSTM_XAHEAD_TILES (dsp_model::xahead), read when a handle -- real or dry -- is made
+void read_xahead_switch(dsp_model* m) {
+    if (const char* v = getenv("DSP_LSTM_XAHEAD")) m->xahead = atoi(v) != 0 ? 1 : 0;
+    if (const char* v = getenv("DSP_LSTM_XAHEAD_TILES")) m->xahead_tiles = std::min(16, std::max(1, atoi(v)));
+}
 
 // a made-up device address for a dry handle's allocation (64 KiB of nothing between neighbours)
 void* dry_alloc(dsp_model* m, size_t bytes) {
@@ -414,8 +427,8 @@ const void* alloc_end(const dsp_model* m, const void* p) {
     if (!c) return nullptr;
     if (m->ws) {
         const char* b = (const char*)m->ws;
-        if (c >= b && c < b + m->ws_off[8])
-            for (int i = 0; i < 8; ++i)
+        if (c >= b && c < b + m->ws_off[kWsRegions])
+            for (int i = 0; i < kWsRegions; ++i)
                 if (c >= b + m->ws_off[i] && c < b + m->ws_off[i + 1]) return b + m->ws_off[i + 1];
     }
     for (const auto& u : m->uploads)
@@ -549,7 +562,7 @@ int ensure_split(dsp_model* m) {
     return rc;
 }
 
-size_t ws_layout(const dsp_model* m, int64_t sites, long long* NTp_out, size_t off[8]) {
+size_t ws_layout(const dsp_model* m, int64_t sites, long long* NTp_out, size_t off[kWsRegions]) {
     long long nt = (sites + 31) / 32;
     long long NTp = (nt + 15) / 16 * 16;
     if (NTp == 0) NTp = 16;
@@ -569,6 +582,8 @@ size_t ws_layout(const dsp_model* m, int64_t sites, long long* NTp_out, size_t o
     const size_t cunits = std::max<size_t>(hmax > 256 ? (size_t)(hmax / 256) : 0, m->np8 == 2 ? 1 : 0);
     off[6] = o; o += (size_t)NTp * cunits * 65536;
     off[7] = o; o += ((size_t)NTp * m->Fwide * 32 * sizeof(float) + 255) / 256 * 256;  // h0 scratch of the side branch
+    // x-ahead sums (LstmArgs::xacc): one 16 KiB block of four accumulator tiles per (live cluster, step, unit tile of 8)
+    off[8] = o; o += m->xahead ? (size_t)std::min<long long>(NTp, m->xahead_tiles) * 2 * m->d.T * 8 * 16384 : 0;
     if (NTp_out) *NTp_out = NTp;
     return o;
 }
@@ -583,7 +598,7 @@ int ensure_ws(dsp_model* m, int64_t sites, hipStream_t stream) {
         m->ws = nullptr; m->ws_sites = 0;
         for (size_t& o : m->ws_off) o = 0;
     }
-    size_t off[8];
+    size_t off[kWsRegions];
     long long NTp;
     const size_t bytes = ws_layout(m, sites, &NTp, off);
     hipError_t e = hipSuccess;
@@ -595,13 +610,14 @@ int ensure_ws(dsp_model* m, int64_t sites, hipStream_t stream) {
         return fail(DSP_ENOMEM, "workspace hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     }
     char* b = (char*)m->ws;
-    for (int i = 0; i < 8; ++i) m->ws_off[i] = off[i];
-    m->ws_off[8] = bytes;
+    for (int i = 0; i < kWsRegions; ++i) m->ws_off[i] = off[i];
+    m->ws_off[kWsRegions] = bytes;
     m->xseq = (float*)(b + off[0]); m->xsig = (float*)(b + off[1]);
     m->bufA = (float*)(b + off[2]); m->bufB = (float*)(b + off[3]); m->comb_in = (float*)(b + off[4]);
     m->h0buf = (float*)(b + off[5]);
     m->cbuf = (float*)(b + off[6]);
     m->h0buf2 = (float*)(b + off[7]);
+    m->xacc = (float*)(b + off[8]);
     m->ws_sites = (int64_t)NTp * 32;
     return 0;
 }
@@ -781,6 +797,13 @@ void pick_form(const dsp_model* m, LstmArgs& a, long long NTp, bool split, bool 
         if (!side_by_side || (a.UT == 4 && a.CG < 4)) a.flags |= 4;
         if (m->wave_handoff) a.flags |= 64;
     }
+    // x ahead: the clustered dense forms of 8 unit tiles (not the front ends' one-ring x part, not the workgroup-local forms) on a
+    // call of few live tiles; the launch keeps the last ring of its x part
+    a.xs = 0;
+    if (m->xahead && a.CG > 0 && a.UT == 8 && !(a.flags & 8) && (a.Ipad >> 3) != 4 && a.n > 0 && (a.n + 31) / 32 <= m->xahead_tiles) {
+        const int D = a.CG == 4 ? 4 : (a.CG == 2 ? 8 : 16);
+        if ((a.Ipad >> 3) >= 2 * D) a.xs = (a.Ipad >> 3) - D;
+    }
 }
 
 // run one BiLSTM stack; returns the buffer holding the last layer's output
@@ -852,6 +875,10 @@ float* run_stack(Launcher& L, const char* name, const std::vector<DevLstmLayer>&
                          (m->extents == 2 && a.NP >= 2 ? std::min(cregion, cb + (size_t)a.NTp * a.NP * 65536) : cregion));
             a.cflags_end = a.cflags ? (const char*)m->cflags + (size_t)m->n_cflag_words * sizeof(unsigned int) : nullptr;
             if (a.cflags && m->extents == 2) a.cflags_end = (const char*)a.cflags + (size_t)kClusterWordsPerLaunch * sizeof(unsigned int);
+            if (a.xs) {
+                a.xacc = m->xacc;
+                a.xacc_end = rsrc_end(m, a.xacc, (size_t)((a.n + 31) / 32) * 2 * a.T * a.UT * 16384);
+            }
         }
         if (m->debug_lstm)   // DSP_DEBUG_LSTM (read once, in dsp_model_create)
             fprintf(stderr, "[lstm] %s k=%zu split=%d CG=%d Ipad=%d H=%d Hp=%d UT=%d SG=%d NQ=%d NTp=%lld n=%lld T=%d Fout=%d x=%p out=%p\n", name, k,
@@ -1010,6 +1037,7 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
     if (const char* v = getenv("DSP_FC_SMALL")) m->fc_small = atoi(v) != 0;
     if (const char* v = getenv("DSP_FORWARD_SPLIT")) m->forward_split = atoi(v) != 0;
     if (const char* v = getenv("DSP_LSTM_HANDOFF")) m->wave_handoff = atoi(v) != 0;
+    read_xahead_switch(m);
     if (const char* v = getenv("DSP_LSTM_SG")) m->sg_override = atoi(v);  // A/B switch
     if (const char* v = getenv("DSP_LSTM_NP8")) m->np8 = atoi(v) == 2 ? 2 : 1;  // A/B switch
     if (const char* v = getenv("DSP_LSTM_PRIO")) m->phase_prio = atoi(v) != 0;    // A/B switch
@@ -1097,7 +1125,7 @@ int32_t dsp_model_create(const dsp_model_cfg* cfg, const float* const* host_weig
 
 size_t dsp_workspace_bytes(const dsp_model* m, int64_t max_sites) {
     if (!m) return 0;
-    size_t off[8];
+    size_t off[kWsRegions];
     return ws_layout(m, max_sites, nullptr, off);
 }
 
@@ -1156,8 +1184,16 @@ double lstm_launch_us(const dsp_model* m, const LstmArgs& a, long long NTp) {
             rounds = (NTp * 2 + cus - 1) / cus;
         } else {
             const bool xshort = (a.Ipad >> 3) == 4;
-            step = (double)nq_live * a.CG * tile_kgroup + 3100.0 + (xshort ? 2400.0 : 0.0);
+            step = (double)(nq_live - a.xs) * a.CG * tile_kgroup + 3100.0 + (xshort ? 2400.0 : 0.0);
             fixed_us = 14.0;                        // (with the clean-up launch behind it)
+            if (a.xs) {
+                // x ahead (an estimate, never timed): one wave per (live cluster, step, unit tile, gate), two of them sharing a
+                // SIMD's matrix pipe; what is left of the hop shows (one ring of x part instead of most of a step in front of it)
+                const long long waves = (a.n + 31) / 32 * 2 * a.T * a.UT * 4;
+                const long long per_simd = (waves + cus * 4 - 1) / (cus * 4);
+                step += 1200.0;
+                fixed_us += 6.0 + (double)per_simd * a.xs * tile_kgroup / (kPlanClockGHz * 1e3);
+            }
         }
     } else if ((a.flags & 2) && a.NP <= 1 && a.UT >= 2 && a.UT % 2 == 0 && a.nqx_lo == 0 && a.nqx_used == (a.Ipad >> 3) &&
                a.NQ == ((a.Ipad + a.Hp) >> 3) && (a.Ipad >> 3) >= 4) {   // dsp_lstm21_kernel (dsp_k_lstm's condition)
@@ -1187,6 +1223,7 @@ double piece_cost_us(const dsp_model* m, long long sites) {
         double us = 0;
         for (const LayerShape& ly : shapes) {
             LstmArgs a{};
+            a.n = sites;
             shape_lstm(m, ly, lstm_id, NTp, a);
             pick_form(m, a, NTp, false, side_by_side, m->cluster != 0);
             us += lstm_launch_us(m, a, NTp) + 2.0;
@@ -1281,9 +1318,10 @@ static int32_t bounds_verdict(dsp_model* m, void* stream) {
     if (prev != m->device) hipSetDevice(prev);
     if (re) return fail(DSP_EHIP, "bounds build: reading the record failed: %s", hipGetErrorString((hipError_t)re));
     if (!rec[0]) return 0;
-    static const char* kinds[] = {"?", "weights", "K4 input", "K4 output", "h0 scratch", "cell-state scratch", "cluster counters", "flat K4 store"};
+    static const char* kinds[] = {"?", "weights", "K4 input", "K4 output", "h0 scratch", "cell-state scratch", "cluster counters", "flat K4 store",
+                                  "x-ahead sums"};
     return fail(DSP_EBOUNDS, "%u access(es) out of range; the first: dsp_kernels.hip:%u, operand %s, workgroup %u, thread %u, byte offset %llu "
-                "(+16) against an extent of %u bytes", rec[0], rec[1], kinds[rec[2] < 8 ? rec[2] : 0], rec[3], rec[4],
+                "(+16) against an extent of %u bytes", rec[0], rec[1], kinds[rec[2] < 9 ? rec[2] : 0], rec[3], rec[4],
                 (unsigned long long)rec[5] | ((unsigned long long)rec[6] << 32), rec[7]);
 }
 
@@ -1519,6 +1557,7 @@ int32_t dsp_debug_dry_run(const dsp_model_cfg* cfg, int32_t n_cus, int64_t n_sit
     m->dry = true;
     m->cfg = *cfg; m->d = d; m->n_cus = n_cus;
     m->extents = extents && !strcmp(extents, "tight") ? 2 : (extents && !strcmp(extents, "wide") ? 0 : 1);
+    read_xahead_switch(m);
     derive_geometry(m);
     m->cflags = (unsigned int*)dry_alloc(m, (size_t)kClusterLaunches * kClusterWordsPerLaunch * sizeof(unsigned int));
     m->n_cflag_words = kClusterLaunches * kClusterWordsPerLaunch;

@@ -888,7 +888,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // One layer of one (site tile, direction) on this workgroup: prologue (ring fill, bias table, initial states, h0 hand-off)
 // and the T steps.  `pi` = this workgroup's index in the cluster (0 when LOCAL), `flag` = the cluster's counters of THIS layer.
 // Returns false when the cluster was given up on the way (wait_arrivals).
-template <int G, int D, bool LOCAL, int DEAD, int NW, bool XSHORT>
+template <int G, int D, bool LOCAL, int DEAD, int NW, bool XSHORT, bool XA>
 __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, const long long gt0, const int pi, gu32* flag) {
     constexpr int WPU = 4 / G;             // waves per unit tile = gate slices; unit tiles per workgroup = G
     DSP_DYN_LDS(smem);
@@ -909,11 +909,17 @@ __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, co
     const uint32_t xrow = (uint32_t)(a.Ipad >> 2) * 512u;
     const uint32_t orow = (uint32_t)F4 * 512u;
     const bool prio = (a.flags & 1) != 0;
+    // XA ("x ahead", LstmArgs::xs): the k-groups [0, xs) of every step were summed by dsp_xahead_kernel; this launch's own x part
+    // is the ring [xs, xs + D) = [nqx - D, nqx), its k-loop wraps from NQ back to xs
+    int xs = 0;
+    if constexpr (XA) xs = a.xs;
 
     const rsrc_t rw = make_rsrc((const char*)(dir ? a.wpk1 : a.wpk0) + (size_t)u * NQ * 4096, dir ? a.wpk1_end : a.wpk0_end, DSP_BND_W);
     const rsrc_t rx = make_rsrc((const char*)a.x + (size_t)gt0 * T * xrow, a.x_end, DSP_BND_X);
     const rsrc_t ro = make_rsrc((const char*)a.out + (size_t)gt0 * T * orow + (size_t)dir * HQ * 512, a.out_end, DSP_BND_OUT);
     const rsrc_t rh0 = make_rsrc((const char*)a.h0buf + (size_t)gt0 * orow + (size_t)dir * HQ * 512, a.h0buf_end, DSP_BND_H0);
+    // (XA) this unit tile's x-ahead sums of the cluster: [t][unit tile][gate][row group][lane] float4
+    const rsrc_t rxa = XA ? make_rsrc((const char*)a.xacc + ((size_t)(gt0 * 2 + dir) * T * a.UT + u) * 16384, a.xacc_end, DSP_BND_XACC) : rw;
     const f32x4* bias4 = (const f32x4*)(dir ? a.sbias1 : a.sbias0);
     const uint32_t voffA = voff + (uint32_t)(gs * G) * 1024u;   // this wave's gates within a k-group's 4 KiB of weights
     const uint32_t voffO = voff + (uint32_t)(gs * G) * 1024u;   // this wave's row groups within a unit tile's 4 KiB of h
@@ -931,8 +937,22 @@ __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, co
     };
     f32x4 A[D][G], B[D];
     f32x16 acc[G];
+    f32x16 accn[XA ? G : 1];   // XA: what the step's accumulators start from (requested a step early)
     auto ldA = [&](int f, int q) __attribute__((always_inline)) {
-        return bld16(rw, voffA + (uint32_t)f * 1024u, (uint32_t)(q < NQ ? q : q - NQ) * 4096u);
+        return bld16(rw, voffA + (uint32_t)f * 1024u, (uint32_t)(q < NQ ? q : q - NQ + xs) * 4096u);
+    };
+    auto load_accn = [&](int step) __attribute__((always_inline)) {
+        if constexpr (XA) {
+            const int t = dir ? (T - 1 - step) : step;
+            const uint32_t so = (uint32_t)t * (uint32_t)a.UT * 16384u;
+#pragma unroll
+            for (int f = 0; f < G; ++f)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 v = bld16(rxa, voff + (uint32_t)((gs * G + f) * 4 + i) * 1024u, so);
+                    accn[f][4 * i] = v[0]; accn[f][4 * i + 1] = v[1]; accn[f][4 * i + 2] = v[2]; accn[f][4 * i + 3] = v[3];
+                }
+        }
     };
     // B fragments: x part (plain loads: written by an earlier launch), h part (sc1: written by the cluster during this one)
     auto ldBx = [&](int q) __attribute__((always_inline)) { return bld16(rx, voff, xo + (uint32_t)q * 1024u); };
@@ -952,7 +972,7 @@ __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, co
     };
     auto refill_B = [&](auto qs, int q, auto kind) __attribute__((always_inline)) {
         constexpr int S = decltype(qs)::value % D;
-        const int qn = q + D < NQ ? q + D : q + D - NQ;
+        const int qn = q + D < NQ ? q + D : q + D - NQ + xs;
         if constexpr (decltype(kind)::value == 1) B[S] = ldBh(qn); else B[S] = ldBx(qn);
     };
     // norefill (compile time): the stage issues NO memory request -- its refills are made up for later, in the same order,
@@ -966,7 +986,7 @@ __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, co
             for (int i = 0; i < 4; ++i) {
                 if (decltype(dead)::value) break;
                 if (decltype(first)::value && i == 0)
-                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[S][f][i], B[S][i], zero16, 0, 0, 0);
+                    acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[S][f][i], B[S][i], XA ? accn[XA ? f : 0] : zero16, 0, 0, 0);
                 else
                     acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[S][f][i], B[S][i], acc[f], 0, 0, 0);
             }
@@ -1017,9 +1037,10 @@ __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, co
 #pragma unroll
     for (int d = 0; d < D; ++d) {
 #pragma unroll
-        for (int f = 0; f < G; ++f) A[d][f] = ldA(f, d);
-        B[d] = ldBx(d);
+        for (int f = 0; f < G; ++f) A[d][f] = ldA(f, xs + d);
+        B[d] = ldBx(xs + d);
     }
+    load_accn(0);
     TSTAMP_AT(13, 1);
     for (int i = tid; i < a.Hp; i += NW * 64) {
         const int h = i & 1, g = (i >> 1) & 3, aa = (i >> 3) & 3, ut = i >> 5;
@@ -1107,6 +1128,32 @@ __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, co
             if constexpr (DEAD > 0) stages_first_sparse(ic<1>{});
             else stages(0, std::true_type{}, ic<1>{});
             for (int q = D; q < NQ - D; q += D) stages(q, std::false_type{}, ic<1>{});
+        } else if constexpr (XA) {
+            // the x part is ONE ring, [xs, xs + D): its stages run on what the ring already holds (x rows requested by the
+            // previous step's last block), but every refill they make is an h row of THIS step -- the poll stands in front of
+            // the first request.  Per-wave hand-off: E stages that request nothing, this wave's deferred arrival, the poll, the
+            // E stages' refills in one burst, the rest of the ring; else (one arrival per workgroup, counted behind the cell
+            // phase) the poll first.
+            if (wavepub) {
+                static_for<0, E>([&](auto i) __attribute__((always_inline)) {
+                    stage(i, xs + decltype(i)::value, std::integral_constant<bool, decltype(i)::value == 0>{}, ic<1>{}, live{}, std::true_type{});
+                });
+                arrive();
+            }
+            asm volatile("" ::: "memory");
+            TSTAMP(1);
+            if (!wait_arrivals(flag, per_step * (unsigned)(step + 1))) return false;   // (given up: the clean-up launch computes this cluster)
+            TSTAMP(2);
+            asm volatile("" ::: "memory");
+            if (wavepub) {
+                static_for<0, E>([&](auto i) __attribute__((always_inline)) { refill_stage(i, xs + decltype(i)::value, ic<1>{}); });
+                static_for<E, D>([&](auto i) __attribute__((always_inline)) {
+                    stage(i, xs + decltype(i)::value, std::false_type{}, ic<1>{}, live{}, refills{});
+                });
+            } else {
+                stages(xs, std::true_type{}, ic<1>{});
+            }
+            for (int q = xs + D; q < NQ - D; q += D) stages(q, std::false_type{}, ic<1>{});
         } else {
             // x part: nothing here depends on h_{t-1}
             unsigned seen = 0;
@@ -1142,6 +1189,7 @@ __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, co
         }
         set_bases(step + 1 < T ? step + 1 : step);   // the last D refills are the next step's first x rows
         stages(NQ - D, std::false_type{}, ic<0>{});
+        if constexpr (XA) { if (step + 1 < T) load_accn(step + 1); }
         if (prio) __builtin_amdgcn_s_setprio(0);
         TSTAMP(3);
 
@@ -1195,8 +1243,9 @@ __device__ __forceinline__ bool lstmc_layer(const LstmArgs& a, const int dir, co
     return true;
 }
 
-template <int G, int D, bool LOCAL = false, int DEAD = 0, int NW = 4, bool XSHORT = false>
+template <int G, int D, bool LOCAL = false, int DEAD = 0, int NW = 4, bool XSHORT = false, bool XA = false>
 __global__ __launch_bounds__(NW * 64, 1) void dsp_lstmc_kernel(LstmArgs a) {
+    static_assert(!XA || (!LOCAL && !XSHORT && DEAD == 0), "x ahead: the clustered dense forms");
     // XSHORT (round 5; clustered, layers of 4 unit tiles whose x part is exactly one ring: nqx == D == 4 -- the front ends at
     // hidden 128): a (site tile, direction) of a front end spread over P = 4 / G workgroups.  Until round 5 the front ends of a
     // small batch ran workgroup-local: 32 recurrences on 32 CUs at 512 sites, 13 steps x 17 k-groups x 4 gates x 256 cycles =
@@ -1220,6 +1269,10 @@ __global__ __launch_bounds__(NW * 64, 1) void dsp_lstmc_kernel(LstmArgs a) {
     if (c >= a.NTp * 2) return;
     const int dir = (int)(c & 1);
     const long long gt0 = c >> 1;
+    // (XA: tiles without a live site are not computed -- by dsp_xahead_kernel, by this launch, by its clean-up launch; nothing
+    // reads their rows but the same tiles of later launches, and no output row comes from them.  All members of such a cluster
+    // leave here, before any of them touches a counter.)
+    if constexpr (XA) { if (gt0 * 32 >= a.n) return; }
     gu32* flag = (gu32*)a.cflags + c * 32;   // word 0: arrivals of the steps; word 1: admission (count | abandoned)
     if (!LOCAL || (a.flags & 16)) BOUNDS_FLAT((const unsigned*)a.cflags + c * 32, 8, a.cflags, a.cflags_end, DSP_BND_FLAGS);
     if constexpr (LOCAL) {
@@ -1235,7 +1288,69 @@ __global__ __launch_bounds__(NW * 64, 1) void dsp_lstmc_kernel(LstmArgs a) {
         __syncthreads();
         if (!admitted) return;
     }
-    lstmc_layer<G, D, LOCAL, DEAD, NW, XSHORT>(a, dir, gt0, pi, flag);
+    lstmc_layer<G, D, LOCAL, DEAD, NW, XSHORT, XA>(a, dir, gt0, pi, flag);
+}
+
+// ------------------------------------------------------------------------------------------------
+// dsp_xahead_kernel (round 6, opt-in: DSP_LSTM_XAHEAD=1): the part of an LSTM layer that is NOT a recurrence, taken out of it.
+// A step of a dense layer sums k-groups [0, nqx) of x_t W_ih^T and [nqx, NQ) of h_{t-1} W_hh^T into one accumulator tile; only
+// the second half waits for the step before.  On a batch of <= 256 sites the clustered launch keeps 8 CUs per (site tile,
+// direction) busy with a chain of 13 steps x 96 k-groups while most of the chip has nothing to do, and two thirds of that chain
+// (layers 1+: nqx = 64 of NQ = 96) is x part.  Here every (cluster, step t, unit tile, gate) gets its own wave -- T x 32 of them
+// per cluster instead of 32 -- which sums the k-groups [0, xs) with the SAME MFMAs in the SAME order, from zero, and leaves the
+// accumulator tile in a.xacc.  The recurrent launch (dsp_lstmc_kernel<.., XA>) starts the step's accumulators from it (the C
+// operand of its first MFMA) and carries on with k-group xs: every sum is made of the same terms in the same order, so the
+// results are bit-identical to the undivided launch -- unlike a split of K across workgroups, which would reorder them.
+// Grid: live clusters x T x UT workgroups of four waves (one gate each); unit tile = blockIdx % UT, so that with 8 unit tiles
+// the weights of unit tile u are read through XCD u's L2 only.  Tiles without a live site are skipped (see dsp_lstmc_kernel).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void dsp_xahead_kernel(LstmArgs a) {
+    constexpr int R = 16;                  // ring depth in k-groups (one k-group = 4 MFMAs = 256 cycles of this wave)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const uint32_t voff = (uint32_t)lane * 16u;
+    const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int UT = a.UT, T = a.T, NQ = a.NQ, xs = a.xs;
+    const int u = (int)(blockIdx.x % (unsigned)UT);
+    const unsigned r = blockIdx.x / (unsigned)UT;
+    const int t = (int)(r % (unsigned)T);
+    const long long c = (long long)(r / (unsigned)T);
+    const int dir = (int)(c & 1);
+    const long long gt0 = c >> 1;
+    if (gt0 * 32 >= a.n) return;
+    const uint32_t xrow = (uint32_t)(a.Ipad >> 2) * 512u;
+    const rsrc_t rw = make_rsrc((const char*)(dir ? a.wpk1 : a.wpk0) + (size_t)u * NQ * 4096, dir ? a.wpk1_end : a.wpk0_end, DSP_BND_W);
+    const rsrc_t rx = make_rsrc((const char*)a.x + (size_t)gt0 * T * xrow, a.x_end, DSP_BND_X);
+    const rsrc_t ro = make_rsrc((const char*)a.xacc + (size_t)c * T * UT * 16384, a.xacc_end, DSP_BND_XACC);
+    const uint32_t xo = (uint32_t)t * xrow;
+    const uint32_t voffA = voff + (uint32_t)g * 1024u;
+    f32x4 A[R], B[R];
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < R; ++d) {
+        const int q = d < xs ? d : 0;      // (a ring deeper than the x part: the spare slots hold k-group 0, unused)
+        A[d] = bld16(rw, voffA, (uint32_t)q * 4096u);
+        B[d] = bld16(rx, voff, xo + (uint32_t)q * 1024u);
+    }
+    for (int q0 = 0; q0 < xs; q0 += R) {
+#pragma unroll
+        for (int sl = 0; sl < R; ++sl) {
+            const int q = q0 + sl;
+            if (q < xs) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[sl][i], B[sl][i], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const int qn = q + R < xs ? q + R : q;   // (past the end: the slot's own k-group again, unused)
+                A[sl] = bld16(rw, voffA, (uint32_t)qn * 4096u);
+                B[sl] = bld16(rx, voff, xo + (uint32_t)qn * 1024u);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    const uint32_t so = ((uint32_t)t * (uint32_t)UT + (uint32_t)u) * 16384u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        bst16(ro, voff + (uint32_t)(g * 4 + i) * 1024u, so, (f32x4{acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]}));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1939,6 +2054,11 @@ extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
         if ((G != 1 && G != 2 && G != 4) || a->UT % G || a->NP > 1 || (!local && !a->cflags) || a->NQ != ((a->Ipad + a->Hp) >> 3) ||
             nqx % D || nqx < ((local || xshort) ? D : 2 * D) || a->NQ % D || a->NQ < 2 * D || (!local && !xshort && !dense4 && a->UT != 8))
             return (int)hipErrorInvalidValue;
+        // x ahead (a->xs > 0): the clustered dense forms of 8 unit tiles; this launch keeps exactly one ring of x part
+        const bool xa = a->xs > 0;
+        if (xa && (local || xshort || dense4 || a->xs != nqx - D || !a->xacc || !ends_ok({{a->xacc, a->xacc_end}}) || a->nqx_lo != 0 ||
+                   a->nqx_used != nqx))
+            return (int)hipErrorInvalidValue;
         // (zero-padded x-part k-groups -- nqx_lo, nqx_used -- are computed like live ones here: their weights are zero)
         const int P = local ? 1 : a->UT / G;
         const unsigned clusters = (unsigned)(a->NTp * 2);
@@ -1957,6 +2077,15 @@ extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
         else if (xshort && dead == 3) DSP_LAUNCH((dsp_lstmc_kernel<2, 4, false, 3, 4, true>), dim3(grid), dim3(256), lds, s, *a);
         else if (xshort && dead == 2) DSP_LAUNCH((dsp_lstmc_kernel<2, 4, false, 2, 4, true>), dim3(grid), dim3(256), lds, s, *a);
         else if (xshort) DSP_LAUNCH((dsp_lstmc_kernel<2, 4, false, 0, 4, true>), dim3(grid), dim3(256), lds, s, *a);
+        else if (xa) {
+            // the x part ahead of the recurrence: live clusters x T x UT workgroups (clusters are numbered tile-major: the live
+            // ones come first)
+            const unsigned live = (unsigned)((a->n + 31) / 32) * 2;
+            DSP_LAUNCH(dsp_xahead_kernel, dim3(live * (unsigned)a->T * (unsigned)a->UT), dim3(256), 0, s, *a);
+            if (G == 4) DSP_LAUNCH((dsp_lstmc_kernel<4, 4, false, 0, 4, false, true>), dim3(grid), dim3(256), lds, s, *a);
+            else if (G == 2) DSP_LAUNCH((dsp_lstmc_kernel<2, 8, false, 0, 4, false, true>), dim3(grid), dim3(256), lds, s, *a);
+            else DSP_LAUNCH((dsp_lstmc_kernel<1, 16, false, 0, 4, false, true>), dim3(grid), dim3(256), lds, s, *a);
+        }
         else if (dense4 && G == 1) DSP_LAUNCH((dsp_lstmc_kernel<1, 4>), dim3(grid), dim3(256), lds, s, *a);
         else if (dense4) DSP_LAUNCH((dsp_lstmc_kernel<2, 4>), dim3(grid), dim3(256), lds, s, *a);
         else if (G == 4) DSP_LAUNCH((dsp_lstmc_kernel<4, 4>), dim3(grid), dim3(256), lds, s, *a);
@@ -1968,6 +2097,7 @@ extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
             // workgroup (a few microseconds when none was)
             LstmArgs b = *a;
             b.CG = 4;
+            b.xs = 0;   // (an abandoned cluster is computed whole, x part included)
             const unsigned g1 = (clusters + 7) / 8 * 8;
             if (a->UT == 8) {
                 b.flags = (a->flags | 8 | 16) & ~4;

@@ -136,3 +136,43 @@ def test_a_cut_call_is_the_concatenation_of_its_pieces():
     parts = names(dry(c, 8192)) + names(dry(c, 4096)) + names(dry(c, 1712))
     assert whole == parts
     assert names(dry(c, 9000, cus=304)).count("dsp_pack_kernel") == 1      # one round of 9,728 sites there
+
+
+def test_x_ahead_is_taken_by_small_calls_only_and_never_refused(monkeypatch):
+    """DSP_LSTM_XAHEAD=1 (opt-in, round 6): calls of <= 8 live site tiles run dsp_xahead_kernel in front of every clustered dense
+    layer of 8 unit tiles -- live clusters x T x 8 workgroups -- and the XA instantiation of the recurrent launch; nothing
+    else changes, nothing is refused in any extents mode, and without the switch no launch of the form is ever made"""
+    c = cfg()
+    plain = {n: names(dry(c, n)) for n in (1, 45, 256, 257, 512, 1100, 9001)}
+    assert not any("xahead" in x or x.endswith("false, true>") for f in plain.values() for x in f)
+    monkeypatch.setenv("DSP_LSTM_XAHEAD", "1")
+    for n in (1, 45, 256):
+        f = dry(c, n)
+        xa = [(k, t, g, b) for k, t, g, b, l in f if k == "dsp_xahead_kernel"]
+        live = (n + 31) // 32 * 2
+        assert [g for k, t, g, b in xa] == [live * 13 * 8] * 3 and all(b == 256 for k, t, g, b in xa), (n, xa)
+        assert names(f).count("dsp_lstmc_kernel<1, 16, false, 0, 4, false, true>") == 3
+        # the rest of the sequence is the plain call's
+        assert [x for x in names(f) if x != "dsp_xahead_kernel"] == [x.replace("<1, 16>", "<1, 16, false, 0, 4, false, true>") for x in plain[n]]
+    for n in (257, 512):
+        assert names(dry(c, n)) == plain[n]
+    # a cut call: 1,100 = 1,024 + 76 -- the 76-site piece is a small call of its own
+    f = names(dry(c, 1100))
+    assert f.count("dsp_pack_kernel") == 2 and f.count("dsp_xahead_kernel") == 3 and f.index("dsp_xahead_kernel") > f.index("dsp_lstmc_kernel<2, 8>")
+    monkeypatch.setenv("DSP_LSTM_XAHEAD_TILES", "16")
+    assert names(dry(c, 512)).count("dsp_xahead_kernel") == 3
+    monkeypatch.setenv("DSP_LSTM_XAHEAD_TILES", "2")
+    assert names(dry(c, 64)).count("dsp_xahead_kernel") == 3 and names(dry(c, 65)).count("dsp_xahead_kernel") == 0
+    monkeypatch.delenv("DSP_LSTM_XAHEAD_TILES")
+    for label, kw, sizes, precisions in CASES:
+        cc = cfg(**kw)
+        for extents in (b"region", b"tight"):
+            for n in (33, 256):
+                dry(cc, n, extents=extents)
+        dry(cc, 100, init=EXPLICIT)
+        dry(cc, 100, cus=64)
+    # the seq-only shape (BASELINE configs[2]): both dense layers of its combined stack; hidden 128 has no such layer
+    assert names(dry(cfg(module=1, num_layers1=2), 100)).count("dsp_xahead_kernel") == 2
+    assert names(dry(cfg(hidden_size=128), 100)).count("dsp_xahead_kernel") == 0
+    # split precision: its own kernels, no clustered form, no x ahead
+    assert names(dry(c, 100, prec=BF16X9)).count("dsp_xahead_kernel") == 0

@@ -82,3 +82,20 @@ def test_the_bounds_build_names_an_access_past_a_shortened_extent():
     r = _sweep({"DSP_AMD_LIB": BOUNDS_LIB, "DSP_BOUNDS_TEST_SHRINK": "4096"}, "default", expect_rc=3)
     assert "out of range" in r.stderr and "operand K4 input" in r.stderr and "dsp_kernels.hip:" in r.stderr, r.stderr[-2000:]
     print(r.stderr.strip().splitlines()[-1])
+
+
+def test_x_ahead_does_not_change_a_bit_and_what_it_costs():
+    """DSP_LSTM_XAHEAD=1 (opt-in; dsp_xahead_kernel + dsp_lstmc_kernel<.., XA>): the x part of the clustered dense layers summed
+    ahead of the recurrence for calls of <= 256 sites.  Written and verified (bit-identical, under the SIMT interpreter:
+    tests/test_kernel_emu.py) in a round without a GPU -- this is its first contact with hardware, hence the LAST test of the
+    last module.  The bytes are held; the timings are printed and kept (gpurun_out/xahead_ab.json), not asserted."""
+    env = {k: v for k, v in os.environ.items() if k not in ("DSP_AMD_LIB", "DSP_RSRC_EXTENTS", "DSP_LSTM_XAHEAD", "DSP_LSTM_HANDOFF", "DSP_LSTM_CLUSTER")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "xahead_ab.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "xahead_ab.json"), "w") as f:
+        json.dump(got, f, sort_keys=True)
+    for k, (off, on) in sorted(got["ms"].items(), key=lambda kv: (kv[0].split("/")[0], int(kv[0].split("/")[1]))):
+        print("%-32s %.4f -> %.4f ms per forward (%+.1f %%)" % (k, off, on, 100.0 * (on - off) / off))
+    assert got["cases"] >= 40 and got["identical"], got["differs"]

@@ -40,7 +40,7 @@ CSRC = os.path.join(ROOT, "deepsignal_plant_amd", "csrc")
 EMU = os.path.join(ROOT, "tests", "native", "emu")
 SWITCHES = ("DSP_LSTM_CLUSTER", "DSP_LSTM_LOCAL8", "DSP_TWO_STREAMS", "DSP_HEAD_ST4", "DSP_LSTM_TILING", "DSP_CLUSTER_TIMEOUT", "DSP_FC_FUSED",
             "DSP_LSTM_FRONT_CLUSTER", "DSP_FC_SMALL", "DSP_LSTM_HANDOFF", "DSP_FORWARD_SPLIT", "DSP_RSRC_EXTENTS", "DSP_EMU_SEED", "DSP_BOUNDS_TEST_SHRINK",
-            "DSP_PRECISION", "EMU_CUS")
+            "DSP_PRECISION", "EMU_CUS", "DSP_LSTM_XAHEAD", "DSP_LSTM_XAHEAD_TILES")
 
 pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="the image's clang++ builds the interpreter")
 LONG = bool(os.environ.get("DSP_EMU_LONG"))
@@ -232,6 +232,58 @@ def test_every_kernel_form_gives_the_same_bytes(emu, kw, label):
         else:
             for got, ref, what in zip((probs, pz, pp), first, ("explicit", "zeros", "philox")):
                 assert np.array_equal(got, ref), (label, mode, what, float(np.abs(got - ref).max()))
+
+
+def test_x_ahead_gives_the_same_bytes(emu, emu_bounds):
+    """DSP_LSTM_XAHEAD=1 (round 6, opt-in): dsp_xahead_kernel sums the k-groups [0, xs) of every step's x part ahead of the
+    recurrence, dsp_lstmc_kernel<.., XA> starts each step's accumulators from those sums and keeps one ring of x part; tiles
+    without a live site are skipped.  Same MFMAs in the same order: the bytes of every cluster size, hand-off, schedule, of
+    abandoned clusters (computed whole by the clean-up launch) and of both x-part lengths (32 and 64 k-groups: layers 0 and 1+)
+    are those of the undivided launches; the bounds build records nothing; above the live-tile limit the form is not taken.
+    (DSP_EMU_LONG=1: all eight switch sets on two sizes, the seq-only shape; the default run a cut of it.)"""
+    kw = dict(seq_len=3 if LONG else 2, signal_len=8, hidden_size=256, num_layers1=2, num_layers2=1)
+    modes = [{}, {"DSP_LSTM_CLUSTER": "2"}, {"DSP_LSTM_CLUSTER": "4"}, {"DSP_LSTM_HANDOFF": "0"}, {"DSP_CLUSTER_TIMEOUT": "0"},
+             {"DSP_EMU_SEED": "2"}, {"DSP_RSRC_EXTENTS": "tight"}, {"DSP_EMU_SEED": "3", "DSP_LSTM_HANDOFF": "0", "DSP_LSTM_CLUSTER": "2"}]
+    if not LONG:
+        modes = [{}, {"DSP_CLUSTER_TIMEOUT": "0", "DSP_LSTM_HANDOFF": "0", "DSP_LSTM_CLUSTER": "2", "DSP_EMU_SEED": "3"}]
+    for n in ((45, 200) if LONG else (45,)):
+        cfg, w, ins, st = _case(kw, n)
+        with env():
+            m = Model(emu, cfg, w)
+            want = (m.forward(ins, states=st)[0], m.forward(ins, philox=(11, 1000))[0])
+            m.close()
+        assert np.abs(want[0] - oc.forward(cfg, w, *ins, states=st)[1]).max() <= 1e-6
+        for k, sw in enumerate(modes if n == 45 else modes[:1]):
+            with env(DSP_LSTM_XAHEAD="1", **sw):
+                m = Model(emu, cfg, w)
+                got = m.forward(ins, states=st)[0]
+                assert np.array_equal(got, want[0]), (n, sw)
+                if LONG or k == 0:
+                    assert np.array_equal(m.forward(ins, philox=(11, 1000))[0], want[1]), (n, sw)
+                m.close()
+        with env(DSP_LSTM_XAHEAD="1"):
+            m = Model(emu_bounds, cfg, w)      # (tight extents, every access compared: a record would come back as DSP_EBOUNDS)
+            got = m.forward(ins, states=st)[0]
+            m.close()
+        assert np.array_equal(got, want[0])
+        if LONG:
+            with env(DSP_LSTM_XAHEAD="1", DSP_LSTM_XAHEAD_TILES="1"):   # (two live tiles or more: not taken)
+                m = Model(emu, cfg, w)
+                got = m.forward(ins, states=st)[0]
+                m.close()
+            assert np.array_equal(got, want[0])
+    if not LONG:
+        return
+    # the seq-only shape of BASELINE configs[2], with a second front-end layer: dense layers of 8 unit tiles in both stacks
+    cfg, w, ins, st = _case(dict(seq_len=2, signal_len=8, hidden_size=256, num_layers1=2, num_layers2=2, module="seq_bilstm"), 40)
+    out = []
+    for xa in ("0", "1"):
+        with env(DSP_LSTM_XAHEAD=xa):
+            m = Model(emu, cfg, w)
+            out.append(m.forward(ins, states=st)[0])
+            m.close()
+    assert np.array_equal(out[0], out[1])
+    assert np.abs(out[0] - oc.forward(cfg, w, *ins, states=st)[1]).max() <= 1e-6
 
 
 def test_ragged_sizes_and_a_cut_call(emu):
