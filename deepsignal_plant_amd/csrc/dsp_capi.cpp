@@ -327,6 +327,7 @@ struct dsp_model {
     // ring of it (LstmArgs::xs; bit-identical results).  DSP_LSTM_XAHEAD_TILES: 1..16, default 8 (256 sites)
     int xahead = 0;
     int xahead_tiles = 8;
+    int xahead_ring = 16;       // DSP_LSTM_XAHEAD_RING=8: the one-gate-per-wave form keeps 8 instead of 16 k-groups of x part (A/B switch)
     float* xacc = nullptr;      // workspace region 8: [live cluster][T][8 unit tiles][4 gates][4][64] float4
     bool wave_handoff = true;   // per-wave, deferred arrivals in the clustered launches (round 5); DSP_LSTM_HANDOFF=0: round 4's (A/B switch)
     bool small_classes = false; // the combined stack has the clustered small-batch forms (8 or 4 unit tiles, dense): batches <= 4,096 sites
@@ -390,6 +391,7 @@ namespace {
 void read_xahead_switch(dsp_model* m) {
     if (const char* v = getenv("DSP_LSTM_XAHEAD")) m->xahead = atoi(v) != 0 ? 1 : 0;
     if (const char* v = getenv("DSP_LSTM_XAHEAD_TILES")) m->xahead_tiles = std::min(16, std::max(1, atoi(v)));
+    if (const char* v = getenv("DSP_LSTM_XAHEAD_RING")) m->xahead_ring = atoi(v) == 8 ? 8 : 16;
 }
 
 // a made-up device address for a dry handle's allocation (64 KiB of nothing between neighbours)
@@ -801,8 +803,9 @@ void pick_form(const dsp_model* m, LstmArgs& a, long long NTp, bool split, bool 
     // call of few live tiles; the launch keeps the last ring of its x part
     a.xs = 0;
     if (m->xahead && a.CG > 0 && a.UT == 8 && !(a.flags & 8) && (a.Ipad >> 3) != 4 && a.n > 0 && (a.n + 31) / 32 <= m->xahead_tiles) {
-        const int D = a.CG == 4 ? 4 : (a.CG == 2 ? 8 : 16);
-        if ((a.Ipad >> 3) >= 2 * D) a.xs = (a.Ipad >> 3) - D;
+        const bool ring8 = a.CG == 1 && m->xahead_ring == 8;
+        const int D = a.CG == 4 ? 4 : (a.CG == 2 || ring8 ? 8 : 16);
+        if ((a.Ipad >> 3) >= 2 * D) { a.xs = (a.Ipad >> 3) - D; if (ring8) a.flags |= 128; }
     }
 }
 
@@ -1605,6 +1608,7 @@ double dsp_debug_piece_cost(const dsp_model_cfg* cfg, int32_t n_cus, int64_t n_s
     if (derive(cfg, &d) || n_cus < 16 || n_sites < 1) return -1.0;
     dsp_model host;
     host.cfg = *cfg; host.d = d; host.n_cus = n_cus;
+    read_xahead_switch(&host);
     derive_geometry(&host);
     return piece_cost_us(&host, n_sites);
 }

@@ -66,7 +66,7 @@ struct LstmArgs {
     const void* cbuf_end;   // (NULL with cbuf)
     const void* cflags_end; // (NULL with cflags; the counters are addressed flat: the end is what the bounds build checks)
     int CG;                // 0, or gates per wave of dsp_lstmc_kernel: 4 / 2 / 1 = a (site tile, direction) spread over UT/CG workgroups
-    int flags;             // bit 0: issue priority by phase (k-loop 2, cell 0); bit 1: <2 unit tiles, 1 site tile> per wave; bit 2: ... and one such workgroup per CU; bit 3: the workgroup-local form of dsp_lstmc_kernel with eight waves; bit 4: ... as the clean-up launch behind a clustered one (abandoned clusters only); bit 6: the per-wave hand-off of the clustered launches (round 5: arrivals per wave, deferred into the next step's x part; poll one block early); bit 8: stamp this launch, bits 9..11: its stamping wave (DSP_TRACE builds only)
+    int flags;             // bit 0: issue priority by phase (k-loop 2, cell 0); bit 1: <2 unit tiles, 1 site tile> per wave; bit 2: ... and one such workgroup per CU; bit 3: the workgroup-local form of dsp_lstmc_kernel with eight waves; bit 4: ... as the clean-up launch behind a clustered one (abandoned clusters only); bit 6: the per-wave hand-off of the clustered launches (round 5: arrivals per wave, deferred into the next step's x part; poll one block early); bit 7: x ahead at one gate per wave with rings 8 deep (xs = nqx - 8); bit 8: stamp this launch, bits 9..11: its stamping wave (DSP_TRACE builds only)
     // Round 6, "x ahead" (DSP_LSTM_XAHEAD=1; clustered dense layers of batches <= 512 sites): the x-part k-groups [0, xs) of every
     // step do not depend on the recurrence -- dsp_xahead_kernel computes their partial sums for ALL T steps at once on the idle
     // compute units (same MFMAs in the same order, from zero) into xacc, [cluster][t][unit tile][gate][4][64 lanes] float4; the

@@ -2050,7 +2050,9 @@ extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
         // dense layers of 4 unit tiles (hidden 97..128: the combined stack of a hid_rnn-128 model) clustered like those of 8:
         // P = 4 / G workgroups, rings four deep
         const bool dense4 = !local && !xshort && a->UT == 4 && (G == 1 || G == 2);
-        const int D = (xshort || dense4) ? 4 : (G == 4 ? 4 : (G == 2 ? 8 : 16));
+        // (flags bit 7, x ahead at one gate per wave only: rings 8 deep instead of 16 -- the launch keeps 8 k-groups of x part)
+        const bool ring8 = a->xs > 0 && G == 1 && (a->flags & 128);
+        const int D = (xshort || dense4) ? 4 : (G == 4 ? 4 : (G == 2 || ring8 ? 8 : 16));
         if ((G != 1 && G != 2 && G != 4) || a->UT % G || a->NP > 1 || (!local && !a->cflags) || a->NQ != ((a->Ipad + a->Hp) >> 3) ||
             nqx % D || nqx < ((local || xshort) ? D : 2 * D) || a->NQ % D || a->NQ < 2 * D || (!local && !xshort && !dense4 && a->UT != 8))
             return (int)hipErrorInvalidValue;
@@ -2084,6 +2086,7 @@ extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
             DSP_LAUNCH(dsp_xahead_kernel, dim3(live * (unsigned)a->T * (unsigned)a->UT), dim3(256), 0, s, *a);
             if (G == 4) DSP_LAUNCH((dsp_lstmc_kernel<4, 4, false, 0, 4, false, true>), dim3(grid), dim3(256), lds, s, *a);
             else if (G == 2) DSP_LAUNCH((dsp_lstmc_kernel<2, 8, false, 0, 4, false, true>), dim3(grid), dim3(256), lds, s, *a);
+            else if (ring8) DSP_LAUNCH((dsp_lstmc_kernel<1, 8, false, 0, 4, false, true>), dim3(grid), dim3(256), lds, s, *a);
             else DSP_LAUNCH((dsp_lstmc_kernel<1, 16, false, 0, 4, false, true>), dim3(grid), dim3(256), lds, s, *a);
         }
         else if (dense4 && G == 1) DSP_LAUNCH((dsp_lstmc_kernel<1, 4>), dim3(grid), dim3(256), lds, s, *a);

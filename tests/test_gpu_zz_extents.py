@@ -89,13 +89,13 @@ def test_x_ahead_does_not_change_a_bit_and_what_it_costs():
     ahead of the recurrence for calls of <= 256 sites.  Written and verified (bit-identical, under the SIMT interpreter:
     tests/test_kernel_emu.py) in a round without a GPU -- this is its first contact with hardware, hence the LAST test of the
     last module.  The bytes are held; the timings are printed and kept (gpurun_out/xahead_ab.json), not asserted."""
-    env = {k: v for k, v in os.environ.items() if k not in ("DSP_AMD_LIB", "DSP_RSRC_EXTENTS", "DSP_LSTM_XAHEAD", "DSP_LSTM_HANDOFF", "DSP_LSTM_CLUSTER")}
+    env = {k: v for k, v in os.environ.items() if k not in ("DSP_AMD_LIB", "DSP_RSRC_EXTENTS", "DSP_LSTM_XAHEAD", "DSP_LSTM_XAHEAD_RING", "DSP_LSTM_XAHEAD_TILES", "DSP_LSTM_HANDOFF", "DSP_LSTM_CLUSTER")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "xahead_ab.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
     got = json.loads(r.stdout.strip().splitlines()[-1])
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "xahead_ab.json"), "w") as f:
         json.dump(got, f, sort_keys=True)
-    for k, (off, on) in sorted(got["ms"].items(), key=lambda kv: (kv[0].split("/")[0], int(kv[0].split("/")[1]))):
-        print("%-32s %.4f -> %.4f ms per forward (%+.1f %%)" % (k, off, on, 100.0 * (on - off) / off))
+    for k, (off, on, on8) in sorted(got["ms"].items(), key=lambda kv: (kv[0].split("/")[0], int(kv[0].split("/")[1]))):
+        print("%-32s %.4f -> %.4f ms per forward (%+.1f %%); rings 8 deep %.4f (%+.1f %%)" % (k, off, on, 100.0 * (on - off) / off, on8, 100.0 * (on8 - off) / off))
     assert got["cases"] >= 40 and got["identical"], got["differs"]

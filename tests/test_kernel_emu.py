@@ -40,7 +40,7 @@ CSRC = os.path.join(ROOT, "deepsignal_plant_amd", "csrc")
 EMU = os.path.join(ROOT, "tests", "native", "emu")
 SWITCHES = ("DSP_LSTM_CLUSTER", "DSP_LSTM_LOCAL8", "DSP_TWO_STREAMS", "DSP_HEAD_ST4", "DSP_LSTM_TILING", "DSP_CLUSTER_TIMEOUT", "DSP_FC_FUSED",
             "DSP_LSTM_FRONT_CLUSTER", "DSP_FC_SMALL", "DSP_LSTM_HANDOFF", "DSP_FORWARD_SPLIT", "DSP_RSRC_EXTENTS", "DSP_EMU_SEED", "DSP_BOUNDS_TEST_SHRINK",
-            "DSP_PRECISION", "EMU_CUS", "DSP_LSTM_XAHEAD", "DSP_LSTM_XAHEAD_TILES")
+            "DSP_PRECISION", "EMU_CUS", "DSP_LSTM_XAHEAD", "DSP_LSTM_XAHEAD_TILES", "DSP_LSTM_XAHEAD_RING")
 
 pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="the image's clang++ builds the interpreter")
 LONG = bool(os.environ.get("DSP_EMU_LONG"))
@@ -240,12 +240,14 @@ def test_x_ahead_gives_the_same_bytes(emu, emu_bounds):
     without a live site are skipped.  Same MFMAs in the same order: the bytes of every cluster size, hand-off, schedule, of
     abandoned clusters (computed whole by the clean-up launch) and of both x-part lengths (32 and 64 k-groups: layers 0 and 1+)
     are those of the undivided launches; the bounds build records nothing; above the live-tile limit the form is not taken.
-    (DSP_EMU_LONG=1: all eight switch sets on two sizes, the seq-only shape; the default run a cut of it.)"""
+    (DSP_LSTM_XAHEAD_RING=8: the one-gate-per-wave form with rings 8 deep, keeping 8 k-groups of x part.)
+    (DSP_EMU_LONG=1: all ten switch sets on two sizes, the seq-only shape; the default run a cut of it.)"""
     kw = dict(seq_len=3 if LONG else 2, signal_len=8, hidden_size=256, num_layers1=2, num_layers2=1)
     modes = [{}, {"DSP_LSTM_CLUSTER": "2"}, {"DSP_LSTM_CLUSTER": "4"}, {"DSP_LSTM_HANDOFF": "0"}, {"DSP_CLUSTER_TIMEOUT": "0"},
-             {"DSP_EMU_SEED": "2"}, {"DSP_RSRC_EXTENTS": "tight"}, {"DSP_EMU_SEED": "3", "DSP_LSTM_HANDOFF": "0", "DSP_LSTM_CLUSTER": "2"}]
+             {"DSP_EMU_SEED": "2"}, {"DSP_RSRC_EXTENTS": "tight"}, {"DSP_EMU_SEED": "3", "DSP_LSTM_HANDOFF": "0", "DSP_LSTM_CLUSTER": "2"},
+             {"DSP_LSTM_XAHEAD_RING": "8"}, {"DSP_LSTM_XAHEAD_RING": "8", "DSP_LSTM_HANDOFF": "0", "DSP_EMU_SEED": "4"}]
     if not LONG:
-        modes = [{}, {"DSP_CLUSTER_TIMEOUT": "0", "DSP_LSTM_HANDOFF": "0", "DSP_LSTM_CLUSTER": "2", "DSP_EMU_SEED": "3"}]
+        modes = [{}, {"DSP_CLUSTER_TIMEOUT": "0", "DSP_LSTM_HANDOFF": "0", "DSP_LSTM_CLUSTER": "2", "DSP_EMU_SEED": "3"}, {"DSP_LSTM_XAHEAD_RING": "8"}]
     for n in ((45, 200) if LONG else (45,)):
         cfg, w, ins, st = _case(kw, n)
         with env():

@@ -34,6 +34,8 @@ bash tools/profile.sh r6_b1024 100 --batch 1024 > /dev/null 2>&1
 # the split-precision kernels (two kernel generations since their last profile)
 bash tools/profile.sh r6_bf16x9 5 --precision bf16x9 > /dev/null 2>&1
 bash tools/profile.sh r6_fp16x3 5 --precision fp16x3 > /dev/null 2>&1
+# 4b. "x ahead" (opt-in, never run on a GPU when it was written): bytes and per-forward times with / without it, rings 8 deep too
+XAHEAD_AB_REPS=200 python3 tools/xahead_ab.py > $O/xahead_ab.json 2> $O/xahead_ab.err; echo "xahead_ab rc=$?"; tail -c 1500 $O/xahead_ab.json
 # 5. the plan's cost model against this box: what dsp_debug_piece_cost says next to what the sweep measured
 python3 - <<'PY' > gpurun_out/r6/plan_vs_measured.txt 2>&1
 import ctypes, json

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of the "x ahead" form of the small-batch LSTM launches (round 6, DSP_LSTM_XAHEAD=1; dsp_kernels.hip dsp_xahead_kernel):
 same bytes, and what a forward costs with and without it.  One JSON line:
-    {"identical": bool, "differs": [...], "ms": {"<model>/<n>": [ms without, ms with]}}
+    {"identical": bool, "differs": [...], "ms": {"<model>/<n>": [ms without, ms with, ms with rings 8 deep]}}
 Written with no GPU at hand (the round's GPU access was closed): the first run of this script on an MI355X is the form's first
 contact with hardware -- tests/test_gpu_zz_extents.py runs it and holds the bytes; the timings are printed, not asserted."""
 import hashlib
@@ -34,11 +34,13 @@ def main():
         for tag, sw in SWITCHES:
             if tag and label != "default":
                 continue
-            for xa in ("0", "1"):
-                for k in ("DSP_LSTM_HANDOFF", "DSP_LSTM_CLUSTER"):
+            for xa in ("0", "1", "ring8"):
+                for k in ("DSP_LSTM_HANDOFF", "DSP_LSTM_CLUSTER", "DSP_LSTM_XAHEAD_RING"):
                     os.environ.pop(k, None)
                 os.environ.update(sw)
-                os.environ["DSP_LSTM_XAHEAD"] = xa      # (read when the handle is made)
+                os.environ["DSP_LSTM_XAHEAD"] = "0" if xa == "0" else "1"      # (read when the handle is made)
+                if xa == "ring8":
+                    os.environ["DSP_LSTM_XAHEAD_RING"] = "8"
                 m = build_model(cfg, w, init_state="randn", seed=5)
                 for n in SIZES:
                     ins = to_dev(onp.make_inputs(cfg, n, 9000 + n))
@@ -64,7 +66,8 @@ def main():
                 digest.setdefault("%s%s/%d/explicit" % (label, tag, n), {})[xa] = hashlib.sha256(probs.cpu().numpy().tobytes()).hexdigest()[:16]
                 del m
     os.environ.pop("DSP_LSTM_XAHEAD", None)
-    differs = sorted(k for k, v in digest.items() if v.get("0") != v.get("1"))
+    os.environ.pop("DSP_LSTM_XAHEAD_RING", None)
+    differs = sorted(k for k, v in digest.items() if not (v.get("0") == v.get("1") == v.get("ring8")))
     print(json.dumps({"identical": not differs, "differs": differs, "cases": len(digest), "ms": ms}, sort_keys=True))
 
 
