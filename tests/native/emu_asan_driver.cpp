@@ -8,7 +8,7 @@
 // with DSP_RSRC_EXTENTS=wide -- the 2 GiB windows of rounds 1-5 -- first, then with the default extents; both must give the same
 // bytes.  Shapes: every kernel form of the forward (front ends of 1 / 2 / 4 unit tiles, combined stacks of 2 / 4 / 8 / 10 unit
 // tiles, split precision), batch sizes with tile tails, one call cut into pieces, explicit / Philox / zero states, the
-// small-batch switch matrix incl. abandoned clusters.  usage: emu_asan_driver [quick]
+// small-batch switch matrix incl. abandoned clusters, the opt-in "x ahead" forms.  usage: emu_asan_driver [quick]
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -93,7 +93,8 @@ std::vector<float> run_model(const dsp_model_cfg& cfg, const std::vector<long>& 
 
 void set_env(const std::vector<std::pair<const char*, const char*>>& kv) {
     static const char* all[] = {"DSP_LSTM_CLUSTER", "DSP_LSTM_TILING", "DSP_LSTM_LOCAL8", "DSP_TWO_STREAMS", "DSP_HEAD_ST4", "DSP_FC_FUSED", "DSP_FC_SMALL", "DSP_LSTM_FRONT_CLUSTER",
-                                "DSP_LSTM_HANDOFF", "DSP_CLUSTER_TIMEOUT", "DSP_FORWARD_SPLIT", "DSP_RSRC_EXTENTS", "DSP_EMU_SEED", "EMU_CUS"};
+                                "DSP_LSTM_HANDOFF", "DSP_CLUSTER_TIMEOUT", "DSP_FORWARD_SPLIT", "DSP_RSRC_EXTENTS", "DSP_EMU_SEED", "EMU_CUS", "DSP_LSTM_XAHEAD",
+                                "DSP_LSTM_XAHEAD_RING", "DSP_LSTM_XAHEAD_TILES"};
     for (const char* k : all) unsetenv(k);
     for (const auto& p : kv) setenv(p.first, p.second, 1);
 }
@@ -117,8 +118,12 @@ int main(int argc, char** argv) {
         {"full-batch kernels", {{"DSP_LSTM_CLUSTER", "0"}, {"DSP_LSTM_TILING", "0"}, {"DSP_LSTM_LOCAL8", "0"}, {"DSP_TWO_STREAMS", "0"}, {"DSP_HEAD_ST4", "1"}, {"DSP_FC_SMALL", "0"}}},
         {"every cluster abandoned, adversarial schedule", {{"DSP_CLUSTER_TIMEOUT", "0"}, {"DSP_EMU_SEED", "3"}}},
         {"clusters of 4, round-4 hand-off, 64 compute units", {{"DSP_LSTM_CLUSTER", "2"}, {"DSP_LSTM_HANDOFF", "0"}, {"EMU_CUS", "64"}}},
+        // x ahead (dsp_xahead_kernel + the XA form of the clustered launches: calls of <= 8 live tiles, the dense layers of 8 unit tiles)
+        {"x ahead", {{"DSP_LSTM_XAHEAD", "1"}}},
+        {"x ahead, rings 8 deep, round-4 hand-off, adversarial schedule", {{"DSP_LSTM_XAHEAD", "1"}, {"DSP_LSTM_XAHEAD_RING", "8"}, {"DSP_LSTM_HANDOFF", "0"}, {"DSP_EMU_SEED", "5"}}},
+        {"x ahead, clusters of 4, up to 16 live tiles", {{"DSP_LSTM_XAHEAD", "1"}, {"DSP_LSTM_CLUSTER", "2"}, {"DSP_LSTM_XAHEAD_TILES", "16"}}},
     };
-    if (quick) modes.resize(3);
+    if (quick) { modes.erase(modes.begin() + 3); modes.resize(4); }
     for (const Case& c : cases) {
         std::vector<float> ref;
         for (const Mode& md : modes) {
