@@ -55,18 +55,20 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def committed_traffic(args):
+def committed_traffic(args, stale=False):
     """The committed rocprofv3 PMC entry of this same command (profiles/traffic.json, written by tools/make_traffic.py on
     the GPU box): HBM-side bytes per launch of the dominant kernel and per step over all kernels.  None unless the entry
-    was measured on the current kernel sources and on this workload."""
+    was measured on the current kernel sources and on this workload.  stale=True: the entry of this workload measured on
+    OTHER sources (reported apart, under its own hash, never as `traffic`)."""
     try:
         entries = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     except Exception:
         return None
     want = {"model_type": args.model_type, "layernum1": args.layernum1, "hid_rnn": args.hid_rnn, "batch": args.batch,
-            "precision": args.precision, "kernel_src_sha16": kernel_source_hash()}
+            "precision": args.precision}
+    now = kernel_source_hash()
     for e in entries:
-        if all(e.get(k) == v for k, v in want.items()):
+        if all(e.get(k) == v for k, v in want.items()) and (e.get("kernel_src_sha16") == now) != stale:
             return e
     return None
 
@@ -417,6 +419,7 @@ def main(argv=None):
         tr = committed_traffic(args)
         traffic = tr.get("hbm_bytes_per_launch") if tr else None
         step_traffic = tr.get("hbm_bytes_per_step_all_kernels") if tr else None
+        old = None if tr else committed_traffic(args, stale=True)
         k4_site = sum(2 * (H if k == 0 else 2 * H) * T * 4 + 2 * H * T * 4 for k in range(model.num_layers1)) / max(model.num_layers1, 1)
         algo_launch = k4_site * B
         cfg_idx = 2 if args.model_type == "seq_bilstm" else (1 if world == 1 else 3)
@@ -458,6 +461,11 @@ def main(argv=None):
                          "events_in_timed_steps": "one pair per forward around the dominant kernel's launches; ms_per_step_by_launch from %s" % (
                              "%d untimed steps with events around every launch" % k_all if k_all else "the timed steps"),
                          "kernel_src_sha16": kernel_source_hash(),
+                         **({"traffic_measured_on_earlier_sources": {
+                             "hbm_bytes_per_launch": old.get("hbm_bytes_per_launch"), "hbm_bytes_per_step_all_kernels": old.get("hbm_bytes_per_step_all_kernels"),
+                             "kernel_src_sha16": old.get("kernel_src_sha16"),
+                             "note": "NOT this build's traffic (hence traffic: null): the PMC passes of this workload on the sources of the hash given; "
+                                     "re-measure with tools/profile.sh + tools/make_traffic.py"}} if old else {}),
                          "note": ("fp32 MFMA and VALU work do not overlap on gfx950 (profiles/r2/micro_mfma_cell_overlap.txt): "
                                  "with the LSTM cell phase counted the bound of this kernel is 0.974 of the MFMA peak "
                                  "(DESIGN.md section 3)") if nprod == 1 else None},

@@ -47,6 +47,8 @@ def test_traffic_is_quoted_only_for_the_sources_it_was_measured_on(tmp_path, mon
     monkeypatch.setattr(bench, "kernel_source_hash", lambda: h)
     (tmp_path / "profiles" / "traffic.json").write_text(json.dumps([entry]))
     assert bench.committed_traffic(args)["hbm_bytes_per_launch"] == 1.25e10
+    assert bench.committed_traffic(args, stale=True) is None
     (tmp_path / "profiles" / "traffic.json").write_text(json.dumps([dict(entry, kernel_src_sha16="0" * 16)]))
     assert bench.committed_traffic(args) is None      # stale: the kernels changed since the PMC pass
+    assert bench.committed_traffic(args, stale=True)["kernel_src_sha16"] == "0" * 16   # ... reported apart, under its own hash, never as `traffic`
     assert bench.committed_traffic(bench.parse_args(["--batch", "4096"])) is None
