@@ -153,3 +153,29 @@ def run_cli_jobs(tmp_path, jobs, world=1, timeout=900, env=None, tag="jobs"):
     out = Results(json.load(open(path + ".out")) if os.path.exists(path + ".out") else [])
     out.proc = proc
     return out
+
+
+def cached_build(cmd, name, timeout=900):
+    """Run the compiler command `cmd` + ["-o", <path>] once per state of the sources: the binary lives in
+    tests/native/_build/<hash of the command and of every native source file>/<name> (git-ignored), so a second run of the suite
+    on unchanged sources does not compile the sanitizer builds again.  Returns the binary's path."""
+    import hashlib
+    import subprocess
+    h = hashlib.sha256(("\0".join(cmd) + "\0" + name).encode())
+    for d in (os.path.join(ROOT, "deepsignal_plant_amd", "csrc"), os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native"),
+              os.path.join(ROOT, "oracle")):
+        for f in sorted(os.listdir(d)):
+            path = os.path.join(d, f)
+            if os.path.isfile(path) and f.endswith((".cpp", ".h", ".hip", ".c", ".hpp")):
+                h.update(f.encode())
+                with open(path, "rb") as fh:
+                    h.update(fh.read())
+    d = os.path.join(ROOT, "tests", "native", "_build", h.hexdigest()[:16])
+    os.makedirs(d, exist_ok=True)
+    out = os.path.join(d, name)
+    if not os.path.exists(out):
+        tmp = out + ".tmp%d" % os.getpid()
+        r = subprocess.run(list(cmd) + ["-o", tmp], capture_output=True, text=True, timeout=timeout)
+        assert r.returncode == 0, r.stderr[-4000:]
+        os.replace(tmp, out)
+    return out

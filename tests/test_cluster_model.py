@@ -23,13 +23,10 @@ MUTANTS = ["nodrain", "latearrive", "nozero", "twice", "never"]
 
 @pytest.fixture(scope="module")
 def binaries(tmp_path_factory):
-    d = tmp_path_factory.mktemp("cluster_model")
-    fast, tsan = str(d / "cluster_model"), str(d / "cluster_model_tsan")
-    for exe, flags in ((fast, ["-O2"]), (tsan, ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=thread"])):
-        r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-pthread", "-I", INC, SRC, "-o", exe] + flags, capture_output=True, text=True,
-                           timeout=300)
-        assert r.returncode == 0, r.stderr[-4000:]
-    return fast, tsan
+    from tests.helpers import cached_build
+    base = ["g++", "-std=c++17", "-Wall", "-Werror", "-pthread", "-I", INC, SRC]
+    return (cached_build(base + ["-O2"], "cluster_model"),
+            cached_build(base + ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=thread"], "cluster_model_tsan"))
 
 
 def test_a_million_scheduled_launches_hold_every_invariant(binaries):

@@ -6,7 +6,7 @@ parity suites instead."""
 import os
 import subprocess
 
-from tests.helpers import GOLDEN, ROOT
+from tests.helpers import GOLDEN, ROOT, cached_build
 
 SRCS = ["dsp_text.cpp", "dsp_freq.cpp", "dsp_featfile.cpp", "dsp_sites.cpp", "dsp_gz.cpp", "dsp_fast5.cpp", "dsp_shmring.cpp", "dsp_pgz.cpp"]
 
@@ -16,13 +16,11 @@ import pytest
 
 @pytest.mark.parametrize("sanitizers", ["address,undefined", "thread"])
 def test_host_code_is_clean_under_asan_and_ubsan(tmp_path, sanitizers):
-    exe = os.path.join(str(tmp_path), "host_asan")
     csrc = os.path.join(ROOT, "deepsignal_plant_amd", "csrc")
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=" + sanitizers] + (
         ["-fno-sanitize-recover=undefined"] if "undefined" in sanitizers else []) + ["-ffp-contract=off", "-pthread", "-I", os.path.join(ROOT, "include"), "-I", csrc,
-           os.path.join(ROOT, "tests", "native", "host_asan.cpp")] + [os.path.join(csrc, s) for s in SRCS] + ["-lz", "-ldl", "-lrt", "-o", exe]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-4000:]
+           os.path.join(ROOT, "tests", "native", "host_asan.cpp")] + [os.path.join(csrc, s) for s in SRCS] + ["-lz", "-ldl", "-lrt"]
+    exe = cached_build(cmd, "host_asan_" + sanitizers.replace(",", "_"))
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1",
                TSAN_OPTIONS="halt_on_error=0:exitcode=66")
     r = subprocess.run([exe, GOLDEN, str(tmp_path)], capture_output=True, text=True, timeout=900, env=env)
@@ -40,15 +38,13 @@ def test_thread_pools_survive_a_system_that_refuses_threads(tmp_path, sanitizers
     calls) and drives the pools: every index of run_indexed still runs exactly once, BGZF deflate / inflate, the parallel
     inflater and the row parser give the bytes they give with all their threads, dsp_pgz_open without a decoder thread
     returns an error; a worker that throws is reported, not propagated.  Under ASan + UBSan, and under TSan."""
-    exe = os.path.join(str(tmp_path), "threads_refused")
     csrc = os.path.join(ROOT, "deepsignal_plant_amd", "csrc")
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=" + sanitizers] + (
         ["-fno-sanitize-recover=undefined"] if "undefined" in sanitizers else []) + [
            "-ffp-contract=off", "-pthread", "-I", os.path.join(ROOT, "include"), "-I", csrc,
            os.path.join(ROOT, "tests", "native", "threads_refused.cpp")] + [os.path.join(csrc, s) for s in ("dsp_text.cpp", "dsp_gz.cpp", "dsp_pgz.cpp")] + [
-           "-lz", "-ldl", "-lrt", "-o", exe]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-4000:]
+           "-lz", "-ldl", "-lrt"]
+    exe = cached_build(cmd, "threads_refused_" + sanitizers.replace(",", "_"))
     r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1",
                                 TSAN_OPTIONS="halt_on_error=0:exitcode=66"))
@@ -64,13 +60,11 @@ def test_device_parser_arithmetic_is_clean_under_asan_and_ubsan_and_equals_the_h
     UBSan: 200,000 rows of random float spellings, 4,000 rows of the writer's grammar, 30,000 byte-mutated blocks.  Every row it
     accepts equals the host parser's bit for bit, every row the host parser rejects is flagged, plain rows are never flagged,
     and the sanitizers report nothing.  Test infrastructure: the product parses on the GPU only."""
-    exe = os.path.join(str(tmp_path), "parse_dev_host")
     csrc = os.path.join(ROOT, "deepsignal_plant_amd", "csrc")
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
            "-ffp-contract=off", "-pthread", "-I", os.path.join(ROOT, "include"), "-I", csrc, os.path.join(ROOT, "tests", "native", "parse_dev_host.cpp"),
-           os.path.join(csrc, "dsp_text.cpp"), "-o", exe]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-4000:]
+           os.path.join(csrc, "dsp_text.cpp")]
+    exe = cached_build(cmd, "parse_dev_host")
     r = subprocess.run([exe, "200000", "30000"], capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
     assert r.returncode == 0 and "parse_dev_host: ok" in r.stdout, (r.stdout[-2000:], r.stderr[-6000:])
