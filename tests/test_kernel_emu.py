@@ -248,7 +248,7 @@ def test_x_ahead_gives_the_same_bytes(emu, emu_bounds):
              {"DSP_LSTM_XAHEAD_RING": "8"}, {"DSP_LSTM_XAHEAD_RING": "8", "DSP_LSTM_HANDOFF": "0", "DSP_EMU_SEED": "4"}]
     if not LONG:
         modes = [{}, {"DSP_CLUSTER_TIMEOUT": "0", "DSP_LSTM_HANDOFF": "0", "DSP_LSTM_CLUSTER": "2", "DSP_EMU_SEED": "3"}, {"DSP_LSTM_XAHEAD_RING": "8"}]
-    for n in ((45, 200) if LONG else (45,)):
+    for n in ((45, 200, 1, 256) if LONG else (45,)):      # (256 sites = the 8 live tiles up to which the form is taken)
         cfg, w, ins, st = _case(kw, n)
         with env():
             m = Model(emu, cfg, w)
