@@ -44,6 +44,9 @@ SWITCHES = ("DSP_LSTM_CLUSTER", "DSP_LSTM_LOCAL8", "DSP_TWO_STREAMS", "DSP_HEAD_
 
 pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="the image's clang++ builds the interpreter")
 LONG = bool(os.environ.get("DSP_EMU_LONG"))
+# DSP_EMU_SANITIZE=1: the extraction and call_freq interpreter libraries are built with AddressSanitizer + UBSan (run with the shared
+# ASan runtime preloaded: test_the_extraction_and_call_freq_kernels_under_sanitizers does)
+SAN = ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-shared-libsan"] if os.environ.get("DSP_EMU_SANITIZE") else []
 
 
 def _cache_dir(*flags):
@@ -514,7 +517,7 @@ def test_issued_matrix_work_against_the_flops_a_forward_is_credited_with(emu):
 def emu_extract():
     """dsp_extract.hip (its static __shared__ variables as `static`, its workgroups one after another: -DDSP_EMU_STATIC_LDS) +
     the host-side site enumerator, for the host; float64 arithmetic in numpy's evaluation order: -ffp-contract=off as in the product"""
-    d = _cache_dir("extract")
+    d = _cache_dir("extract", *SAN)
     out = os.path.join(d, "libdsp_extract_emu.so")
     if not os.path.exists(out):
         stub = os.path.join(d, "err_stub.cpp")
@@ -524,7 +527,7 @@ def emu_extract():
         tmp = out + ".tmp%d" % os.getpid()
         cmd = [CLANG, "-std=c++17", "-O2", "-march=native", "-Wno-psabi", "-fPIC", "-shared", "-DDSP_EMU", "-DDSP_EMU_STATIC_LDS", "-ffp-contract=off", "-Wno-unused-value",
                "-I", EMU, "-I", os.path.join(ROOT, "include"), "-I", CSRC, stub, os.path.join(EMU, "hip_emu.cpp"), "-x", "c++", os.path.join(CSRC, "dsp_extract.hip"),
-               "-o", tmp, "-pthread"]
+               "-o", tmp, "-pthread"] + SAN
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-4000:]
         os.replace(tmp, out)
@@ -601,7 +604,7 @@ def test_the_call_freq_kernels_reproduce_the_references_tables():
     from deepsignal_plant_amd import call_mods_freq as cf
     from tests.helpers import GOLDEN
     from tests.test_call_freq import CALLS, _rows_from_calls
-    d = _cache_dir("freq")
+    d = _cache_dir("freq", *SAN)
     out = os.path.join(d, "libdsp_freq_emu.so")
     if not os.path.exists(out):
         stub = os.path.join(d, "err_stub.cpp")
@@ -610,7 +613,7 @@ def test_the_call_freq_kernels_reproduce_the_references_tables():
                     'extern "C" const char* dsp_last_error(void) { return g.c_str(); }\n')
         tmp = out + ".tmp%d" % os.getpid()
         cmd = [CLANG, "-std=c++17", "-O2", "-march=native", "-Wno-psabi", "-fPIC", "-shared", "-DDSP_EMU", "-ffp-contract=off", "-Wno-unused-value", "-I", EMU,
-               "-I", os.path.join(ROOT, "include"), "-I", CSRC, stub, os.path.join(EMU, "hip_emu.cpp"), "-x", "c++", os.path.join(CSRC, "dsp_freq_dev.hip"), "-o", tmp, "-pthread"]
+               "-I", os.path.join(ROOT, "include"), "-I", CSRC, stub, os.path.join(EMU, "hip_emu.cpp"), "-x", "c++", os.path.join(CSRC, "dsp_freq_dev.hip"), "-o", tmp, "-pthread"] + SAN
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-4000:]
         os.replace(tmp, out)
@@ -665,3 +668,21 @@ def test_the_call_freq_kernels_reproduce_the_references_tables():
             assert H.dsp_freq_add_sites(table._h, ns, *[p(c) for c in cols]) == ns
             H.dsp_freq_add_counts(table._h, r.n)
             assert table.format(kw.get("sort", False), kw.get("bed", False)) == open(os.path.join(GOLDEN, "f5_freq_%s.txt" % tag), "rb").read(), (tag, blocks)
+
+
+@pytest.mark.skipif(not LONG or bool(SAN), reason="DSP_EMU_LONG=1: the two tests above again, their interpreter libraries built with ASan + UBSan")
+def test_the_extraction_and_call_freq_kernels_under_sanitizers():
+    """csrc/dsp_extract.hip and csrc/dsp_freq_dev.hip -- every hand-written kernel file besides the forward's and the parser's,
+    which have their own sanitizer runs above -- interpreted under AddressSanitizer + UBSan: the same two tests in a child
+    process with the shared ASan runtime preloaded; every "device" array is an exactly sized numpy array or malloc block."""
+    import sys
+    rt = subprocess.run([CLANG, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.exists(rt):
+        pytest.skip("no shared ASan runtime in this image")
+    e = dict(os.environ, DSP_EMU_SANITIZE="1", LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=0",
+             UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider", "-k",
+                        "extraction_kernels_match or call_freq_kernels_reproduce"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=3000)
+    print(r.stdout[-1500:])
+    assert r.returncode == 0 and "2 passed" in r.stdout, (r.stdout[-3000:], r.stderr[-6000:])
+    assert "AddressSanitizer" not in r.stdout + r.stderr and "runtime error" not in r.stdout + r.stderr, (r.stdout + r.stderr)[-6000:]
