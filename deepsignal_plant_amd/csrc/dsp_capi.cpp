@@ -799,12 +799,13 @@ void pick_form(const dsp_model* m, LstmArgs& a, long long NTp, bool split, bool 
         if (!side_by_side || (a.UT == 4 && a.CG < 4)) a.flags |= 4;
         if (m->wave_handoff) a.flags |= 64;
     }
-    // x ahead: the clustered dense forms of 8 unit tiles (not the front ends' one-ring x part, not the workgroup-local forms) on a
+    // x ahead: the clustered dense forms of 8 or 4 unit tiles (not the front ends' one-ring x part, not the workgroup-local forms) on a
     // call of few live tiles; the launch keeps the last ring of its x part
     a.xs = 0;
-    if (m->xahead && a.CG > 0 && a.UT == 8 && !(a.flags & 8) && (a.Ipad >> 3) != 4 && a.n > 0 && (a.n + 31) / 32 <= m->xahead_tiles) {
-        const bool ring8 = a.CG == 1 && m->xahead_ring == 8;
-        const int D = a.CG == 4 ? 4 : (a.CG == 2 || ring8 ? 8 : 16);
+    const bool dense8 = a.UT == 8 && !(a.flags & 8), dense4 = a.UT == 4 && a.CG < 4;   // (dsp_k_lstm's forms; 4 gates per wave at 4 unit tiles = workgroup-local)
+    if (m->xahead && a.CG > 0 && (dense8 || dense4) && (a.Ipad >> 3) != 4 && a.n > 0 && (a.n + 31) / 32 <= m->xahead_tiles) {
+        const bool ring8 = dense8 && a.CG == 1 && m->xahead_ring == 8;
+        const int D = dense4 ? 4 : (a.CG == 4 ? 4 : (a.CG == 2 || ring8 ? 8 : 16));
         if ((a.Ipad >> 3) >= 2 * D) { a.xs = (a.Ipad >> 3) - D; if (ring8) a.flags |= 128; }
     }
 }

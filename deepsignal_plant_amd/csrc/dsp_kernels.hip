@@ -2056,9 +2056,9 @@ extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
         if ((G != 1 && G != 2 && G != 4) || a->UT % G || a->NP > 1 || (!local && !a->cflags) || a->NQ != ((a->Ipad + a->Hp) >> 3) ||
             nqx % D || nqx < ((local || xshort) ? D : 2 * D) || a->NQ % D || a->NQ < 2 * D || (!local && !xshort && !dense4 && a->UT != 8))
             return (int)hipErrorInvalidValue;
-        // x ahead (a->xs > 0): the clustered dense forms of 8 unit tiles; this launch keeps exactly one ring of x part
+        // x ahead (a->xs > 0): the clustered dense forms (8 unit tiles, or 4: hidden 97..128); this launch keeps exactly one ring of x part
         const bool xa = a->xs > 0;
-        if (xa && (local || xshort || dense4 || a->xs != nqx - D || !a->xacc || !ends_ok({{a->xacc, a->xacc_end}}) || a->nqx_lo != 0 ||
+        if (xa && (local || xshort || a->xs != nqx - D || !a->xacc || !ends_ok({{a->xacc, a->xacc_end}}) || a->nqx_lo != 0 ||
                    a->nqx_used != nqx))
             return (int)hipErrorInvalidValue;
         // (zero-padded x-part k-groups -- nqx_lo, nqx_used -- are computed like live ones here: their weights are zero)
@@ -2084,7 +2084,9 @@ extern "C" int dsp_k_lstm(const LstmArgs* a, hipStream_t s) {
             // ones come first)
             const unsigned live = (unsigned)((a->n + 31) / 32) * 2;
             DSP_LAUNCH(dsp_xahead_kernel, dim3(live * (unsigned)a->T * (unsigned)a->UT), dim3(256), 0, s, *a);
-            if (G == 4) DSP_LAUNCH((dsp_lstmc_kernel<4, 4, false, 0, 4, false, true>), dim3(grid), dim3(256), lds, s, *a);
+            if (dense4 && G == 1) DSP_LAUNCH((dsp_lstmc_kernel<1, 4, false, 0, 4, false, true>), dim3(grid), dim3(256), lds, s, *a);
+            else if (dense4) DSP_LAUNCH((dsp_lstmc_kernel<2, 4, false, 0, 4, false, true>), dim3(grid), dim3(256), lds, s, *a);
+            else if (G == 4) DSP_LAUNCH((dsp_lstmc_kernel<4, 4, false, 0, 4, false, true>), dim3(grid), dim3(256), lds, s, *a);
             else if (G == 2) DSP_LAUNCH((dsp_lstmc_kernel<2, 8, false, 0, 4, false, true>), dim3(grid), dim3(256), lds, s, *a);
             else if (ring8) DSP_LAUNCH((dsp_lstmc_kernel<1, 8, false, 0, 4, false, true>), dim3(grid), dim3(256), lds, s, *a);
             else DSP_LAUNCH((dsp_lstmc_kernel<1, 16, false, 0, 4, false, true>), dim3(grid), dim3(256), lds, s, *a);

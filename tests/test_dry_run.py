@@ -171,8 +171,10 @@ def test_x_ahead_is_taken_by_small_calls_only_and_never_refused(monkeypatch):
                 dry(cc, n, extents=extents)
         dry(cc, 100, init=EXPLICIT)
         dry(cc, 100, cus=64)
-    # the seq-only shape (BASELINE configs[2]): both dense layers of its combined stack; hidden 128 has no such layer
+    # the seq-only shape (BASELINE configs[2]): both dense layers of its combined stack
     assert names(dry(cfg(module=1, num_layers1=2), 100)).count("dsp_xahead_kernel") == 2
-    assert names(dry(cfg(hidden_size=128), 100)).count("dsp_xahead_kernel") == 0
+    h128 = names(dry(cfg(hidden_size=128), 100))      # dense layers of 4 unit tiles: clusters of 4, rings 4 deep
+    assert h128.count("dsp_xahead_kernel") == 3 and h128.count("dsp_lstmc_kernel<1, 4, false, 0, 4, false, true>") == 3
+    assert names(dry(cfg(hidden_size=64), 100)).count("dsp_xahead_kernel") == 0       # 2 unit tiles: no clustered form
     # split precision: its own kernels, no clustered form, no x ahead
     assert names(dry(c, 100, prec=BF16X9)).count("dsp_xahead_kernel") == 0

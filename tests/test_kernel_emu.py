@@ -277,6 +277,17 @@ def test_x_ahead_gives_the_same_bytes(emu, emu_bounds):
                 got = m.forward(ins, states=st)[0]
                 m.close()
             assert np.array_equal(got, want[0])
+    # hidden 128: dense layers of 4 unit tiles on clusters of 4 (2 with DSP_LSTM_CLUSTER=2), rings 4 deep
+    cfg, w, ins, st = _case(dict(SMALL4, seq_len=2), 45)
+    out = []
+    for sw in (({}, {"DSP_LSTM_XAHEAD": "1"}, {"DSP_LSTM_XAHEAD": "1", "DSP_LSTM_CLUSTER": "2", "DSP_LSTM_HANDOFF": "0"}, {"DSP_LSTM_XAHEAD": "1", "DSP_CLUSTER_TIMEOUT": "0"})
+               if LONG else ({}, {"DSP_LSTM_XAHEAD": "1"})):
+        with env(**sw):
+            m = Model(emu, cfg, w)
+            out.append(m.forward(ins, states=st)[0])
+            m.close()
+        assert np.array_equal(out[-1], out[0]), sw
+    assert np.abs(out[0] - oc.forward(cfg, w, *ins, states=st)[1]).max() <= 1e-6
     if not LONG:
         return
     # the seq-only shape of BASELINE configs[2], with a second front-end layer: dense layers of 8 unit tiles in both stacks

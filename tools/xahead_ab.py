@@ -17,6 +17,7 @@ MODELS = [
     ("default", dict()),
     ("cfg3_seq_only", dict(module="seq_bilstm", num_layers1=2)),
     ("one_combined_layer_s40", dict(signal_len=40, hidden_size=256, num_layers1=1)),
+    ("hid128", dict(hidden_size=128, num_layers1=2, num_layers2=2)),
 ]
 SIZES = (1, 16, 33, 64, 100, 128, 200, 256, 257, 300)
 SWITCHES = [("", {}), ("/round4_handoff", {"DSP_LSTM_HANDOFF": "0"}), ("/G2", {"DSP_LSTM_CLUSTER": "2"})]
