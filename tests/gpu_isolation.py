@@ -18,7 +18,8 @@ A child that dies (fatal signal, or the module's time limit):
 Nothing is retried: a test that killed its process has failed.
 
 Switches: DSP_GPU_ISOLATE=0 runs everything in the pytest process as before (debuggers, `--pdb`);
-DSP_GPU_MODULE_TIMEOUT seconds per child (default 1500); DSP_GPU_CHILD_* are set by the parent for the child.
+DSP_GPU_MODULE_TIMEOUT seconds per child (default 1500, or the module's own GPU_MODULE_TIMEOUT attribute); DSP_GPU_CHILD_* are
+set by the parent for the child.
 """
 import json
 import os
@@ -142,10 +143,11 @@ def _describe_exit(rc, timed_out):
 class ModuleRunner:
     """Runs the selected tests of one module in fresh children and hands back {nodeid: [report, ...]}."""
 
-    def __init__(self, config, module_path, nodeids):
+    def __init__(self, config, module_path, nodeids, limit=None):
         self.config = config
         self.module_path = module_path
         self.nodeids = list(nodeids)
+        self.limit = limit     # the module's own GPU_MODULE_TIMEOUT (seconds), if it states one
         self.reports = {}      # nodeid -> list of deserialised reports
         self.synthetic = {}    # nodeid -> failure text (died / never ran)
         self.log_paths = []
@@ -166,7 +168,7 @@ class ModuleRunner:
         out_dir = _out_dir()
         remaining = list(self.nodeids)
         max_deaths = int(os.environ.get("DSP_GPU_MAX_DEATHS", "3"))
-        limit = float(os.environ.get("DSP_GPU_MODULE_TIMEOUT", "1500"))
+        limit = float(os.environ.get("DSP_GPU_MODULE_TIMEOUT") or self.limit or 1500)
         attempt = 0
         stop_after_failure = self.config.getoption("maxfail", 0) == 1
         while remaining:
@@ -267,6 +269,7 @@ class GpuIsolation:
     def __init__(self, config):
         self.config = config
         self.by_module = {}   # module path -> ordered node ids selected in this session
+        self.limits = {}      # module path -> its GPU_MODULE_TIMEOUT attribute
         self.runners = {}
 
     @pytest.hookimpl(trylast=True)
@@ -275,6 +278,7 @@ class GpuIsolation:
         for it in items:
             if is_gpu_item(it):
                 self.by_module.setdefault(str(it.path), []).append(it.nodeid)
+                self.limits[str(it.path)] = getattr(getattr(it, "module", None), "GPU_MODULE_TIMEOUT", None)
         if self.by_module:
             # The collecting process maps the product library too (dlopen + the pure dsp_abi_version() of _native.lib(): no HIP
             # call, no device touched -- the tests still run in the children): whoever audits "which in-tree .so did the pytest
@@ -292,7 +296,7 @@ class GpuIsolation:
         mod = str(item.path)
         runner = self.runners.get(mod)
         if runner is None:
-            runner = self.runners[mod] = ModuleRunner(self.config, mod, self.by_module.get(mod, [item.nodeid])).run()
+            runner = self.runners[mod] = ModuleRunner(self.config, mod, self.by_module.get(mod, [item.nodeid]), self.limits.get(mod)).run()
         ihook = item.ihook
         ihook.pytest_runtest_logstart(nodeid=item.nodeid, location=item.location)
         reports = runner.reports.get(item.nodeid)

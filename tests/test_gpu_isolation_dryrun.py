@@ -153,3 +153,22 @@ def test_a_module_over_its_time_limit_is_killed_and_named(tmp_path):
     got = _outcomes(r.stdout)
     assert got.get("test_gpu_b.py::test_hangs") == "FAILED" and got.get("test_gpu_b.py::test_after") == "PASSED", r.stdout
     assert "exceeded the module's time limit" in r.stdout, r.stdout
+
+
+def test_a_module_states_its_own_time_limit(tmp_path):
+    """GPU_MODULE_TIMEOUT in the module (tests/test_gpu_zz_extents.py raises the default for its sweeps): used when the
+    environment does not set DSP_GPU_MODULE_TIMEOUT"""
+    _tree(tmp_path)
+    (tmp_path / "test_gpu_b.py").write_text(textwrap.dedent("""
+        import time, pytest
+        pytestmark = pytest.mark.gpu
+        GPU_MODULE_TIMEOUT = 2
+        def test_hangs():
+            time.sleep(600)
+        def test_after():
+            pass
+    """))
+    r = _run(tmp_path, "-rA", "-m", "gpu", "-k", "gpu_b")
+    got = _outcomes(r.stdout)
+    assert got.get("test_gpu_b.py::test_hangs") == "FAILED" and got.get("test_gpu_b.py::test_after") == "PASSED", r.stdout
+    assert "exceeded the module's time limit" in r.stdout, r.stdout

@@ -20,6 +20,7 @@ import pytest
 from tests.helpers import ROOT
 
 pytestmark = pytest.mark.gpu
+GPU_MODULE_TIMEOUT = 3600      # (tests/gpu_isolation.py: three sweeps, one of them under the software-checked bounds build)
 BOUNDS_LIB = os.path.join(ROOT, "deepsignal_plant_amd", "libdsp_amd_bounds.so")
 
 
