@@ -34,6 +34,14 @@ bash tools/profile.sh r6_b1024 100 --batch 1024 > /dev/null 2>&1
 # the split-precision kernels (two kernel generations since their last profile)
 bash tools/profile.sh r6_bf16x9 5 --precision bf16x9 > /dev/null 2>&1
 bash tools/profile.sh r6_fp16x3 5 --precision fp16x3 > /dev/null 2>&1
+# 4a. all eleven shapes of the extents sweep (the suite runs six): default extents / tight / the bounds-recording build
+python3 tools/extents_sweep.py > $O/extents_sweep_region.json 2> $O/extents_sweep_region.err
+DSP_RSRC_EXTENTS=tight python3 tools/extents_sweep.py > $O/extents_sweep_tight.json 2> $O/extents_sweep_tight.err
+DSP_AMD_LIB=$PWD/deepsignal_plant_amd/libdsp_amd_bounds.so python3 tools/extents_sweep.py > $O/extents_sweep_bounds.json 2> $O/extents_sweep_bounds.err
+python3 -c "
+import json
+r = [json.loads(open('$O/extents_sweep_%s.json' % k).read().strip().splitlines()[-1]) for k in ('region', 'tight', 'bounds')]
+print('extents sweep: %d cases; tight == region: %s; bounds build == region: %s' % (len(r[0]), r[1] == r[0], r[2] == r[0]))"
 # 4b. "x ahead" (opt-in, never run on a GPU when it was written): bytes and per-forward times with / without it, rings 8 deep too
 XAHEAD_AB_REPS=200 python3 tools/xahead_ab.py > $O/xahead_ab.json 2> $O/xahead_ab.err; echo "xahead_ab rc=$?"; tail -c 1500 $O/xahead_ab.json
 # 5. the plan's cost model against this box: what dsp_debug_piece_cost says next to what the sweep measured
