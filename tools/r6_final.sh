@@ -31,6 +31,9 @@ for b in 512 1024 2048 4096; do echo "== batch $b"; python3 tools/per_launch.py 
 bash tools/batch_sweep.sh $O/batch_sweep.jsonl > $O/batch_sweep.txt 2>&1
 bash tools/profile.sh r6_b512 200 --batch 512 > /dev/null 2>&1
 bash tools/profile.sh r6_b1024 100 --batch 1024 > /dev/null 2>&1
+# 128 sites with and without "x ahead": kernel stats of the recurrent launches, dsp_xahead_kernel next to them
+bash tools/profile.sh r6_b128 200 --batch 128 > /dev/null 2>&1
+DSP_LSTM_XAHEAD=1 bash tools/profile.sh r6_b128_xahead 200 --batch 128 > /dev/null 2>&1
 # the split-precision kernels (two kernel generations since their last profile)
 bash tools/profile.sh r6_bf16x9 5 --precision bf16x9 > /dev/null 2>&1
 bash tools/profile.sh r6_fp16x3 5 --precision fp16x3 > /dev/null 2>&1
