@@ -162,6 +162,14 @@ class Model(object):
         assert rc == 0, self.L.dsp_last_error()
         return probs, logits, labels
 
+    def activation(self, which, n):
+        """dsp_debug_read_activation: 0 = the combined stack's input (relu(fc) of both branches), 1 = its output; [n, T, features]"""
+        feats = self.cfg.hidden_size if which == 0 else 2 * self.cfg.hidden_size
+        out = np.zeros((n, self.cfg.seq_len, feats), np.float32)
+        rc = self.L.dsp_debug_read_activation(self.h, None, ctypes.c_int32(which), ctypes.c_int64(n), ctypes.c_void_p(out.ctypes.data))
+        assert rc == 0, self.L.dsp_last_error()
+        return out
+
     def close(self):
         self.L.dsp_model_destroy(self.h)
 
@@ -171,10 +179,18 @@ class Model(object):
 @pytest.mark.parametrize("name", ["tiny_h64_l2", "nobase_h128"] + (["nosiglen_h128", "both_default", "signal_only", "seq_cfg3"] if LONG else []))
 def test_the_kernels_source_reproduces_the_reference_fixture(emu, name):
     f = load_f1(name)
+    inter = {}
     with env():
         m = Model(emu, f["cfg"], f["w"])
         probs, logits, labels = m.forward(f["inputs"], states=f["states"])
+        # the reference's intermediates (forward hooks, first 8 sites) against the K4 buffers read back through the C ABI
+        if "lstm_comb" in f["inter"]:
+            inter["lstm_comb"] = (m.activation(1, f["n"])[: f["inter"]["lstm_comb"].shape[0]], f["inter"]["lstm_comb"])
+        if f["cfg"].module == "both_bilstm" and "relu_seq" in f["inter"]:
+            inter["relu_fc"] = (m.activation(0, f["n"])[: f["inter"]["relu_seq"].shape[0]], np.concatenate((f["inter"]["relu_seq"], f["inter"]["relu_signal"]), axis=2))
         m.close()
+    for k, (got, ref) in inter.items():
+        assert np.abs(got - ref).max() <= 5e-6, (name, k, float(np.abs(got - ref).max()))
     dp = float(np.abs(probs - f["probs"]).max())
     print(name, "interpreted kernels vs the reference: max|dprob| %.2e (n = %d)" % (dp, f["n"]))
     assert dp <= 1e-6 and np.abs(logits - f["logits"]).max() <= 2e-5
