@@ -29,6 +29,13 @@ def pytest_collection_modifyitems(config, items):
         items[:] = first + [it for it in items if "test_gpu_ranks8" not in it.nodeid]
 
 
+def pytest_collection_finish(session):
+    """the long native runs of the selected tests start now, next to the Python-level tests (tests/bgjobs.py)"""
+    from tests import bgjobs
+    if not session.config.option.collectonly:
+        bgjobs.start_for(session.items)
+
+
 @pytest.hookimpl(tryfirst=True)
 def pytest_runtest_setup(item):
     """A breadcrumb per GPU test under gpurun_out/ (scratch, merged back from the GPU box), written by the process that runs

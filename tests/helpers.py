@@ -163,7 +163,7 @@ def cached_build(cmd, name, timeout=900):
     import subprocess
     h = hashlib.sha256(("\0".join(cmd) + "\0" + name).encode())
     for d in (os.path.join(ROOT, "deepsignal_plant_amd", "csrc"), os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native"),
-              os.path.join(ROOT, "oracle")):
+              os.path.join(ROOT, "tests", "native", "emu"), os.path.join(ROOT, "tests", "native", "emu", "hip"), os.path.join(ROOT, "oracle")):
         for f in sorted(os.listdir(d)):
             path = os.path.join(d, f)
             if os.path.isfile(path) and f.endswith((".cpp", ".h", ".hip", ".c", ".hpp")):
@@ -173,9 +173,18 @@ def cached_build(cmd, name, timeout=900):
     d = os.path.join(ROOT, "tests", "native", "_build", h.hexdigest()[:16])
     os.makedirs(d, exist_ok=True)
     out = os.path.join(d, name)
-    if not os.path.exists(out):
-        tmp = out + ".tmp%d" % os.getpid()
-        r = subprocess.run(list(cmd) + ["-o", tmp], capture_output=True, text=True, timeout=timeout)
-        assert r.returncode == 0, r.stderr[-4000:]
-        os.replace(tmp, out)
+    with _BUILD_GUARD:
+        lock = _BUILD_LOCKS.setdefault(out, threading.Lock())
+    with lock:      # (background jobs of one session may ask for the same binary at once: one of them compiles it)
+        if not os.path.exists(out):
+            tmp = out + ".tmp%d.%d" % (os.getpid(), threading.get_ident())
+            r = subprocess.run(list(cmd) + ["-o", tmp], capture_output=True, text=True, timeout=timeout)
+            assert r.returncode == 0, r.stderr[-4000:]
+            os.replace(tmp, out)
     return out
+
+
+import threading  # noqa: E402
+
+_BUILD_GUARD = threading.Lock()
+_BUILD_LOCKS = {}

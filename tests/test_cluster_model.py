@@ -21,26 +21,49 @@ INC = os.path.join(ROOT, "deepsignal_plant_amd", "csrc")
 MUTANTS = ["nodrain", "latearrive", "nozero", "twice", "never"]
 
 
-@pytest.fixture(scope="module")
-def binaries(tmp_path_factory):
-    from tests.helpers import cached_build
-    base = ["g++", "-std=c++17", "-Wall", "-Werror", "-pthread", "-I", INC, SRC]
-    return (cached_build(base + ["-O2"], "cluster_model"),
-            cached_build(base + ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=thread"], "cluster_model_tsan"))
+from tests import bgjobs  # noqa: E402
+from tests.helpers import cached_build  # noqa: E402
+
+BASE = ["g++", "-std=c++17", "-Wall", "-Werror", "-pthread", "-I", INC, SRC]
 
 
-def test_a_million_scheduled_launches_hold_every_invariant(binaries):
+def _fast():
+    return cached_build(BASE + ["-O2"], "cluster_model")
+
+
+def _tsan():
+    return cached_build(BASE + ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=thread"], "cluster_model_tsan")
+
+
+# every run is a background job (tests/bgjobs.py): started when collection ends, next to the Python-level tests
+@bgjobs.job("cluster_explore")
+def _explore():
+    fast = _fast()
+    procs = [subprocess.Popen([fast, "explore", "62500", "none", str(k * 10_000_000)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for k in range(4)]
+    return [(p.communicate(timeout=600)[0], p.returncode) for p in procs]
+
+
+@bgjobs.job("cluster_tsan_threads")
+def _tsan_threads():
+    return subprocess.run([_tsan(), "threads", "120"], capture_output=True, text=True, timeout=600, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0:exitcode=66"))
+
+
+for _m in MUTANTS:
+    bgjobs.job("cluster_explore_" + _m)(lambda m=_m: subprocess.run([_fast(), "explore", "20000", m], capture_output=True, text=True, timeout=300))
+    bgjobs.job("cluster_tsan_" + _m)(lambda m=_m: subprocess.run([_tsan(), "threads", "150", m], capture_output=True, text=True, timeout=600,
+                                                                  env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66")))
+
+
+@bgjobs.uses(lambda p: ["cluster_explore"])
+def test_a_million_scheduled_launches_hold_every_invariant():
     """No deadlock within the tick budget; in a cluster that is not abandoned every wave runs to its last step, every row read
     behind a passed poll is complete, no LDS gate slot is read stale, the rows are the sequential reference's; an abandoned
     cluster is recomputed exactly once by the clean-up launch, a cluster that ran is never recomputed; without adversity no
     cluster is abandoned."""
-    fast, _ = binaries
-    procs = [subprocess.Popen([fast, "explore", "62500", "none", str(k * 10_000_000)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-             for k in range(4)]
     launches = abandoned = 0
-    for p in procs:
-        out = p.communicate(timeout=600)[0]
-        assert p.returncode == 0 and "cluster_model: ok" in out, out[-2000:]
+    for out, rc in bgjobs.result("cluster_explore"):
+        assert rc == 0 and "cluster_model: ok" in out, out[-2000:]
         launches += int(out.split("= ")[1].split()[0])
         abandoned += int(out.split("clean, ")[1].split()[0])
     print("explorer: %d launches scheduled, %d abandoned and recomputed" % (launches, abandoned))
@@ -54,28 +77,26 @@ def test_a_million_scheduled_launches_hold_every_invariant(binaries):
     ("twice", "recomputed a cluster that was not abandoned"),
     ("never", "wrong h row behind the launch"),
 ])
-def test_the_explorer_fails_on_every_mutant(binaries, mutant, expect):
-    fast, _ = binaries
-    r = subprocess.run([fast, "explore", "20000", mutant], capture_output=True, text=True, timeout=300)
+@bgjobs.uses(lambda p: ["cluster_explore_" + p["mutant"]])
+def test_the_explorer_fails_on_every_mutant(mutant, expect):
+    r = bgjobs.result("cluster_explore_" + mutant)
     assert r.returncode == 1 and "VIOLATION" in r.stdout and expect in r.stdout, (r.returncode, r.stdout[-1500:])
 
 
-def test_threads_under_tsan_report_nothing(binaries):
-    _, tsan = binaries
-    r = subprocess.run([tsan, "threads", "120"], capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0:exitcode=66"))
+@bgjobs.uses(lambda p: ["cluster_tsan_threads"])
+def test_threads_under_tsan_report_nothing():
+    r = bgjobs.result("cluster_tsan_threads")
     assert r.returncode == 0 and "cluster_model: ok" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-4000:])
     assert "WARNING: ThreadSanitizer" not in r.stderr, r.stderr[-6000:]
     print(r.stdout.strip())
 
 
 @pytest.mark.parametrize("mutant", MUTANTS)
-def test_the_threads_engine_fails_on_every_mutant(binaries, mutant):
+@bgjobs.uses(lambda p: ["cluster_tsan_" + p["mutant"]])
+def test_the_threads_engine_fails_on_every_mutant(mutant):
     """nodrain = the arrival's add without release semantics (the device: no s_waitcnt vmcnt(0) in front of it): a data race on the
     h rows that only ThreadSanitizer can see on an x86 host -- and does."""
-    _, tsan = binaries
-    r = subprocess.run([tsan, "threads", "150", mutant], capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66"))
+    r = bgjobs.result("cluster_tsan_" + mutant)
     race = "WARNING: ThreadSanitizer: data race" in r.stderr
     assert r.returncode != 0 and (race or "VIOLATION" in r.stdout), (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
     if mutant == "nodrain":

@@ -341,6 +341,24 @@ def test_ragged_sizes_and_a_cut_call(emu):
     assert np.abs(out["1"] - oc.forward(cfg, w, *ins, init_mode="philox", seed=7, site_offset=0)[1]).max() <= 2e-6
 
 
+@pytest.mark.skipif(not LONG, reason="DSP_EMU_LONG=1: up to 9,001 sites through the interpreter, five minutes")
+def test_the_forms_each_batch_size_takes_by_itself(emu):
+    """no switch set: 513 sites (clusters of 4), 1,025 (of 2), 2,049 (one eight-wave workgroup per site tile and direction),
+    4,097 (4,096 + 1: a cut), 9,001 (a round of 8,192 sites on the full-batch kernels + 809) of a hidden-256 model, Philox
+    states, against the C oracle"""
+    cfg = onp.OracleConfig(seq_len=2, signal_len=8, hidden_size=256, num_layers1=2, num_layers2=1)
+    w = onp.make_weights(cfg, 5, 2.0)
+    for n in (513, 1025, 2049, 4097, 9001):
+        ins = onp.make_inputs(cfg, n, 100 + n)
+        with env():
+            m = Model(emu, cfg, w)
+            pp = m.forward(ins, philox=(7, 5 * n))[0]
+            m.close()
+        d = float(np.abs(pp - oc.forward(cfg, w, *ins, init_mode="philox", seed=7, site_offset=5 * n)[1]).max())
+        print("%5d sites: max|dprob| vs the C oracle %.2e" % (n, d))
+        assert d <= 2e-6, n
+
+
 def test_the_many_pass_kernel_and_padded_shapes(emu):
     """hidden 320 (two passes per step, the cell state in the scratch behind a descriptor), hidden 100 (padded unit tiles), a
     signal window wider than 32 features, no k-mer / no lengths"""
@@ -447,31 +465,39 @@ def test_the_kernels_under_address_and_ub_sanitizers(tmp_path):
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-6000:]
 
 
+def _parse_kernels_job(kernel):
+    """build (once per state of the sources) and run tests/native/parse_dev_host.cpp -DPARSE_THROUGH_KERNELS under ASan + UBSan"""
+    from tests.helpers import cached_build
+    exe = cached_build([CLANG, "-std=c++17", "-O1", "-g", "-march=native", "-Wno-psabi", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
+                        "-fno-sanitize-recover=undefined", "-ffp-contract=off", "-DDSP_EMU", "-DPARSE_THROUGH_KERNELS", "-Wno-unused-value", "-Wno-unused-function",
+                        "-I", EMU, "-I", os.path.join(ROOT, "include"), "-I", CSRC, os.path.join(ROOT, "tests", "native", "parse_dev_host.cpp"),
+                        os.path.join(CSRC, "dsp_text.cpp"), "-x", "c++", os.path.join(CSRC, "dsp_parse_dev.hip"), os.path.join(EMU, "hip_emu.cpp"), "-pthread"],
+                       "parse_kernels_asan")
+    n, m = ("200000", "30000") if LONG else ("5000", "800")
+    e = {k: v for k, v in os.environ.items() if k not in ("DSP_PARSE_KERNEL", "DSP_PARSE_RB")}
+    e.update(ASAN_OPTIONS="detect_stack_use_after_return=0", UBSAN_OPTIONS="print_stacktrace=1")
+    if kernel == "rows":
+        e["DSP_PARSE_KERNEL"] = "rows"
+    return subprocess.run([exe, n, m], capture_output=True, text=True, timeout=3000, env=e)
+
+
+from tests import bgjobs  # noqa: E402
+
+for _k in ("tokens", "rows"):
+    bgjobs.job("parse_kernels_" + _k)(lambda k=_k: _parse_kernels_job(k))
+
+
 @pytest.mark.parametrize("kernel", ["tokens", "rows"])
-def test_the_row_parsers_kernels_under_sanitizers_against_the_host_parser(tmp_path_factory, kernel):
+@bgjobs.uses(lambda p: ["parse_kernels_" + p["kernel"]])
+def test_the_row_parsers_kernels_under_sanitizers_against_the_host_parser(kernel):
     """csrc/dsp_parse_dev.hip -- the token-parallel kernel and the thread-per-row pair -- compiled for the host by the interpreter
     and run under ASan + UBSan over random float spellings, the writer's grammar and byte-mutated blocks
     (tests/native/parse_dev_host.cpp -DPARSE_THROUGH_KERNELS): every array the kernels touch -- the staged text and its 64 bytes
     of slack, the row offsets, the segment table, the outputs -- is exactly sized, so a cursor that runs past a row, a table
     entry followed out of the block, a token stored one too far is a report.  Every accepted row equals the host parser's bit for
     bit, every row it rejects is flagged.  (Round 5's one unexplained death of a GPU-suite run fell between test_gpu_parse.py and
-    the eight-rank bench: this is those kernels with a sanitizer on.)"""
-    exe = os.path.join(_cache_dir("parse"), "parse_kernels_asan")
-    if not os.path.exists(exe):
-        tmp = exe + ".tmp%d" % os.getpid()
-        cmd = [CLANG, "-std=c++17", "-O1", "-g", "-march=native", "-Wno-psabi", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
-               "-ffp-contract=off", "-DDSP_EMU", "-DPARSE_THROUGH_KERNELS", "-Wno-unused-value", "-Wno-unused-function", "-I", EMU, "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-               os.path.join(ROOT, "tests", "native", "parse_dev_host.cpp"), os.path.join(CSRC, "dsp_text.cpp"), "-x", "c++", os.path.join(CSRC, "dsp_parse_dev.hip"),
-               os.path.join(EMU, "hip_emu.cpp"), "-o", tmp, "-pthread"]
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stderr[-4000:]
-        os.replace(tmp, exe)
-    n, m = ("200000", "30000") if LONG else ("5000", "800")
-    e = {k: v for k, v in os.environ.items() if k not in ("DSP_PARSE_KERNEL", "DSP_PARSE_RB")}
-    e.update(ASAN_OPTIONS="detect_stack_use_after_return=0", UBSAN_OPTIONS="print_stacktrace=1")
-    if kernel == "rows":
-        e["DSP_PARSE_KERNEL"] = "rows"
-    r = subprocess.run([exe, n, m], capture_output=True, text=True, timeout=3000, env=e)
+    the eight-rank bench: this is those kernels with a sanitizer on.)  A background job (tests/bgjobs.py)."""
+    r = bgjobs.result("parse_kernels_" + kernel)
     print(r.stdout)
     assert r.returncode == 0 and "parse_dev_host: ok (through the interpreted kernels" in r.stdout, (r.stdout[-2000:], r.stderr[-6000:])
     assert ("thread-per-row" in r.stdout) == (kernel == "rows")

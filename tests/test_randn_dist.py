@@ -247,18 +247,36 @@ def test_f9_fixture_is_self_consistent():
     assert abs(dm[0]) < 1e-3 and abs(dm[1] - 1) < 1e-3 and abs(dm[4]) < 5e-3 and abs(dm[5]) < 5e-3 and abs(dm[8] - 3) < 0.02
 
 
+# the oracle's forwards of the level-2 tests (15-30 s each, in C with the GIL released) are background jobs (tests/bgjobs.py):
+# started when collection ends, next to the tests in front of them
+from tests import bgjobs  # noqa: E402
+
+
+def _p1_job(model, sites, control=None):
+    d, _ = load_f9()
+    cfg, w, ins = f9_model(d, model)
+    return oracle_p1(cfg, w, ins, sites, 256, seed=4242, control=control)
+
+
+for _m in ("default", "sharp_x3", "f8_trained_h256"):
+    bgjobs.job("randn_p1_" + _m)(lambda m=_m: _p1_job(m, 12))
+bgjobs.job("randn_ctrl_h_and_c_on_one_stream")(lambda: _p1_job("f8_trained_h256", 16, "h_and_c_on_one_stream"))
+bgjobs.job("randn_ctrl_sigma_0p9")(lambda: _p1_job("default", 32, "sigma_0p9"))
+
+
 @pytest.mark.parametrize("model", ["default", "sharp_x3", "f8_trained_h256"])
+@bgjobs.uses(lambda p: ["randn_p1_" + p["model"]])
 def test_level2_oracle_philox_outputs_are_distributed_like_the_references(model):
     """12 rows x 256 Philox draws from the oracle against the reference's 1,024 torch.randn draws of the same rows
     (the GPU half does all 64 rows x 4,096 draws)"""
     d, _ = load_f9()
-    cfg, w, ins = f9_model(d, model)
-    got = oracle_p1(cfg, w, ins, 12, 256, seed=4242)
+    got = bgjobs.result("randn_p1_" + model)
     bad, info = output_violations(got, d["p1_" + model][:, :12])
     print(model, info)
     assert bad == [], (model, bad, info)
 
 
+@bgjobs.uses(lambda p: ["randn_ctrl_h_and_c_on_one_stream", "randn_ctrl_sigma_0p9"])
 def test_level2_rejects_what_it_can_see_of_the_mis_keyed_generators():
     """What the OUTPUT level sees of the three mis-keyings with the few hundred draws the CPU suite can afford: 'h and c on
     one stream' on the trained model (the most sensitive to its states: pooled KS), 'sigma 0.9' on the default-scale
@@ -270,10 +288,9 @@ def test_level2_rejects_what_it_can_see_of_the_mis_keyed_generators():
     # ('both directions on one stream' is not run here: 256 draws of 16 rows showed a spread ratio of 1.017 and a pooled KS p
     # of 0.69 -- nothing; the GPU half prints what 4,096 draws of 64 rows show of it)
     for model, sites, controls in (("f8_trained_h256", 16, ("h_and_c_on_one_stream",)), ("default", 32, ("sigma_0p9",))):
-        cfg, w, ins = f9_model(d, model)
         ref = d["p1_" + model][:, :sites]
         for control in controls:
-            got = oracle_p1(cfg, w, ins, sites, 256, seed=4242, control=control)
+            got = bgjobs.result("randn_ctrl_" + control)
             bad, info = output_violations(got, ref)
             print(model, control, "->", bad or "not visible in the outputs", "|", info)
             seen[control] = bool(bad)
