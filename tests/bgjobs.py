@@ -14,6 +14,7 @@ import os
 import threading
 
 _REGISTRY = {}        # name -> function
+_MODULE_JOBS = {}     # test file's basename -> job names every selected test of that file wants (module fixtures)
 _FUTURES = {}         # name -> Future
 _LOCK = threading.Lock()
 _POOL = None
@@ -32,6 +33,11 @@ def uses(names_of):
         fn._bgjobs = names_of
         return fn
     return deco
+
+
+def module_uses(basename, names):
+    """any selected test of the file `basename` starts these jobs (what the file's module-scoped fixtures wait for)"""
+    _MODULE_JOBS[basename] = list(names)
 
 
 def _enabled():
@@ -60,6 +66,8 @@ def start_for(items):
     if not _enabled():
         return
     for it in items:
+        for name in _MODULE_JOBS.get(os.path.basename(str(getattr(it, "path", ""))), ()):
+            start(name)
         names_of = getattr(getattr(it, "function", None), "_bgjobs", None)
         if names_of is None:
             continue

@@ -87,15 +87,26 @@ def _compile(out, *flags):
     os.replace(tmp, out)
 
 
+def _compile_emu_lib(name, *flags):
+    out = os.path.join(_cache_dir("emu"), name)
+    if not os.path.exists(out):
+        _compile(out, *flags)
+    return out
+
+
+# the two interpreter builds are background jobs (tests/bgjobs.py) that any selected test of this file starts at collection end:
+# a minute of compilation each, side by side, next to the tests in front of this module
+from tests import bgjobs  # noqa: E402
+
+bgjobs.job("emu_lib")(lambda: _compile_emu_lib("libdsp_amd_emu.so"))
+bgjobs.job("emu_lib_bounds")(lambda: _compile_emu_lib("libdsp_amd_emu_bounds.so", "-DDSP_BOUNDS"))
+bgjobs.module_uses("test_kernel_emu.py", ["emu_lib", "emu_lib_bounds"])
+
+
 @pytest.fixture(scope="module")
-def libs(tmp_path_factory):
-    """the interpreter build of the library and its bounds-recording twin, compiled side by side"""
-    import concurrent.futures
-    d = _cache_dir("emu")
-    with concurrent.futures.ThreadPoolExecutor(2) as ex:
-        a = ex.submit(_build, os.path.join(d, "libdsp_amd_emu.so"))
-        b = ex.submit(_build, os.path.join(d, "libdsp_amd_emu_bounds.so"), "-DDSP_BOUNDS")
-        return a.result(), b.result()
+def libs():
+    """the interpreter build of the library and its bounds-recording twin"""
+    return _build(bgjobs.result("emu_lib")), _build(bgjobs.result("emu_lib_bounds"))
 
 
 @pytest.fixture(scope="module")
@@ -480,8 +491,6 @@ def _parse_kernels_job(kernel):
         e["DSP_PARSE_KERNEL"] = "rows"
     return subprocess.run([exe, n, m], capture_output=True, text=True, timeout=3000, env=e)
 
-
-from tests import bgjobs  # noqa: E402
 
 for _k in ("tokens", "rows"):
     bgjobs.job("parse_kernels_" + _k)(lambda k=_k: _parse_kernels_job(k))
