@@ -74,3 +74,12 @@ def start_for(items):
         params = dict(getattr(getattr(it, "callspec", None), "params", {}) or {})
         for name in names_of(params):
             start(name)
+
+
+def shutdown():
+    """tests/conftest.py, pytest_sessionfinish: jobs that have not started yet (a run that ended early: -x) are dropped"""
+    global _POOL
+    with _LOCK:
+        if _POOL is not None:
+            _POOL.shutdown(wait=False, cancel_futures=True)
+            _POOL = None

@@ -36,6 +36,11 @@ def pytest_collection_finish(session):
         bgjobs.start_for(session.items)
 
 
+def pytest_sessionfinish(session, exitstatus):
+    from tests import bgjobs
+    bgjobs.shutdown()
+
+
 @pytest.hookimpl(tryfirst=True)
 def pytest_runtest_setup(item):
     """A breadcrumb per GPU test under gpurun_out/ (scratch, merged back from the GPU box), written by the process that runs
