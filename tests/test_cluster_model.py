@@ -14,15 +14,14 @@ import sys
 
 import pytest
 
-from tests.helpers import ROOT
+from tests import bgjobs
+from tests.helpers import ROOT, cached_build
 
 SRC = os.path.join(ROOT, "tests", "native", "cluster_model.cpp")
 INC = os.path.join(ROOT, "deepsignal_plant_amd", "csrc")
 MUTANTS = ["nodrain", "latearrive", "nozero", "twice", "never"]
 
 
-from tests import bgjobs  # noqa: E402
-from tests.helpers import cached_build  # noqa: E402
 
 BASE = ["g++", "-std=c++17", "-Wall", "-Werror", "-pthread", "-I", INC, SRC]
 

@@ -33,6 +33,7 @@ import pytest
 from deepsignal_plant_amd import _native as nat   # (the ctypes structures only: the emulated library is bound by hand below)
 from oracle import c_oracle as oc
 from oracle import forward_np as onp
+from tests import bgjobs
 from tests.helpers import ROOT, load_f1
 
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
@@ -96,8 +97,6 @@ def _compile_emu_lib(name, *flags):
 
 # the two interpreter builds are background jobs (tests/bgjobs.py) that any selected test of this file starts at collection end:
 # a minute of compilation each, side by side, next to the tests in front of this module
-from tests import bgjobs  # noqa: E402
-
 bgjobs.job("emu_lib")(lambda: _compile_emu_lib("libdsp_amd_emu.so"))
 bgjobs.job("emu_lib_bounds")(lambda: _compile_emu_lib("libdsp_amd_emu_bounds.so", "-DDSP_BOUNDS"))
 bgjobs.module_uses("test_kernel_emu.py", ["emu_lib", "emu_lib_bounds"])
